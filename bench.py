@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py -- SpMM throughput of the MI355X engine on BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): BASELINE config 4, the configuration the metric "SpMM GFLOP/s + achieved
+HBM GB/s (fp32, N=16) at 1/2/4/8 MI355X" is quoted on and which fits one GPU: synthetic CSR
+4,000,000 x 4,000,000, Poisson(40) non-zeros per row, U(-1,1) values (counter-based generator,
+seed 4, generated directly in HBM), N = 16, fp32, alpha = 0.85, beta = -2.06, column-major B and C.
+At N > 1 the SAME matrix is row-range partitioned (strong scaling), B is replicated, every rank
+computes its slab of C in place and one RCCL all-gather completes C on all ranks.
+
+A "step" is one full pass  C_out = alpha*A*B + beta*C_in  from the API layout (column-major B in
+HBM -> B panel repack -> CSR row-group kernel -> column-major C_out [-> all-gather]).  FLOPs use the
+reference's convention 2*N*(nnz+M) (sextans-host.cpp:255-260).  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      dominant kernel (spmm_csr_rowgroup): algorithmic bytes per launch
+                (8*nnz + 4*(M+1) + 4*K*N + 8*M*N) / mean launch duration measured
+                with HIP events on the launch stream, against the 8 TB/s HBM3E spec peak.
+  cpu_baseline  the reference's cpu_spmm_CSR (oracle/_ref, kind "reference") or our C restatement
+                (kind "port") timed single-threaded on a bounded row sample of the same workload.
+  also          secondary measurements (nasa4704 N=16 = BASELINE config 2; compute-only time).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALPHA, BETA = 0.85, -2.06
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the copy ceiling
+
+
+def alg_bytes(M, K, N, nnz, beta_nonzero=True):
+    return 8 * nnz + 4 * (M + 1) + 4 * K * N + 4 * M * N * (2 if beta_nonzero else 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=4_000_000, help="M = K of the synthetic matrix")
+    ap.add_argument("--mean-nnz", type=float, default=40.0)
+    ap.add_argument("--n", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from sextans_amd import api, dist as sxd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        sys.exit(2)
+    api.lib()   # raises if the HIP library was not built: no fallback
+    if not torch.cuda.is_available() or api.device_count() < 1:
+        raise SystemExit("bench.py: no MI355X visible; the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    M = K = args.rows
+    N = api.round_up_n(args.n)
+    ranges = sxd.partition_rows_even(M, world)
+    r0, r1 = ranges[rank]
+    m_loc = r1 - r0
+
+    # ---- inputs, generated in HBM
+    d_rp, d_ci, d_v, nnz_loc = api.gen_csr_device(local_rank, M, K, args.mean_nnz, 4, r0, r1)
+    B = torch.empty(K * N, dtype=torch.float32, device=dev)
+    Cin = torch.empty(M * N, dtype=torch.float32, device=dev)
+    Cout = torch.zeros(M * N, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    api.gen_uniform_device(local_rank, B.data_ptr(), K * N, 41, stream)
+    api.gen_uniform_device(local_rank, Cin.data_ptr(), M * N, 42, stream)
+    torch.cuda.synchronize()
+
+    eng = api.Engine(local_rank)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
+    eng.set_matrix_csr_device(m_loc, K, nnz_loc, d_rp, d_ci, d_v)
+    cin_ptr = Cin.data_ptr() + 4 * r0
+    cout_ptr = Cout.data_ptr() + 4 * r0
+
+    def compute():
+        eng.spmm_device(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr, cout_ptr, M, stream)
+
+    def step():
+        compute()
+        if world > 1:
+            sxd.all_gather_c(Cout, M, N, ranges, rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def timed(fn, iters):
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize(); barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    for _ in range(args.warmup):
+        step()
+    dt = timed(step, args.steps)
+    dt_compute = timed(compute, args.steps) if world > 1 else dt
+
+    nnz_tot = nnz_loc
+    if world > 1:
+        t = torch.tensor([nnz_loc], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        nnz_tot = int(t.item())
+    flops = 2.0 * N * (nnz_tot + M)
+    sec_per_step = dt / args.steps
+    value = flops / sec_per_step / 1e9
+
+    # ---- dominant-kernel roofline: HIP events around each kernel launch on the launch stream
+    eng.set_option("profile", 1)
+    eng.profile_reset()
+    for _ in range(10):
+        compute()
+    torch.cuda.synchronize()
+    k_ns, k_n, rp_ns = eng.profile_read()
+    eng.set_option("profile", 0)
+    eng.profile_reset()
+    bytes_launch = alg_bytes(m_loc, K, N, nnz_loc)
+    achieved = bytes_launch / (k_ns * 1e-9) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": eng.last_kernel(), "kernel_us": round(k_ns / 1e3, 2),
+                "alg_bytes_per_launch": bytes_launch, "launches_timed": k_n,
+                "repack_us": round(rp_ns / 1e3, 2)}
+
+    out = {
+        "metric": "SpMM GFLOP/s + achieved HBM GB/s (fp32, N=16) at 1/2/4/8 MI355X",
+        "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"config4: synthetic CSR {M}x{K}, Poisson({args.mean_nnz:g}) nnz/row, "
+                               f"U(-1,1) fp32, N={N}, alpha=0.85, beta=-2.06, column-major B/C, seed 4",
+                   "M": M, "K": K, "N": N, "nnz": nnz_tot,
+                   "parallelism": f"A row-split x{world}, B replicated, all-gather(C)" if world > 1 else "1 GPU"},
+        "hbm_gbs_algorithmic_step": round(alg_bytes(M, K, N, nnz_tot) / sec_per_step / 1e9, 1),
+        "roofline": roofline,
+    }
+    also = {}
+    if world > 1:
+        also["compute_only_ms_per_step"] = round(dt_compute / args.steps * 1e3, 4)
+        also["compute_only_gflops"] = round(flops / (dt_compute / args.steps) / 1e9, 2)
+
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(api, M, K, N, args, Cout, flops_per_row=None)
+        try:
+            also["nasa4704_N16"] = nasa_secondary(api, torch, dev, stream)
+        except Exception as e:   # secondary measurement only
+            also["nasa4704_N16"] = {"error": str(e)}
+    if also:
+        out["also"] = also
+
+    eng.close()
+    for q in (d_rp, d_ci, d_v):
+        api.device_free(local_rank, q)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(api, M, K, N, args, Cout, flops_per_row):
+    """Single-thread CPU baseline on the first R rows of the same matrix (same B, same C_in):
+    the reference's own cpu_spmm_CSR when oracle/_ref is present, else our C restatement.
+    Also cross-checks the GPU result on those rows bit-for-bit."""
+    from oracle.bindings import Oracle, Ref
+    o = Oracle()
+    kind, ref = "port", None
+    try:
+        ref = Ref()
+        kind = "reference"
+    except Exception:
+        pass
+    Bh = api.gen_uniform_host(K * N, 41)
+    Cin_h = api.gen_uniform_host(M * N, 42)      # element i of stream 42 is C_in[i] (column-major M x N)
+    cores = 1
+
+    def run(R):
+        rp, ci, v = api.gen_csr_host(M, K, args.mean_nnz, 4, 0, R)
+        # rows [0,R) as an R x K problem: C sample = first R rows of every column of C_in
+        Cs = np.ascontiguousarray(Cin_h.reshape(N, M)[:, :R]).reshape(-1)
+        if ref is not None:
+            sec = ref.spmm(R, N, K, np.float32(ALPHA), rp, ci, v, Bh, np.float32(BETA), Cs)
+        else:
+            sec = o.time_spmm_rows(0, R, R, N, K, np.float32(ALPHA), rp, ci, v, Bh, np.float32(BETA), Cs)
+        return sec, int(rp[-1]), Cs
+
+    R = min(M, 50_000)
+    sec, nnz_s, Cs = run(R)
+    if sec < args.cpu_seconds / 4 and R < M:
+        R = int(min(M, max(R, R * args.cpu_seconds / max(sec, 1e-3))))
+        sec, nnz_s, Cs = run(R)
+    gf = 2.0 * N * (nnz_s + R) / sec / 1e9
+    got = Cout.view(N, M)[:, :R].cpu().numpy().reshape(-1)
+    match = bool(np.array_equal(got.view(np.uint32), Cs.view(np.uint32)))
+    return {"value": round(gf, 3), "unit": "GFLOP/s", "cores": cores, "kind": kind,
+            "sample": f"rows [0,{R}) of the same matrix ({nnz_s} nnz), same B and C_in, "
+                      f"{sec:.2f} s single thread; host has {os.cpu_count()} logical cores",
+            "gpu_matches_cpu_bitwise_on_sample": match}
+
+
+def nasa_secondary(api, torch, dev, stream):
+    """BASELINE config 2: nasa4704.mtx, N=16 -- latency-bound and cache-resident; per-launch mean
+    over 1000 back-to-back steps."""
+    path = os.path.join(ROOT, "matrices", "nasa4704", "nasa4704.mtx")
+    rp, ci, v, M, K, nnz = api.read_suitsparse_matrix(path)
+    N = 16
+    e = api.Engine(dev.index)
+    e.set_matrix_csr(M, K, rp, ci, v)
+    B = torch.from_numpy(api.init_dense_B(K, N)).to(dev)
+    Cin = torch.from_numpy(api.init_dense_C(M, N)).to(dev)
+    Cout = torch.empty_like(Cin)
+    f = lambda: e.spmm_device(N, ALPHA, B.data_ptr(), K, BETA, Cin.data_ptr(), Cout.data_ptr(), M, stream)
+    for _ in range(20):
+        f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(1000):
+        f()
+    torch.cuda.synchronize()
+    per = (time.perf_counter() - t0) / 1000
+    e.set_option("profile", 1)
+    for _ in range(50):
+        f()
+    torch.cuda.synchronize()
+    k_ns, _, rp_ns = e.profile_read()
+    e.close()
+    by = alg_bytes(M, K, N, nnz)
+    return {"us_per_step": round(per * 1e6, 2), "gflops": round(2.0 * N * (nnz + M) / per / 1e9, 1),
+            "kernel_us": round(k_ns / 1e3, 2), "repack_us": round(rp_ns / 1e3, 2),
+            "alg_gbs_kernel": round(by / (k_ns * 1e-9) / 1e9, 1)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+/*
+ * sextans_amd.h -- C ABI of the MI355X-native SpMM engine (drop-in boundary for the Sextans path).
+ *
+ * Plain C types only: pointers, sizes, scalars.  No torch / C++ types cross this boundary.
+ * Every entry point names the reference interface it replaces (paths relative to
+ * linghaosong/Sextans, branch tapa).  All functions return 0 (SEXTANS_OK) on success or a
+ * SEXTANS_ERR_* code; nothing here ever calls exit() (the reference's loader does,
+ * sparse_helper.h:100-109,120-123,146-149,181-191).
+ *
+ * Conventions shared with the reference:
+ *   - A is M x K sparse, B is K x N dense, C is M x N dense, C = alpha*A*B + beta*C
+ *     (sparse_helper.h:273-277);
+ *   - dense matrices are COLUMN MAJOR fp32 (B[k + ldb*n], C[m + ldc*n]);
+ *   - indices are 0-based 32-bit ints, values fp32;
+ *   - N is used as given by the caller; the CLI rounds it up to a multiple of 8 first
+ *     (sextans-host.cpp:51) via sextans_round_up_n().
+ *
+ * The compute entry points run ONLY on an AMD GPU (gfx950).  There is no CPU fallback: without
+ * a usable HIP device they return SEXTANS_ERR_NO_DEVICE.
+ */
+#ifndef SEXTANS_AMD_H
+#define SEXTANS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ error codes */
+#define SEXTANS_OK 0
+#define SEXTANS_ERR_OPEN 1         /* "Could not open ..."                  sparse_helper.h:181-184 */
+#define SEXTANS_ERR_BANNER 2       /* "Could not process Matrix Market banner" sparse_helper.h:100-103 */
+#define SEXTANS_ERR_SIZE 3         /* "Could not read Matrix Market format"  sparse_helper.h:105-109 */
+#define SEXTANS_ERR_NOT_COORD 4    /* "... is not a coordinate file!"        sparse_helper.h:188-191 */
+#define SEXTANS_ERR_COMPLEX 5      /* "complex matrix, not supported yet!"   sparse_helper.h:120-123 */
+#define SEXTANS_ERR_INDEX 6        /* index < 1 (reference) or > M/K (ours)  sparse_helper.h:146-149 */
+#define SEXTANS_ERR_ALLOC 7
+#define SEXTANS_ERR_PARSE 8        /* malformed entry (the reference reads garbage silently) */
+#define SEXTANS_ERR_INVALID 9      /* bad argument */
+#define SEXTANS_ERR_NO_DEVICE 10   /* no HIP device / wrong architecture: NO CPU fallback */
+#define SEXTANS_ERR_HIP 11         /* a HIP runtime call failed; see sextans_last_error() */
+#define SEXTANS_ERR_STATE 12       /* e.g. spmm before set_matrix */
+
+#define SEXTANS_FMT_CSR 0          /* enum MATRIX_FORMAT {CSR, CSC}, sparse_helper.h:20 */
+#define SEXTANS_FMT_CSC 1
+
+const char *sextans_error_string(int code);
+/* Thread-local text of the last HIP failure (empty string if none). */
+const char *sextans_last_error(void);
+
+/* ------------------------------------------------------------------ L2: host sparse library */
+
+/* Replaces read_suitsparse_matrix (sparse_helper.h:169-259): loads a SuiteSparse Matrix-Market
+ * coordinate file into CSR (ptr has M+1 entries, idx = columns) or CSC (ptr has K+1 entries,
+ * idx = rows).  Same observable semantics: case-insensitive banner, real/integer/pattern,
+ * pattern -> 1.0f, entries whose fp32 bits are exactly 0 are dropped (-0.0 is kept), only
+ * `symmetric` mirrors off-diagonals, duplicates kept in file order, nnz is the post-drop
+ * post-mirror count.  Output arrays are malloc'ed; release with sextans_host_free(). */
+int sextans_mtx_read(const char *path, int format, int *M, int *K, int *nnz, int **ptr, int **idx,
+                     float **val);
+void sextans_host_free(void *p);
+
+/* Replaces CSC_2_CSR (sparse_helper.h:475-509).  Caller provides row_ptr[M+1], col_idx[nnz],
+ * csr_val[nnz].  Per-row column order = CSC traversal order (ascending columns). */
+int sextans_csc_to_csr(int M, int K, int nnz, const int *col_ptr, const int *row_idx,
+                       const float *csc_val, int *row_ptr, int *col_idx, float *csr_val);
+
+/* Replaces the dense-operand initialisation of sextans-host.cpp:94-111:
+ * B[k + K*n] = 1.0f;  C[m + M*n] = (float)(1.0*(m+1)*(n+1)/M/N). */
+void sextans_init_dense_B(int K, int N, float *B);
+void sextans_init_dense_C(int M, int N, float *C);
+
+/* tapa::round_up<8>(N), sextans-host.cpp:51. */
+int sextans_round_up_n(int N);
+
+/* Replaces the verification loop of sextans-host.cpp:262-289.  Returns the mismatch count
+ * (|a-b| / (min(|a|,|b|) + 1e-4) > 1e-4) and writes the percentage; pass iff *percent < 2.0. */
+int sextans_verify(int M, int N, const float *c_cpu, const float *c_dev, float *percent);
+
+/* Throughput formula of sextans-host.cpp:219,255-260: 2*N*(nnz+M)/1e9/seconds. */
+double sextans_gflops(int M, int N, int64_t nnz, double seconds);
+
+/* Host golden used ONLY by the CLI's built-in self check (the reference's main() runs
+ * cpu_spmm_CSR for the same purpose, sextans-host.cpp:206-219).  It is never a fallback for
+ * the device path. */
+int sextans_selfcheck_golden(int M, int N, int K, float alpha, const int *row_ptr,
+                             const int *col_idx, const float *val, const float *B, float beta,
+                             float *C_inout);
+
+/* ------------------------------------------------------------------ L1: the SpMM engine (HIP) */
+
+typedef struct sextans_engine *sextans_handle_t;
+
+/* Number of usable gfx950 devices (0 and SEXTANS_ERR_NO_DEVICE when there is none). */
+int sextans_device_count(int *count);
+
+/* Engine bound to one HIP device.  Re-entrant per handle; a handle must not be used from two
+ * threads at once (the reference is single-threaded). */
+int sextans_create(sextans_handle_t *h, int device);
+int sextans_destroy(sextans_handle_t h);
+
+/* Tunables.  key: "kernel" (0 auto, 1 row-group gather, 2 LDS-window), "lanes_per_row"
+ * (2/4/8, N-tile = 4*lanes), "stage_a" (0/1 stage the CSR stream through LDS), "xcd_remap"
+ * (0/1), "exact" (1 = no FMA, reference rounding; 0 = allow FMA), "profile" (0/1 hipEvent
+ * per-kernel timing).  Unknown keys -> SEXTANS_ERR_INVALID. */
+int sextans_set_option(sextans_handle_t h, const char *key, int64_t value);
+int sextans_get_option(sextans_handle_t h, const char *key, int64_t *value);
+
+/* Upload a CSR matrix (host pointers) once; later spmm calls reuse the device copy.  This is
+ * the analogue of the reference's FPGA-side preparation (generate_edge_list_for_all_PEs +
+ * edge_list_64bit, sextans-host.cpp:114-148), which is likewise outside its timed region. */
+int sextans_set_matrix_csr(sextans_handle_t h, int M, int K, int64_t nnz, const int *row_ptr,
+                           const int *col_idx, const float *val);
+/* Same, for arrays that already live on the engine's device (not copied, not owned). */
+int sextans_set_matrix_csr_device(sextans_handle_t h, int M, int K, int64_t nnz,
+                                  const int *d_row_ptr, const int *d_col_idx, const float *d_val);
+
+/* Replaces tapa::invoke(Sextans, ...) (sextans-host.cpp:237-251, prototype sextans.h:20-26) with
+ * the argument meaning of cpu_spmm_CSR (sparse_helper.h:262-272): host buffers in, C updated in
+ * place, column major, ld = K for B and M for C.  The kernel runs rp_time (>=1) times, every
+ * repeat from the same C input (the reference reads C_in and writes a separate C_out), and
+ * *elapsed_ns receives the device time of ALL repeats (tapa::invoke returns the same;
+ * sextans-host.cpp:252 divides by rp_time).  Host<->device copies are outside *elapsed_ns. */
+int sextans_spmm_host(sextans_handle_t h, int N, float alpha, const float *B, float beta, float *C,
+                      int rp_time, double *elapsed_ns);
+
+/* Device-resident form: all pointers are device pointers on the engine's device, column major
+ * with explicit leading dimensions (ldb >= K, ldc >= M).  d_C_in and d_C_out may alias.
+ * Enqueues on `stream` (a hipStream_t passed as void*; NULL = default stream) and returns
+ * without synchronising. */
+int sextans_spmm_device(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
+                        float beta, const float *d_C_in, float *d_C_out, int64_t ldc, void *stream);
+
+/* One-shot convenience with exactly cpu_spmm_CSR's argument list (sparse_helper.h:262-272):
+ * create + upload + run + download + destroy on device 0. */
+int sextans_spmm_csr(int M, int N, int K, int NNZ, float ALPHA, const int *CSRRowPtr,
+                     const int *CSRColIndex, const float *CSRVal, const float *mat_B, float BETA,
+                     float *mat_C);
+
+/* Per-kernel device timing collected while option "profile" = 1: mean duration in ns of the
+ * dominant SpMM kernel launches since the last reset, and how many were timed. */
+int sextans_profile_read(sextans_handle_t h, double *mean_kernel_ns, int64_t *launches,
+                         double *mean_repack_ns);
+int sextans_profile_reset(sextans_handle_t h);
+
+/* Name of the kernel the dispatcher last used (static string), for logs and rocprof matching. */
+const char *sextans_last_kernel(sextans_handle_t h);
+
+/* ------------------------------------------------------------------ synthetic inputs (bench) */
+
+/* Deterministic counter-based synthetic CSR (BASELINE config 4): row lengths Poisson(mean_nnz)
+ * from an integer inverse-CDF table, columns uniform without replacement and sorted, values
+ * U(-1,1).  Host and device generators produce identical bits for the same (seed,row).
+ * Host form generates rows [r0,r1) only (row_ptr has r1-r0+1 entries starting at 0). */
+int sextans_gen_csr_host(int M, int K, double mean_nnz, uint64_t seed, int r0, int r1,
+                         int **row_ptr, int **col_idx, float **val, int64_t *nnz);
+/* Device form: allocates device arrays on `device` (free with sextans_device_free). */
+int sextans_gen_csr_device(int device, int M, int K, double mean_nnz, uint64_t seed, int r0, int r1,
+                           int **d_row_ptr, int **d_col_idx, float **d_val, int64_t *nnz);
+/* U(-1,1) fp32 fill, element i of stream `seed` (same bits on host and device). */
+int sextans_gen_uniform_host(float *dst, int64_t n, uint64_t seed);
+int sextans_gen_uniform_device(int device, float *d_dst, int64_t n, uint64_t seed, void *stream);
+int sextans_device_free(int device, void *d_ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEXTANS_AMD_H */

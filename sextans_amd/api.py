@@ -1,0 +1,307 @@
+"""ctypes mirror of include/sextans_amd.h -- the host-side call surface of the engine.
+
+Function names follow the reference's host library (src/sparse_helper.h, src/sextans-host.cpp) so
+tests read like the reference's own harness:
+
+    read_suitsparse_matrix  sparse_helper.h:169      CSC_2_CSR   sparse_helper.h:475
+    Engine.spmm             cpu_spmm_CSR argument meaning (sparse_helper.h:262) behind the
+                            tapa::invoke(Sextans, ...) boundary (sextans-host.cpp:237-251)
+
+All compute goes through libsextans_amd.so (HIP, gfx950).  There is no Python or CPU fallback: a
+missing library raises at import of this module's `lib()`; a missing GPU raises SextansError
+(SEXTANS_ERR_NO_DEVICE) at Engine creation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsextans_amd.so")
+CLI_PATH = os.path.join(_HERE, "bin", "sextans")
+
+FMT_CSR, FMT_CSC = 0, 1
+ERR_NO_DEVICE = 10
+
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_lib = None
+
+
+class SextansError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        msg = lib().sextans_error_string(code).decode()
+        detail = lib().sextans_last_error().decode()
+        super().__init__(f"{where}: [{code}] {msg}" + (f" ({detail})" if detail else ""))
+
+
+def lib():
+    """Load libsextans_amd.so once.  torch (if importable) is imported first so that this library
+    binds to the same libamdhip64.so.7 instance torch uses (one HIP runtime per process)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP engine with `python -m sextans_amd.build` "
+            "(there is no CPU fallback)")
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    pi, pf = C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.POINTER(C.c_float))
+    ip = C.POINTER(C.c_int)
+    L.sextans_error_string.restype = C.c_char_p
+    L.sextans_error_string.argtypes = [C.c_int]
+    L.sextans_last_error.restype = C.c_char_p
+    L.sextans_mtx_read.argtypes = [C.c_char_p, C.c_int, ip, ip, ip, pi, pi, pf]
+    L.sextans_host_free.argtypes = [C.c_void_p]
+    L.sextans_host_free.restype = None
+    L.sextans_csc_to_csr.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f32p, _i32p, _i32p,
+                                     _f32p]
+    L.sextans_init_dense_B.argtypes = [C.c_int, C.c_int, _f32p]
+    L.sextans_init_dense_B.restype = None
+    L.sextans_init_dense_C.argtypes = [C.c_int, C.c_int, _f32p]
+    L.sextans_init_dense_C.restype = None
+    L.sextans_round_up_n.argtypes = [C.c_int]
+    L.sextans_verify.argtypes = [C.c_int, C.c_int, _f32p, _f32p, C.POINTER(C.c_float)]
+    L.sextans_gflops.restype = C.c_double
+    L.sextans_gflops.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_double]
+    L.sextans_selfcheck_golden.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, _i32p, _i32p,
+                                           _f32p, _f32p, C.c_float, _f32p]
+    L.sextans_device_count.argtypes = [ip]
+    L.sextans_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.sextans_destroy.argtypes = [C.c_void_p]
+    L.sextans_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.sextans_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
+    L.sextans_set_matrix_csr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, _i32p, _i32p,
+                                         _f32p]
+    L.sextans_set_matrix_csr_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sextans_spmm_host.argtypes = [C.c_void_p, C.c_int, C.c_float, _f32p, C.c_float, _f32p,
+                                    C.c_int, C.POINTER(C.c_double)]
+    L.sextans_spmm_device.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64,
+                                      C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.sextans_spmm_csr.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _i32p, _i32p,
+                                   _f32p, _f32p, C.c_float, _f32p]
+    L.sextans_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                       C.POINTER(C.c_double)]
+    L.sextans_profile_reset.argtypes = [C.c_void_p]
+    L.sextans_last_kernel.restype = C.c_char_p
+    L.sextans_last_kernel.argtypes = [C.c_void_p]
+    L.sextans_gen_csr_host.argtypes = [C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_int, C.c_int,
+                                       pi, pi, pf, C.POINTER(C.c_int64)]
+    L.sextans_gen_csr_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64,
+                                         C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_int64)]
+    L.sextans_gen_uniform_host.argtypes = [_f32p, C.c_int64, C.c_uint64]
+    L.sextans_gen_uniform_device.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_uint64,
+                                             C.c_void_p]
+    L.sextans_device_free.argtypes = [C.c_int, C.c_void_p]
+    _lib = L
+    return L
+
+
+def _check(rc, where):
+    if rc != 0:
+        raise SextansError(rc, where)
+
+
+def _buf(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a if a.size else np.zeros(1, dtype)
+
+
+def _take(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+# ------------------------------------------------------------------ L2: host sparse library
+
+def read_suitsparse_matrix(path, fmt=FMT_CSR):
+    """-> (ptr, idx, val, M, K, nnz); raises SextansError where the reference would exit(1)."""
+    L = lib()
+    M, K, nnz = C.c_int(), C.c_int(), C.c_int()
+    p, i, v = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()
+    _check(L.sextans_mtx_read(os.fsencode(path), fmt, M, K, nnz, p, i, v), f"mtx_read({path})")
+    n_ptr = (M.value if fmt == FMT_CSR else K.value) + 1
+    out = (_take(p, n_ptr, np.int32), _take(i, nnz.value, np.int32),
+           _take(v, nnz.value, np.float32), M.value, K.value, nnz.value)
+    for q in (p, i, v):
+        L.sextans_host_free(q)
+    return out
+
+
+def CSC_2_CSR(M, K, NNZ, csc_col_ptr, csc_row_idx, csc_val):
+    rp = np.zeros(M + 1, np.int32)
+    ci = np.zeros(max(NNZ, 1), np.int32)
+    cv = np.zeros(max(NNZ, 1), np.float32)
+    _check(lib().sextans_csc_to_csr(M, K, NNZ, _buf(csc_col_ptr, np.int32),
+                                    _buf(csc_row_idx, np.int32), _buf(csc_val, np.float32),
+                                    rp, ci, cv), "csc_to_csr")
+    return rp, ci[:NNZ].copy(), cv[:NNZ].copy()
+
+
+def init_dense_B(K, N):
+    B = np.empty(K * N, np.float32)
+    lib().sextans_init_dense_B(K, N, _buf(B, np.float32) if B.size == 0 else B)
+    return B
+
+
+def init_dense_C(M, N):
+    Cm = np.empty(M * N, np.float32)
+    lib().sextans_init_dense_C(M, N, _buf(Cm, np.float32) if Cm.size == 0 else Cm)
+    return Cm
+
+
+def round_up_n(N):
+    return lib().sextans_round_up_n(N)
+
+
+def verify(M, N, c_cpu, c_dev):
+    pct = C.c_float()
+    n = lib().sextans_verify(M, N, _buf(c_cpu, np.float32), _buf(c_dev, np.float32), C.byref(pct))
+    return n, pct.value
+
+
+def gflops(M, N, nnz, seconds):
+    return lib().sextans_gflops(M, N, nnz, seconds)
+
+
+def device_count():
+    n = C.c_int()
+    rc = lib().sextans_device_count(C.byref(n))
+    return 0 if rc else n.value
+
+
+# ------------------------------------------------------------------ L1: the engine
+
+class Engine:
+    """One engine per HIP device; upload A once, launch SpMM many times."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        self.device = device
+        _check(lib().sextans_create(C.byref(self._h), device), "sextans_create")
+        self.M = self.K = self.nnz = 0
+
+    def close(self):
+        if self._h:
+            lib().sextans_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_option(self, key, value):
+        _check(lib().sextans_set_option(self._h, key.encode(), int(value)), f"set_option({key})")
+
+    def get_option(self, key):
+        v = C.c_int64()
+        _check(lib().sextans_get_option(self._h, key.encode(), C.byref(v)), f"get_option({key})")
+        return v.value
+
+    def set_matrix_csr(self, M, K, row_ptr, col_idx, val):
+        nnz = int(np.asarray(col_idx).shape[0])
+        _check(lib().sextans_set_matrix_csr(self._h, M, K, nnz, _buf(row_ptr, np.int32),
+                                            _buf(col_idx, np.int32), _buf(val, np.float32)),
+               "set_matrix_csr")
+        self.M, self.K, self.nnz = M, K, nnz
+
+    def set_matrix_csr_device(self, M, K, nnz, d_row_ptr, d_col_idx, d_val):
+        _check(lib().sextans_set_matrix_csr_device(self._h, M, K, nnz, d_row_ptr, d_col_idx,
+                                                   d_val), "set_matrix_csr_device")
+        self.M, self.K, self.nnz = M, K, nnz
+
+    def spmm(self, N, alpha, B, beta, C_inout, rp_time=1):
+        """Host buffers, C updated in place (cpu_spmm_CSR semantics).  Returns device ns for all
+        rp_time repeats (what tapa::invoke returns, sextans-host.cpp:237)."""
+        B = np.ascontiguousarray(B, np.float32)
+        if not (isinstance(C_inout, np.ndarray) and C_inout.dtype == np.float32
+                and C_inout.flags.c_contiguous):
+            raise TypeError("C must be a contiguous float32 numpy array (updated in place)")
+        if B.size != self.K * N or C_inout.size != self.M * N:
+            raise ValueError("B must hold K*N and C must hold M*N floats")
+        ns = C.c_double()
+        _check(lib().sextans_spmm_host(self._h, N, alpha, _buf(B, np.float32), beta,
+                                       C_inout if C_inout.size else np.zeros(1, np.float32),
+                                       rp_time, C.byref(ns)), "spmm_host")
+        return ns.value
+
+    def spmm_device(self, N, alpha, d_B, ldb, beta, d_C_in, d_C_out, ldc, stream=None):
+        _check(lib().sextans_spmm_device(self._h, N, alpha, d_B, ldb, beta, d_C_in, d_C_out, ldc,
+                                         stream), "spmm_device")
+
+    def profile_read(self):
+        k, n, r = C.c_double(), C.c_int64(), C.c_double()
+        _check(lib().sextans_profile_read(self._h, C.byref(k), C.byref(n), C.byref(r)),
+               "profile_read")
+        return k.value, n.value, r.value
+
+    def profile_reset(self):
+        _check(lib().sextans_profile_reset(self._h), "profile_reset")
+
+    def last_kernel(self):
+        return lib().sextans_last_kernel(self._h).decode()
+
+
+def spmm_csr(M, N, K, NNZ, ALPHA, CSRRowPtr, CSRColIndex, CSRVal, mat_B, BETA, mat_C):
+    """One-shot call with cpu_spmm_CSR's argument list (sparse_helper.h:262-272); in place."""
+    _check(lib().sextans_spmm_csr(M, N, K, NNZ, ALPHA, _buf(CSRRowPtr, np.int32),
+                                  _buf(CSRColIndex, np.int32), _buf(CSRVal, np.float32),
+                                  _buf(mat_B, np.float32), BETA, mat_C), "spmm_csr")
+    return mat_C
+
+
+# ------------------------------------------------------------------ synthetic inputs
+
+def gen_csr_host(M, K, mean_nnz, seed, r0=0, r1=None):
+    L = lib()
+    r1 = M if r1 is None else r1
+    p, i, v = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()
+    nnz = C.c_int64()
+    _check(L.sextans_gen_csr_host(M, K, mean_nnz, seed, r0, r1, p, i, v, C.byref(nnz)),
+           "gen_csr_host")
+    out = (_take(p, r1 - r0 + 1, np.int32), _take(i, nnz.value, np.int32),
+           _take(v, nnz.value, np.float32))
+    for q in (p, i, v):
+        L.sextans_host_free(q)
+    return out
+
+
+def gen_csr_device(device, M, K, mean_nnz, seed, r0=0, r1=None):
+    """-> (d_row_ptr, d_col_idx, d_val, nnz) raw device pointers (ints); free with device_free."""
+    r1 = M if r1 is None else r1
+    p, i, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    nnz = C.c_int64()
+    _check(lib().sextans_gen_csr_device(device, M, K, mean_nnz, seed, r0, r1, C.byref(p),
+                                        C.byref(i), C.byref(v), C.byref(nnz)), "gen_csr_device")
+    return p.value, i.value, v.value, nnz.value
+
+
+def gen_uniform_host(n, seed):
+    a = np.empty(max(n, 1), np.float32)
+    _check(lib().sextans_gen_uniform_host(a, n, seed), "gen_uniform_host")
+    return a[:n]
+
+
+def gen_uniform_device(device, d_ptr, n, seed, stream=None):
+    _check(lib().sextans_gen_uniform_device(device, d_ptr, n, seed, stream), "gen_uniform_device")
+
+
+def device_free(device, d_ptr):
+    _check(lib().sextans_device_free(device, d_ptr), "device_free")

@@ -1,0 +1,370 @@
+// engine.hip -- the SpMM engine behind the C ABI (include/sextans_amd.h): replaces the
+// tapa::invoke(Sextans, ...) boundary of the reference (sextans-host.cpp:237-251, sextans.h:20-26).
+//
+// One engine = one HIP device.  The CSR arrays are uploaded once (sextans_set_matrix_csr); every
+// spmm call then enqueues: (1) B repack column-major -> N-tile panels, (2) the CSR row-group
+// kernel(s), all on the caller's stream, no host synchronisation in the device-resident form.
+// There is NO CPU fallback anywhere in this file: no device => SEXTANS_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sextans_amd.h"
+#include "spmm_csr_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+#define SX_HIP(call)                                                                    \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            char buf_[512];                                                             \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call,                 \
+                     hipGetErrorString(e_), __FILE__, __LINE__);                        \
+            g_last_error = buf_;                                                        \
+            return SEXTANS_ERR_HIP;                                                     \
+        }                                                                               \
+    } while (0)
+
+struct EventPair { hipEvent_t a, b; };
+
+}  // namespace
+
+struct sextans_engine {
+    int device = 0;
+    // matrix
+    int M = 0, K = 0;
+    int64_t nnz = 0;
+    const int *d_rp = nullptr, *d_ci = nullptr;
+    const float *d_v = nullptr;
+    bool owns_matrix = false;
+    // workspaces
+    float *d_Bp = nullptr;
+    size_t Bp_cap = 0;              // floats
+    float *d_B = nullptr, *d_Cin = nullptr, *d_Cout = nullptr;   // host-path staging
+    size_t B_cap = 0, C_cap = 0;
+    // options
+    int64_t opt_kernel = 0, opt_lpr = 4, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;
+    // profiling
+    std::vector<EventPair> ev_kernel, ev_repack;
+    const char *last_kernel = "none";
+};
+
+namespace {
+
+int check_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        g_last_error = "hipGetDeviceCount: no HIP device";
+        return SEXTANS_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) return SEXTANS_ERR_INVALID;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return SEXTANS_ERR_NO_DEVICE;
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+        g_last_error = std::string("device is ") + p.gcnArchName + ", engine is built for gfx950 only";
+        return SEXTANS_ERR_NO_DEVICE;
+    }
+    return SEXTANS_OK;
+}
+
+void free_matrix(sextans_engine *h) {
+    if (h->owns_matrix) {
+        (void)hipFree((void *)h->d_rp);
+        (void)hipFree((void *)h->d_ci);
+        (void)hipFree((void *)h->d_v);
+    }
+    h->d_rp = h->d_ci = nullptr;
+    h->d_v = nullptr;
+    h->owns_matrix = false;
+}
+
+int ensure(float **p, size_t *cap, size_t need) {
+    if (*cap >= need && *p) return SEXTANS_OK;
+    if (*p) SX_HIP(hipFree(*p));
+    *p = nullptr; *cap = 0;
+    SX_HIP(hipMalloc((void **)p, (need ? need : 1) * sizeof(float)));
+    *cap = need;
+    return SEXTANS_OK;
+}
+
+struct Prof {
+    sextans_engine *h; std::vector<EventPair> *vec; hipStream_t s; bool on; EventPair ep{};
+    Prof(sextans_engine *h_, std::vector<EventPair> *v, hipStream_t s_) : h(h_), vec(v), s(s_), on(h_->opt_profile != 0) {
+        if (on) {
+            (void)hipEventCreate(&ep.a); (void)hipEventCreate(&ep.b);
+            (void)hipEventRecord(ep.a, s);
+        }
+    }
+    ~Prof() {
+        if (on) { (void)hipEventRecord(ep.b, s); vec->push_back(ep); }
+    }
+};
+
+template <int W>
+void launch_repack(const float *dB, int64_t ldb, float *dBp, int K, int col_base, int ntiles,
+                   hipStream_t s) {
+    dim3 grid((unsigned)((K + sx::kBlock - 1) / sx::kBlock), (unsigned)ntiles);
+    hipLaunchKernelGGL(sx::repack_b_panels<W>, grid, dim3(sx::kBlock), 0, s, dB, ldb, dBp, K,
+                       col_base);
+}
+
+template <int LPR>
+void launch_rowgroup(sextans_engine *h, const float *dBp, const float *dCin, float *dCout,
+                     int64_t ldc, int ntiles, float alpha, float beta, hipStream_t s) {
+    constexpr int RB = sx::kBlock / LPR;
+    constexpr int CH = 2048;
+    const int nrowblk = (h->M + RB - 1) / RB;
+    const unsigned nwg = (unsigned)nrowblk * (unsigned)ntiles;
+    const int64_t pstride = (int64_t)h->K * 4 * LPR;
+    const int xcd = (int)h->opt_xcd;
+#define SX_LAUNCH(EX, ST)                                                                       \
+    hipLaunchKernelGGL((sx::spmm_csr_rowgroup<LPR, CH, EX, ST>), dim3(nwg), dim3(sx::kBlock), 0, \
+                       s, h->d_rp, h->d_ci, h->d_v, dBp, pstride, dCin, dCout, ldc, h->M, ntiles, \
+                       nrowblk, alpha, beta, xcd)
+    if (h->opt_exact) { if (h->opt_stage) SX_LAUNCH(true, true); else SX_LAUNCH(true, false); }
+    else              { if (h->opt_stage) SX_LAUNCH(false, true); else SX_LAUNCH(false, false); }
+#undef SX_LAUNCH
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *sextans_last_error(void) { return g_last_error.c_str(); }
+
+int sextans_device_count(int *count) {
+    if (!count) return SEXTANS_ERR_INVALID;
+    *count = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SEXTANS_ERR_NO_DEVICE;
+    int ok = 0;
+    for (int d = 0; d < n; ++d)
+        if (check_device(d) == SEXTANS_OK) ++ok;
+    *count = ok;
+    return ok > 0 ? SEXTANS_OK : SEXTANS_ERR_NO_DEVICE;
+}
+
+int sextans_create(sextans_handle_t *out, int device) {
+    if (!out) return SEXTANS_ERR_INVALID;
+    *out = nullptr;
+    if (int rc = check_device(device)) return rc;
+    SX_HIP(hipSetDevice(device));
+    auto *h = new sextans_engine();
+    h->device = device;
+    *out = h;
+    return SEXTANS_OK;
+}
+
+int sextans_destroy(sextans_handle_t h) {
+    if (!h) return SEXTANS_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    free_matrix(h);
+    (void)hipFree(h->d_Bp); (void)hipFree(h->d_B); (void)hipFree(h->d_Cin); (void)hipFree(h->d_Cout);
+    sextans_profile_reset(h);
+    delete h;
+    return SEXTANS_OK;
+}
+
+static int64_t *option_slot(sextans_handle_t h, const char *key) {
+    if (!strcmp(key, "kernel")) return &h->opt_kernel;
+    if (!strcmp(key, "lanes_per_row")) return &h->opt_lpr;
+    if (!strcmp(key, "stage_a")) return &h->opt_stage;
+    if (!strcmp(key, "xcd_remap")) return &h->opt_xcd;
+    if (!strcmp(key, "exact")) return &h->opt_exact;
+    if (!strcmp(key, "profile")) return &h->opt_profile;
+    return nullptr;
+}
+
+int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
+    if (!h || !key) return SEXTANS_ERR_INVALID;
+    int64_t *slot = option_slot(h, key);
+    if (!slot) return SEXTANS_ERR_INVALID;
+    if (slot == &h->opt_lpr && value != 2 && value != 4 && value != 8) return SEXTANS_ERR_INVALID;
+    *slot = value;
+    return SEXTANS_OK;
+}
+
+int sextans_get_option(sextans_handle_t h, const char *key, int64_t *value) {
+    if (!h || !key || !value) return SEXTANS_ERR_INVALID;
+    int64_t *slot = option_slot(h, key);
+    if (!slot) return SEXTANS_ERR_INVALID;
+    *value = *slot;
+    return SEXTANS_OK;
+}
+
+int sextans_set_matrix_csr(sextans_handle_t h, int M, int K, int64_t nnz, const int *row_ptr,
+                           const int *col_idx, const float *val) {
+    if (!h || M < 0 || K < 0 || nnz < 0 || !row_ptr || (nnz > 0 && (!col_idx || !val)))
+        return SEXTANS_ERR_INVALID;
+    if (nnz > 0x7fffffffLL) return SEXTANS_ERR_INVALID;   // 32-bit row_ptr like the reference
+    if (row_ptr[0] != 0 || row_ptr[M] != (int)nnz) return SEXTANS_ERR_INVALID;
+    SX_HIP(hipSetDevice(h->device));
+    free_matrix(h);
+    int *rp = nullptr, *ci = nullptr;
+    float *v = nullptr;
+    SX_HIP(hipMalloc((void **)&rp, sizeof(int) * ((size_t)M + 1)));
+    SX_HIP(hipMalloc((void **)&ci, sizeof(int) * (size_t)(nnz ? nnz : 1)));
+    SX_HIP(hipMalloc((void **)&v, sizeof(float) * (size_t)(nnz ? nnz : 1)));
+    SX_HIP(hipMemcpy(rp, row_ptr, sizeof(int) * ((size_t)M + 1), hipMemcpyHostToDevice));
+    if (nnz) {
+        SX_HIP(hipMemcpy(ci, col_idx, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+        SX_HIP(hipMemcpy(v, val, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
+    }
+    h->d_rp = rp; h->d_ci = ci; h->d_v = v;
+    h->owns_matrix = true;
+    h->M = M; h->K = K; h->nnz = nnz;
+    return SEXTANS_OK;
+}
+
+int sextans_set_matrix_csr_device(sextans_handle_t h, int M, int K, int64_t nnz,
+                                  const int *d_row_ptr, const int *d_col_idx, const float *d_val) {
+    if (!h || M < 0 || K < 0 || nnz < 0 || !d_row_ptr) return SEXTANS_ERR_INVALID;
+    if (nnz > 0x7fffffffLL) return SEXTANS_ERR_INVALID;
+    SX_HIP(hipSetDevice(h->device));
+    free_matrix(h);
+    h->d_rp = d_row_ptr; h->d_ci = d_col_idx; h->d_v = d_val;
+    h->owns_matrix = false;
+    h->M = M; h->K = K; h->nnz = nnz;
+    return SEXTANS_OK;
+}
+
+int sextans_spmm_device(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
+                        float beta, const float *d_C_in, float *d_C_out, int64_t ldc,
+                        void *stream) {
+    if (!h || N <= 0 || (N % 8) != 0 || !d_B || !d_C_in || !d_C_out) return SEXTANS_ERR_INVALID;
+    if (!h->d_rp) return SEXTANS_ERR_STATE;
+    if (ldb < h->K || ldc < h->M) return SEXTANS_ERR_INVALID;
+    SX_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (h->M == 0) return SEXTANS_OK;
+    if (int rc = ensure(&h->d_Bp, &h->Bp_cap, (size_t)h->K * (size_t)N)) return rc;
+
+    // N-tile plan: as many tiles of width W = 4*lanes_per_row as fit, then 16- and 8-wide tiles for
+    // the remainder (N is a multiple of 8, the reference's N-tile granularity: sextans.cpp:57-60).
+    const int W = 4 * (int)h->opt_lpr;
+    struct Seg { int width, col0, ntiles; };
+    std::vector<Seg> plan;
+    int col = 0;
+    for (int w : {W, 16, 8}) {
+        if (w > W) continue;
+        const int nt = (N - col) / w;
+        if (nt > 0) { plan.push_back({w, col, nt}); col += nt * w; }
+    }
+
+    {
+        Prof p(h, &h->ev_repack, s);
+        for (const Seg &g : plan) {
+            float *dst = h->d_Bp + (size_t)h->K * (size_t)g.col0;
+            switch (g.width) {
+                case 32: launch_repack<32>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s); break;
+                case 16: launch_repack<16>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s); break;
+                default: launch_repack<8>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s); break;
+            }
+        }
+    }
+    {
+        Prof p(h, &h->ev_kernel, s);
+        for (const Seg &g : plan) {
+            const float *bp = h->d_Bp + (size_t)h->K * (size_t)g.col0;
+            const float *cin = d_C_in + (int64_t)g.col0 * ldc;
+            float *cout = d_C_out + (int64_t)g.col0 * ldc;
+            switch (g.width) {
+                case 32: launch_rowgroup<8>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s); break;
+                case 16: launch_rowgroup<4>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s); break;
+                default: launch_rowgroup<2>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s); break;
+            }
+        }
+        h->last_kernel = "spmm_csr_rowgroup";
+    }
+    SX_HIP(hipGetLastError());
+    return SEXTANS_OK;
+}
+
+int sextans_spmm_host(sextans_handle_t h, int N, float alpha, const float *B, float beta, float *C,
+                      int rp_time, double *elapsed_ns) {
+    if (!h || !B || !C || N <= 0 || (N % 8) != 0) return SEXTANS_ERR_INVALID;
+    if (!h->d_rp) return SEXTANS_ERR_STATE;
+    if (rp_time < 1) rp_time = 1;
+    SX_HIP(hipSetDevice(h->device));
+    const size_t nB = (size_t)h->K * (size_t)N, nC = (size_t)h->M * (size_t)N;
+    if (int rc = ensure(&h->d_B, &h->B_cap, nB)) return rc;
+    size_t ccap = h->C_cap;
+    if (int rc = ensure(&h->d_Cin, &ccap, nC)) return rc;
+    if (int rc = ensure(&h->d_Cout, &h->C_cap, nC)) return rc;
+    SX_HIP(hipMemcpy(h->d_B, B, nB * sizeof(float), hipMemcpyHostToDevice));
+    SX_HIP(hipMemcpy(h->d_Cin, C, nC * sizeof(float), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    SX_HIP(hipEventCreate(&e0));
+    SX_HIP(hipEventCreate(&e1));
+    SX_HIP(hipEventRecord(e0, nullptr));
+    for (int r = 0; r < rp_time; ++r) {
+        if (int rc = sextans_spmm_device(h, N, alpha, h->d_B, h->K, beta, h->d_Cin, h->d_Cout, h->M,
+                                         nullptr))
+            return rc;
+    }
+    SX_HIP(hipEventRecord(e1, nullptr));
+    SX_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    SX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (elapsed_ns) *elapsed_ns = (double)ms * 1e6;
+    SX_HIP(hipMemcpy(C, h->d_Cout, nC * sizeof(float), hipMemcpyDeviceToHost));
+    return SEXTANS_OK;
+}
+
+int sextans_spmm_csr(int M, int N, int K, int NNZ, float ALPHA, const int *CSRRowPtr,
+                     const int *CSRColIndex, const float *CSRVal, const float *mat_B, float BETA,
+                     float *mat_C) {
+    sextans_handle_t h = nullptr;
+    if (int rc = sextans_create(&h, 0)) return rc;
+    int rc = sextans_set_matrix_csr(h, M, K, NNZ, CSRRowPtr, CSRColIndex, CSRVal);
+    if (!rc) rc = sextans_spmm_host(h, N, ALPHA, mat_B, BETA, mat_C, 1, nullptr);
+    sextans_destroy(h);
+    return rc;
+}
+
+int sextans_profile_reset(sextans_handle_t h) {
+    if (!h) return SEXTANS_ERR_INVALID;
+    for (auto *vec : {&h->ev_kernel, &h->ev_repack}) {
+        for (auto &ep : *vec) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+        vec->clear();
+    }
+    return SEXTANS_OK;
+}
+
+int sextans_profile_read(sextans_handle_t h, double *mean_kernel_ns, int64_t *launches,
+                         double *mean_repack_ns) {
+    if (!h) return SEXTANS_ERR_INVALID;
+    SX_HIP(hipSetDevice(h->device));
+    auto mean = [&](std::vector<EventPair> &v, double *out) -> int {
+        double tot = 0.0;
+        for (auto &ep : v) {
+            SX_HIP(hipEventSynchronize(ep.b));
+            float ms = 0.f;
+            SX_HIP(hipEventElapsedTime(&ms, ep.a, ep.b));
+            tot += (double)ms * 1e6;
+        }
+        if (out) *out = v.empty() ? 0.0 : tot / (double)v.size();
+        return SEXTANS_OK;
+    };
+    if (int rc = mean(h->ev_kernel, mean_kernel_ns)) return rc;
+    if (int rc = mean(h->ev_repack, mean_repack_ns)) return rc;
+    if (launches) *launches = (int64_t)h->ev_kernel.size();
+    return SEXTANS_OK;
+}
+
+const char *sextans_last_kernel(sextans_handle_t h) { return h ? h->last_kernel : "none"; }
+
+int sextans_device_free(int device, void *d_ptr) {
+    SX_HIP(hipSetDevice(device));
+    SX_HIP(hipFree(d_ptr));
+    return SEXTANS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+"""Multi-GPU form of the path: A row-range partitioned, B replicated, all-gather of C panels.
+
+The reference is single-device; its only sharding is static (rows -> PEs by row % 64, B broadcast
+down a daisy chain: sparse_helper.h:370, sextans.cpp:916-927).  The same independence of output
+rows is what this module uses across GPUs: every rank owns a contiguous, nnz-balanced row range
+of A, computes its M_g x N slab of C in place inside the full column-major C buffer, and one
+all-gather (RCCL over xGMI when the backend is "nccl", gloo in the CPU tests) completes C on
+every rank.  No reduction collective is needed (no K split).
+
+Host-side logic here is pure numpy/torch.distributed and runs on CPU; the compute itself is the
+HIP engine (sextans_amd.api.Engine) -- this module never computes SpMM.
+"""
+import numpy as np
+
+
+def partition_rows_by_nnz(row_ptr, world):
+    """Contiguous row ranges with (nearly) equal non-zero counts: split points by binary search in
+    row_ptr.  Returns [(r0, r1)] * world, covering [0, M) in order; ranges may be empty."""
+    row_ptr = np.asarray(row_ptr)
+    M = len(row_ptr) - 1
+    nnz = int(row_ptr[-1])
+    cuts = [0]
+    for g in range(1, world):
+        target = (nnz * g) // world
+        r = int(np.searchsorted(row_ptr, target, side="left"))
+        r = min(max(r, cuts[-1]), M)
+        cuts.append(r)
+    cuts.append(M)
+    return [(cuts[g], cuts[g + 1]) for g in range(world)]
+
+
+def partition_rows_even(M, world):
+    """Equal row counts (M must divide evenly for the in-place single-buffer all-gather)."""
+    base, rem = divmod(M, world)
+    out, r = [], 0
+    for g in range(world):
+        n = base + (1 if g < rem else 0)
+        out.append((r, r + n))
+        r += n
+    return out
+
+
+def slice_csr(row_ptr, col_idx, val, r0, r1):
+    """Local CSR of rows [r0, r1): row_ptr rebased to 0, column indices unchanged (B is replicated)."""
+    row_ptr = np.asarray(row_ptr)
+    a, b = int(row_ptr[r0]), int(row_ptr[r1])
+    return (row_ptr[r0:r1 + 1] - row_ptr[r0]).astype(np.int32), col_idx[a:b], val[a:b]
+
+
+def all_gather_c(C_full, M, N, ranges, rank, group=None):
+    """Complete the column-major M x N matrix `C_full` (flat torch tensor, CPU or GPU) on every rank.
+
+    On entry rank g has written rows ranges[g] of every column; on return all rows are present.
+    C is column major, so a row slab is strided: the gather is done per column, in place (each
+    rank's send buffer is a view of its own rows inside the receive column), and on the nccl
+    backend the N per-column collectives are coalesced into one RCCL group launch.
+    """
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    lens = [r1 - r0 for r0, r1 in ranges]
+    even = len(set(lens)) == 1 and lens[0] * world == M
+    backend = dist.get_backend(group)
+    cols = C_full.view(N, M)
+
+    if even:
+        r0, r1 = ranges[rank]
+
+        def one_column(n):
+            dist.all_gather_into_tensor(cols[n], cols[n][r0:r1], group=group)
+
+        if backend == "nccl":
+            with dist._coalescing_manager(group=group, device=C_full.device, async_ops=False):
+                for n in range(N):
+                    one_column(n)
+        else:
+            for n in range(N):
+                one_column(n)
+        return
+
+    # Uneven (nnz-balanced) ranges: one packed collective of padded slabs, then scatter into place.
+    import torch
+    lmax = max(lens)
+    r0, r1 = ranges[rank]
+    send = torch.zeros((N, lmax), dtype=C_full.dtype, device=C_full.device)
+    send[:, :r1 - r0] = cols[:, r0:r1]
+    recv = torch.empty((world, N, lmax), dtype=C_full.dtype, device=C_full.device)
+    dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+    for g, (a, b) in enumerate(ranges):
+        if g != rank and b > a:
+            cols[:, a:b] = recv[g, :, :b - a]

@@ -1,0 +1,138 @@
+"""Product host library (sextans_amd/csrc/host_mtx.cpp behind include/sextans_amd.h) against the
+golden vectors and the oracle -- CPU only, no compute calls on a device."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from util import ALPHA, BETA, CASES, NASA, ROOT, bits_equal, default_C, formula_B, formula_C
+
+MANIFEST = json.load(open(os.path.join(CASES, "manifest.json")))
+
+
+def test_library_exports_every_declared_symbol(sx):
+    """Every function include/sextans_amd.h declares is exported by libsextans_amd.so."""
+    hdr = open(os.path.join(ROOT, "include", "sextans_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sextans_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    out = subprocess.run(["nm", "-D", "--defined-only", sx.api.LIB_PATH], capture_output=True, text=True, check=True)
+    exported = {ln.split()[-1] for ln in out.stdout.splitlines() if ln.strip()}
+    missing = sorted(declared - exported)
+    assert not missing, f"declared but not exported: {missing}"
+    L = sx.api.lib()
+    for name in declared:
+        getattr(L, name)
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST))
+def test_loader_matches_reference_golden(sx, name):
+    g = np.load(os.path.join(CASES, name + ".npz"))
+    path = os.path.join(CASES, name + ".mtx")
+    rp, ci, v, M, K, nnz = sx.read_suitsparse_matrix(path, sx.api.FMT_CSR)
+    assert (M, K, nnz) == (int(g["M"]), int(g["K"]), int(g["nnz"]))
+    assert np.array_equal(rp, g["csr_ptr"]) and np.array_equal(ci, g["csr_idx"]) and bits_equal(v, g["csr_val"])
+    cp, ri, cv, _, _, _ = sx.read_suitsparse_matrix(path, sx.api.FMT_CSC)
+    assert np.array_equal(cp, g["csc_ptr"]) and np.array_equal(ri, g["csc_idx"]) and bits_equal(cv, g["csc_val"])
+    rp2, ci2, v2 = sx.CSC_2_CSR(M, K, nnz, cp, ri, cv)
+    assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and bits_equal(v2, v)
+
+
+def test_loader_nasa4704(sx, oracle):
+    rp, ci, v, M, K, nnz = sx.read_suitsparse_matrix(NASA)
+    M2, K2, nnz2, rp2, ci2, v2 = oracle.load_csr(NASA)
+    assert (M, K, nnz) == (M2, K2, nnz2) == (4704, 4704, 104756)
+    assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2) and bits_equal(v, v2)
+
+
+def test_loader_errors_are_codes_not_exit(sx, tmp_path):
+    def w(name, text):
+        p = tmp_path / name
+        p.write_text(text)
+        return str(p)
+    E = sx.SextansError
+    hdr = "%%MatrixMarket matrix coordinate real general\n"
+    cases = [
+        (str(tmp_path / "missing.mtx"), 1),
+        (w("a.mtx", "%%NotMM matrix coordinate real general\n1 1 1\n1 1 1.0\n"), 2),
+        (w("a2.mtx", "%%MatrixMarket matrix coordinate real\n1 1 1\n1 1 1.0\n"), 2),
+        (w("a3.mtx", "%%MatrixMarket matrix coordinate quaternion general\n1 1 1\n1 1 1.0\n"), 2),
+        (w("b.mtx", "%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n"), None),
+        (w("c.mtx", "%%MatrixMarket matrix coordinate complex general\n1 1 1\n1 1 1 0\n"), 5),
+        (w("d.mtx", hdr + "2 2 1\n0 1 1.0\n"), 6),
+        (w("d2.mtx", hdr + "2 2 1\n3 1 1.0\n"), 6),      # ours only: the reference has no upper check
+        (w("e.mtx", hdr + "2 2 2\n1 1 1.0\n"), 8),       # truncated
+        (w("f.mtx", hdr + "2 2 1\n1 x 1.0\n"), 8),
+        (w("g.mtx", hdr), 3),
+    ]
+    for path, code in cases:
+        with pytest.raises(E) as ei:
+            sx.read_suitsparse_matrix(path)
+        if code is not None:
+            assert ei.value.code == code, (path, ei.value.code)
+        else:
+            assert ei.value.code in (3, 4)
+    # zero-valued entries are dropped BEFORE the index check (sparse_helper.h:145-149)
+    rp, ci, v, M, K, nnz = sx.read_suitsparse_matrix(w("h.mtx", hdr + "2 2 2\n0 0 0.0\n2 2 3.5\n"))
+    assert nnz == 1 and list(rp) == [0, 0, 1] and v[0] == 3.5
+    # "%%MatrixMarket" is a prefix match (strncmp, mmio.h:279)
+    assert sx.read_suitsparse_matrix(w("i.mtx", "%%MatrixMarketXYZ matrix coordinate real general\n1 1 1\n1 1 2\n"))[5] == 1
+
+
+def test_dense_init_verify_gflops_roundup(sx, oracle):
+    for (M, K, N) in [(4704, 4704, 16), (7, 5, 8), (13965, 100, 24)]:
+        assert bits_equal(sx.init_dense_B(K, N), oracle.init_B(K, N))
+        assert bits_equal(sx.init_dense_C(M, N), oracle.init_C(M, N))
+        assert bits_equal(sx.init_dense_C(M, N), default_C(M, N))
+    assert [sx.round_up_n(n) for n in (1, 8, 9, 16, 17, 127, 128)] == [8, 8, 16, 16, 24, 128, 128]
+    rs = np.random.RandomState(3)
+    a = rs.uniform(-1, 1, 600).astype(np.float32)
+    b = a + (rs.uniform(-1, 1, 600) * 3e-4 * (rs.rand(600) < 0.3)).astype(np.float32)
+    assert sx.verify(100, 6, a, b) == pytest.approx(oracle.verify(100, 6, a, b))
+    assert sx.verify(100, 6, a, b)[0] > 0
+    assert sx.gflops(4704, 16, 104756, 2e-3) == oracle.gflops(4704, 16, 104756, 2e-3)
+
+
+def test_selfcheck_golden_matches_oracle(sx, oracle):
+    """The CLI's CPU golden (used only for its built-in self check) is bit-identical to the oracle."""
+    import ctypes as C
+    rs = np.random.RandomState(11)
+    from util import random_csr
+    M, K, N = 300, 280, 24
+    rp, ci, v = random_csr(rs, M, K, 8, long_rows=1)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    c1, c2 = C0.copy(), C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, c1)
+    assert sx.api.lib().sextans_selfcheck_golden(M, N, K, ALPHA, rp, ci, v, B, BETA, c2) == 0
+    assert np.array_equal(c1.view(np.uint32), c2.view(np.uint32))
+
+
+def test_no_device_fails_loudly(sx):
+    """Without a gfx950 device the compute entry points refuse: there is no CPU fallback."""
+    if sx.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(sx.SextansError) as ei:
+        sx.Engine(0)
+    assert ei.value.code == sx.api.ERR_NO_DEVICE
+    c = np.zeros(8, np.float32)
+    with pytest.raises(sx.SextansError) as ei:
+        sx.spmm_csr(1, 8, 1, 1, 1.0, np.array([0, 1], np.int32), np.array([0], np.int32),
+                    np.array([1.0], np.float32), np.ones(8, np.float32), 0.0, c)
+    assert ei.value.code == sx.api.ERR_NO_DEVICE
+
+
+def test_cli_usage_and_errors(sx):
+    cli = sx.api.CLI_PATH
+    r = subprocess.run([cli], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage:" in r.stdout and "[matrix A file] [N] [rp_time] [alpha] [beta]" in r.stdout
+    r = subprocess.run([cli, "a", "b", "c", "d", "e", "f"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage:" in r.stdout
+    r = subprocess.run([cli, "/nonexistent.mtx", "16"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Could not open /nonexistent.mtx" in r.stdout
+    assert "N = 16" in r.stdout and "alpha = 0.85" in r.stdout and "beta = -2.06" in r.stdout
+    r = subprocess.run([cli, "/nonexistent.mtx", "13", "3", "1.5", "-0.25"], capture_output=True, text=True)
+    assert "N = 16" in r.stdout and "alpha = 1.5" in r.stdout and "beta = -0.25" in r.stdout

@@ -1,0 +1,264 @@
+"""Parity tests proper: the HIP engine, called through the C ABI, against the oracle and the
+committed reference goldens.  fp32 work is compared BIT-EXACT: the default (exact) kernels keep the
+reference's arithmetic order and rounding (sparse_helper.h:279-289); the non-exact (FMA) variants
+are held to the stated tolerance |d| <= 1e-4 * (|alpha| * sum|a*b| + |beta*c|)  (SURVEY.md 8c)."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from util import (ALPHA, BETA, CASES, GOLDEN, NASA, bits_equal, default_C, formula_B, formula_C,
+                  random_csr)
+
+pytestmark = pytest.mark.gpu
+MANIFEST = json.load(open(os.path.join(CASES, "manifest.json")))
+
+
+def run(engine, M, K, rp, ci, v, N, alpha, B, beta, C0, **opts):
+    defaults = dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1)
+    defaults.update(opts)
+    for k, val in defaults.items():
+        engine.set_option(k, val)
+    engine.set_matrix_csr(M, K, rp, ci, v)
+    out = C0.copy()
+    engine.spmm(N, alpha, B, beta, out)
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST))
+@pytest.mark.parametrize("N", [8, 24])
+def test_reference_golden_cases(engine, name, N):
+    g = np.load(os.path.join(CASES, name + ".npz"))
+    M, K = int(g["M"]), int(g["K"])
+    out = run(engine, M, K, g["csr_ptr"], g["csr_idx"], g["csr_val"], N, ALPHA, formula_B(K, N), BETA,
+              formula_C(M, N))
+    assert bits_equal(out, g[f"C_N{N}"])
+
+
+def test_nasa4704_canonical_run_matches_reference_hashes(engine, sx):
+    """The reference's only shipped test: nasa4704, B == 1, C init, alpha 0.85, beta -2.06."""
+    rp, ci, v, M, K, nnz = sx.read_suitsparse_matrix(NASA)
+    want = {16: "988205f823683783aea5cd8c7eb0f88846b59bd957d3429ba63e2110bd3ad88f",
+            128: "0a6b46a1581cfd04de887ebb3c815eebf7c93b9dca17e0010bb1fb869f51817e"}
+    for N in (16, 128):
+        for lpr in (2, 4, 8):
+            out = run(engine, M, K, rp, ci, v, N, ALPHA, sx.init_dense_B(K, N), BETA,
+                      sx.init_dense_C(M, N), lanes_per_row=lpr)
+            assert hashlib.sha256(out.tobytes()).hexdigest() == want[N], (N, lpr)
+    g = np.load(os.path.join(GOLDEN, "nasa4704_N16.npz"))
+    out = run(engine, M, K, rp, ci, v, 16, ALPHA, formula_B(K, 16), BETA, formula_C(M, 16))
+    assert bits_equal(out, g["C_formula"])
+    # reference pass criterion (sextans-host.cpp:272-282): zero mismatches
+    assert sx.verify(M, 16, g["C_formula"], out) == (0, 0.0)
+
+
+@pytest.mark.parametrize("N", [8, 16, 24, 32, 40, 64, 128])
+@pytest.mark.parametrize("lpr,stage", [(4, 1), (4, 0), (2, 1), (8, 1), (8, 0), (2, 0)])
+def test_random_matrix_bit_exact_vs_oracle(engine, oracle, N, lpr, stage):
+    rs = np.random.RandomState(1000 + N)
+    M, K = 1237, 911
+    rp, ci, v = random_csr(rs, M, K, 11, long_rows=2)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, lanes_per_row=lpr, stage_a=stage)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+def test_long_rows_span_lds_chunks(engine, oracle):
+    """Rows longer than the 2048-entry LDS chunk, and workgroups whose rows cross chunk edges."""
+    rs = np.random.RandomState(5)
+    M, K, N = 300, 9000, 16
+    lens = rs.randint(0, 60, M)
+    lens[[3, 150, 299]] = [5000, 2049, 8999]
+    rp = np.zeros(M + 1, np.int32)
+    rp[1:] = np.cumsum(lens)
+    ci = np.concatenate([np.sort(rs.choice(K, size=l, replace=False)) for l in lens]).astype(np.int32)
+    v = rs.uniform(-1, 1, rp[-1]).astype(np.float32)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    for stage in (0, 1):
+        out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, stage_a=stage)
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("alpha,beta", [(1.0, 0.0), (0.0, 1.0), (0.0, 0.0), (-1.5, 0.75), (1.0, 1.0)])
+def test_alpha_beta_edge_values(engine, oracle, alpha, beta):
+    rs = np.random.RandomState(9)
+    M, K, N = 200, 150, 16
+    rp, ci, v = random_csr(rs, M, K, 7)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, np.float32(alpha), rp, ci, v, B, np.float32(beta), want)
+    out = run(engine, M, K, rp, ci, v, N, alpha, B, beta, C0)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+def test_degenerate_shapes(engine, oracle):
+    # all-empty matrix: C = alpha*0 + beta*C
+    M, K, N = 70, 5, 8
+    rp = np.zeros(M + 1, np.int32)
+    C0 = formula_C(M, N)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, np.zeros(0, np.int32), np.zeros(0, np.float32), formula_B(K, N), BETA, want)
+    out = run(engine, M, K, rp, np.zeros(0, np.int32), np.zeros(0, np.float32), N, ALPHA, formula_B(K, N), BETA, C0)
+    assert bits_equal(out, want)
+    # single row / single column / M not a multiple of the row block
+    for (M, K) in [(1, 1), (1, 300), (65, 1), (63, 64), (257, 33)]:
+        rs = np.random.RandomState(M * 1000 + K)
+        rp, ci, v = random_csr(rs, M, K, min(K, 5), empty_frac=0.0)
+        B = rs.uniform(-1, 1, K * N).astype(np.float32)
+        C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+        want = C0.copy()
+        oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+        out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0)
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (M, K)
+
+
+def test_non_exact_fma_variant_within_stated_tolerance(engine, oracle):
+    rs = np.random.RandomState(21)
+    M, K, N = 800, 700, 16
+    rp, ci, v = random_csr(rs, M, K, 30)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, exact=0)
+    # condition-aware bound of SURVEY.md 8c(ii): 1e-4 * (|alpha| * sum_j |a_ij b_jn| + |beta c_in|)
+    absA = np.abs(v)
+    bound = np.zeros(M * N, np.float64)
+    Bm = np.abs(B.reshape(N, K))
+    rows = np.repeat(np.arange(M), np.diff(rp))
+    for n in range(N):
+        bound[n * M:(n + 1) * M] = np.bincount(rows, weights=absA * Bm[n, ci], minlength=M)
+    bound = 1e-4 * (abs(float(ALPHA)) * bound + np.abs(float(BETA) * C0))
+    assert np.all(np.abs(out.astype(np.float64) - want) <= bound + 1e-30)
+    rel = np.linalg.norm(out.astype(np.float64) - want) / np.linalg.norm(want)
+    assert rel < 1e-6
+
+
+def test_rp_time_repeats_read_same_c_in(engine, oracle):
+    """rp_time > 1 repeats the same computation from the same C input (the reference keeps C_in and
+    C_out separate, sextans.h:20-26), so the result is independent of rp_time."""
+    rs = np.random.RandomState(31)
+    M, K, N = 500, 400, 16
+    rp, ci, v = random_csr(rs, M, K, 12)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    engine.set_matrix_csr(M, K, rp, ci, v)
+    out = C0.copy()
+    ns = engine.spmm(N, ALPHA, B, BETA, out, rp_time=7)
+    assert ns > 0 and np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+def test_one_shot_cpu_spmm_csr_signature(sx, oracle):
+    rs = np.random.RandomState(41)
+    M, K, N = 123, 77, 8
+    rp, ci, v = random_csr(rs, M, K, 6)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    out = C0.copy()
+    sx.spmm_csr(M, N, K, len(ci), ALPHA, rp, ci, v, B, BETA, out)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+def test_device_resident_strided_and_aliased(engine, oracle):
+    """sextans_spmm_device with ldb > K, ldc > M, a row-offset C (multi-GPU slab form) and
+    C_in == C_out."""
+    import torch
+    rs = np.random.RandomState(51)
+    M, K, N = 333, 222, 16
+    rp, ci, v = random_csr(rs, M, K, 9)
+    ldb, ldc, r0 = K + 13, 2 * M + 5, 40          # C lives inside a taller matrix, at row offset r0
+    Bfull = rs.uniform(-1, 1, ldb * N).astype(np.float32)
+    Cfull = rs.uniform(-1, 1, ldc * N).astype(np.float32)
+    Bc = np.ascontiguousarray(Bfull.reshape(N, ldb)[:, :K]).reshape(-1)
+    Cc = np.ascontiguousarray(Cfull.reshape(N, ldc)[:, r0:r0 + M]).reshape(-1)
+    want = Cc.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, Bc, BETA, want)
+    dB = torch.from_numpy(Bfull).cuda()
+    dC = torch.from_numpy(Cfull).cuda()
+    engine.set_matrix_csr(M, K, rp, ci, v)
+    st = torch.cuda.current_stream().cuda_stream
+    ptr = dC.data_ptr() + 4 * r0
+    engine.spmm_device(N, ALPHA, dB.data_ptr(), ldb, BETA, ptr, ptr, ldc, st)
+    torch.cuda.synchronize()
+    got_full = dC.cpu().numpy()
+    got = np.ascontiguousarray(got_full.reshape(N, ldc)[:, r0:r0 + M]).reshape(-1)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # everything outside the slab is untouched
+    mask = np.ones((N, ldc), bool)
+    mask[:, r0:r0 + M] = False
+    assert np.array_equal(got_full.reshape(N, ldc)[mask], Cfull.reshape(N, ldc)[mask])
+
+
+def test_full_size_properties_config4_scale(sx, engine):
+    """Size-independent properties at a BASELINE-scale matrix (synthetic CSR, 1M x 1M, ~40 nnz/row,
+    N = 16) where the oracle would take too long: linearity in B and beta-only idempotence."""
+    import torch
+    from sextans_amd import api
+    M = K = 1_000_000
+    N = 16
+    p, i, v, nnz = api.gen_csr_device(0, M, K, 40.0, 4)
+    try:
+        engine.set_matrix_csr_device(M, K, nnz, p, i, v)
+        B1 = torch.empty(K * N, device="cuda"); B2 = torch.empty(K * N, device="cuda")
+        api.gen_uniform_device(0, B1.data_ptr(), K * N, 11); api.gen_uniform_device(0, B2.data_ptr(), K * N, 12)
+        Z = torch.zeros(M * N, device="cuda")
+        outs = []
+        for Bx in (B1, B2, B1 + B2):
+            o = torch.empty(M * N, device="cuda")
+            engine.spmm_device(N, 1.0, Bx.data_ptr(), K, 0.0, Z.data_ptr(), o.data_ptr(), M, torch.cuda.current_stream().cuda_stream)
+            outs.append(o)
+        torch.cuda.synchronize()
+        err = (outs[0] + outs[1] - outs[2]).abs().max().item()
+        scale = outs[2].abs().max().item()
+        assert err <= 1e-4 * scale and scale > 1.0      # A(B1+B2) = AB1 + AB2 up to fp32 rounding
+        # alpha = 0: C_out = 0*psum + beta*C_in exactly
+        Cin = torch.empty(M * N, device="cuda"); api.gen_uniform_device(0, Cin.data_ptr(), M * N, 13)
+        o = torch.empty(M * N, device="cuda")
+        engine.spmm_device(N, 0.0, B1.data_ptr(), K, -2.0, Cin.data_ptr(), o.data_ptr(), M, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(o, -2.0 * Cin)
+        # sampled rows against the oracle-equivalent host arithmetic (float32, CSR order)
+        rp_h = torch.empty(0)
+        rows = [0, 1, 12345, 999_999]
+        hp, hi, hv = api.gen_csr_host(M, K, 40.0, 4, 0, 2)
+        B1h = B1.cpu().numpy()
+        o1 = outs[0].cpu().numpy()
+        for r in (0, 1):
+            for n in (0, 7, 15):
+                acc = np.float32(0)
+                for j in range(hp[r], hp[r + 1]):
+                    acc = np.float32(acc + np.float32(hv[j] * B1h[hi[j] + K * n]))
+                assert np.float32(np.float32(1.0) * acc + np.float32(0.0) * np.float32(0.0)) == o1[r + M * n]
+    finally:
+        engine.set_matrix_csr(1, 1, np.array([0, 0], np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
+        for q in (p, i, v):
+            api.device_free(0, q)
+
+
+def test_cli_canonical_run(sx):
+    """`sextans nasa4704.mtx 16` -- the reference's swsim/hw target (CMakeLists.txt:47-64)."""
+    r = subprocess.run([sx.api.CLI_PATH, NASA, "16"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    for needle in ("start host", "N = 16", "alpha = 0.85", "beta = -2.06",
+                   "A: sparse matrix, 4704 x 4704. NNZ = 104756", "B: dense matrix, 4704 x 16",
+                   "CPU GFLOPS:", "launch kernel", "Kernel time is", "GFLOPS:", "Success!",
+                   "num_mismatch = 0, percent = 0.00%"):
+        assert needle in out, (needle, out)
+    r = subprocess.run([sx.api.CLI_PATH, NASA, "100", "5", "1.25", "0.5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "N = 104" in r.stdout and "Success!" in r.stdout
+    assert "num_mismatch = 0" in r.stdout

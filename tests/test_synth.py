@@ -1,0 +1,59 @@
+"""Synthetic-input generators of the measurement harness (BASELINE config 4 shape)."""
+import numpy as np
+import pytest
+
+
+def test_host_generator_properties(sx):
+    from sextans_amd import api
+    M, K = 20000, 5000
+    rp, ci, v = api.gen_csr_host(M, K, 40.0, 4)
+    lens = np.diff(rp)
+    assert rp[0] == 0 and rp[-1] == len(ci) == len(v)
+    assert abs(lens.mean() - 40.0) < 0.3 and abs(lens.var() - 40.0) < 2.0      # Poisson(40)
+    assert ci.min() >= 0 and ci.max() < K
+    inner = np.ones(len(ci), bool)
+    inner[rp[:-1][lens > 0]] = False
+    assert np.all(np.diff(ci)[inner[1:]] > 0)                                   # sorted, distinct
+    assert v.min() >= -1.0 and v.max() < 1.0 and abs(v.mean()) < 0.01
+    # any row range reproduces the same rows (counter-based)
+    rp2, ci2, v2 = api.gen_csr_host(M, K, 40.0, 4, 777, 1234)
+    assert np.array_equal(ci2, ci[rp[777]:rp[1234]]) and np.array_equal(v2, v[rp[777]:rp[1234]])
+    assert np.array_equal(rp2, rp[777:1235] - rp[777])
+    # different seed, different matrix
+    assert not np.array_equal(api.gen_csr_host(M, K, 40.0, 5)[1][:100], ci[:100])
+    # tiny K forces the without-replacement fix-up path: rows stay strictly increasing and < K
+    rp3, ci3, _ = api.gen_csr_host(500, 48, 40.0, 9)
+    for r in range(500):
+        seg = ci3[rp3[r]:rp3[r + 1]]
+        assert np.all(np.diff(seg) > 0) and (len(seg) == 0 or (seg[0] >= 0 and seg[-1] < 48))
+    u = api.gen_uniform_host(100000, 3)
+    assert u.min() >= -1 and u.max() < 1 and abs(u.mean()) < 0.01 and abs(u.var() - 1 / 3) < 0.01
+
+
+@pytest.mark.gpu
+def test_device_generator_bit_identical_to_host(sx, engine):
+    import torch
+    from sextans_amd import api
+    M, K = 30000, 4_000_000
+    p, i, v, nnz = api.gen_csr_device(0, M, K, 40.0, 4, 100, 25000)
+    try:
+        hp, hi, hv = api.gen_csr_host(M, K, 40.0, 4, 100, 25000)
+        assert nnz == len(hi)
+        import ctypes as C
+        def pull(ptr, n, dt):
+            t = torch.empty(n, dtype=dt, device="cuda")
+            torch.cuda.synchronize()
+            hip = C.CDLL("libamdhip64.so.7")
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            assert hip.hipMemcpy(t.data_ptr(), ptr, n * 4, 3) == 0
+            return t.cpu().numpy()
+        assert np.array_equal(pull(p, len(hp), torch.int32), hp)
+        assert np.array_equal(pull(i, nnz, torch.int32), hi)
+        assert np.array_equal(pull(v, nnz, torch.float32).view(np.uint32), hv.view(np.uint32))
+    finally:
+        for q in (p, i, v):
+            api.device_free(0, q)
+    t = torch.empty(100000, device="cuda")
+    api.gen_uniform_device(0, t.data_ptr(), 100000, 3, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy().view(np.uint32), api.gen_uniform_host(100000, 3).view(np.uint32))
