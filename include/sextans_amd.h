@@ -101,10 +101,11 @@ int sextans_device_count(int *count);
 int sextans_create(sextans_handle_t *h, int device);
 int sextans_destroy(sextans_handle_t h);
 
-/* Tunables.  key: "kernel" (0 auto, 1 row-group gather, 2 LDS-window), "lanes_per_row"
+/* Tunables.  key: "kernel" (0 auto, 1 row-group gather, 2 LDS panel), "lanes_per_row"
  * (2/4/8, N-tile = 4*lanes), "stage_a" (0/1 stage the CSR stream through LDS), "xcd_remap"
  * (0/1), "exact" (1 = no FMA, reference rounding; 0 = allow FMA), "profile" (0/1 hipEvent
- * per-kernel timing).  Unknown keys -> SEXTANS_ERR_INVALID. */
+ * per-kernel timing), "panel_min_reuse_x100" (a row block uses the LDS panel when
+ * nnz >= value/100 * distinct columns; default 400).  Unknown keys -> SEXTANS_ERR_INVALID. */
 int sextans_set_option(sextans_handle_t h, const char *key, int64_t value);
 int sextans_get_option(sextans_handle_t h, const char *key, int64_t *value);
 
@@ -151,14 +152,23 @@ const char *sextans_last_kernel(sextans_handle_t h);
 /* ------------------------------------------------------------------ synthetic inputs (bench) */
 
 /* Deterministic counter-based synthetic CSR (BASELINE config 4): row lengths Poisson(mean_nnz)
- * from an integer inverse-CDF table, columns uniform without replacement and sorted, values
- * U(-1,1).  Host and device generators produce identical bits for the same (seed,row).
+ * from an integer inverse-CDF table, columns uniform without replacement and sorted (bandwidth 0:
+ * over [0,K); bandwidth bw > 0: over the band [row-bw, row+bw], a FEM/SuiteSparse-like matrix with
+ * locality), values U(-1,1).  Host and device generators produce identical bits for the same (seed,row).
  * Host form generates rows [r0,r1) only (row_ptr has r1-r0+1 entries starting at 0). */
-int sextans_gen_csr_host(int M, int K, double mean_nnz, uint64_t seed, int r0, int r1,
+int sextans_gen_csr_host(int M, int K, double mean_nnz, int bandwidth, uint64_t seed, int r0, int r1,
                          int **row_ptr, int **col_idx, float **val, int64_t *nnz);
 /* Device form: allocates device arrays on `device` (free with sextans_device_free). */
-int sextans_gen_csr_device(int device, int M, int K, double mean_nnz, uint64_t seed, int r0, int r1,
-                           int **d_row_ptr, int **d_col_idx, float **d_val, int64_t *nnz);
+int sextans_gen_csr_device(int device, int M, int K, double mean_nnz, int bandwidth, uint64_t seed, int r0,
+                           int r1, int **d_row_ptr, int **d_col_idx, float **d_val, int64_t *nnz);
+/* 3-D finite-element-like matrix: 27-point node stencil on an nx*ny*nz grid with `dof` unknowns per
+ * node (dense dof x dof coupling blocks), M = K = nx*ny*nz*dof, values U(-1,1).  Stand-in for
+ * SuiteSparse FEM inputs that cannot be downloaded here (Boeing/pcrystk02 = 13965 rows, 3 dof,
+ * ~69 nnz/row is reproduced by 19 x 15 x 16 x 3 + trimming). */
+int sextans_gen_fem3d_host(int nx, int ny, int nz, int dof, uint64_t seed, int r0, int r1, int **row_ptr,
+                           int **col_idx, float **val, int64_t *nnz);
+int sextans_gen_fem3d_device(int device, int nx, int ny, int nz, int dof, uint64_t seed, int r0, int r1,
+                             int **d_row_ptr, int **d_col_idx, float **d_val, int64_t *nnz);
 /* U(-1,1) fp32 fill, element i of stream `seed` (same bits on host and device). */
 int sextans_gen_uniform_host(float *dst, int64_t n, uint64_t seed);
 int sextans_gen_uniform_device(int device, float *d_dst, int64_t n, uint64_t seed, void *stream);

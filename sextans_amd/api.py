@@ -91,12 +91,18 @@ def lib():
     L.sextans_profile_reset.argtypes = [C.c_void_p]
     L.sextans_last_kernel.restype = C.c_char_p
     L.sextans_last_kernel.argtypes = [C.c_void_p]
-    L.sextans_gen_csr_host.argtypes = [C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_int, C.c_int,
+    L.sextans_gen_csr_host.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_int, C.c_int,
                                        pi, pi, pf, C.POINTER(C.c_int64)]
-    L.sextans_gen_csr_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_uint64,
+    L.sextans_gen_csr_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64,
                                          C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_int64)]
+    L.sextans_gen_fem3d_host.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                                         pi, pi, pf, C.POINTER(C.c_int64)]
+    L.sextans_gen_fem3d_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
+                                           C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_int64)]
     L.sextans_gen_uniform_host.argtypes = [_f32p, C.c_int64, C.c_uint64]
     L.sextans_gen_uniform_device.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_uint64,
                                              C.c_void_p]
@@ -269,12 +275,12 @@ def spmm_csr(M, N, K, NNZ, ALPHA, CSRRowPtr, CSRColIndex, CSRVal, mat_B, BETA, m
 
 # ------------------------------------------------------------------ synthetic inputs
 
-def gen_csr_host(M, K, mean_nnz, seed, r0=0, r1=None):
+def gen_csr_host(M, K, mean_nnz, seed, r0=0, r1=None, bandwidth=0):
     L = lib()
     r1 = M if r1 is None else r1
     p, i, v = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()
     nnz = C.c_int64()
-    _check(L.sextans_gen_csr_host(M, K, mean_nnz, seed, r0, r1, p, i, v, C.byref(nnz)),
+    _check(L.sextans_gen_csr_host(M, K, mean_nnz, bandwidth, seed, r0, r1, p, i, v, C.byref(nnz)),
            "gen_csr_host")
     out = (_take(p, r1 - r0 + 1, np.int32), _take(i, nnz.value, np.int32),
            _take(v, nnz.value, np.float32))
@@ -283,13 +289,34 @@ def gen_csr_host(M, K, mean_nnz, seed, r0=0, r1=None):
     return out
 
 
-def gen_csr_device(device, M, K, mean_nnz, seed, r0=0, r1=None):
+def gen_csr_device(device, M, K, mean_nnz, seed, r0=0, r1=None, bandwidth=0):
     """-> (d_row_ptr, d_col_idx, d_val, nnz) raw device pointers (ints); free with device_free."""
     r1 = M if r1 is None else r1
     p, i, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
     nnz = C.c_int64()
-    _check(lib().sextans_gen_csr_device(device, M, K, mean_nnz, seed, r0, r1, C.byref(p),
+    _check(lib().sextans_gen_csr_device(device, M, K, mean_nnz, bandwidth, seed, r0, r1, C.byref(p),
                                         C.byref(i), C.byref(v), C.byref(nnz)), "gen_csr_device")
+    return p.value, i.value, v.value, nnz.value
+
+
+def gen_fem3d_host(nx, ny, nz, dof, seed, r0=0, r1=None):
+    L = lib()
+    r1 = nx * ny * nz * dof if r1 is None else r1
+    p, i, v = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()
+    nnz = C.c_int64()
+    _check(L.sextans_gen_fem3d_host(nx, ny, nz, dof, seed, r0, r1, p, i, v, C.byref(nnz)), "gen_fem3d_host")
+    out = (_take(p, r1 - r0 + 1, np.int32), _take(i, nnz.value, np.int32), _take(v, nnz.value, np.float32))
+    for q in (p, i, v):
+        L.sextans_host_free(q)
+    return out
+
+
+def gen_fem3d_device(device, nx, ny, nz, dof, seed, r0=0, r1=None):
+    r1 = nx * ny * nz * dof if r1 is None else r1
+    p, i, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    nnz = C.c_int64()
+    _check(lib().sextans_gen_fem3d_device(device, nx, ny, nz, dof, seed, r0, r1, C.byref(p), C.byref(i),
+                                          C.byref(v), C.byref(nnz)), "gen_fem3d_device")
     return p.value, i.value, v.value, nnz.value
 
 

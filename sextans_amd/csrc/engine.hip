@@ -7,11 +7,13 @@
 // There is NO CPU fallback anywhere in this file: no device => SEXTANS_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
 
+#include "panel_plan.h"
 #include "sextans_amd.h"
 #include "spmm_csr_kernels.h"
 
@@ -37,6 +39,7 @@ struct EventPair { hipEvent_t a, b; };
 
 struct sextans_engine {
     int device = 0;
+    int num_cus = 256;
     // matrix
     int M = 0, K = 0;
     int64_t nnz = 0;
@@ -48,8 +51,19 @@ struct sextans_engine {
     size_t Bp_cap = 0;              // floats
     float *d_B = nullptr, *d_Cin = nullptr, *d_Cout = nullptr;   // host-path staging
     size_t B_cap = 0, C_cap = 0;
+    // block-dictionary plan for the LDS-panel kernel (built lazily, per lanes_per_row)
+    int plan_lpr = 0;               // 0 = no plan
+    int64_t plan_min_reuse = -1;
+    int *d_dict_ptr = nullptr, *d_dict = nullptr, *d_blk_row = nullptr, *d_row_off = nullptr;
+    int *d_pcol32 = nullptr;
+    float *d_pval = nullptr;
+    int plan_nblk = 0;
+    unsigned short *d_lidx = nullptr;
+    double plan_panel_frac = 0.0;   // share of non-zeros living in dictionary blocks
+    int plan_max_dict = 0;          // largest block dictionary (entries)
     // options
     int64_t opt_kernel = 0, opt_lpr = 4, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;
+    int64_t opt_min_reuse_x100 = 400;   // a block uses the LDS panel if nnz >= 4 * distinct columns
     // profiling
     std::vector<EventPair> ev_kernel, ev_repack;
     const char *last_kernel = "none";
@@ -73,7 +87,19 @@ int check_device(int device) {
     return SEXTANS_OK;
 }
 
+void free_plan(sextans_engine *h) {
+    (void)hipFree(h->d_dict_ptr); (void)hipFree(h->d_dict); (void)hipFree(h->d_lidx); (void)hipFree(h->d_blk_row);
+    (void)hipFree(h->d_row_off); (void)hipFree(h->d_pcol32); (void)hipFree(h->d_pval);
+    h->d_dict_ptr = h->d_dict = h->d_blk_row = h->d_row_off = h->d_pcol32 = nullptr;
+    h->d_pval = nullptr;
+    h->plan_nblk = 0;
+    h->d_lidx = nullptr;
+    h->plan_lpr = 0;
+    h->plan_panel_frac = 0.0;
+}
+
 void free_matrix(sextans_engine *h) {
+    free_plan(h);
     if (h->owns_matrix) {
         (void)hipFree((void *)h->d_rp);
         (void)hipFree((void *)h->d_ci);
@@ -132,6 +158,73 @@ void launch_rowgroup(sextans_engine *h, const float *dBp, const float *dCin, flo
 #undef SX_LAUNCH
 }
 
+constexpr int kPanelFloats = 9216;    // at most 36 KiB of LDS for the B panel (576 rows at N-tile 16)
+
+template <class T>
+int upload(T **dst, const std::vector<T> &src) {
+    SX_HIP(hipMalloc((void **)dst, sizeof(T) * (src.empty() ? 1 : src.size())));
+    if (!src.empty()) SX_HIP(hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+    return SEXTANS_OK;
+}
+
+// Build (or reuse) the packed row-bucketed form of A for `lpr` lanes per row.  The CSR arrays are read
+// back from the device copy, so this works for host- and device-provided matrices alike; it runs once
+// per matrix ("upload once"), outside any timed region, like the reference's host-side scheduling
+// and packing (generate_edge_list_for_all_PEs + edge_list_64bit, sextans-host.cpp:114-148).
+int ensure_plan(sextans_engine *h, int lpr) {
+    if (h->plan_lpr == lpr && h->plan_min_reuse == h->opt_min_reuse_x100) return SEXTANS_OK;
+    free_plan(h);
+    const size_t n1 = (size_t)(h->nnz ? h->nnz : 1);
+    std::vector<int> rp((size_t)h->M + 1), ci(n1);
+    std::vector<float> va(n1);
+    SX_HIP(hipMemcpy(rp.data(), h->d_rp, sizeof(int) * ((size_t)h->M + 1), hipMemcpyDeviceToHost));
+    if (h->nnz) {
+        SX_HIP(hipMemcpy(ci.data(), h->d_ci, sizeof(int) * (size_t)h->nnz, hipMemcpyDeviceToHost));
+        SX_HIP(hipMemcpy(va.data(), h->d_v, sizeof(float) * (size_t)h->nnz, hipMemcpyDeviceToHost));
+    }
+    sx::PanelPlan plan;
+    const int RB = sx::kBlock / lpr;
+    sx::build_panel_plan(h->M, h->K, rp.data(), ci.data(), va.data(), RB, kPanelFloats / (4 * lpr),
+                         (double)h->opt_min_reuse_x100 / 100.0, plan);
+    h->plan_nblk = (int)plan.blk_row.size() - 1;
+    if (int rc = upload(&h->d_blk_row, plan.blk_row)) return rc;
+    if (int rc = upload(&h->d_dict_ptr, plan.dict_ptr)) return rc;
+    if (int rc = upload(&h->d_dict, plan.dict)) return rc;
+    if (int rc = upload(&h->d_row_off, plan.row_off)) return rc;
+    if (int rc = upload(&h->d_lidx, plan.idx16)) return rc;
+    if (int rc = upload(&h->d_pcol32, plan.col32)) return rc;
+    if (int rc = upload(&h->d_pval, plan.val)) return rc;
+    h->plan_lpr = lpr;
+    h->plan_min_reuse = h->opt_min_reuse_x100;
+    h->plan_panel_frac = plan.nnz_total ? (double)plan.nnz_in_panel_blocks / (double)plan.nnz_total : 0.0;
+    h->plan_max_dict = plan.max_dict;
+    return SEXTANS_OK;
+}
+
+template <int LPR>
+void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, float *dCout, int64_t ldc,
+                  int ntiles, float alpha, float beta, hipStream_t s) {
+    constexpr int RB = sx::kBlock / LPR;
+    constexpr int NT = 4 * LPR;
+    const unsigned nwg = (unsigned)h->plan_nblk * (unsigned)ntiles;
+    const int64_t pstride = (int64_t)h->K * NT;
+    const int xcd = (int)h->opt_xcd;
+    // LDS = B panel sized for the largest dictionary of this matrix (rounded to 1 KiB) + C tile.
+    int panel_floats = ((h->plan_max_dict * NT + 255) / 256) * 256;
+    if (panel_floats > kPanelFloats) panel_floats = kPanelFloats;
+    const size_t lds = (size_t)(panel_floats + NT * (RB + 1)) * sizeof(int);
+    if (h->opt_exact)
+        hipLaunchKernelGGL((sx::spmm_csr_panel<LPR, true>), dim3(nwg), dim3(sx::kBlock), lds, s, h->d_rp,
+                           h->d_row_off, h->d_lidx, h->d_pcol32, h->d_pval, h->d_blk_row, h->d_dict_ptr,
+                           h->d_dict, dBp, pstride, dCin, dCout, ldc, ntiles, h->plan_nblk, alpha, beta,
+                           xcd, panel_floats);
+    else
+        hipLaunchKernelGGL((sx::spmm_csr_panel<LPR, false>), dim3(nwg), dim3(sx::kBlock), lds, s, h->d_rp,
+                           h->d_row_off, h->d_lidx, h->d_pcol32, h->d_pval, h->d_blk_row, h->d_dict_ptr,
+                           h->d_dict, dBp, pstride, dCin, dCout, ldc, ntiles, h->plan_nblk, alpha, beta,
+                           xcd, panel_floats);
+}
+
 }  // namespace
 
 extern "C" {
@@ -157,6 +250,11 @@ int sextans_create(sextans_handle_t *out, int device) {
     SX_HIP(hipSetDevice(device));
     auto *h = new sextans_engine();
     h->device = device;
+    {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0)
+            h->num_cus = p.multiProcessorCount;
+    }
     *out = h;
     return SEXTANS_OK;
 }
@@ -178,6 +276,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "xcd_remap")) return &h->opt_xcd;
     if (!strcmp(key, "exact")) return &h->opt_exact;
     if (!strcmp(key, "profile")) return &h->opt_profile;
+    if (!strcmp(key, "panel_min_reuse_x100")) return &h->opt_min_reuse_x100;
     return nullptr;
 }
 
@@ -268,19 +367,36 @@ int sextans_spmm_device(sextans_handle_t h, int N, float alpha, const float *d_B
             }
         }
     }
+    // Kernel choice: "kernel" 1 = row-group gather, 2 = LDS panel, 0 = auto (panel when at least half
+    // of the non-zeros sit in row blocks whose B rows are reused -- "only where a tile has reuse").
+    bool use_panel = false;
+    if (h->opt_kernel != 1 && h->nnz > 0) {
+        if (int rc = ensure_plan(h, (int)h->opt_lpr)) return rc;
+        use_panel = (h->opt_kernel == 2) || h->plan_panel_frac >= 0.5;
+    }
     {
         Prof p(h, &h->ev_kernel, s);
         for (const Seg &g : plan) {
             const float *bp = h->d_Bp + (size_t)h->K * (size_t)g.col0;
             const float *cin = d_C_in + (int64_t)g.col0 * ldc;
             float *cout = d_C_out + (int64_t)g.col0 * ldc;
+            const bool panel_here = use_panel && g.width == W;   // the plan is built for width W
             switch (g.width) {
-                case 32: launch_rowgroup<8>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s); break;
-                case 16: launch_rowgroup<4>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s); break;
-                default: launch_rowgroup<2>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s); break;
+                case 32:
+                    if (panel_here) launch_panel<8>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s);
+                    else launch_rowgroup<8>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s);
+                    break;
+                case 16:
+                    if (panel_here) launch_panel<4>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s);
+                    else launch_rowgroup<4>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s);
+                    break;
+                default:
+                    if (panel_here) launch_panel<2>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s);
+                    else launch_rowgroup<2>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s);
+                    break;
             }
         }
-        h->last_kernel = "spmm_csr_rowgroup";
+        h->last_kernel = use_panel ? "spmm_csr_panel" : "spmm_csr_rowgroup";
     }
     SX_HIP(hipGetLastError());
     return SEXTANS_OK;

@@ -28,6 +28,7 @@
 namespace sx {
 
 constexpr int kBlock = 256;   // 4 wavefronts
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // plain vector: stays in VGPRs when staged
 
 // Bijective XCD-aware remap of a linear workgroup id: the dispatcher places workgroup b on XCD
 // b % 8, so giving each XCD a contiguous chunk of logical ids keeps neighbouring row blocks
@@ -178,6 +179,192 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
         if (orow < M) {
             const int64_t o = (int64_t)orow + (col0 + n) * ldc;
             Cout[o] = epilogue<EXACT>(alpha, s_c[n * TS + r], beta, Cin[o]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-panel kernel ("the dense B panel staged into LDS"): the CDNA4 form of the reference's on-chip
+// B window (PEG_Bmtx local_B, sextans.cpp:337,353-381) fed by a packed non-zero stream with
+// window-local column indices (edge_list_64bit, sparse_helper.h:419-443).  Input is the
+// row-bucketed packed form of A built by panel_plan.cpp:
+//   dictionary block: the block's distinct B rows are copied ONCE from the row-major B panel in
+//     global memory into LDS (64-byte rows for N-tile 16, ascending column order so the copy reads
+//     whole 128-byte lines); every non-zero then reads its B row from LDS through a 16-bit local
+//     index -- 6 bytes of A stream per non-zero instead of 8 and no per-non-zero L1/L2 gather;
+//   direct block (no reuse / too many distinct columns): 32-bit columns, B rows gathered from
+//     global memory as in spmm_csr_rowgroup.
+// The A stream is NOT staged through LDS: every row starts on a 4-entry boundary, each of the LPR
+// lanes of a row fetches 4 entries with one 8-byte (indices) + one 16-byte (values) load, and the
+// entries are handed round the row group with DPP quad broadcasts (no LDS, no barrier).  LDS holds
+// only the B panel and the C tile, so ~4 workgroups fit per CU.
+// Arithmetic and per-row order are those of spmm_csr_rowgroup: bit-identical to cpu_spmm_CSR.
+// ------------------------------------------------------------------------------------------------
+template <int LPR, int S>
+__device__ __forceinline__ int slot_bcast(int x) {
+    static_assert(S >= 0 && S < LPR, "source lane inside the row group");
+    if constexpr (LPR == 4) {
+        return __builtin_amdgcn_update_dpp(0, x, S * 0x55, 0xF, 0xF, true);   // quad_perm [S,S,S,S]
+    } else if constexpr (LPR == 2) {
+        return __builtin_amdgcn_update_dpp(0, x, S | (S << 2) | ((2 + S) << 4) | ((2 + S) << 6), 0xF, 0xF, true);
+    } else {
+        return __shfl(x, S, LPR);
+    }
+}
+
+template <int LPR, bool EXACT>
+__global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
+    const int *__restrict__ row_ptr, const int *__restrict__ row_off,
+    const unsigned short *__restrict__ p_idx16, const int *__restrict__ p_col32,
+    const float *__restrict__ p_val, const int *__restrict__ blk_row,
+    const int *__restrict__ dict_ptr, const int *__restrict__ dict, const float *__restrict__ Bp,
+    int64_t panel_stride, const float *Cin, float *Cout, int64_t ldc, int ntiles, int nblk,
+    float alpha, float beta, int use_xcd_remap, int panel_floats) {
+    constexpr int NT = 4 * LPR;
+    constexpr int RB = kBlock / LPR;
+    constexpr int TS = RB + 1;
+    constexpr int BATCH = 4 * LPR;            // entries a row group holds per fetch (4 per lane)
+    constexpr int OPT = (RB * NT) / kBlock;   // outputs per thread
+    // Dynamic LDS: [panel_floats floats of B panel][NT*TS floats of C tile].
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    float *panel = reinterpret_cast<float *>(smem);
+    float *s_c = reinterpret_cast<float *>(smem + panel_floats);
+
+    const unsigned nwg = (unsigned)nblk * (unsigned)ntiles;
+    unsigned wg = blockIdx.x;
+    if (use_xcd_remap) wg = xcd_remap(wg, nwg);
+    const int blk = (int)(wg / (unsigned)ntiles);
+    const int tile = (int)(wg % (unsigned)ntiles);
+
+    const int tid = threadIdx.x;
+    const int slot = tid / LPR;
+    const int q = tid % LPR;
+    const int row0 = blk_row[blk];
+    const int row1 = blk_row[blk + 1];        // row1 - row0 <= RB
+    const int row = row0 + slot;
+    const int u0 = dict_ptr[blk];
+    const int nu = dict_ptr[blk + 1] - u0;
+    const bool use_dict = nu > 0;
+
+    const float *bq = Bp + (int64_t)tile * panel_stride + 4 * q;
+    int len = 0;
+    int64_t off = 0;
+    if (row < row1) { len = row_ptr[row + 1] - row_ptr[row]; off = row_off[row]; }
+
+    // this lane's 4 entries of a batch: indices (unpacked to int) and values
+    auto fetch = [&](int pos, int (&oi)[4], float (&ov)[4]) {
+        const int64_t o = off + pos + 4 * q;   // stream is padded: reads past the row stay in bounds
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(p_val + o);
+        ov[0] = v.x; ov[1] = v.y; ov[2] = v.z; ov[3] = v.w;
+        if (use_dict) {
+            const uint2 w = *reinterpret_cast<const uint2 *>(p_idx16 + o);
+            oi[0] = (int)(w.x & 0xffffu); oi[1] = (int)(w.x >> 16);
+            oi[2] = (int)(w.y & 0xffffu); oi[3] = (int)(w.y >> 16);
+        } else {
+            const int4 c = *reinterpret_cast<const int4 *>(p_col32 + o);
+            oi[0] = c.x; oi[1] = c.y; oi[2] = c.z; oi[3] = c.w;
+        }
+    };
+    int ix[4], nx[4];
+    float vx[4], nv[4];
+    fetch(0, ix, vx);
+
+    // C_in for this thread's outputs: issued now, consumed in the epilogue (clamped addresses).
+    const int64_t col0 = (int64_t)tile * NT;
+    float cin[OPT];
+#pragma unroll
+    for (int i = 0; i < OPT; ++i) {
+        const int e = tid + i * kBlock;
+        const int n = e / RB, r = e % RB;
+        cin[i] = Cin[(int64_t)min(row0 + r, row1 - 1) + (col0 + n) * ldc];
+    }
+
+    if (use_dict) {
+        // Stage the block's distinct B rows: slot s copies dictionary entries s, s+RB, ...; indices are
+        // clamped (duplicates rewrite the same bytes) so 8 row loads are in flight per slot.
+        for (int i0 = slot; i0 < nu; i0 += 8 * RB) {
+            f32x4 v[8];
+            int ii[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ii[u] = min(i0 + u * RB, nu - 1);
+                v[u] = *reinterpret_cast<const f32x4 *>(bq + (int64_t)dict[u0 + ii[u]] * NT);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4 *>(panel + ii[u] * NT + 4 * q) = v[u];
+        }
+        __syncthreads();
+    }
+
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *pq = panel + 4 * q;
+
+// One sub-batch = 8 consecutive entries starting at entry `base` of the current batch: broadcast the
+// entries held by lane (k/4) of the row group, issue all B-row reads (BROW: LDS panel or global
+// gather -- kept as two separate code paths so the LDS reads stay ds_read_b128, not flat loads), then
+// accumulate in order.
+#define SX_BROW_LDS(idx) (*reinterpret_cast<const float4 *>(pq + (idx) * NT))
+#define SX_BROW_GLB(idx) (*reinterpret_cast<const float4 *>(bq + (int64_t)(idx) * NT))
+#define SX_STEP_DECL(k) int i##k = 0; float a##k = 0.f; float4 b##k = make_float4(0.f, 0.f, 0.f, 0.f);
+#define SX_STEP_LOAD(BROW, k, base, live)                                                            \
+    if constexpr ((base) + (k) < BATCH) {                                                            \
+        i##k = slot_bcast<LPR, ((base) + (k)) / 4>(ix[(k) % 4]);                                     \
+        a##k = __int_as_float(slot_bcast<LPR, ((base) + (k)) / 4>(__float_as_int(vx[(k) % 4])));     \
+        if (live) b##k = BROW(i##k);                                                                 \
+    }
+#define SX_STEP_MAC(k, base, live) \
+    if constexpr ((base) + (k) < BATCH) { if (live) mac4<EXACT>(acc, a##k, b##k); }
+#define SX_SUB(BROW, base, cnt)                                                                          \
+    {                                                                                                    \
+        SX_STEP_DECL(0) SX_STEP_DECL(1) SX_STEP_DECL(2) SX_STEP_DECL(3) SX_STEP_DECL(4) SX_STEP_DECL(5)  \
+        SX_STEP_DECL(6) SX_STEP_DECL(7)                                                                  \
+        SX_STEP_LOAD(BROW, 0, base, (base) + 0 < (cnt)) SX_STEP_LOAD(BROW, 1, base, (base) + 1 < (cnt)) \
+        SX_STEP_LOAD(BROW, 2, base, (base) + 2 < (cnt)) SX_STEP_LOAD(BROW, 3, base, (base) + 3 < (cnt)) \
+        SX_STEP_LOAD(BROW, 4, base, (base) + 4 < (cnt)) SX_STEP_LOAD(BROW, 5, base, (base) + 5 < (cnt)) \
+        SX_STEP_LOAD(BROW, 6, base, (base) + 6 < (cnt)) SX_STEP_LOAD(BROW, 7, base, (base) + 7 < (cnt)) \
+        SX_STEP_MAC(0, base, (base) + 0 < (cnt)) SX_STEP_MAC(1, base, (base) + 1 < (cnt))               \
+        SX_STEP_MAC(2, base, (base) + 2 < (cnt)) SX_STEP_MAC(3, base, (base) + 3 < (cnt))               \
+        SX_STEP_MAC(4, base, (base) + 4 < (cnt)) SX_STEP_MAC(5, base, (base) + 5 < (cnt))               \
+        SX_STEP_MAC(6, base, (base) + 6 < (cnt)) SX_STEP_MAC(7, base, (base) + 7 < (cnt))               \
+    }
+#define SX_ROW_LOOP(BROW)                                                                      \
+    {                                                                                          \
+        int pos = 0;                                                                           \
+        /* full batches: every entry is live, no per-entry predicate */                        \
+        while (pos + BATCH <= len) {                                                           \
+            fetch(pos + BATCH, nx, nv); /* next batch in flight while this one is consumed */  \
+            SX_SUB(BROW, 0, BATCH) SX_SUB(BROW, 8, BATCH) SX_SUB(BROW, 16, BATCH) SX_SUB(BROW, 24, BATCH) \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) { ix[e] = nx[e]; vx[e] = nv[e]; }    \
+            pos += BATCH;                                                                      \
+        }                                                                                      \
+        /* tail: fewer than BATCH entries left, predicated per entry */                        \
+        if (pos < len) {                                                                       \
+            const int cnt = len - pos;                                                         \
+            SX_SUB(BROW, 0, cnt) SX_SUB(BROW, 8, cnt) SX_SUB(BROW, 16, cnt) SX_SUB(BROW, 24, cnt) \
+        }                                                                                      \
+    }
+    if (use_dict) SX_ROW_LOOP(SX_BROW_LDS) else SX_ROW_LOOP(SX_BROW_GLB)
+#undef SX_ROW_LOOP
+#undef SX_SUB
+#undef SX_STEP_MAC
+#undef SX_STEP_LOAD
+#undef SX_STEP_DECL
+#undef SX_BROW_GLB
+#undef SX_BROW_LDS
+
+    s_c[(4 * q + 0) * TS + slot] = acc.x;
+    s_c[(4 * q + 1) * TS + slot] = acc.y;
+    s_c[(4 * q + 2) * TS + slot] = acc.z;
+    s_c[(4 * q + 3) * TS + slot] = acc.w;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < OPT; ++i) {
+        const int e = tid + i * kBlock;
+        const int n = e / RB, r = e % RB;
+        const int orow = row0 + r;
+        if (orow < row1) {
+            const int64_t o = (int64_t)orow + (col0 + n) * ldc;
+            Cout[o] = epilogue<EXACT>(alpha, s_c[n * TS + r], beta, cin[i]);
         }
     }
 }

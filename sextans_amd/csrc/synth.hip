@@ -8,7 +8,8 @@
 //
 //   row length  : Poisson(mean) by integer inverse-CDF (64-bit thresholds computed once on the
 //                 host in long double and handed to both generators), clipped to [0, min(K, 511)]
-//   columns     : `len` draws floor(u * K / 2^64), sorted ascending, duplicates pushed to the next
+//   columns     : `len` draws uniform over [0,K) (bandwidth 0) or over the band [row-bw, row+bw]
+//                 (bandwidth bw > 0: FEM-like locality), sorted ascending, duplicates pushed to the next
 //                 free column, then clamped from the top so all stay < K (strictly increasing)
 //   values      : U[-1, 1) with 24 random bits: k * 2^-23 - 1 (exact in fp32)
 #include <hip/hip_runtime.h>
@@ -46,26 +47,73 @@ SX_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
 SX_HD float u01m1(uint64_t bits) {
     return (float)(uint32_t)(bits >> 40) * (1.0f / 8388608.0f) - 1.0f;
 }
-SX_HD int row_len(const uint64_t *table, uint64_t seed, int row, int K) {
-    const uint64_t u = rnd(seed, (uint64_t)row, 0);
+// Generator spec shared by host and device code.  kind 0: Poisson row lengths, columns uniform over
+// [0,K) (bw == 0) or over the band [row-bw, row+bw] (bw > 0).  kind 1: 3-D finite-element-like
+// matrix (27-point node stencil on an nx*ny*nz grid, dof unknowns per node, dense dof x dof blocks):
+// the structure of SuiteSparse FEM matrices such as Boeing/pcrystk02 (3 dof, ~69 nnz/row).
+struct Spec {
+    int kind, K, bw, nx, ny, nz, dof;
+    uint64_t seed;
+};
+
+SX_HD int fem_neighbors(const Spec &sp, int node, int *nb) {
+    const int x = node % sp.nx, y = (node / sp.nx) % sp.ny, z = node / (sp.nx * sp.ny);
+    int n = 0;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = x + dx, yy = y + dy, zz = z + dz;
+                if (xx < 0 || xx >= sp.nx || yy < 0 || yy >= sp.ny || zz < 0 || zz >= sp.nz) continue;
+                if (nb) nb[n] = xx + sp.nx * (yy + sp.ny * zz);
+                ++n;
+            }
+    return n;
+}
+
+SX_HD int row_len(const Spec &sp, const uint64_t *table, int row) {
+    if (sp.kind == 1) return fem_neighbors(sp, row / sp.dof, nullptr) * sp.dof;
+    const uint64_t u = rnd(sp.seed, (uint64_t)row, 0);
     int len = 0;
     while (len < kTable - 1 && u >= table[len]) ++len;
-    return len < K ? len : K;
+    int span = sp.K;
+    if (sp.bw > 0) {
+        const int lo = row - sp.bw < 0 ? 0 : row - sp.bw;
+        const int hi = row + sp.bw >= sp.K ? sp.K - 1 : row + sp.bw;
+        span = hi >= lo ? hi - lo + 1 : (2 * sp.bw + 1 < sp.K ? 2 * sp.bw + 1 : sp.K);
+    }
+    return len < span ? len : span;
 }
-SX_HD void fill_row(uint64_t seed, int row, int K, int len, int *c, float *v) {
-    for (int i = 0; i < len; ++i) {
-        const int x = (int)mulhi64(rnd(seed, (uint64_t)row, 1 + (uint64_t)i), (uint64_t)K);
-        int p = i;
-        while (p > 0 && c[p - 1] > x) { c[p] = c[p - 1]; --p; }
-        c[p] = x;
+
+SX_HD void fill_row(const Spec &sp, int row, int len, int *c, float *v) {
+    if (sp.kind == 1) {
+        int nb[27];
+        const int n = fem_neighbors(sp, row / sp.dof, nb);   // ascending node order by construction
+        int i = 0;
+        for (int a = 0; a < n; ++a)
+            for (int e = 0; e < sp.dof; ++e) c[i++] = nb[a] * sp.dof + e;
+    } else {
+        // bw == 0: columns uniform over [0, K); bw > 0: banded, uniform over [row-bw, row+bw] clipped.
+        int lo = 0, span = sp.K;
+        if (sp.bw > 0) {
+            lo = row - sp.bw < 0 ? 0 : row - sp.bw;
+            int hi = row + sp.bw >= sp.K ? sp.K - 1 : row + sp.bw;
+            if (hi < lo) { hi = sp.K - 1; lo = sp.K - 1 - 2 * sp.bw < 0 ? 0 : sp.K - 1 - 2 * sp.bw; }
+            span = hi - lo + 1;
+        }
+        for (int i = 0; i < len; ++i) {
+            const int x = lo + (int)mulhi64(rnd(sp.seed, (uint64_t)row, 1 + (uint64_t)i), (uint64_t)span);
+            int p = i;
+            while (p > 0 && c[p - 1] > x) { c[p] = c[p - 1]; --p; }
+            c[p] = x;
+        }
+        for (int i = 1; i < len; ++i)
+            if (c[i] <= c[i - 1]) c[i] = c[i - 1] + 1;
+        for (int i = len - 1; i >= 0; --i) {
+            const int cap = lo + span - 1 - (len - 1 - i);
+            if (c[i] > cap) c[i] = cap;
+        }
     }
-    for (int i = 1; i < len; ++i)
-        if (c[i] <= c[i - 1]) c[i] = c[i - 1] + 1;
-    for (int i = len - 1; i >= 0; --i) {
-        const int cap = K - 1 - (len - 1 - i);
-        if (c[i] > cap) c[i] = cap;
-    }
-    for (int i = 0; i < len; ++i) v[i] = u01m1(rnd(seed ^ kValSalt, (uint64_t)row, (uint64_t)i));
+    for (int i = 0; i < len; ++i) v[i] = u01m1(rnd(sp.seed ^ kValSalt, (uint64_t)row, (uint64_t)i));
 }
 
 void poisson_table(double mean, uint64_t *t) {
@@ -80,14 +128,13 @@ void poisson_table(double mean, uint64_t *t) {
     t[kTable - 1] = UINT64_MAX;
 }
 
-__global__ void k_row_len(const uint64_t *table, uint64_t seed, int r0, int nrows, int K, int *lens) {
+__global__ void k_row_len(Spec sp, const uint64_t *table, int r0, int nrows, int *lens) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nrows) lens[i] = row_len(table, seed, r0 + i, K);
+    if (i < nrows) lens[i] = row_len(sp, table, r0 + i);
 }
-__global__ void k_fill_rows(uint64_t seed, int r0, int nrows, int K, const int *rp, int *col,
-                            float *val) {
+__global__ void k_fill_rows(Spec sp, int r0, int nrows, const int *rp, int *col, float *val) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nrows) fill_row(seed, r0 + i, K, rp[i + 1] - rp[i], col + rp[i], val + rp[i]);
+    if (i < nrows) fill_row(sp, r0 + i, rp[i + 1] - rp[i], col + rp[i], val + rp[i]);
 }
 __global__ void k_uniform(float *dst, int64_t n, uint64_t seed) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -97,46 +144,36 @@ __global__ void k_uniform(float *dst, int64_t n, uint64_t seed) {
 
 #define SY_HIP(call) do { if ((call) != hipSuccess) return SEXTANS_ERR_HIP; } while (0)
 
-}  // namespace
-
-extern "C" {
-
-int sextans_gen_csr_host(int M, int K, double mean_nnz, uint64_t seed, int r0, int r1, int **row_ptr,
-                         int **col_idx, float **val, int64_t *nnz) {
-    if (M < 0 || K <= 0 || r0 < 0 || r1 < r0 || r1 > M || mean_nnz <= 0 || mean_nnz > 300 ||
-        !row_ptr || !col_idx || !val || !nnz)
-        return SEXTANS_ERR_INVALID;
+int gen_host(const Spec &sp, double mean, int r0, int r1, int **row_ptr, int **col_idx, float **val,
+             int64_t *nnz) {
     std::vector<uint64_t> table(kTable);
-    poisson_table(mean_nnz, table.data());
+    poisson_table(mean, table.data());
     const int nrows = r1 - r0;
     int *rp = (int *)malloc(sizeof(int) * ((size_t)nrows + 1));
     if (!rp) return SEXTANS_ERR_ALLOC;
     int64_t tot = 0;
     rp[0] = 0;
     for (int i = 0; i < nrows; ++i) {
-        tot += row_len(table.data(), seed, r0 + i, K);
+        tot += row_len(sp, table.data(), r0 + i);
         if (tot > 0x7fffffffLL) { free(rp); return SEXTANS_ERR_INVALID; }
         rp[i + 1] = (int)tot;
     }
     int *c = (int *)malloc(sizeof(int) * (size_t)(tot ? tot : 1));
     float *v = (float *)malloc(sizeof(float) * (size_t)(tot ? tot : 1));
     if (!c || !v) { free(rp); free(c); free(v); return SEXTANS_ERR_ALLOC; }
-    for (int i = 0; i < nrows; ++i) fill_row(seed, r0 + i, K, rp[i + 1] - rp[i], c + rp[i], v + rp[i]);
+    for (int i = 0; i < nrows; ++i) fill_row(sp, r0 + i, rp[i + 1] - rp[i], c + rp[i], v + rp[i]);
     *row_ptr = rp; *col_idx = c; *val = v; *nnz = tot;
     return SEXTANS_OK;
 }
 
-int sextans_gen_csr_device(int device, int M, int K, double mean_nnz, uint64_t seed, int r0, int r1,
-                           int **d_row_ptr, int **d_col_idx, float **d_val, int64_t *nnz) {
-    if (M < 0 || K <= 0 || r0 < 0 || r1 < r0 || r1 > M || mean_nnz <= 0 || mean_nnz > 300 ||
-        !d_row_ptr || !d_col_idx || !d_val || !nnz)
-        return SEXTANS_ERR_INVALID;
+int gen_device(int device, const Spec &sp, double mean, int r0, int r1, int **d_row_ptr,
+               int **d_col_idx, float **d_val, int64_t *nnz) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
         return SEXTANS_ERR_NO_DEVICE;
     SY_HIP(hipSetDevice(device));
     std::vector<uint64_t> table(kTable);
-    poisson_table(mean_nnz, table.data());
+    poisson_table(mean, table.data());
     uint64_t *d_table = nullptr;
     SY_HIP(hipMalloc((void **)&d_table, sizeof(uint64_t) * kTable));
     SY_HIP(hipMemcpy(d_table, table.data(), sizeof(uint64_t) * kTable, hipMemcpyHostToDevice));
@@ -144,7 +181,7 @@ int sextans_gen_csr_device(int device, int M, int K, double mean_nnz, uint64_t s
     int *d_rp = nullptr;
     SY_HIP(hipMalloc((void **)&d_rp, sizeof(int) * ((size_t)nrows + 1)));
     const unsigned grid = (unsigned)((nrows + 255) / 256);
-    if (nrows) hipLaunchKernelGGL(k_row_len, dim3(grid), dim3(256), 0, 0, d_table, seed, r0, nrows, K, d_rp + 1);
+    if (nrows) hipLaunchKernelGGL(k_row_len, dim3(grid), dim3(256), 0, 0, sp, d_table, r0, nrows, d_rp + 1);
     std::vector<int> rp((size_t)nrows + 1, 0);
     if (nrows) SY_HIP(hipMemcpy(rp.data() + 1, d_rp + 1, sizeof(int) * (size_t)nrows, hipMemcpyDeviceToHost));
     int64_t tot = 0;
@@ -158,11 +195,56 @@ int sextans_gen_csr_device(int device, int M, int K, double mean_nnz, uint64_t s
     float *d_v = nullptr;
     SY_HIP(hipMalloc((void **)&d_c, sizeof(int) * (size_t)(tot ? tot : 1)));
     SY_HIP(hipMalloc((void **)&d_v, sizeof(float) * (size_t)(tot ? tot : 1)));
-    if (nrows) hipLaunchKernelGGL(k_fill_rows, dim3(grid), dim3(256), 0, 0, seed, r0, nrows, K, d_rp, d_c, d_v);
+    if (nrows) hipLaunchKernelGGL(k_fill_rows, dim3(grid), dim3(256), 0, 0, sp, r0, nrows, d_rp, d_c, d_v);
     SY_HIP(hipDeviceSynchronize());
     SY_HIP(hipFree(d_table));
     *d_row_ptr = d_rp; *d_col_idx = d_c; *d_val = d_v; *nnz = tot;
     return SEXTANS_OK;
+}
+
+bool fem_ok(int nx, int ny, int nz, int dof) {
+    return nx > 0 && ny > 0 && nz > 0 && dof > 0 && dof <= 8 &&
+           (int64_t)nx * ny * nz * dof <= 0x7fffffffLL;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sextans_gen_csr_host(int M, int K, double mean_nnz, int bandwidth, uint64_t seed, int r0, int r1,
+                         int **row_ptr, int **col_idx, float **val, int64_t *nnz) {
+    if (M < 0 || K <= 0 || r0 < 0 || r1 < r0 || r1 > M || mean_nnz <= 0 || mean_nnz > 300 || bandwidth < 0 ||
+        !row_ptr || !col_idx || !val || !nnz)
+        return SEXTANS_ERR_INVALID;
+    const Spec sp{0, K, bandwidth, 0, 0, 0, 0, seed};
+    return gen_host(sp, mean_nnz, r0, r1, row_ptr, col_idx, val, nnz);
+}
+
+int sextans_gen_csr_device(int device, int M, int K, double mean_nnz, int bandwidth, uint64_t seed, int r0,
+                           int r1, int **d_row_ptr, int **d_col_idx, float **d_val, int64_t *nnz) {
+    if (M < 0 || K <= 0 || r0 < 0 || r1 < r0 || r1 > M || mean_nnz <= 0 || mean_nnz > 300 || bandwidth < 0 ||
+        !d_row_ptr || !d_col_idx || !d_val || !nnz)
+        return SEXTANS_ERR_INVALID;
+    const Spec sp{0, K, bandwidth, 0, 0, 0, 0, seed};
+    return gen_device(device, sp, mean_nnz, r0, r1, d_row_ptr, d_col_idx, d_val, nnz);
+}
+
+int sextans_gen_fem3d_host(int nx, int ny, int nz, int dof, uint64_t seed, int r0, int r1, int **row_ptr,
+                           int **col_idx, float **val, int64_t *nnz) {
+    if (!fem_ok(nx, ny, nz, dof) || !row_ptr || !col_idx || !val || !nnz) return SEXTANS_ERR_INVALID;
+    const int M = nx * ny * nz * dof;
+    if (r0 < 0 || r1 < r0 || r1 > M) return SEXTANS_ERR_INVALID;
+    const Spec sp{1, M, 0, nx, ny, nz, dof, seed};
+    return gen_host(sp, 1.0, r0, r1, row_ptr, col_idx, val, nnz);
+}
+
+int sextans_gen_fem3d_device(int device, int nx, int ny, int nz, int dof, uint64_t seed, int r0, int r1,
+                             int **d_row_ptr, int **d_col_idx, float **d_val, int64_t *nnz) {
+    if (!fem_ok(nx, ny, nz, dof) || !d_row_ptr || !d_col_idx || !d_val || !nnz) return SEXTANS_ERR_INVALID;
+    const int M = nx * ny * nz * dof;
+    if (r0 < 0 || r1 < r0 || r1 > M) return SEXTANS_ERR_INVALID;
+    const Spec sp{1, M, 0, nx, ny, nz, dof, seed};
+    return gen_device(device, sp, 1.0, r0, r1, d_row_ptr, d_col_idx, d_val, nnz);
 }
 
 int sextans_gen_uniform_host(float *dst, int64_t n, uint64_t seed) {

@@ -18,7 +18,7 @@ MANIFEST = json.load(open(os.path.join(CASES, "manifest.json")))
 
 
 def run(engine, M, K, rp, ci, v, N, alpha, B, beta, C0, **opts):
-    defaults = dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1)
+    defaults = dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0, panel_min_reuse_x100=400)
     defaults.update(opts)
     for k, val in defaults.items():
         engine.set_option(k, val)
@@ -30,11 +30,12 @@ def run(engine, M, K, rp, ci, v, N, alpha, B, beta, C0, **opts):
 
 @pytest.mark.parametrize("name", sorted(MANIFEST))
 @pytest.mark.parametrize("N", [8, 24])
-def test_reference_golden_cases(engine, name, N):
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_reference_golden_cases(engine, name, N, kernel):
     g = np.load(os.path.join(CASES, name + ".npz"))
     M, K = int(g["M"]), int(g["K"])
     out = run(engine, M, K, g["csr_ptr"], g["csr_idx"], g["csr_val"], N, ALPHA, formula_B(K, N), BETA,
-              formula_C(M, N))
+              formula_C(M, N), kernel=kernel, panel_min_reuse_x100=0)
     assert bits_equal(out, g[f"C_N{N}"])
 
 
@@ -45,9 +46,11 @@ def test_nasa4704_canonical_run_matches_reference_hashes(engine, sx):
             128: "0a6b46a1581cfd04de887ebb3c815eebf7c93b9dca17e0010bb1fb869f51817e"}
     for N in (16, 128):
         for lpr in (2, 4, 8):
-            out = run(engine, M, K, rp, ci, v, N, ALPHA, sx.init_dense_B(K, N), BETA,
-                      sx.init_dense_C(M, N), lanes_per_row=lpr)
-            assert hashlib.sha256(out.tobytes()).hexdigest() == want[N], (N, lpr)
+            for kernel in (1, 2, 0):
+                out = run(engine, M, K, rp, ci, v, N, ALPHA, sx.init_dense_B(K, N), BETA,
+                          sx.init_dense_C(M, N), lanes_per_row=lpr, kernel=kernel)
+                assert hashlib.sha256(out.tobytes()).hexdigest() == want[N], (N, lpr, kernel)
+    assert engine.last_kernel() == "spmm_csr_panel"     # nasa4704 has reuse (>= 4x): auto picks the LDS panel
     g = np.load(os.path.join(GOLDEN, "nasa4704_N16.npz"))
     out = run(engine, M, K, rp, ci, v, 16, ALPHA, formula_B(K, 16), BETA, formula_C(M, 16))
     assert bits_equal(out, g["C_formula"])
@@ -65,8 +68,67 @@ def test_random_matrix_bit_exact_vs_oracle(engine, oracle, N, lpr, stage):
     C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
     want = C0.copy()
     oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
-    out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, lanes_per_row=lpr, stage_a=stage)
+    out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, lanes_per_row=lpr, stage_a=stage, kernel=1)
     assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("N", [8, 16, 24, 32, 64, 128])
+@pytest.mark.parametrize("lpr", [2, 4, 8])
+@pytest.mark.parametrize("min_reuse", [0, 150, 400])
+@pytest.mark.parametrize("kernel", [2])
+def test_panel_kernel_bit_exact_vs_oracle(engine, oracle, sx, N, lpr, min_reuse, kernel):
+    """LDS-panel kernel on a matrix that mixes dictionary blocks (FEM-like rows with shared columns)
+    and direct blocks (random rows / rows with too many distinct columns)."""
+    from sextans_amd import api
+    rs = np.random.RandomState(2000 + N + lpr)
+    frp, fci, fv = api.gen_fem3d_host(9, 7, 5, 3, 7)            # 945 rows, heavy column reuse
+    rrp, rci, rv = random_csr(rs, 700, 945, 12, long_rows=1)   # little reuse; one long row
+    M, K = 945 + 700, 945
+    rp = np.concatenate([frp, frp[-1] + rrp[1:]]).astype(np.int32)
+    ci = np.concatenate([fci, rci]).astype(np.int32)
+    v = np.concatenate([fv, rv]).astype(np.float32)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, lanes_per_row=lpr, kernel=kernel,
+              panel_min_reuse_x100=min_reuse)
+    assert engine.last_kernel() == "spmm_csr_panel"
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+def test_panel_kernel_dictionary_capacity_edges(engine, oracle):
+    """Row blocks with exactly / just over the LDS dictionary capacity (576 distinct columns at
+    N-tile 16) and a block whose 64 rows all hit the same single column."""
+    rs = np.random.RandomState(77)
+    K, N = 4000, 16
+    rows = []
+    for nd in (576, 577, 575):                      # three 64-row blocks, nd distinct columns each
+        cols = np.sort(rs.choice(K, size=nd, replace=False))
+        for r in range(64):
+            pick = np.sort(rs.choice(cols, size=40, replace=False))
+            rows.append(pick)
+        # make sure every dictionary column is used at least once
+        rows[-1] = cols[-40:]
+        per = nd // 64 + 1
+        for r in range(64):
+            extra = cols[r * per:(r + 1) * per]
+            rows[len(rows) - 64 + r] = np.unique(np.concatenate([rows[len(rows) - 64 + r], extra]))
+    for r in range(64):
+        rows.append(np.array([1234]))
+    M = len(rows)
+    rp = np.zeros(M + 1, np.int32)
+    rp[1:] = np.cumsum([len(r) for r in rows])
+    ci = np.concatenate(rows).astype(np.int32)
+    v = rs.uniform(-1, 1, len(ci)).astype(np.float32)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    for reuse in (0, 150):
+        for kernel in (2,):
+            out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, kernel=kernel, panel_min_reuse_x100=reuse)
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
 
 
 def test_long_rows_span_lds_chunks(engine, oracle):
@@ -83,8 +145,9 @@ def test_long_rows_span_lds_chunks(engine, oracle):
     C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
     want = C0.copy()
     oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
-    for stage in (0, 1):
-        out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, stage_a=stage)
+    for stage, kernel in ((0, 1), (1, 1), (1, 2), (1, 0)):
+        out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, stage_a=stage, kernel=kernel,
+                  panel_min_reuse_x100=0)
         assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
 
 
@@ -99,6 +162,28 @@ def test_alpha_beta_edge_values(engine, oracle, alpha, beta):
     oracle.spmm(M, N, K, np.float32(alpha), rp, ci, v, B, np.float32(beta), want)
     out = run(engine, M, K, rp, ci, v, N, alpha, B, beta, C0)
     assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+def test_panel_kernel_medium_fem_plus_direct_tail(engine, oracle, sx):
+    """A few thousand row blocks (multi-threaded plan builder), dictionary blocks followed by direct
+    blocks with long rows."""
+    from sextans_amd import api
+    rs = np.random.RandomState(123)
+    frp, fci, fv = api.gen_fem3d_host(40, 40, 40, 3, 5)          # 192000 rows, ~3900 blocks
+    M = K = 192000
+    extra_rp, extra_ci, extra_v = random_csr(rs, 3000, K, 30, long_rows=2)   # direct blocks at the end
+    rp = np.concatenate([frp, frp[-1] + extra_rp[1:]]).astype(np.int32)
+    ci = np.concatenate([fci, extra_ci]).astype(np.int32)
+    v = np.concatenate([fv, extra_v]).astype(np.float32)
+    M = 192000 + 3000
+    for N in (16, 24):
+        B = rs.uniform(-1, 1, K * N).astype(np.float32)
+        C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+        want = C0.copy()
+        oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+        for kernel in (2, 0):
+            out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, kernel=kernel)
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (N, kernel)
 
 
 def test_degenerate_shapes(engine, oracle):
@@ -118,8 +203,9 @@ def test_degenerate_shapes(engine, oracle):
         C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
         want = C0.copy()
         oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
-        out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0)
-        assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (M, K)
+        for kernel in (0, 1, 2):
+            out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, kernel=kernel, panel_min_reuse_x100=0)
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (M, K, kernel)
 
 
 def test_non_exact_fma_variant_within_stated_tolerance(engine, oracle):
@@ -154,6 +240,8 @@ def test_rp_time_repeats_read_same_c_in(engine, oracle):
     C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
     want = C0.copy()
     oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    for k, val in dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0).items():
+        engine.set_option(k, val)
     engine.set_matrix_csr(M, K, rp, ci, v)
     out = C0.copy()
     ns = engine.spmm(N, ALPHA, B, BETA, out, rp_time=7)
@@ -189,6 +277,8 @@ def test_device_resident_strided_and_aliased(engine, oracle):
     oracle.spmm(M, N, K, ALPHA, rp, ci, v, Bc, BETA, want)
     dB = torch.from_numpy(Bfull).cuda()
     dC = torch.from_numpy(Cfull).cuda()
+    for k, val in dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0).items():
+        engine.set_option(k, val)
     engine.set_matrix_csr(M, K, rp, ci, v)
     st = torch.cuda.current_stream().cuda_stream
     ptr = dC.data_ptr() + 4 * r0
@@ -212,6 +302,8 @@ def test_full_size_properties_config4_scale(sx, engine):
     N = 16
     p, i, v, nnz = api.gen_csr_device(0, M, K, 40.0, 4)
     try:
+        for k, val in dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=1).items():
+            engine.set_option(k, val)
         engine.set_matrix_csr_device(M, K, nnz, p, i, v)
         B1 = torch.empty(K * N, device="cuda"); B2 = torch.empty(K * N, device="cuda")
         api.gen_uniform_device(0, B1.data_ptr(), K * N, 11); api.gen_uniform_device(0, B2.data_ptr(), K * N, 12)
@@ -232,8 +324,6 @@ def test_full_size_properties_config4_scale(sx, engine):
         torch.cuda.synchronize()
         assert torch.equal(o, -2.0 * Cin)
         # sampled rows against the oracle-equivalent host arithmetic (float32, CSR order)
-        rp_h = torch.empty(0)
-        rows = [0, 1, 12345, 999_999]
         hp, hi, hv = api.gen_csr_host(M, K, 40.0, 4, 0, 2)
         B1h = B1.cpu().numpy()
         o1 = outs[0].cpu().numpy()

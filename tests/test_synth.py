@@ -26,6 +26,14 @@ def test_host_generator_properties(sx):
     for r in range(500):
         seg = ci3[rp3[r]:rp3[r + 1]]
         assert np.all(np.diff(seg) > 0) and (len(seg) == 0 or (seg[0] >= 0 and seg[-1] < 48))
+    # banded and FEM-like kinds
+    rp4, ci4, _ = api.gen_csr_host(3000, 3000, 40.0, 4, bandwidth=200)
+    rows = np.repeat(np.arange(3000), np.diff(rp4))
+    assert np.abs(ci4 - rows).max() <= 200 and ci4.min() >= 0 and ci4.max() < 3000
+    frp, fci, fv = api.gen_fem3d_host(35, 19, 7, 3, 2)          # the pcrystk02 stand-in
+    assert len(frp) - 1 == 13965 and frp[-1] == 968715 and np.diff(frp).max() == 81
+    assert all(np.all(np.diff(fci[frp[r]:frp[r + 1]]) > 0) for r in range(0, 13965, 131))
+    assert fci.max() == 13964 and np.array_equal(fci[frp[0]:frp[1]], fci[frp[1]:frp[2]])   # dof rows share columns
     u = api.gen_uniform_host(100000, 3)
     assert u.min() >= -1 and u.max() < 1 and abs(u.mean()) < 0.01 and abs(u.var() - 1 / 3) < 0.01
 
@@ -50,6 +58,20 @@ def test_device_generator_bit_identical_to_host(sx, engine):
         assert np.array_equal(pull(p, len(hp), torch.int32), hp)
         assert np.array_equal(pull(i, nnz, torch.int32), hi)
         assert np.array_equal(pull(v, nnz, torch.float32).view(np.uint32), hv.view(np.uint32))
+    finally:
+        for q in (p, i, v):
+            api.device_free(0, q)
+    p, i, v, nnz = api.gen_fem3d_device(0, 35, 19, 7, 3, 2, 50, 9000)
+    try:
+        hp, hi, hv = api.gen_fem3d_host(35, 19, 7, 3, 2, 50, 9000)
+        assert nnz == len(hi)
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so.7")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        ti = torch.empty(nnz, dtype=torch.int32, device="cuda")
+        tv = torch.empty(nnz, dtype=torch.float32, device="cuda")
+        assert hip.hipMemcpy(ti.data_ptr(), i, nnz * 4, 3) == 0 and hip.hipMemcpy(tv.data_ptr(), v, nnz * 4, 3) == 0
+        assert np.array_equal(ti.cpu().numpy(), hi) and np.array_equal(tv.cpu().numpy().view(np.uint32), hv.view(np.uint32))
     finally:
         for q in (p, i, v):
             api.device_free(0, q)
