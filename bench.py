@@ -21,7 +21,9 @@ Extra objects in the line:
                 with HIP events on the launch stream, against the 8 TB/s HBM3E spec peak.
   cpu_baseline  the reference's cpu_spmm_CSR (oracle/_ref, kind "reference") or our C restatement
                 (kind "port") timed single-threaded on a bounded row sample of the same workload.
-  also          secondary measurements (nasa4704 N=16 = BASELINE config 2; compute-only time).
+  also          secondary measurements: BASELINE config 2 (nasa4704 N=16), config 3 (pcrystk02 N=128 on
+                its labelled stand-in, a 35x19x7 3-dof FEM grid: 13965 rows, 968715 nnz), and a
+                SuiteSparse-like 4M-row FEM matrix (the class with B-row reuse); compute-only time.
 """
 import argparse
 import json
@@ -51,6 +53,7 @@ def main():
     ap.add_argument("--mean-nnz", type=float, default=40.0)
     ap.add_argument("--n", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value")
     args = ap.parse_args()
@@ -150,8 +153,15 @@ def main():
     eng.profile_reset()
     bytes_launch = alg_bytes(m_loc, K, N, nnz_loc)
     achieved = bytes_launch / (k_ns * 1e-9) / 1e9
+    # HBM traffic of this kernel comes from separate rocprofv3 --pmc passes of this same command
+    # (tools/prof.sh -> profiles/*_traffic.json); only valid for the default single-GPU workload.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_config4_traffic.json")
+    if world == 1 and args.rows == 4_000_000 and args.mean_nnz == 40.0 and N == 16 and not args.opt \
+            and os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": eng.last_kernel(), "kernel_us": round(k_ns / 1e3, 2),
                 "alg_bytes_per_launch": bytes_launch, "launches_timed": k_n,
                 "repack_us": round(rp_ns / 1e3, 2)}
@@ -177,10 +187,17 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(api, M, K, N, args, Cout, flops_per_row=None)
-        try:
-            also["nasa4704_N16"] = nasa_secondary(api, torch, dev, stream)
-        except Exception as e:   # secondary measurement only
-            also["nasa4704_N16"] = {"error": str(e)}
+        del B, Cin, Cout
+        torch.cuda.empty_cache()
+        for key, fn in () if args.no_also else (("config2_nasa4704_N16", lambda: nasa_secondary(api, torch, dev, stream)),
+                        ("config3_pcrystk02_surrogate_N128",
+                         lambda: fem_secondary(api, torch, dev, stream, (35, 19, 7, 3), 128, 300)),
+                        ("suitesparse_like_fem_4M_N16",
+                         lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 10))):
+            try:
+                also[key] = fn()
+            except Exception as e:   # secondary measurements only
+                also[key] = {"error": str(e)}
     if also:
         out["also"] = also
 
@@ -233,36 +250,62 @@ def cpu_baseline(api, M, K, N, args, Cout, flops_per_row):
             "gpu_matches_cpu_bitwise_on_sample": match}
 
 
+def _measure(api, torch, e, M, K, N, nnz, dev, stream, iters):
+    """Steady-state step time (wall, synchronised) and HIP-event time of the dominant kernel."""
+    B = torch.empty(K * N, dtype=torch.float32, device=dev)
+    Cin = torch.empty(M * N, dtype=torch.float32, device=dev)
+    Cout = torch.empty(M * N, dtype=torch.float32, device=dev)
+    api.gen_uniform_device(dev.index, B.data_ptr(), K * N, 41, stream)
+    api.gen_uniform_device(dev.index, Cin.data_ptr(), M * N, 42, stream)
+    f = lambda: e.spmm_device(N, ALPHA, B.data_ptr(), K, BETA, Cin.data_ptr(), Cout.data_ptr(), M, stream)
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        f()
+    torch.cuda.synchronize()
+    per = (time.perf_counter() - t0) / iters
+    e.set_option("profile", 1); e.profile_reset()
+    for _ in range(min(iters, 20)):
+        f()
+    torch.cuda.synchronize()
+    k_ns, _, rp_ns = e.profile_read()
+    e.set_option("profile", 0); e.profile_reset()
+    by = alg_bytes(M, K, N, nnz)
+    return {"M": M, "K": K, "N": N, "nnz": nnz, "kernel": e.last_kernel(),
+            "us_per_step": round(per * 1e6, 2), "gflops": round(2.0 * N * (nnz + M) / per / 1e9, 1),
+            "kernel_us": round(k_ns / 1e3, 2), "repack_us": round(rp_ns / 1e3, 2),
+            "alg_gbs_kernel": round(by / (k_ns * 1e-9) / 1e9, 1),
+            "roofline_frac_kernel": round(by / (k_ns * 1e-9) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
 def nasa_secondary(api, torch, dev, stream):
     """BASELINE config 2: nasa4704.mtx, N=16 -- latency-bound and cache-resident; per-launch mean
     over 1000 back-to-back steps."""
     path = os.path.join(ROOT, "matrices", "nasa4704", "nasa4704.mtx")
     rp, ci, v, M, K, nnz = api.read_suitsparse_matrix(path)
-    N = 16
     e = api.Engine(dev.index)
     e.set_matrix_csr(M, K, rp, ci, v)
-    B = torch.from_numpy(api.init_dense_B(K, N)).to(dev)
-    Cin = torch.from_numpy(api.init_dense_C(M, N)).to(dev)
-    Cout = torch.empty_like(Cin)
-    f = lambda: e.spmm_device(N, ALPHA, B.data_ptr(), K, BETA, Cin.data_ptr(), Cout.data_ptr(), M, stream)
-    for _ in range(20):
-        f()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(1000):
-        f()
-    torch.cuda.synchronize()
-    per = (time.perf_counter() - t0) / 1000
-    e.set_option("profile", 1)
-    for _ in range(50):
-        f()
-    torch.cuda.synchronize()
-    k_ns, _, rp_ns = e.profile_read()
+    out = _measure(api, torch, e, M, K, 16, nnz, dev, stream, 1000)
     e.close()
-    by = alg_bytes(M, K, N, nnz)
-    return {"us_per_step": round(per * 1e6, 2), "gflops": round(2.0 * N * (nnz + M) / per / 1e9, 1),
-            "kernel_us": round(k_ns / 1e3, 2), "repack_us": round(rp_ns / 1e3, 2),
-            "alg_gbs_kernel": round(by / (k_ns * 1e-9) / 1e9, 1)}
+    return out
+
+
+def fem_secondary(api, torch, dev, stream, dims, N, iters):
+    """SuiteSparse-like FEM input (27-point node stencil, `dof` unknowns per node): the class of
+    matrices with B-row reuse, where the LDS-panel kernel applies.  dims = (nx, ny, nz, dof)."""
+    nx, ny, nz, dof = dims
+    M = K = nx * ny * nz * dof
+    p, i, v, nnz = api.gen_fem3d_device(dev.index, nx, ny, nz, dof, 3)
+    e = api.Engine(dev.index)
+    e.set_matrix_csr_device(M, K, nnz, p, i, v)
+    out = _measure(api, torch, e, M, K, N, nnz, dev, stream, iters)
+    out["matrix"] = f"fem3d {nx}x{ny}x{nz}, {dof} dof/node"
+    e.close()
+    for q in (p, i, v):
+        api.device_free(dev.index, q)
+    return out
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline $EXTRA"
+CMD="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-also $EXTRA"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o stats -- $CMD > $OUT/bench_under_rocprof.log 2>&1
 find /tmp/rp_stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
