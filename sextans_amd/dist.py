@@ -47,7 +47,7 @@ def slice_csr(row_ptr, col_idx, val, r0, r1):
     return (row_ptr[r0:r1 + 1] - row_ptr[r0]).astype(np.int32), col_idx[a:b], val[a:b]
 
 
-def all_gather_c(C_full, M, N, ranges, rank, group=None):
+def all_gather_c(C_full, M, N, ranges, rank, group=None, _force=False):
     """Complete the column-major M x N matrix `C_full` (flat torch tensor, CPU or GPU) on every rank.
 
     On entry rank g has written rows ranges[g] of every column; on return all rows are present.
@@ -58,7 +58,7 @@ def all_gather_c(C_full, M, N, ranges, rank, group=None):
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not _force:
         return
     lens = [r1 - r0 for r0, r1 in ranges]
     even = len(set(lens)) == 1 and lens[0] * world == M
@@ -72,8 +72,12 @@ def all_gather_c(C_full, M, N, ranges, rank, group=None):
             dist.all_gather_into_tensor(cols[n], cols[n][r0:r1], group=group)
 
         if backend == "nccl":
-            with dist._coalescing_manager(group=group, device=C_full.device, async_ops=False):
-                for n in range(N):
+            try:
+                with dist._coalescing_manager(group=group, device=C_full.device, async_ops=False):
+                    for n in range(N):
+                        one_column(n)
+            except (AttributeError, TypeError, RuntimeError, NotImplementedError):
+                for n in range(N):   # coalescing unavailable in this torch build: plain per-column calls
                     one_column(n)
         else:
             for n in range(N):
