@@ -23,7 +23,8 @@ Extra objects in the line:
                 (kind "port") timed single-threaded on a bounded row sample of the same workload.
   also          secondary measurements: BASELINE config 2 (nasa4704 N=16), config 3 (pcrystk02 N=128 on
                 its labelled stand-in, a 35x19x7 3-dof FEM grid: 13965 rows, 968715 nnz), and a
-                SuiteSparse-like 4M-row FEM matrix (the class with B-row reuse); compute-only time.
+                SuiteSparse-like 4M-row FEM matrix (the class with B-row reuse), config 5 (blocked-ELL bf16
+                MFMA path, full size); compute-only time at N > 1.
 """
 import argparse
 import json
@@ -193,7 +194,8 @@ def main():
                         ("config3_pcrystk02_surrogate_N128",
                          lambda: fem_secondary(api, torch, dev, stream, (35, 19, 7, 3), 128, 300)),
                         ("suitesparse_like_fem_4M_N16",
-                         lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 10))):
+                         lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 10)),
+                        ("config5_blocked_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream))):
             try:
                 also[key] = fn()
             except Exception as e:   # secondary measurements only
@@ -289,6 +291,44 @@ def nasa_secondary(api, torch, dev, stream):
     e.set_matrix_csr(M, K, rp, ci, v)
     out = _measure(api, torch, e, M, K, 16, nnz, dev, stream, 1000)
     e.close()
+    return out
+
+
+def bell_secondary(api, torch, dev, stream, M=1_048_576, W=328, N=256, iters=5):
+    """BASELINE config 5: blocked-ELL 32x32 bf16 blocks, 1% block fill, N=256, bf16 MFMA path.
+    F = 2*N*(1024*nblocks + M); bytes = 2048*nb + 4*nb + 2*K*N + 8*M*N."""
+    K = M
+    dc, dv = api.gen_bell_device(dev.index, M, K, W, 5)
+    e = api.Engine(dev.index)
+    e.set_matrix_bell_device(M, K, W, dc, dv)
+    api.device_free(dev.index, dv)                      # the engine keeps its own fragment-order copy
+    B = torch.empty(K * N, dtype=torch.int16, device=dev)
+    Cin = torch.empty(M * N, dtype=torch.float32, device=dev)
+    Cout = torch.empty(M * N, dtype=torch.float32, device=dev)
+    api.gen_uniform_bf16_device(dev.index, B.data_ptr(), K * N, 51, stream)
+    api.gen_uniform_device(dev.index, Cin.data_ptr(), M * N, 52, stream)
+    f = lambda: e.spmm_bell_device(N, ALPHA, B.data_ptr(), K, BETA, Cin.data_ptr(), Cout.data_ptr(), M, stream)
+    f(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        f()
+    torch.cuda.synchronize()
+    per = (time.perf_counter() - t0) / iters
+    e.set_option("profile", 1); e.profile_reset()
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    k_ns, _, rp_ns = e.profile_read()
+    nb = (M // 32) * W
+    flops = 2.0 * N * (1024.0 * nb + M)
+    by = 2048 * nb + 4 * nb + 2 * K * N + 8 * M * N
+    out = {"M": M, "K": K, "N": N, "blocks": nb, "kernel": e.last_kernel(), "ms_per_step": round(per * 1e3, 3),
+           "tflops": round(flops / per / 1e12, 1), "kernel_ms": round(k_ns / 1e6, 3),
+           "repack_b_us": round(rp_ns / 1e3, 1), "alg_gbs_kernel": round(by / (k_ns * 1e-9) / 1e9, 1),
+           "roofline_frac_kernel": round(by / (k_ns * 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
+           "mfma_util_vs_2.5PF": round(flops / (k_ns * 1e-9) / 2.5e15, 4), "dtype": "bf16 in, f32 accumulate"}
+    e.close()
+    api.device_free(dev.index, dc)
     return out
 
 

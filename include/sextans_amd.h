@@ -140,6 +140,19 @@ int sextans_spmm_csr(int M, int N, int K, int NNZ, float ALPHA, const int *CSRRo
                      const int *CSRColIndex, const float *CSRVal, const float *mat_B, float BETA,
                      float *mat_C);
 
+/* ---- Blocked-ELL bf16 path (BASELINE config 5; no counterpart in the reference, whose PEs are scalar
+ * fp32 MACs): A is M x K in dense 32x32 bf16 blocks, `ell_width` block slots per block row;
+ * block_col[br*ell_width + s] is the block column of slot s (or -1 = empty slot), block_val holds the
+ * slots' 32x32 bf16 values row-major (1024 values per slot).  B is bf16 COLUMN MAJOR K x N (ldb % 8 == 0),
+ * C fp32 column major, C = alpha*A*B + beta*C with fp32 accumulation on v_mfma_f32_32x32x16_bf16.
+ * M, K, N must be multiples of 32.  bf16 values are passed as their 16-bit patterns (uint16_t). */
+int sextans_set_matrix_bell(sextans_handle_t h, int M, int K, int ell_width, const int *block_col,
+                            const uint16_t *block_val);
+int sextans_set_matrix_bell_device(sextans_handle_t h, int M, int K, int ell_width,
+                                   const int *d_block_col, const uint16_t *d_block_val);
+int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint16_t *d_B, int64_t ldb,
+                             float beta, const float *d_C_in, float *d_C_out, int64_t ldc, void *stream);
+
 /* Per-kernel device timing collected while option "profile" = 1: mean duration in ns of the
  * dominant SpMM kernel launches since the last reset, and how many were timed. */
 int sextans_profile_read(sextans_handle_t h, double *mean_kernel_ns, int64_t *launches,
@@ -169,6 +182,14 @@ int sextans_gen_fem3d_host(int nx, int ny, int nz, int dof, uint64_t seed, int r
                            int **col_idx, float **val, int64_t *nnz);
 int sextans_gen_fem3d_device(int device, int nx, int ny, int nz, int dof, uint64_t seed, int r0, int r1,
                              int **d_row_ptr, int **d_col_idx, float **d_val, int64_t *nnz);
+/* Blocked-ELL synthetic input (BASELINE config 5): every block row gets `ell_width` distinct sorted
+ * block columns, values bf16(U(-1,1)).  Device form allocates (free with sextans_device_free). */
+int sextans_gen_bell_host(int M, int K, int ell_width, uint64_t seed, int **block_col, uint16_t **block_val);
+int sextans_gen_bell_device(int device, int M, int K, int ell_width, uint64_t seed, int **d_block_col,
+                            uint16_t **d_block_val);
+/* bf16(U(-1,1)) fill (same bits on host and device). */
+int sextans_gen_uniform_bf16_host(uint16_t *dst, int64_t n, uint64_t seed);
+int sextans_gen_uniform_bf16_device(int device, uint16_t *d_dst, int64_t n, uint64_t seed, void *stream);
 /* U(-1,1) fp32 fill, element i of stream `seed` (same bits on host and device). */
 int sextans_gen_uniform_host(float *dst, int64_t n, uint64_t seed);
 int sextans_gen_uniform_device(int device, float *d_dst, int64_t n, uint64_t seed, void *stream);

@@ -61,6 +61,11 @@ class Oracle:
         L.orc_init_C.argtypes = [C.c_int, C.c_int, _f32p]
         L.orc_verify.restype = C.c_int
         L.orc_verify.argtypes = [C.c_int, C.c_int, _f32p, _f32p, C.POINTER(C.c_float)]
+        u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS")
+        f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+        L.orc_bell_spmm.restype = None
+        L.orc_bell_spmm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _i32p, u16p, u16p, C.c_float,
+                                    C.c_float, _f32p, f64p]
         L.orc_gflops.restype = C.c_double
         L.orc_gflops.argtypes = [C.c_int, C.c_int, C.c_long, C.c_double]
 
@@ -109,6 +114,15 @@ class Oracle:
     def time_spmm_rows(self, r0, r1, M, N, K, alpha, row_ptr, col_idx, val, B, beta, C_inout):
         return self.lib.orc_time_spmm_rows(r0, r1, M, N, K, alpha, row_ptr, _pad(col_idx),
                                            _pad(val), B, beta, C_inout)
+
+    def bell_spmm(self, M, K, N, ell_width, block_col, block_val, B_bf16, alpha, beta, C_inout):
+        """Blocked-ELL bf16 restatement (config 5; parity unpinned by the reference).  In place on
+        C_inout; returns sum|a*b| per output (float64) for condition-aware tolerances."""
+        asum = np.zeros(M * N, np.float64)
+        self.lib.orc_bell_spmm(M, K, N, ell_width, np.ascontiguousarray(block_col, np.int32),
+                               np.ascontiguousarray(block_val, np.uint16),
+                               np.ascontiguousarray(B_bf16, np.uint16), alpha, beta, C_inout, asum)
+        return asum
 
     def init_B(self, K, N):
         B = np.empty(K * N, np.float32)

@@ -292,3 +292,46 @@ double orc_time_spmm_rows(int r0, int r1, int M, int N, int K, float alpha, cons
     clock_gettime(CLOCK_MONOTONIC, &t1);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ---- Blocked-ELL bf16 SpMM (BASELINE config 5).  NO reference analogue: parity for this path is
+ * UNPINNED by the reference; this is our own fp32 CPU restatement on bf16 inputs:
+ * every bf16 x bf16 product is exact in fp32; products are accumulated in fp32 in slot order, k
+ * ascending, then C = alpha*acc + beta*C as in cpu_spmm_CSR (sparse_helper.h:286-288).  The GPU's
+ * MFMA sums the 16 products of a k-step in hardware order, so tests compare within a stated
+ * tolerance relative to sum|a*b|, and also against a float64 evaluation. */
+static float orc_bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+void orc_bell_spmm(int M, int K, int N, int ell_width, const int *block_col, const uint16_t *block_val,
+                   const uint16_t *B /* bf16 column-major, ld = K */, float alpha, float beta,
+                   float *C /* fp32 column-major, ld = M */, double *abs_sum /* optional M*N: sum|a*b| */) {
+    const int mb = M / 32;
+    for (int br = 0; br < mb; ++br) {
+        for (int i = 0; i < 32; ++i) {
+            const int m = br * 32 + i;
+            for (int n = 0; n < N; ++n) {
+                float acc = 0.0f;
+                double asum = 0.0;
+                for (int s = 0; s < ell_width; ++s) {
+                    const int bc = block_col[(size_t)br * ell_width + s];
+                    if (bc < 0) continue;
+                    const uint16_t *a = block_val + ((size_t)br * ell_width + s) * 1024 + (size_t)i * 32;
+                    const uint16_t *b = B + (size_t)n * K + (size_t)bc * 32;
+                    for (int k = 0; k < 32; ++k) {
+                        const float p = orc_bf16_to_f32(a[k]) * orc_bf16_to_f32(b[k]);
+                        acc += p;
+                        asum += fabs((double)p);
+                    }
+                }
+                const size_t o = (size_t)m + (size_t)M * n;
+                if (abs_sum) abs_sum[o] = asum;
+                C[o] = alpha * acc + beta * C[o];
+            }
+        }
+    }
+    (void)K;
+}

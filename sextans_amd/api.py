@@ -103,6 +103,17 @@ def lib():
                                            C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                            C.POINTER(C.c_int64)]
+    u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS")
+    L.sextans_set_matrix_bell.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _i32p, u16p]
+    L.sextans_set_matrix_bell_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.sextans_spmm_bell_device.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.sextans_gen_bell_host.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, pi,
+                                        C.POINTER(C.POINTER(C.c_uint16))]
+    L.sextans_gen_bell_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.sextans_gen_uniform_bf16_host.argtypes = [u16p, C.c_int64, C.c_uint64]
+    L.sextans_gen_uniform_bf16_device.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]
     L.sextans_gen_uniform_host.argtypes = [_f32p, C.c_int64, C.c_uint64]
     L.sextans_gen_uniform_device.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_uint64,
                                              C.c_void_p]
@@ -252,6 +263,19 @@ class Engine:
         _check(lib().sextans_spmm_device(self._h, N, alpha, d_B, ldb, beta, d_C_in, d_C_out, ldc,
                                          stream), "spmm_device")
 
+    # ---- blocked-ELL bf16 path (BASELINE config 5)
+    def set_matrix_bell(self, M, K, ell_width, block_col, block_val_bf16):
+        _check(lib().sextans_set_matrix_bell(self._h, M, K, ell_width, _buf(block_col, np.int32),
+                                             _buf(block_val_bf16, np.uint16)), "set_matrix_bell")
+
+    def set_matrix_bell_device(self, M, K, ell_width, d_block_col, d_block_val):
+        _check(lib().sextans_set_matrix_bell_device(self._h, M, K, ell_width, d_block_col, d_block_val),
+               "set_matrix_bell_device")
+
+    def spmm_bell_device(self, N, alpha, d_B_bf16, ldb, beta, d_C_in, d_C_out, ldc, stream=None):
+        _check(lib().sextans_spmm_bell_device(self._h, N, alpha, d_B_bf16, ldb, beta, d_C_in, d_C_out, ldc,
+                                              stream), "spmm_bell_device")
+
     def profile_read(self):
         k, n, r = C.c_double(), C.c_int64(), C.c_double()
         _check(lib().sextans_profile_read(self._h, C.byref(k), C.byref(n), C.byref(r)),
@@ -318,6 +342,32 @@ def gen_fem3d_device(device, nx, ny, nz, dof, seed, r0=0, r1=None):
     _check(lib().sextans_gen_fem3d_device(device, nx, ny, nz, dof, seed, r0, r1, C.byref(p), C.byref(i),
                                           C.byref(v), C.byref(nnz)), "gen_fem3d_device")
     return p.value, i.value, v.value, nnz.value
+
+
+def gen_bell_host(M, K, ell_width, seed):
+    L = lib()
+    c, v = C.POINTER(C.c_int)(), C.POINTER(C.c_uint16)()
+    _check(L.sextans_gen_bell_host(M, K, ell_width, seed, c, v), "gen_bell_host")
+    n = (M // 32) * ell_width
+    out = (_take(c, n, np.int32), np.ctypeslib.as_array(v, shape=(n * 1024,)).astype(np.uint16, copy=True))
+    L.sextans_host_free(c); L.sextans_host_free(v)
+    return out
+
+
+def gen_bell_device(device, M, K, ell_width, seed):
+    c, v = C.c_void_p(), C.c_void_p()
+    _check(lib().sextans_gen_bell_device(device, M, K, ell_width, seed, C.byref(c), C.byref(v)), "gen_bell_device")
+    return c.value, v.value
+
+
+def gen_uniform_bf16_host(n, seed):
+    a = np.empty(max(n, 1), np.uint16)
+    _check(lib().sextans_gen_uniform_bf16_host(a, n, seed), "gen_uniform_bf16_host")
+    return a[:n]
+
+
+def gen_uniform_bf16_device(device, d_ptr, n, seed, stream=None):
+    _check(lib().sextans_gen_uniform_bf16_device(device, d_ptr, n, seed, stream), "gen_uniform_bf16_device")
 
 
 def gen_uniform_host(n, seed):

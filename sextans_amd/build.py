@@ -18,7 +18,7 @@ LIB = os.path.join(LIBDIR, "libsextans_amd.so")
 CLI = os.path.join(BINDIR, "sextans")
 
 LIB_SOURCES = ["engine.hip", "synth.hip", "host_mtx.cpp", "panel_plan.cpp"]
-HEADERS = ["spmm_csr_kernels.h", "panel_plan.h", os.path.join("..", "..", "include", "sextans_amd.h")]
+HEADERS = ["spmm_csr_kernels.h", "bell_kernels.h", "panel_plan.h", os.path.join("..", "..", "include", "sextans_amd.h")]
 
 # -ffp-contract=off: the EXACT kernels and the CLI golden need "multiply, round, add" (the
 # reference's arithmetic, sparse_helper.h:283); hipcc's default is to contract into FMA.

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "bell_kernels.h"
 #include "panel_plan.h"
 #include "sextans_amd.h"
 #include "spmm_csr_kernels.h"
@@ -62,6 +63,13 @@ struct sextans_engine {
     double plan_panel_frac = 0.0;   // share of non-zeros living in dictionary blocks
     int plan_max_dict = 0;          // largest block dictionary (entries)
     bool plan_built = false;        // false: only the sampled verdict exists (no packed stream)
+    // blocked-ELL bf16 matrix (MFMA path)
+    int bell_M = 0, bell_K = 0, bell_W = 0;
+    const int *d_bell_col = nullptr;
+    int *d_bell_col_owned = nullptr;
+    void *d_bell_Af = nullptr;      // A blocks in MFMA fragment order (owned)
+    void *d_bell_Bf = nullptr;      // B in fragment order (workspace)
+    size_t bell_Bf_cap = 0;         // bytes
     // options
     int64_t opt_kernel = 0, opt_lpr = 4, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;
     int64_t opt_min_reuse_x100 = 400;   // a block uses the LDS panel if nnz >= 4 * distinct columns
@@ -98,6 +106,12 @@ void free_plan(sextans_engine *h) {
     h->plan_lpr = 0;
     h->plan_panel_frac = 0.0;
     h->plan_built = false;
+}
+
+void free_bell(sextans_engine *h) {
+    (void)hipFree(h->d_bell_col_owned); (void)hipFree(h->d_bell_Af);
+    h->d_bell_col_owned = nullptr; h->d_bell_col = nullptr; h->d_bell_Af = nullptr;
+    h->bell_M = h->bell_K = h->bell_W = 0;
 }
 
 void free_matrix(sextans_engine *h) {
@@ -311,6 +325,8 @@ int sextans_destroy(sextans_handle_t h) {
     if (!h) return SEXTANS_ERR_INVALID;
     (void)hipSetDevice(h->device);
     free_matrix(h);
+    free_bell(h);
+    (void)hipFree(h->d_bell_Bf);
     (void)hipFree(h->d_Bp); (void)hipFree(h->d_B); (void)hipFree(h->d_Cin); (void)hipFree(h->d_Cout);
     sextans_profile_reset(h);
     delete h;
@@ -491,6 +507,82 @@ int sextans_spmm_csr(int M, int N, int K, int NNZ, float ALPHA, const int *CSRRo
     if (!rc) rc = sextans_spmm_host(h, N, ALPHA, mat_B, BETA, mat_C, 1, nullptr);
     sextans_destroy(h);
     return rc;
+}
+
+int sextans_set_matrix_bell_device(sextans_handle_t h, int M, int K, int ell_width,
+                                   const int *d_block_col, const uint16_t *d_block_val) {
+    if (!h || M <= 0 || K <= 0 || (M % 32) || (K % 32) || ell_width <= 0 || !d_block_col || !d_block_val)
+        return SEXTANS_ERR_INVALID;
+    SX_HIP(hipSetDevice(h->device));
+    free_bell(h);
+    const int64_t nslots = (int64_t)(M / 32) * ell_width;
+    SX_HIP(hipMalloc(&h->d_bell_Af, (size_t)nslots * 2048));
+    const int64_t threads = nslots * 128;
+    hipLaunchKernelGGL(sx::bell_repack_a, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, nullptr,
+                       d_block_val, (sx::u32x4 *)h->d_bell_Af, nslots);
+    SX_HIP(hipDeviceSynchronize());
+    h->d_bell_col = d_block_col;
+    h->bell_M = M; h->bell_K = K; h->bell_W = ell_width;
+    return SEXTANS_OK;
+}
+
+int sextans_set_matrix_bell(sextans_handle_t h, int M, int K, int ell_width, const int *block_col,
+                            const uint16_t *block_val) {
+    if (!h || M <= 0 || K <= 0 || (M % 32) || (K % 32) || ell_width <= 0 || !block_col || !block_val)
+        return SEXTANS_ERR_INVALID;
+    SX_HIP(hipSetDevice(h->device));
+    const size_t nslots = (size_t)(M / 32) * (size_t)ell_width;
+    int *d_col = nullptr;
+    uint16_t *d_val = nullptr;
+    SX_HIP(hipMalloc((void **)&d_col, nslots * sizeof(int)));
+    SX_HIP(hipMalloc((void **)&d_val, nslots * 2048));
+    SX_HIP(hipMemcpy(d_col, block_col, nslots * sizeof(int), hipMemcpyHostToDevice));
+    SX_HIP(hipMemcpy(d_val, block_val, nslots * 2048, hipMemcpyHostToDevice));
+    int rc = sextans_set_matrix_bell_device(h, M, K, ell_width, d_col, d_val);
+    (void)hipFree(d_val);
+    if (rc) { (void)hipFree(d_col); return rc; }
+    h->d_bell_col_owned = d_col;
+    return SEXTANS_OK;
+}
+
+int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint16_t *d_B, int64_t ldb,
+                             float beta, const float *d_C_in, float *d_C_out, int64_t ldc, void *stream) {
+    if (!h || N <= 0 || (N % 32) || !d_B || !d_C_in || !d_C_out) return SEXTANS_ERR_INVALID;
+    if (!h->d_bell_Af) return SEXTANS_ERR_STATE;
+    if (ldb < h->bell_K || (ldb % 8) || ldc < h->bell_M) return SEXTANS_ERR_INVALID;
+    SX_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int kblocks = h->bell_K / 32, mblocks = h->bell_M / 32, ntiles = N / 32;
+    const size_t need = (size_t)h->bell_K * (size_t)N * 2;
+    if (h->bell_Bf_cap < need) {
+        if (h->d_bell_Bf) SX_HIP(hipFree(h->d_bell_Bf));
+        h->d_bell_Bf = nullptr; h->bell_Bf_cap = 0;
+        SX_HIP(hipMalloc(&h->d_bell_Bf, need));
+        h->bell_Bf_cap = need;
+    }
+    {
+        Prof p(h, &h->ev_repack, s);
+        const int64_t threads = (int64_t)kblocks * ntiles * 128;
+        hipLaunchKernelGGL(sx::bell_repack_b, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_B,
+                           ldb, (sx::u32x4 *)h->d_bell_Bf, kblocks, ntiles);
+    }
+    {
+        Prof p(h, &h->ev_kernel, s);
+        const auto *Af = (const sx::bf16x8 *)h->d_bell_Af;
+        const auto *Bf = (const sx::bf16x8 *)h->d_bell_Bf;
+#define SX_BELL(NSUB)                                                                                  \
+    {                                                                                                  \
+        const int64_t waves = (int64_t)mblocks * (ntiles / NSUB);                                      \
+        hipLaunchKernelGGL((sx::spmm_bell_mfma<NSUB>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, \
+                           h->d_bell_col, Af, Bf, d_C_in, d_C_out, ldc, mblocks, h->bell_W, ntiles, alpha, \
+                           beta);                                                                      \
+    }
+        if (ntiles % 4 == 0) SX_BELL(4) else if (ntiles % 2 == 0) SX_BELL(2) else SX_BELL(1)
+#undef SX_BELL
+        h->last_kernel = "spmm_bell_mfma";
+    }
+    SX_HIP(hipGetLastError());
+    return SEXTANS_OK;
 }
 
 int sextans_profile_reset(sextans_handle_t h) {

@@ -56,6 +56,18 @@ struct Spec {
     uint64_t seed;
 };
 
+SX_HD uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    u = __float_as_uint(f);
+#else
+    memcpy(&u, &f, 4);
+#endif
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+constexpr uint64_t kBellSalt = 0x62656c6cULL;   // "bell"
+
 SX_HD int fem_neighbors(const Spec &sp, int node, int *nb) {
     const int x = node % sp.nx, y = (node / sp.nx) % sp.ny, z = node / (sp.nx * sp.ny);
     int n = 0;
@@ -202,6 +214,48 @@ int gen_device(int device, const Spec &sp, double mean, int r0, int r1, int **d_
     return SEXTANS_OK;
 }
 
+__global__ void k_uniform_bf16(uint16_t *dst, int64_t n, uint64_t seed) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = f32_to_bf16_rne(u01m1(rnd(seed, (uint64_t)i, 0x51)));
+}
+// block columns of one block row: ell_width distinct sorted values in [0, kblocks)
+__global__ void k_bell_cols(Spec sp, int mblocks, int ell_width, int *block_col) {
+    const int br = blockIdx.x * blockDim.x + threadIdx.x;
+    if (br >= mblocks) return;
+    int *c = block_col + (int64_t)br * ell_width;
+    for (int i = 0; i < ell_width; ++i) {
+        const int x = (int)mulhi64(rnd(sp.seed, (uint64_t)br, 1 + (uint64_t)i), (uint64_t)sp.K);
+        int p = i;
+        while (p > 0 && c[p - 1] > x) { c[p] = c[p - 1]; --p; }
+        c[p] = x;
+    }
+    for (int i = 1; i < ell_width; ++i)
+        if (c[i] <= c[i - 1]) c[i] = c[i - 1] + 1;
+    for (int i = ell_width - 1; i >= 0; --i) {
+        const int cap = sp.K - 1 - (ell_width - 1 - i);
+        if (c[i] > cap) c[i] = cap;
+    }
+}
+SX_HD uint16_t bell_value(uint64_t seed, int64_t slot, int e) {
+    return f32_to_bf16_rne(u01m1(rnd(seed ^ kBellSalt, (uint64_t)slot, (uint64_t)e)));
+}
+__global__ void k_bell_vals(uint64_t seed, int64_t nslots, uint16_t *val) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread = 8 consecutive values
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nslots * 128; i += stride) {
+        const int64_t slot = i >> 7;
+        const int e0 = (int)(i & 127) * 8;
+        uint16_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bell_value(seed, slot, e0 + e);
+        uint4 w;
+        w.x = v[0] | ((uint32_t)v[1] << 16); w.y = v[2] | ((uint32_t)v[3] << 16);
+        w.z = v[4] | ((uint32_t)v[5] << 16); w.w = v[6] | ((uint32_t)v[7] << 16);
+        *reinterpret_cast<uint4 *>(val + i * 8) = w;
+    }
+}
+
 bool fem_ok(int nx, int ny, int nz, int dof) {
     return nx > 0 && ny > 0 && nz > 0 && dof > 0 && dof <= 8 &&
            (int64_t)nx * ny * nz * dof <= 0x7fffffffLL;
@@ -245,6 +299,74 @@ int sextans_gen_fem3d_device(int device, int nx, int ny, int nz, int dof, uint64
     if (r0 < 0 || r1 < r0 || r1 > M) return SEXTANS_ERR_INVALID;
     const Spec sp{1, M, 0, nx, ny, nz, dof, seed};
     return gen_device(device, sp, 1.0, r0, r1, d_row_ptr, d_col_idx, d_val, nnz);
+}
+
+int sextans_gen_bell_host(int M, int K, int ell_width, uint64_t seed, int **block_col, uint16_t **block_val) {
+    if (M <= 0 || K <= 0 || M % 32 || K % 32 || ell_width <= 0 || ell_width > K / 32 || !block_col || !block_val)
+        return SEXTANS_ERR_INVALID;
+    const int mb = M / 32, kb = K / 32;
+    const int64_t nslots = (int64_t)mb * ell_width;
+    int *c = (int *)malloc(sizeof(int) * (size_t)nslots);
+    uint16_t *v = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)nslots * 1024);
+    if (!c || !v) { free(c); free(v); return SEXTANS_ERR_ALLOC; }
+    for (int br = 0; br < mb; ++br) {
+        int *row = c + (int64_t)br * ell_width;
+        for (int i = 0; i < ell_width; ++i) {
+            const int x = (int)mulhi64(rnd(seed, (uint64_t)br, 1 + (uint64_t)i), (uint64_t)kb);
+            int p = i;
+            while (p > 0 && row[p - 1] > x) { row[p] = row[p - 1]; --p; }
+            row[p] = x;
+        }
+        for (int i = 1; i < ell_width; ++i)
+            if (row[i] <= row[i - 1]) row[i] = row[i - 1] + 1;
+        for (int i = ell_width - 1; i >= 0; --i) {
+            const int cap = kb - 1 - (ell_width - 1 - i);
+            if (row[i] > cap) row[i] = cap;
+        }
+    }
+    for (int64_t sl = 0; sl < nslots; ++sl)
+        for (int e = 0; e < 1024; ++e) v[sl * 1024 + e] = bell_value(seed, sl, e);
+    *block_col = c; *block_val = v;
+    return SEXTANS_OK;
+}
+
+int sextans_gen_bell_device(int device, int M, int K, int ell_width, uint64_t seed, int **d_block_col,
+                            uint16_t **d_block_val) {
+    if (M <= 0 || K <= 0 || M % 32 || K % 32 || ell_width <= 0 || ell_width > K / 32 || !d_block_col ||
+        !d_block_val)
+        return SEXTANS_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SEXTANS_ERR_NO_DEVICE;
+    SY_HIP(hipSetDevice(device));
+    const int mb = M / 32, kb = K / 32;
+    const int64_t nslots = (int64_t)mb * ell_width;
+    int *c = nullptr;
+    uint16_t *v = nullptr;
+    SY_HIP(hipMalloc((void **)&c, sizeof(int) * (size_t)nslots));
+    SY_HIP(hipMalloc((void **)&v, sizeof(uint16_t) * (size_t)nslots * 1024));
+    const Spec sp{0, kb, 0, 0, 0, 0, 0, seed};
+    hipLaunchKernelGGL(k_bell_cols, dim3((unsigned)((mb + 255) / 256)), dim3(256), 0, 0, sp, mb, ell_width, c);
+    hipLaunchKernelGGL(k_bell_vals, dim3(65536), dim3(256), 0, 0, seed, nslots, v);
+    SY_HIP(hipDeviceSynchronize());
+    *d_block_col = c; *d_block_val = v;
+    return SEXTANS_OK;
+}
+
+int sextans_gen_uniform_bf16_host(uint16_t *dst, int64_t n, uint64_t seed) {
+    if (!dst || n < 0) return SEXTANS_ERR_INVALID;
+    for (int64_t i = 0; i < n; ++i) dst[i] = f32_to_bf16_rne(u01m1(rnd(seed, (uint64_t)i, 0x51)));
+    return SEXTANS_OK;
+}
+
+int sextans_gen_uniform_bf16_device(int device, uint16_t *d_dst, int64_t n, uint64_t seed, void *stream) {
+    if (!d_dst || n < 0) return SEXTANS_ERR_INVALID;
+    SY_HIP(hipSetDevice(device));
+    if (n == 0) return SEXTANS_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_uniform_bf16, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_dst, n, seed);
+    SY_HIP(hipGetLastError());
+    return SEXTANS_OK;
 }
 
 int sextans_gen_uniform_host(float *dst, int64_t n, uint64_t seed) {

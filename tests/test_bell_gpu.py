@@ -1,0 +1,104 @@
+"""Blocked-ELL bf16 MFMA path (BASELINE config 5).  The reference has no such path, so parity here is
+UNPINNED by the reference: the checker is our fp32 CPU restatement on the same bf16 inputs plus a
+float64 evaluation.  Tolerance (stated): |gpu - f64| <= 4e-6 * sum|a*b| + 1e-6*|beta*c|  -- fp32
+accumulation of exact bf16 products; the MFMA's in-instruction summation order is hardware-defined,
+so bit equality with a sequential CPU sum is not expected."""
+import numpy as np
+import pytest
+
+
+def bf16_to_f32(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def f64_reference(M, K, N, W, bcol, bval, B16, alpha, beta, C0):
+    A = np.zeros((M, K), np.float64)
+    blocks = bf16_to_f32(bval).reshape(M // 32, W, 32, 32).astype(np.float64)
+    for br in range(M // 32):
+        for s in range(W):
+            bc = bcol[br * W + s]
+            if bc >= 0:
+                A[br * 32:(br + 1) * 32, bc * 32:(bc + 1) * 32] += blocks[br, s]
+    Bm = bf16_to_f32(B16).reshape(N, K).T.astype(np.float64)
+    Cm = C0.reshape(N, M).T.astype(np.float64)
+    out = alpha * (A @ Bm) + beta * Cm
+    asum = np.abs(A) @ np.abs(Bm)
+    return out.T.reshape(-1), asum.T.reshape(-1)
+
+
+def test_bell_host_generator_properties(sx):
+    from sextans_amd import api
+    M, K, W = 512, 2048, 7
+    c, v = api.gen_bell_host(M, K, W, 5)
+    c = c.reshape(M // 32, W)
+    assert c.min() >= 0 and c.max() < K // 32 and np.all(np.diff(c, axis=1) > 0)
+    f = bf16_to_f32(v)
+    assert f.min() >= -1 and f.max() <= 1 and abs(f.mean()) < 0.01
+    c2, v2 = api.gen_bell_host(M, K, W, 5)
+    assert np.array_equal(c.reshape(-1), c2) and np.array_equal(v, v2)
+    c3, _ = api.gen_bell_host(64, 64, 2, 1)          # tiny K/32 = 2 == ell_width: columns must be [0,1]
+    assert np.array_equal(c3.reshape(2, 2), [[0, 1], [0, 1]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,W", [(256, 512, 128, 5), (64, 64, 32, 2), (512, 1024, 256, 9), (96, 320, 64, 3),
+                                     (128, 256, 96, 4)])
+def test_bell_mfma_vs_cpu_restatement(engine, oracle, sx, M, K, N, W):
+    import torch
+    from sextans_amd import api
+    rs = np.random.RandomState(M + N)
+    bcol, bval = api.gen_bell_host(M, K, W, 5)
+    if W >= 4:                                          # some empty slots (-1) in the ELL structure
+        bcol = bcol.copy().reshape(M // 32, W)
+        bcol[::2, -1] = -1
+        bcol[1, 0] = -1
+        bcol = bcol.reshape(-1)
+    B16 = api.gen_uniform_bf16_host(K * N, 6)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    alpha, beta = np.float32(0.85), np.float32(-2.06)
+    want32 = C0.copy()
+    oracle.bell_spmm(M, K, N, W, bcol, bval, B16, alpha, beta, want32)
+    want64, asum = f64_reference(M, K, N, W, bcol, bval, B16, float(alpha), float(beta), C0)
+    engine.set_matrix_bell(M, K, W, bcol, bval)
+    dB = torch.from_numpy(B16.view(np.int16)).cuda()
+    dCin = torch.from_numpy(C0).cuda()
+    dC = torch.zeros(M * N, device="cuda")
+    engine.spmm_bell_device(N, alpha, dB.data_ptr(), K, beta, dCin.data_ptr(), dC.data_ptr(), M,
+                            torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert engine.last_kernel() == "spmm_bell_mfma"
+    got = dC.cpu().numpy().astype(np.float64)
+    tol = 4e-6 * asum + 1e-6 * np.abs(float(beta) * C0) + 1e-30
+    assert np.all(np.abs(got - want64) <= tol), float(np.max(np.abs(got - want64) / tol))
+    assert np.all(np.abs(want32.astype(np.float64) - want64) <= tol)        # the fp32 oracle is inside the same band
+    rel = np.linalg.norm(got - want64) / np.linalg.norm(want64)
+    assert rel < 1e-6
+    # transpose-detecting: asymmetric inputs above; also in-place C (C_in == C_out)
+    dC2 = dCin.clone()
+    engine.spmm_bell_device(N, alpha, dB.data_ptr(), K, beta, dC2.data_ptr(), dC2.data_ptr(), M,
+                            torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(dC2, dC)
+
+
+@pytest.mark.gpu
+def test_bell_device_generator_matches_host(engine, sx):
+    import ctypes as C
+    import torch
+    from sextans_amd import api
+    M, K, W = 1024, 4096, 11
+    hc, hv = api.gen_bell_host(M, K, W, 5)
+    dc, dv = api.gen_bell_device(0, M, K, W, 5)
+    try:
+        hip = C.CDLL("libamdhip64.so.7")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        tc = torch.empty(len(hc), dtype=torch.int32, device="cuda")
+        tv = torch.empty(len(hv), dtype=torch.int16, device="cuda")
+        assert hip.hipMemcpy(tc.data_ptr(), dc, len(hc) * 4, 3) == 0 and hip.hipMemcpy(tv.data_ptr(), dv, len(hv) * 2, 3) == 0
+        assert np.array_equal(tc.cpu().numpy(), hc) and np.array_equal(tv.cpu().numpy().view(np.uint16), hv)
+    finally:
+        api.device_free(0, dc); api.device_free(0, dv)
+    t = torch.empty(10000, dtype=torch.int16, device="cuda")
+    api.gen_uniform_bf16_device(0, t.data_ptr(), 10000, 6, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy().view(np.uint16), api.gen_uniform_bf16_host(10000, 6))
