@@ -103,14 +103,21 @@ def main():
     eng.set_matrix_csr_device(m_loc, K, nnz_loc, d_rp, d_ci, d_v)
     cin_ptr = Cin.data_ptr() + 4 * r0
     cout_ptr = Cout.data_ptr() + 4 * r0
+    # N > 1: the rank's slab is written packed (ldc_out = rows per rank) into its slot of a staging
+    # buffer, ONE RCCL all-gather moves all slabs, a local strided copy writes column-major C_out.
+    sg = sxd.SlabGather(M, N, ranges, rank, dev) if world > 1 else None
 
     def compute():
-        eng.spmm_device(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr, cout_ptr, M, stream)
+        if sg is None:
+            eng.spmm_device(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr, cout_ptr, M, stream)
+        else:
+            eng.spmm_device2(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr, M, sg.local_ptr(), sg.lmax, stream)
 
     def step():
         compute()
-        if world > 1:
-            sxd.all_gather_c(Cout, M, N, ranges, rank)
+        if sg is not None:
+            sg.gather()
+            sg.unpack_into(Cout)
 
     def barrier():
         if world > 1:

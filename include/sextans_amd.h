@@ -134,6 +134,12 @@ int sextans_spmm_host(sextans_handle_t h, int N, float alpha, const float *B, fl
 int sextans_spmm_device(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
                         float beta, const float *d_C_in, float *d_C_out, int64_t ldc, void *stream);
 
+/* Same with separate leading dimensions for C_in and C_out (multi-GPU: a rank reads its rows of the
+ * full column-major C_in, ldc_in = M, and writes a packed M_local x N slab, ldc_out = M_local). */
+int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
+                         float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out,
+                         int64_t ldc_out, void *stream);
+
 /* One-shot convenience with exactly cpu_spmm_CSR's argument list (sparse_helper.h:262-272):
  * create + upload + run + download + destroy on device 0. */
 int sextans_spmm_csr(int M, int N, int K, int NNZ, float ALPHA, const int *CSRRowPtr,

@@ -84,6 +84,8 @@ def lib():
                                     C.c_int, C.POINTER(C.c_double)]
     L.sextans_spmm_device.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64,
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.sextans_spmm_device2.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
+                                       C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     L.sextans_spmm_csr.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _i32p, _i32p,
                                    _f32p, _f32p, C.c_float, _f32p]
     L.sextans_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
@@ -275,6 +277,10 @@ class Engine:
     def spmm_bell_device(self, N, alpha, d_B_bf16, ldb, beta, d_C_in, d_C_out, ldc, stream=None):
         _check(lib().sextans_spmm_bell_device(self._h, N, alpha, d_B_bf16, ldb, beta, d_C_in, d_C_out, ldc,
                                               stream), "spmm_bell_device")
+
+    def spmm_device2(self, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out, ldc_out, stream=None):
+        _check(lib().sextans_spmm_device2(self._h, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out,
+                                          ldc_out, stream), "spmm_device2")
 
     def profile_read(self):
         k, n, r = C.c_double(), C.c_int64(), C.c_double()

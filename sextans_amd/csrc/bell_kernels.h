@@ -51,8 +51,8 @@ __global__ __launch_bounds__(256) void bell_repack_b(const unsigned short *__res
 template <int NSUB>
 __global__ __launch_bounds__(256) void spmm_bell_mfma(
     const int *__restrict__ block_col, const bf16x8 *__restrict__ Af, const bf16x8 *__restrict__ Bf,
-    const float *Cin, float *Cout, int64_t ldc, int mblocks, int ell_width, int ntiles, float alpha,
-    float beta) {
+    const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc, int mblocks, int ell_width, int ntiles,
+    float alpha, float beta) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     const int ngroups = ntiles / NSUB;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void spmm_bell_mfma(
             const int nl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int64_t o = m + (int64_t)((ng * NSUB + t) * 32 + nl) * ldc;
             const float t0 = alpha * acc[t][r];
-            const float t1 = beta * Cin[o];
+            const float t1 = beta * Cin[m + (int64_t)((ng * NSUB + t) * 32 + nl) * ldc_in];
             Cout[o] = t0 + t1;
         }
     }

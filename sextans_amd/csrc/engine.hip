@@ -157,7 +157,7 @@ void launch_repack(const float *dB, int64_t ldb, float *dBp, int K, int col_base
 }
 
 template <int LPR>
-void launch_rowgroup(sextans_engine *h, const float *dBp, const float *dCin, float *dCout,
+void launch_rowgroup(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout,
                      int64_t ldc, int ntiles, float alpha, float beta, hipStream_t s) {
     constexpr int RB = sx::kBlock / LPR;
     constexpr int CH = 2048;
@@ -167,8 +167,8 @@ void launch_rowgroup(sextans_engine *h, const float *dBp, const float *dCin, flo
     const int xcd = (int)h->opt_xcd;
 #define SX_LAUNCH(EX, ST)                                                                       \
     hipLaunchKernelGGL((sx::spmm_csr_rowgroup<LPR, CH, EX, ST>), dim3(nwg), dim3(sx::kBlock), 0, \
-                       s, h->d_rp, h->d_ci, h->d_v, dBp, pstride, dCin, dCout, ldc, h->M, ntiles, \
-                       nrowblk, alpha, beta, xcd)
+                       s, h->d_rp, h->d_ci, h->d_v, dBp, pstride, dCin, ldc_in, dCout, ldc, h->M, \
+                       ntiles, nrowblk, alpha, beta, xcd)
     if (h->opt_exact) { if (h->opt_stage) SX_LAUNCH(true, true); else SX_LAUNCH(true, false); }
     else              { if (h->opt_stage) SX_LAUNCH(false, true); else SX_LAUNCH(false, false); }
 #undef SX_LAUNCH
@@ -264,8 +264,8 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
 }
 
 template <int LPR>
-void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, float *dCout, int64_t ldc,
-                  int ntiles, float alpha, float beta, hipStream_t s) {
+void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout,
+                  int64_t ldc, int ntiles, float alpha, float beta, hipStream_t s) {
     constexpr int RB = sx::kBlock / LPR;
     constexpr int NT = 4 * LPR;
     const unsigned nwg = (unsigned)h->plan_nblk * (unsigned)ntiles;
@@ -278,13 +278,13 @@ void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, float 
     if (h->opt_exact)
         hipLaunchKernelGGL((sx::spmm_csr_panel<LPR, true>), dim3(nwg), dim3(sx::kBlock), lds, s, h->d_rp,
                            h->d_row_off, h->d_lidx, h->d_pcol32, h->d_pval, h->d_blk_row, h->d_dict_ptr,
-                           h->d_dict, dBp, pstride, dCin, dCout, ldc, ntiles, h->plan_nblk, alpha, beta,
-                           xcd, panel_floats);
+                           h->d_dict, dBp, pstride, dCin, ldc_in, dCout, ldc, ntiles, h->plan_nblk, alpha,
+                           beta, xcd, panel_floats);
     else
         hipLaunchKernelGGL((sx::spmm_csr_panel<LPR, false>), dim3(nwg), dim3(sx::kBlock), lds, s, h->d_rp,
                            h->d_row_off, h->d_lidx, h->d_pcol32, h->d_pval, h->d_blk_row, h->d_dict_ptr,
-                           h->d_dict, dBp, pstride, dCin, dCout, ldc, ntiles, h->plan_nblk, alpha, beta,
-                           xcd, panel_floats);
+                           h->d_dict, dBp, pstride, dCin, ldc_in, dCout, ldc, ntiles, h->plan_nblk, alpha,
+                           beta, xcd, panel_floats);
 }
 
 }  // namespace
@@ -400,9 +400,15 @@ int sextans_set_matrix_csr_device(sextans_handle_t h, int M, int K, int64_t nnz,
 int sextans_spmm_device(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
                         float beta, const float *d_C_in, float *d_C_out, int64_t ldc,
                         void *stream) {
+    return sextans_spmm_device2(h, N, alpha, d_B, ldb, beta, d_C_in, ldc, d_C_out, ldc, stream);
+}
+
+int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
+                         float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out, int64_t ldc,
+                         void *stream) {
     if (!h || N <= 0 || (N % 8) != 0 || !d_B || !d_C_in || !d_C_out) return SEXTANS_ERR_INVALID;
     if (!h->d_rp) return SEXTANS_ERR_STATE;
-    if (ldb < h->K || ldc < h->M) return SEXTANS_ERR_INVALID;
+    if (ldb < h->K || ldc < h->M || ldc_in < h->M) return SEXTANS_ERR_INVALID;
     SX_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     if (h->M == 0) return SEXTANS_OK;
@@ -442,21 +448,21 @@ int sextans_spmm_device(sextans_handle_t h, int N, float alpha, const float *d_B
         Prof p(h, &h->ev_kernel, s);
         for (const Seg &g : plan) {
             const float *bp = h->d_Bp + (size_t)h->K * (size_t)g.col0;
-            const float *cin = d_C_in + (int64_t)g.col0 * ldc;
+            const float *cin = d_C_in + (int64_t)g.col0 * ldc_in;
             float *cout = d_C_out + (int64_t)g.col0 * ldc;
             const bool panel_here = use_panel && g.width == W;   // the plan is built for width W
             switch (g.width) {
                 case 32:
-                    if (panel_here) launch_panel<8>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s);
-                    else launch_rowgroup<8>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s);
+                    if (panel_here) launch_panel<8>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
+                    else launch_rowgroup<8>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
                     break;
                 case 16:
-                    if (panel_here) launch_panel<4>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s);
-                    else launch_rowgroup<4>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s);
+                    if (panel_here) launch_panel<4>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
+                    else launch_rowgroup<4>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
                     break;
                 default:
-                    if (panel_here) launch_panel<2>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s);
-                    else launch_rowgroup<2>(h, bp, cin, cout, ldc, g.ntiles, alpha, beta, s);
+                    if (panel_here) launch_panel<2>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
+                    else launch_rowgroup<2>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
                     break;
             }
         }
@@ -574,8 +580,8 @@ int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint1
     {                                                                                                  \
         const int64_t waves = (int64_t)mblocks * (ntiles / NSUB);                                      \
         hipLaunchKernelGGL((sx::spmm_bell_mfma<NSUB>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, \
-                           h->d_bell_col, Af, Bf, d_C_in, d_C_out, ldc, mblocks, h->bell_W, ntiles, alpha, \
-                           beta);                                                                      \
+                           h->d_bell_col, Af, Bf, d_C_in, ldc, d_C_out, ldc, mblocks, h->bell_W, ntiles,    \
+                           alpha, beta);                                                                      \
     }
         if (ntiles % 4 == 0) SX_BELL(4) else if (ntiles % 2 == 0) SX_BELL(2) else SX_BELL(1)
 #undef SX_BELL

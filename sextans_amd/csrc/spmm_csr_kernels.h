@@ -82,8 +82,8 @@ __device__ __forceinline__ float epilogue(float alpha, float acc, float beta, fl
 template <int LPR, int CH, bool EXACT, bool STAGE>
 __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
     const int *__restrict__ row_ptr, const int *__restrict__ col_idx, const float *__restrict__ val,
-    const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, float *Cout, int64_t ldc,
-    int M, int ntiles, int nrowblk, float alpha, float beta, int use_xcd_remap) {
+    const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout,
+    int64_t ldc, int M, int ntiles, int nrowblk, float alpha, float beta, int use_xcd_remap) {
     constexpr int NT = 4 * LPR;
     constexpr int RB = kBlock / LPR;
     constexpr int TS = RB + 1;   // padded row stride of the transposed C tile in LDS
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
         const int orow = row0 + r;
         if (orow < M) {
             const int64_t o = (int64_t)orow + (col0 + n) * ldc;
-            Cout[o] = epilogue<EXACT>(alpha, s_c[n * TS + r], beta, Cin[o]);
+            Cout[o] = epilogue<EXACT>(alpha, s_c[n * TS + r], beta, Cin[(int64_t)orow + (col0 + n) * ldc_in]);
         }
     }
 }
@@ -218,8 +218,8 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     const unsigned short *__restrict__ p_idx16, const int *__restrict__ p_col32,
     const float *__restrict__ p_val, const int *__restrict__ blk_row,
     const int *__restrict__ dict_ptr, const int *__restrict__ dict, const float *__restrict__ Bp,
-    int64_t panel_stride, const float *Cin, float *Cout, int64_t ldc, int ntiles, int nblk,
-    float alpha, float beta, int use_xcd_remap, int panel_floats) {
+    int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc, int ntiles,
+    int nblk, float alpha, float beta, int use_xcd_remap, int panel_floats) {
     constexpr int NT = 4 * LPR;
     constexpr int RB = kBlock / LPR;
     constexpr int TS = RB + 1;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     for (int i = 0; i < OPT; ++i) {
         const int e = tid + i * kBlock;
         const int n = e / RB, r = e % RB;
-        cin[i] = Cin[(int64_t)min(row0 + r, row1 - 1) + (col0 + n) * ldc];
+        cin[i] = Cin[(int64_t)min(row0 + r, row1 - 1) + (col0 + n) * ldc_in];
     }
 
     if (use_dict) {

@@ -48,7 +48,8 @@ def slice_csr(row_ptr, col_idx, val, r0, r1):
 
 
 def all_gather_c(C_full, M, N, ranges, rank, group=None, _force=False):
-    """Complete the column-major M x N matrix `C_full` (flat torch tensor, CPU or GPU) on every rank.
+    """(In-place per-column form; see SlabGather for the single-collective form bench.py uses.)
+    Complete the column-major M x N matrix `C_full` (flat torch tensor, CPU or GPU) on every rank.
 
     On entry rank g has written rows ranges[g] of every column; on return all rows are present.
     C is column major, so a row slab is strided: the gather is done per column, in place (each
@@ -95,3 +96,46 @@ def all_gather_c(C_full, M, N, ranges, rank, group=None, _force=False):
     for g, (a, b) in enumerate(ranges):
         if g != rank and b > a:
             cols[:, a:b] = recv[g, :, :b - a]
+
+
+class SlabGather:
+    """All-gather of C as ONE large collective (the form bench.py uses at N > 1).
+
+    Column-major C makes a rank's row slab strided, and N per-column collectives of a few MB each
+    are latency-bound on xGMI.  Instead every rank's SpMM writes a PACKED column-major slab
+    (`ldc_out = lmax`, pointer `local_ptr()`) into its slot of a staging buffer S[world][N][lmax];
+    a single in-place all_gather_into_tensor moves 4*N*lmax bytes per rank (32 MB for BASELINE
+    config 4 at 8 GPUs); `unpack_into` then writes the full column-major C with one strided copy
+    (HBM-local, ~0.1 ms for 256 MB).  Uneven (nnz-balanced) ranges are padded to the longest.
+    """
+
+    def __init__(self, M, N, ranges, rank, device, dtype=None):
+        import torch
+        self.M, self.N, self.ranges, self.rank = M, N, list(ranges), rank
+        self.world = len(self.ranges)
+        self.lens = [b - a for a, b in self.ranges]
+        self.lmax = max(max(self.lens), 1)
+        self.even = len(set(self.lens)) == 1 and self.lens[0] * self.world == M
+        self.S = torch.zeros((self.world, N, self.lmax), dtype=dtype or torch.float32, device=device)
+
+    def local_slab(self):
+        """(N, lmax) view = column-major lmax x N slab of this rank (leading dimension lmax)."""
+        return self.S[self.rank]
+
+    def local_ptr(self):
+        return self.S[self.rank].data_ptr()
+
+    def gather(self, group=None, _force=False):
+        import torch.distributed as dist
+        if self.world > 1 or _force:
+            dist.all_gather_into_tensor(self.S.view(-1), self.S[self.rank].reshape(-1), group=group)
+
+    def unpack_into(self, C_full):
+        """C_full: flat column-major M x N tensor on the same device."""
+        cols = C_full.view(self.N, self.M)
+        if self.even:
+            cols.view(self.N, self.world, self.lmax).copy_(self.S.permute(1, 0, 2))
+        else:
+            for g, (a, b) in enumerate(self.ranges):
+                if b > a:
+                    cols[:, a:b] = self.S[g, :, :b - a]

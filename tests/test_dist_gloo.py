@@ -49,6 +49,13 @@ def _worker(rank, world, port, mode, q):
         t = torch.from_numpy(Cfull)
         sxd.all_gather_c(t, M, N, ranges, rank)
         ok = np.array_equal(t.numpy().view(np.uint32), want.view(np.uint32))
+        # single-collective form: the slab is written packed (ldc_out = lmax) into the staging buffer
+        sg = sxd.SlabGather(M, N, ranges, rank, torch.device("cpu"))
+        sg.local_slab()[:, :r1 - r0] = torch.from_numpy(slab.reshape(N, r1 - r0))
+        sg.gather()
+        t2 = torch.full((M * N,), float("nan"))
+        sg.unpack_into(t2)
+        ok = ok and np.array_equal(t2.numpy().view(np.uint32), want.view(np.uint32))
         q.put((rank, ok, ranges))
     finally:
         dist.destroy_process_group()

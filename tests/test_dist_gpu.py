@@ -37,11 +37,24 @@ def test_nccl_allgather_paths_single_rank(engine, oracle):
             sxd.all_gather_c(dC, M, N, ranges, 0, _force=True)          # even: coalesced in-place columns
         torch.cuda.synchronize()
         assert np.array_equal(dC.cpu().numpy().view(np.uint32), want.view(np.uint32))
-        # uneven form: one packed collective (world 1 => a single range shorter than M is not valid, so
-        # call the packed path with M split logically: ranges must cover [0,M); force lens != M*world)
-        dC2 = dC.clone()
-        sxd.all_gather_c(dC2[: (M - 1) * 0 + M * N], M, N, [(0, M)], 0, _force=True)
+        # single-collective form used by bench.py at N > 1: packed slab (ldc_out = lmax) written straight
+        # into the staging buffer by the kernel, one all_gather_into_tensor, strided unpack
+        for ranges in ([(0, M)], ):
+            sg = sxd.SlabGather(M, N, ranges, 0, torch.device("cuda", 0))
+            engine.spmm_device2(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr(), M, sg.local_ptr(), sg.lmax, st)
+            sg.gather(_force=True)
+            out = torch.full((M * N,), float("nan"), device="cuda")
+            sg.unpack_into(out)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        # a slab of rows [r0, r1) of a taller C_in (ldc_in = M) into a packed slab (ldc_out = r1 - r0)
+        r0, r1 = 100, 420
+        lrp, lci, lv = sxd.slice_csr(rp, ci, v, r0, r1)
+        engine.set_matrix_csr(r1 - r0, K, lrp, lci, lv)
+        slab = torch.full(((r1 - r0) * N,), float("nan"), device="cuda")
+        engine.spmm_device2(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr() + 4 * r0, M, slab.data_ptr(), r1 - r0, st)
         torch.cuda.synchronize()
-        assert torch.equal(dC2, dC)
+        got = slab.cpu().numpy().reshape(N, r1 - r0)
+        assert np.array_equal(got.view(np.uint32), want.reshape(N, M)[:, r0:r1].copy().view(np.uint32))
     finally:
         dist.destroy_process_group()
