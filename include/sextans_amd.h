@@ -89,6 +89,38 @@ int sextans_selfcheck_golden(int M, int N, int K, float alpha, const int *row_pt
                              const int *col_idx, const float *val, const float *B, float beta,
                              float *C_inout);
 
+/* ------------------------------------------------------------------ packed row-bucketed form of A
+ *
+ * The engine's counterpart of the reference's packed non-zero stream (generate_edge_list_for_all_PEs
+ * + edge_list_64bit, sparse_helper.h:292-473; 64-bit words with a window-local 14-bit column): rows
+ * bucketed into blocks of <= 256/lanes_per_row rows whose distinct columns fit the 36 KiB LDS panel;
+ * per block an ascending dictionary; per non-zero a 16-bit dictionary index (or the 32-bit column in
+ * blocks without reuse) + fp32 value, every row starting on a 4-entry boundary.  sextans_set_matrix_*
+ * builds the same arrays internally; these entry points expose them (inspection, tests, reuse). */
+typedef struct sextans_packed {
+    int M, K;
+    int64_t nnz;
+    int lanes_per_row;            /* 2, 4 or 8 (N tile = 4 * lanes) */
+    int nblk;                     /* row blocks */
+    int *blk_row;                 /* nblk + 1: block b owns rows [blk_row[b], blk_row[b+1]) */
+    int *dict_ptr;                /* nblk + 1 offsets into dict; empty range = "direct" block */
+    int *dict;                    /* distinct columns of each dictionary block, ascending */
+    int *row_off;                 /* M + 1: first stream entry of each row (multiple of 4) */
+    uint16_t *idx16;              /* stream_len: dictionary index per entry (dictionary blocks) */
+    int *col32;                   /* stream_len: column per entry (direct blocks) */
+    float *val;                   /* stream_len: value per entry (0 in padding) */
+    int64_t stream_len;
+    int max_dict;                 /* largest dictionary */
+    int64_t nnz_in_panel_blocks;  /* non-zeros covered by dictionary blocks */
+} sextans_packed;
+
+/* min_reuse_x100: a block gets a dictionary only if nnz >= min_reuse_x100/100 * distinct columns. */
+int sextans_pack_csr(int M, int K, const int *row_ptr, const int *col_idx, const float *val,
+                     int lanes_per_row, int min_reuse_x100, sextans_packed *out);
+void sextans_packed_free(sextans_packed *p);
+/* Decoder: reconstructs col_idx[nnz], val[nnz] of the CSR matrix with row extents row_ptr. */
+int sextans_unpack_csr(const sextans_packed *p, const int *row_ptr, int *col_idx, float *val);
+
 /* ------------------------------------------------------------------ L1: the SpMM engine (HIP) */
 
 typedef struct sextans_engine *sextans_handle_t;

@@ -28,6 +28,16 @@ _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _lib = None
 
 
+class Packed(C.Structure):
+    """Mirror of struct sextans_packed (include/sextans_amd.h)."""
+    _fields_ = [("M", C.c_int), ("K", C.c_int), ("nnz", C.c_int64), ("lanes_per_row", C.c_int),
+                ("nblk", C.c_int), ("blk_row", C.POINTER(C.c_int)), ("dict_ptr", C.POINTER(C.c_int)),
+                ("dict", C.POINTER(C.c_int)), ("row_off", C.POINTER(C.c_int)),
+                ("idx16", C.POINTER(C.c_uint16)), ("col32", C.POINTER(C.c_int)),
+                ("val", C.POINTER(C.c_float)), ("stream_len", C.c_int64), ("max_dict", C.c_int),
+                ("nnz_in_panel_blocks", C.c_int64)]
+
+
 class SextansError(RuntimeError):
     def __init__(self, code, where=""):
         self.code = code
@@ -71,6 +81,10 @@ def lib():
     L.sextans_gflops.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_double]
     L.sextans_selfcheck_golden.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, _i32p, _i32p,
                                            _f32p, _f32p, C.c_float, _f32p]
+    L.sextans_pack_csr.argtypes = [C.c_int, C.c_int, _i32p, _i32p, _f32p, C.c_int, C.c_int, C.POINTER(Packed)]
+    L.sextans_packed_free.argtypes = [C.POINTER(Packed)]
+    L.sextans_packed_free.restype = None
+    L.sextans_unpack_csr.argtypes = [C.POINTER(Packed), _i32p, _i32p, _f32p]
     L.sextans_device_count.argtypes = [ip]
     L.sextans_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     L.sextans_destroy.argtypes = [C.c_void_p]
@@ -164,6 +178,30 @@ def CSC_2_CSR(M, K, NNZ, csc_col_ptr, csc_row_idx, csc_val):
                                     _buf(csc_row_idx, np.int32), _buf(csc_val, np.float32),
                                     rp, ci, cv), "csc_to_csr")
     return rp, ci[:NNZ].copy(), cv[:NNZ].copy()
+
+
+def pack_csr(M, K, row_ptr, col_idx, val, lanes_per_row=4, min_reuse_x100=400):
+    """Build the packed row-bucketed form (host); returns a dict of numpy arrays + scalars."""
+    L = lib()
+    P = Packed()
+    _check(L.sextans_pack_csr(M, K, _buf(row_ptr, np.int32), _buf(col_idx, np.int32), _buf(val, np.float32),
+                              lanes_per_row, min_reuse_x100, C.byref(P)), "pack_csr")
+    try:
+        nb, sl = P.nblk, P.stream_len
+        out = dict(M=P.M, K=P.K, nnz=P.nnz, lanes_per_row=P.lanes_per_row, nblk=nb, stream_len=sl,
+                   max_dict=P.max_dict, nnz_in_panel_blocks=P.nnz_in_panel_blocks,
+                   blk_row=_take(P.blk_row, nb + 1, np.int32), dict_ptr=_take(P.dict_ptr, nb + 1, np.int32),
+                   row_off=_take(P.row_off, M + 1, np.int32), idx16=_take(P.idx16, sl, np.uint16),
+                   col32=_take(P.col32, sl, np.int32), val=_take(P.val, sl, np.float32))
+        out["dict"] = _take(P.dict, int(out["dict_ptr"][-1]), np.int32)
+        # decode through the C decoder as well
+        ci = np.zeros(max(int(P.nnz), 1), np.int32)
+        va = np.zeros(max(int(P.nnz), 1), np.float32)
+        _check(L.sextans_unpack_csr(C.byref(P), _buf(row_ptr, np.int32), ci, va), "unpack_csr")
+        out["decoded_col_idx"], out["decoded_val"] = ci[:P.nnz], va[:P.nnz]
+        return out
+    finally:
+        L.sextans_packed_free(C.byref(P))
 
 
 def init_dense_B(K, N):

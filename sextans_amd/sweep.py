@@ -1,0 +1,86 @@
+"""SuiteSparse sweep harness: the paper-style evaluation loop over many .mtx
+files and N values -- what a user of the reference does by calling `sextans <A.mtx> <N>` in a shell
+loop (README.md:18,31) -- with one JSON record per (matrix, N).
+
+    python -m sextans_amd.sweep matrices/nasa4704/nasa4704.mtx more/*.mtx --n 8,16,32,64,128 --rp 50
+
+Each record: matrix name, M, K, nnz, N, kernel chosen by the dispatcher, device ms per SpMM
+(rp_time repeats, sextans-host.cpp:252 convention), GFLOP/s with the reference's formula
+2*N*(nnz+M) (sextans-host.cpp:255-260), algorithmic GB/s and fraction of the 8 TB/s HBM roofline
+(8*nnz + 4*(M+1) + 4*K*N + 8*M*N bytes), and -- with --check -- the reference's pass criterion
+(mismatch % < 2, sextans-host.cpp:272-282) against the host golden, like the CLI's self check.
+GPU only: there is no CPU path for the product computation.
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+
+from . import api
+
+HBM_PEAK_GBS = 8000.0
+
+
+def sweep(paths, n_values, rp_time=20, alpha=0.85, beta=-2.06, check=False, device=0, options=None, out=sys.stdout):
+    records = []
+    with api.Engine(device) as eng:
+        for k, v in (options or {}).items():
+            eng.set_option(k, v)
+        for path in paths:
+            name = os.path.splitext(os.path.basename(path))[0]
+            try:
+                rp, ci, va, M, K, nnz = api.read_suitsparse_matrix(path)
+            except api.SextansError as e:
+                rec = {"matrix": name, "error": str(e)}
+                records.append(rec); print(json.dumps(rec), file=out, flush=True)
+                continue
+            if M == 0 or K == 0:
+                continue
+            eng.set_matrix_csr(M, K, rp, ci, va)
+            for n in n_values:
+                N = api.round_up_n(n)
+                B = api.init_dense_B(K, N)
+                C0 = api.init_dense_C(M, N)
+                C = C0.copy()
+                ns = eng.spmm(N, alpha, B, beta, C, rp_time=rp_time)
+                sec = ns * 1e-9 / max(rp_time, 1)
+                by = 8 * nnz + 4 * (M + 1) + 4 * K * N + 8 * M * N
+                rec = {"matrix": name, "M": M, "K": K, "nnz": nnz, "N": N, "kernel": eng.last_kernel(),
+                       "ms": round(sec * 1e3, 6), "gflops": round(api.gflops(M, N, nnz, sec), 2),
+                       "alg_gbs": round(by / sec / 1e9, 2),
+                       "roofline_frac": round(by / sec / 1e9 / HBM_PEAK_GBS, 5)}
+                if check:
+                    gold = C0.copy()
+                    rc = api.lib().sextans_selfcheck_golden(M, N, K, alpha, rp, api._buf(ci, np.int32),
+                                                            api._buf(va, np.float32), B, beta, gold)
+                    mism, pct = api.verify(M, N, gold, C)
+                    rec.update(mismatch=int(mism), mismatch_pct=round(float(pct), 4), passed=bool(rc == 0 and pct < 2.0),
+                               bit_identical=bool(np.array_equal(gold.view(np.uint32), C.view(np.uint32))))
+                records.append(rec)
+                print(json.dumps(rec), file=out, flush=True)
+    return records
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("paths", nargs="+", help=".mtx files or globs")
+    ap.add_argument("--n", default="8,16,32,64,128", help="comma-separated N values (rounded up to 8)")
+    ap.add_argument("--rp", type=int, default=20, help="rp_time repeats per measurement")
+    ap.add_argument("--alpha", type=float, default=0.85)
+    ap.add_argument("--beta", type=float, default=-2.06)
+    ap.add_argument("--check", action="store_true", help="compare with the host golden (reference criterion)")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value")
+    a = ap.parse_args(argv)
+    paths = []
+    for p in a.paths:
+        paths.extend(sorted(glob.glob(p)) or [p])
+    opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.opt}
+    sweep(paths, [int(x) for x in a.n.split(",")], a.rp, a.alpha, a.beta, a.check, a.device, opts)
+
+
+if __name__ == "__main__":
+    main()
