@@ -136,7 +136,7 @@ int sextans_destroy(sextans_handle_t h);
 /* Tunables.  key: "kernel" (0 auto, 1 row-group gather, 2 LDS panel), "lanes_per_row"
  * (2/4/8, N-tile = 4*lanes), "stage_a" (0/1 stage the CSR stream through LDS), "xcd_remap"
  * (0/1), "exact" (1 = no FMA, reference rounding; 0 = allow FMA), "profile" (0/1 hipEvent
- * per-kernel timing), "panel_min_reuse_x100" (a row block uses the LDS panel when
+ * per-kernel timing), "phase_timing" (0/1, see sextans_phase_timing_read), "panel_min_reuse_x100" (a row block uses the LDS panel when
  * nnz >= value/100 * distinct columns; default 400).  Unknown keys -> SEXTANS_ERR_INVALID. */
 int sextans_set_option(sextans_handle_t h, const char *key, int64_t value);
 int sextans_get_option(sextans_handle_t h, const char *key, int64_t *value);
@@ -196,6 +196,11 @@ int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint1
 int sextans_profile_read(sextans_handle_t h, double *mean_kernel_ns, int64_t *launches,
                          double *mean_repack_ns);
 int sextans_profile_reset(sextans_handle_t h);
+
+/* Debug aid (option "phase_timing" = 1): wave cycles of the panel kernel's phases summed over a 1/128
+ * sample of workgroups: {meta+extents+first entries, dictionary->B rows->LDS, row streaming, C tile
+ * + epilogue, sampled waves, 0, 0, 0} since the option was set. */
+int sextans_phase_timing_read(sextans_handle_t h, int64_t out[8]);
 
 /* Name of the kernel the dispatcher last used (static string), for logs and rocprof matching. */
 const char *sextans_last_kernel(sextans_handle_t h);

@@ -105,6 +105,7 @@ def lib():
     L.sextans_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                        C.POINTER(C.c_double)]
     L.sextans_profile_reset.argtypes = [C.c_void_p]
+    L.sextans_phase_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.sextans_last_kernel.restype = C.c_char_p
     L.sextans_last_kernel.argtypes = [C.c_void_p]
     L.sextans_gen_csr_host.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_int, C.c_int,
@@ -325,6 +326,11 @@ class Engine:
         _check(lib().sextans_profile_read(self._h, C.byref(k), C.byref(n), C.byref(r)),
                "profile_read")
         return k.value, n.value, r.value
+
+    def phase_timing_read(self):
+        out = (C.c_int64 * 8)()
+        _check(lib().sextans_phase_timing_read(self._h, out), "phase_timing_read")
+        return list(out)
 
     def profile_reset(self):
         _check(lib().sextans_profile_reset(self._h), "profile_reset")

@@ -70,8 +70,10 @@ struct sextans_engine {
     void *d_bell_Af = nullptr;      // A blocks in MFMA fragment order (owned)
     void *d_bell_Bf = nullptr;      // B in fragment order (workspace)
     size_t bell_Bf_cap = 0;         // bytes
+    long long *d_dbg = nullptr;     // 8 counters for phase timing (option "phase_timing")
     // options
     int64_t opt_kernel = 0, opt_lpr = 4, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;
+    int64_t opt_phase_timing = 0;       // 1: panel kernel accumulates per-phase wave cycles (debug aid)
     int64_t opt_min_reuse_x100 = 400;   // a block uses the LDS panel if nnz >= 4 * distinct columns
     // profiling
     std::vector<EventPair> ev_kernel, ev_repack;
@@ -279,12 +281,12 @@ void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_
         hipLaunchKernelGGL((sx::spmm_csr_panel<LPR, true>), dim3(nwg), dim3(sx::kBlock), lds, s, h->d_rp,
                            h->d_row_off, h->d_lidx, h->d_pcol32, h->d_pval, h->d_blk_row, h->d_dict_ptr,
                            h->d_dict, dBp, pstride, dCin, ldc_in, dCout, ldc, ntiles, h->plan_nblk, alpha,
-                           beta, xcd, panel_floats);
+                           beta, xcd, panel_floats, (long long *)h->d_dbg);
     else
         hipLaunchKernelGGL((sx::spmm_csr_panel<LPR, false>), dim3(nwg), dim3(sx::kBlock), lds, s, h->d_rp,
                            h->d_row_off, h->d_lidx, h->d_pcol32, h->d_pval, h->d_blk_row, h->d_dict_ptr,
                            h->d_dict, dBp, pstride, dCin, ldc_in, dCout, ldc, ntiles, h->plan_nblk, alpha,
-                           beta, xcd, panel_floats);
+                           beta, xcd, panel_floats, (long long *)h->d_dbg);
 }
 
 }  // namespace
@@ -329,6 +331,7 @@ int sextans_destroy(sextans_handle_t h) {
     (void)hipFree(h->d_bell_Bf);
     (void)hipFree(h->d_Bp); (void)hipFree(h->d_B); (void)hipFree(h->d_Cin); (void)hipFree(h->d_Cout);
     sextans_profile_reset(h);
+    (void)hipFree(h->d_dbg);
     delete h;
     return SEXTANS_OK;
 }
@@ -341,6 +344,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "exact")) return &h->opt_exact;
     if (!strcmp(key, "profile")) return &h->opt_profile;
     if (!strcmp(key, "panel_min_reuse_x100")) return &h->opt_min_reuse_x100;
+    if (!strcmp(key, "phase_timing")) return &h->opt_phase_timing;
     return nullptr;
 }
 
@@ -350,6 +354,20 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
     if (!slot) return SEXTANS_ERR_INVALID;
     if (slot == &h->opt_lpr && value != 2 && value != 4 && value != 8) return SEXTANS_ERR_INVALID;
     *slot = value;
+    if (slot == &h->opt_phase_timing) {
+        (void)hipSetDevice(h->device);
+        if (value && !h->d_dbg && hipMalloc((void **)&h->d_dbg, 64) != hipSuccess) return SEXTANS_ERR_HIP;
+        if (h->d_dbg) (void)hipMemset(h->d_dbg, 0, 64);
+        if (!value && h->d_dbg) { (void)hipFree(h->d_dbg); h->d_dbg = nullptr; }
+    }
+    return SEXTANS_OK;
+}
+
+int sextans_phase_timing_read(sextans_handle_t h, int64_t out[8]) {
+    if (!h || !out || !h->d_dbg) return SEXTANS_ERR_STATE;
+    SX_HIP(hipSetDevice(h->device));
+    SX_HIP(hipDeviceSynchronize());
+    SX_HIP(hipMemcpy(out, h->d_dbg, 64, hipMemcpyDeviceToHost));
     return SEXTANS_OK;
 }
 
@@ -403,6 +421,38 @@ int sextans_spmm_device(sextans_handle_t h, int N, float alpha, const float *d_B
     return sextans_spmm_device2(h, N, alpha, d_B, ldb, beta, d_C_in, ldc, d_C_out, ldc, stream);
 }
 
+namespace {
+struct Seg { int width, col0, ntiles; };
+
+// Everything that may allocate or run host-side preprocessing for an N-column SpMM: B-panel workspace,
+// N-tile plan, and (for kernel != 1) the packed row-bucketed form of A.  Idempotent; called by
+// sextans_spmm_device2 and, ahead of the timed region, by sextans_spmm_host.
+int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_panel) {
+    if (int rc = ensure(&h->d_Bp, &h->Bp_cap, (size_t)h->K * (size_t)N)) return rc;
+    // main tile width: 4*lanes_per_row, but never wider than N itself (N = 8 -> 2 lanes per row); then
+    // 16- and 8-wide tiles for the remainder (N is a multiple of 8, the reference's N-tile
+    // granularity: sextans.cpp:57-60).
+    int lpr = (int)h->opt_lpr;
+    while (lpr > 2 && 4 * lpr > N) lpr /= 2;
+    W = 4 * lpr;
+    plan.clear();
+    int col = 0;
+    for (int w : {W, 16, 8}) {
+        if (w > W) continue;
+        const int nt = (N - col) / w;
+        if (nt > 0) { plan.push_back({w, col, nt}); col += nt * w; }
+    }
+    // Kernel choice: "kernel" 1 = row-group gather, 2 = LDS panel, 0 = auto (panel when at least half
+    // of the non-zeros sit in row blocks whose B rows are reused -- "only where a tile has reuse").
+    use_panel = false;
+    if (h->opt_kernel != 1 && h->nnz > 0) {
+        if (int rc = ensure_plan(h, lpr, h->opt_kernel == 2)) return rc;
+        use_panel = h->plan_built && ((h->opt_kernel == 2) || h->plan_panel_frac >= 0.5);
+    }
+    return SEXTANS_OK;
+}
+}  // namespace
+
 int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
                          float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out, int64_t ldc,
                          void *stream) {
@@ -412,19 +462,10 @@ int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_
     SX_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     if (h->M == 0) return SEXTANS_OK;
-    if (int rc = ensure(&h->d_Bp, &h->Bp_cap, (size_t)h->K * (size_t)N)) return rc;
-
-    // N-tile plan: as many tiles of width W = 4*lanes_per_row as fit, then 16- and 8-wide tiles for
-    // the remainder (N is a multiple of 8, the reference's N-tile granularity: sextans.cpp:57-60).
-    const int W = 4 * (int)h->opt_lpr;
-    struct Seg { int width, col0, ntiles; };
     std::vector<Seg> plan;
-    int col = 0;
-    for (int w : {W, 16, 8}) {
-        if (w > W) continue;
-        const int nt = (N - col) / w;
-        if (nt > 0) { plan.push_back({w, col, nt}); col += nt * w; }
-    }
+    int W = 0;
+    bool use_panel = false;
+    if (int rc = prepare(h, N, plan, W, use_panel)) return rc;
 
     {
         Prof p(h, &h->ev_repack, s);
@@ -436,13 +477,6 @@ int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_
                 default: launch_repack<8>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s); break;
             }
         }
-    }
-    // Kernel choice: "kernel" 1 = row-group gather, 2 = LDS panel, 0 = auto (panel when at least half
-    // of the non-zeros sit in row blocks whose B rows are reused -- "only where a tile has reuse").
-    bool use_panel = false;
-    if (h->opt_kernel != 1 && h->nnz > 0) {
-        if (int rc = ensure_plan(h, (int)h->opt_lpr, h->opt_kernel == 2)) return rc;
-        use_panel = h->plan_built && ((h->opt_kernel == 2) || h->plan_panel_frac >= 0.5);
     }
     {
         Prof p(h, &h->ev_kernel, s);
@@ -485,6 +519,10 @@ int sextans_spmm_host(sextans_handle_t h, int N, float alpha, const float *B, fl
     if (int rc = ensure(&h->d_Cout, &h->C_cap, nC)) return rc;
     SX_HIP(hipMemcpy(h->d_B, B, nB * sizeof(float), hipMemcpyHostToDevice));
     SX_HIP(hipMemcpy(h->d_Cin, C, nC * sizeof(float), hipMemcpyHostToDevice));
+    {   // allocations and the one-time packing of A stay outside the timed region
+        std::vector<Seg> plan; int W = 0; bool up = false;
+        if (int rc = prepare(h, N, plan, W, up)) return rc;
+    }
     hipEvent_t e0, e1;
     SX_HIP(hipEventCreate(&e0));
     SX_HIP(hipEventCreate(&e1));

@@ -219,7 +219,8 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     const float *__restrict__ p_val, const int *__restrict__ blk_row,
     const int *__restrict__ dict_ptr, const int *__restrict__ dict, const float *__restrict__ Bp,
     int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc, int ntiles,
-    int nblk, float alpha, float beta, int use_xcd_remap, int panel_floats) {
+    int nblk, float alpha, float beta, int use_xcd_remap, int panel_floats, long long *dbg) {
+    const long long t0 = dbg ? clock64() : 0;   // dbg: optional phase timing (engine option "phase_timing")
     constexpr int NT = 4 * LPR;
     constexpr int RB = kBlock / LPR;
     constexpr int TS = RB + 1;
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
         cin[i] = Cin[(int64_t)min(row0 + r, row1 - 1) + (col0 + n) * ldc_in];
     }
 
+    const long long t1 = dbg ? clock64() : 0;
     if (use_dict) {
         // Stage the block's distinct B rows: slot s copies dictionary entries s, s+RB, ...; indices are
         // clamped (duplicates rewrite the same bytes) so 8 row loads are in flight per slot.
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
         __syncthreads();
     }
 
+    const long long t2 = dbg ? clock64() : 0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const float *pq = panel + 4 * q;
 
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
 #undef SX_BROW_GLB
 #undef SX_BROW_LDS
 
+    const long long t3 = dbg ? clock64() : 0;
     s_c[(4 * q + 0) * TS + slot] = acc.x;
     s_c[(4 * q + 1) * TS + slot] = acc.y;
     s_c[(4 * q + 2) * TS + slot] = acc.z;
@@ -366,6 +370,14 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
             const int64_t o = (int64_t)orow + (col0 + n) * ldc;
             Cout[o] = epilogue<EXACT>(alpha, s_c[n * TS + r], beta, cin[i]);
         }
+    }
+    if (dbg && (tid & 63) == 0 && (blockIdx.x & 127) == 5) {   // 1 workgroup in 128: negligible perturbation
+        const long long t4 = clock64();
+        atomicAdd((unsigned long long *)&dbg[0], (unsigned long long)(t1 - t0));   // meta, row extents, first entries
+        atomicAdd((unsigned long long *)&dbg[1], (unsigned long long)(t2 - t1));   // dictionary -> B rows -> LDS, barrier
+        atomicAdd((unsigned long long *)&dbg[2], (unsigned long long)(t3 - t2));   // row streaming / compute
+        atomicAdd((unsigned long long *)&dbg[3], (unsigned long long)(t4 - t3));   // C tile + epilogue
+        atomicAdd((unsigned long long *)&dbg[4], 1ull);
     }
 }
 
