@@ -247,6 +247,16 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     const int nu = dict_ptr[blk + 1] - u0;
     const bool use_dict = nu > 0;
 
+    // Dictionary indices of this slot's panel rows (slot, slot+RB, ...; clamped): requested FIRST, they
+    // depend only on the scalar block meta, so their latency overlaps the row-extent round trip instead
+    // of following it.
+    constexpr int MAXD = 9;   // 576-entry dictionary / 64 slots (N tile 16); larger ones take the loop below
+    int dix[MAXD];
+    if (use_dict) {
+#pragma unroll
+        for (int u = 0; u < MAXD; ++u) dix[u] = dict[u0 + min(slot + u * RB, nu - 1)];
+    }
+
     const float *bq = Bp + (int64_t)tile * panel_stride + 4 * q;
     int len = 0;
     int64_t off = 0;
@@ -282,18 +292,23 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
 
     const long long t1 = dbg ? clock64() : 0;
     if (use_dict) {
-        // Stage the block's distinct B rows: slot s copies dictionary entries s, s+RB, ...; indices are
-        // clamped (duplicates rewrite the same bytes) so 8 row loads are in flight per slot.
-        for (int i0 = slot; i0 < nu; i0 += 8 * RB) {
-            f32x4 v[8];
-            int ii[8];
+        // Stage the block's distinct B rows: slot s copies dictionary entries s, s+RB, ... (indices were
+        // requested at kernel entry; clamped duplicates rewrite the same bytes).
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                ii[u] = min(i0 + u * RB, nu - 1);
-                v[u] = *reinterpret_cast<const f32x4 *>(bq + (int64_t)dict[u0 + ii[u]] * NT);
-            }
+        for (int h0 = 0; h0 < MAXD; h0 += 5) {
+            f32x4 v[5];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4 *>(panel + ii[u] * NT + 4 * q) = v[u];
+            for (int u = 0; u < 5; ++u)
+                if (h0 + u < MAXD) v[u] = *reinterpret_cast<const f32x4 *>(bq + (int64_t)dix[h0 + u] * NT);
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+                if (h0 + u < MAXD)
+                    *reinterpret_cast<f32x4 *>(panel + min(slot + (h0 + u) * RB, nu - 1) * NT + 4 * q) = v[u];
+        }
+        // dictionaries beyond MAXD*RB entries (other N-tile widths): plain loop
+        for (int i = slot + MAXD * RB; i < nu; i += RB) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(bq + (int64_t)dict[u0 + i] * NT);
+            *reinterpret_cast<f32x4 *>(panel + i * NT + 4 * q) = v;
         }
         __syncthreads();
     }
