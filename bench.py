@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--n", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--chunks", type=int, default=4, help="N>1: row chunks for gather/compute overlap (1 = off)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value")
     args = ap.parse_args()
@@ -105,17 +106,36 @@ def main():
     cout_ptr = Cout.data_ptr() + 4 * r0
     # N > 1: the rank's slab is written packed (ldc_out = rows per rank) into its slot of a staging
     # buffer, ONE RCCL all-gather moves all slabs, a local strided copy writes column-major C_out.
-    sg = sxd.SlabGather(M, N, ranges, rank, dev) if world > 1 else None
+    # With --chunks > 1 (default 4) the slab is produced in row chunks and the all-gather of chunk i
+    # overlaps the SpMM of chunk i+1 (PipelinedSlabGather).
+    sg = pg = None
+    if world > 1:
+        if args.chunks > 1 and M % world == 0:
+            pg = sxd.PipelinedSlabGather(M, N, ranges, rank, dev, nchunks=args.chunks)
+        else:
+            sg = sxd.SlabGather(M, N, ranges, rank, dev)
+
+    def chunk(c0, c1, out_ptr, ld_out, first):
+        eng.spmm_device_rows(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr + 4 * c0, M, out_ptr, ld_out, c0, c1,
+                             reuse_b_panels=not first, stream=stream)
 
     def compute():
-        if sg is None:
+        if world == 1:
             eng.spmm_device(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr, cout_ptr, M, stream)
+        elif pg is not None:
+            for i, ((c0, c1), S) in enumerate(zip(pg.chunks, pg.S)):
+                chunk(c0, c1, S[rank].data_ptr(), c1 - c0, i == 0)
         else:
             eng.spmm_device2(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr, M, sg.local_ptr(), sg.lmax, stream)
 
     def step():
-        compute()
-        if sg is not None:
+        if world == 1:
+            compute()
+        elif pg is not None:
+            pg.run(chunk)
+            pg.finish(Cout)
+        else:
+            compute()
             sg.gather()
             sg.unpack_into(Cout)
 

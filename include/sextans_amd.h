@@ -172,6 +172,16 @@ int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_
                          float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out,
                          int64_t ldc_out, void *stream);
 
+/* Row-range form: computes rows [row_begin, row_end) only.  d_C_in / d_C_out address row_begin as
+ * their row 0 (ldc_in, ldc_out >= row_end - row_begin).  Used to pipeline a rank's slab in chunks so the
+ * all-gather of chunk i overlaps the SpMM of chunk i+1.  flags: SEXTANS_ROWS_REUSE_B_PANELS = the B
+ * panels repacked by the previous call on this handle are still valid (same B, same N): skip the repack.
+ * Row ranges always use the row-group gather kernel. */
+#define SEXTANS_ROWS_REUSE_B_PANELS 1
+int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
+                             float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out,
+                             int64_t ldc_out, int row_begin, int row_end, int flags, void *stream);
+
 /* One-shot convenience with exactly cpu_spmm_CSR's argument list (sparse_helper.h:262-272):
  * create + upload + run + download + destroy on device 0. */
 int sextans_spmm_csr(int M, int N, int K, int NNZ, float ALPHA, const int *CSRRowPtr,

@@ -100,6 +100,9 @@ def lib():
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.sextans_spmm_device2.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    L.sextans_spmm_device_rows.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
+                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                           C.c_int, C.c_void_p]
     L.sextans_spmm_csr.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _i32p, _i32p,
                                    _f32p, _f32p, C.c_float, _f32p]
     L.sextans_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
@@ -320,6 +323,12 @@ class Engine:
     def spmm_device2(self, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out, ldc_out, stream=None):
         _check(lib().sextans_spmm_device2(self._h, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out,
                                           ldc_out, stream), "spmm_device2")
+
+    def spmm_device_rows(self, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out, ldc_out, row_begin, row_end,
+                         reuse_b_panels=False, stream=None):
+        _check(lib().sextans_spmm_device_rows(self._h, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out,
+                                              ldc_out, row_begin, row_end, 1 if reuse_b_panels else 0,
+                                              stream), "spmm_device_rows")
 
     def profile_read(self):
         k, n, r = C.c_double(), C.c_int64(), C.c_double()

@@ -160,17 +160,19 @@ void launch_repack(const float *dB, int64_t ldb, float *dBp, int K, int col_base
 
 template <int LPR>
 void launch_rowgroup(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout,
-                     int64_t ldc, int ntiles, float alpha, float beta, hipStream_t s) {
+                     int64_t ldc, int row_begin, int row_end, int ntiles, float alpha, float beta,
+                     hipStream_t s) {
     constexpr int RB = sx::kBlock / LPR;
     constexpr int CH = 2048;
-    const int nrowblk = (h->M + RB - 1) / RB;
+    const int nrowblk = (row_end - row_begin + RB - 1) / RB;
+    if (nrowblk <= 0) return;
     const unsigned nwg = (unsigned)nrowblk * (unsigned)ntiles;
     const int64_t pstride = (int64_t)h->K * 4 * LPR;
     const int xcd = (int)h->opt_xcd;
 #define SX_LAUNCH(EX, ST)                                                                       \
     hipLaunchKernelGGL((sx::spmm_csr_rowgroup<LPR, CH, EX, ST>), dim3(nwg), dim3(sx::kBlock), 0, \
-                       s, h->d_rp, h->d_ci, h->d_v, dBp, pstride, dCin, ldc_in, dCout, ldc, h->M, \
-                       ntiles, nrowblk, alpha, beta, xcd)
+                       s, h->d_rp, h->d_ci, h->d_v, dBp, pstride, dCin, ldc_in, dCout, ldc, row_begin, \
+                       row_end, ntiles, nrowblk, alpha, beta, xcd)
     if (h->opt_exact) { if (h->opt_stage) SX_LAUNCH(true, true); else SX_LAUNCH(true, false); }
     else              { if (h->opt_stage) SX_LAUNCH(false, true); else SX_LAUNCH(false, false); }
 #undef SX_LAUNCH
@@ -456,18 +458,31 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
 int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
                          float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out, int64_t ldc,
                          void *stream) {
+    if (!h) return SEXTANS_ERR_INVALID;
+    return sextans_spmm_device_rows(h, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out, ldc, 0, h->M, 0,
+                                    stream);
+}
+
+int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
+                             float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out, int64_t ldc,
+                             int row_begin, int row_end, int flags, void *stream) {
     if (!h || N <= 0 || (N % 8) != 0 || !d_B || !d_C_in || !d_C_out) return SEXTANS_ERR_INVALID;
     if (!h->d_rp) return SEXTANS_ERR_STATE;
-    if (ldb < h->K || ldc < h->M || ldc_in < h->M) return SEXTANS_ERR_INVALID;
+    if (row_begin < 0 || row_end < row_begin || row_end > h->M) return SEXTANS_ERR_INVALID;
+    const bool whole = row_begin == 0 && row_end == h->M;
+    const int nrows = row_end - row_begin;
+    if (ldb < h->K || ldc < nrows || ldc_in < nrows) return SEXTANS_ERR_INVALID;
     SX_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    if (h->M == 0) return SEXTANS_OK;
+    if (nrows == 0) return SEXTANS_OK;
     std::vector<Seg> plan;
     int W = 0;
     bool use_panel = false;
     if (int rc = prepare(h, N, plan, W, use_panel)) return rc;
+    if (!whole) use_panel = false;   // row ranges cut across the panel plan's row blocks: gather kernel
+    const bool skip_repack = (flags & SEXTANS_ROWS_REUSE_B_PANELS) != 0;
 
-    {
+    if (!skip_repack) {
         Prof p(h, &h->ev_repack, s);
         for (const Seg &g : plan) {
             float *dst = h->d_Bp + (size_t)h->K * (size_t)g.col0;
@@ -488,15 +503,15 @@ int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_
             switch (g.width) {
                 case 32:
                     if (panel_here) launch_panel<8>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
-                    else launch_rowgroup<8>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
+                    else launch_rowgroup<8>(h, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
                     break;
                 case 16:
                     if (panel_here) launch_panel<4>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
-                    else launch_rowgroup<4>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
+                    else launch_rowgroup<4>(h, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
                     break;
                 default:
                     if (panel_here) launch_panel<2>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
-                    else launch_rowgroup<2>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
+                    else launch_rowgroup<2>(h, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
                     break;
             }
         }

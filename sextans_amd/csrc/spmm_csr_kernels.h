@@ -83,7 +83,10 @@ template <int LPR, int CH, bool EXACT, bool STAGE>
 __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
     const int *__restrict__ row_ptr, const int *__restrict__ col_idx, const float *__restrict__ val,
     const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout,
-    int64_t ldc, int M, int ntiles, int nrowblk, float alpha, float beta, int use_xcd_remap) {
+    int64_t ldc, int row_begin, int M, int ntiles, int nrowblk, float alpha, float beta,
+    int use_xcd_remap) {
+    // Rows [row_begin, M) are processed; C pointers address row_begin as their row 0 (row-range calls
+    // of the multi-GPU pipeline write a packed slab chunk); row_ptr is indexed with the global row.
     constexpr int NT = 4 * LPR;
     constexpr int RB = kBlock / LPR;
     constexpr int TS = RB + 1;   // padded row stride of the transposed C tile in LDS
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
     const int tid = threadIdx.x;
     const int slot = tid / LPR;
     const int q = tid % LPR;
-    const int row0 = rowblk * RB;
+    const int row0 = row_begin + rowblk * RB;
     const int row = row0 + slot;
 
     const float *bq = Bp + (int64_t)tile * panel_stride + 4 * q;
@@ -177,8 +180,8 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
         const int n = e / RB, r = e % RB;
         const int orow = row0 + r;
         if (orow < M) {
-            const int64_t o = (int64_t)orow + (col0 + n) * ldc;
-            Cout[o] = epilogue<EXACT>(alpha, s_c[n * TS + r], beta, Cin[(int64_t)orow + (col0 + n) * ldc_in]);
+            const int64_t lr = (int64_t)(orow - row_begin);
+            Cout[lr + (col0 + n) * ldc] = epilogue<EXACT>(alpha, s_c[n * TS + r], beta, Cin[lr + (col0 + n) * ldc_in]);
         }
     }
 }

@@ -139,3 +139,50 @@ class SlabGather:
             for g, (a, b) in enumerate(self.ranges):
                 if b > a:
                     cols[:, a:b] = self.S[g, :, :b - a]
+
+
+class PipelinedSlabGather:
+    """SlabGather with compute/communication overlap: the rank's slab is produced in `nchunks` row
+    chunks; as soon as chunk c is computed its all-gather starts (async, on RCCL's stream) while the
+    SpMM of chunk c+1 runs.  Requires equal row counts per rank (the synthetic config 4); per chunk
+    one in-place all_gather_into_tensor of 4*N*chunk_rows bytes per rank.
+
+        pg = PipelinedSlabGather(M, N, ranges, rank, device, nchunks=4)
+        pg.run(lambda c0, c1, out_ptr, ld_out, first: engine.spmm_device_rows(..., row_begin=c0, row_end=c1,
+                                                                            reuse_b_panels=not first, ...))
+        pg.finish(C_full)      # waits for the collectives, writes column-major C
+    """
+
+    def __init__(self, M, N, ranges, rank, device, nchunks=4, dtype=None):
+        import torch
+        self.M, self.N, self.ranges, self.rank = M, N, list(ranges), rank
+        self.world = len(self.ranges)
+        lens = {b - a for a, b in self.ranges}
+        if len(lens) != 1 or next(iter(lens)) * self.world != M:
+            raise ValueError("PipelinedSlabGather needs equal row counts per rank")
+        self.L = next(iter(lens))
+        nchunks = max(1, min(nchunks, self.L))
+        cuts = [self.L * c // nchunks for c in range(nchunks + 1)]
+        self.chunks = [(cuts[c], cuts[c + 1]) for c in range(nchunks) if cuts[c + 1] > cuts[c]]
+        self.S = [torch.zeros((self.world, N, c1 - c0), dtype=dtype or torch.float32, device=device)
+                  for c0, c1 in self.chunks]
+        self.works = []
+
+    def run(self, compute_chunk, group=None, _force=False):
+        """compute_chunk(c0, c1, out_ptr, ld_out, first) must enqueue the SpMM of local rows [c0, c1) writing
+        a packed column-major (c1-c0) x N slab at out_ptr."""
+        import torch.distributed as dist
+        self.works = []
+        for i, ((c0, c1), S) in enumerate(zip(self.chunks, self.S)):
+            compute_chunk(c0, c1, S[self.rank].data_ptr(), c1 - c0, i == 0)
+            if self.world > 1 or _force:
+                self.works.append(dist.all_gather_into_tensor(S.view(-1), S[self.rank].reshape(-1),
+                                                              group=group, async_op=True))
+
+    def finish(self, C_full):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        cols = C_full.view(self.N, self.world, self.L)
+        for (c0, c1), S in zip(self.chunks, self.S):
+            cols[:, :, c0:c1].copy_(S.permute(1, 0, 2))

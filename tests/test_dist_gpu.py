@@ -47,6 +47,18 @@ def test_nccl_allgather_paths_single_rank(engine, oracle):
             sg.unpack_into(out)
             torch.cuda.synchronize()
             assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        # pipelined form (bench.py at N > 1): row chunks via sextans_spmm_device_rows, B panels repacked once,
+        # async all-gathers overlapping the next chunk
+        pg = sxd.PipelinedSlabGather(M, N, [(0, M)], 0, torch.device("cuda", 0), nchunks=4)
+
+        def chunk(c0, c1, out_ptr, ld_out, first):
+            engine.spmm_device_rows(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr() + 4 * c0, M, out_ptr, ld_out,
+                                    c0, c1, reuse_b_panels=not first, stream=st)
+        pg.run(chunk, _force=True)
+        out = torch.full((M * N,), float("nan"), device="cuda")
+        pg.finish(out)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
         # a slab of rows [r0, r1) of a taller C_in (ldc_in = M) into a packed slab (ldc_out = r1 - r0)
         r0, r1 = 100, 420
         lrp, lci, lv = sxd.slice_csr(rp, ci, v, r0, r1)
