@@ -1,0 +1,44 @@
+"""Operator-style embedding: torch.sparse_csr in, dense out, over the C ABI.
+
+    C = spmm(A_csr, B, alpha=1.0, beta=0.0, C=None)
+
+A: torch.sparse_csr_tensor (fp32 values, int32/int64 indices) on a GPU; B: dense (K, N) fp32; returns a
+dense (M, N) tensor (row-major view of the engine's column-major result, no copy).  N is padded up to a
+multiple of 8 internally (the reference's N-tile granularity, sextans-host.cpp:51).  One cached engine
+per (device, matrix identity); not part of the reference, whose only front end is the CLI.
+"""
+import torch
+
+from . import api
+
+_cache = {}
+
+
+def spmm(A, B, alpha=1.0, beta=0.0, C=None):
+    if A.layout != torch.sparse_csr or not A.is_cuda or not B.is_cuda:
+        raise TypeError("spmm expects a CUDA/HIP torch.sparse_csr matrix and a CUDA/HIP dense B")
+    M, K = A.shape
+    if B.shape[0] != K:
+        raise ValueError("shape mismatch")
+    N = B.shape[1]
+    Np = api.round_up_n(N)
+    dev = A.device.index or 0
+    crow, col, val = A.crow_indices(), A.col_indices(), A.values()
+    key = (dev, crow.data_ptr(), col.data_ptr(), val.data_ptr(), M, K, val.numel())
+    ent = _cache.get(key)
+    if ent is None:
+        crow32, col32 = crow.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
+        val32 = val.to(torch.float32).contiguous()
+        eng = api.Engine(dev)
+        eng.set_matrix_csr_device(M, K, val32.numel(), crow32.data_ptr(), col32.data_ptr(), val32.data_ptr())
+        ent = _cache[key] = (eng, crow32, col32, val32)      # keep the arrays alive: the engine does not copy
+    eng = ent[0]
+    # column-major K x Np = the transpose of a row-major (Np, K) tensor
+    Bcm = torch.zeros((Np, K), dtype=torch.float32, device=B.device)
+    Bcm[:N] = B.to(torch.float32).t()
+    Ccm = torch.zeros((Np, M), dtype=torch.float32, device=B.device)
+    if C is not None and beta != 0.0:
+        Ccm[:N] = C.to(torch.float32).t()
+    stream = torch.cuda.current_stream(B.device).cuda_stream
+    eng.spmm_device(Np, float(alpha), Bcm.data_ptr(), K, float(beta), Ccm.data_ptr(), Ccm.data_ptr(), M, stream)
+    return Ccm[:N].t()
