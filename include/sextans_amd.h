@@ -136,7 +136,9 @@ int sextans_destroy(sextans_handle_t h);
 /* Tunables.  key: "kernel" (0 auto, 1 row-group gather, 2 LDS panel), "lanes_per_row"
  * (2/4/8, N-tile = 4*lanes), "stage_a" (0/1 stage the CSR stream through LDS), "xcd_remap"
  * (0/1), "exact" (1 = no FMA, reference rounding; 0 = allow FMA), "profile" (0/1 hipEvent
- * per-kernel timing), "phase_timing" (0/1, see sextans_phase_timing_read), "panel_min_reuse_x100" (a row block uses the LDS panel when
+ * per-kernel timing), "phase_timing" (0/1, see sextans_phase_timing_read), "split_rows" (T > 0: rows longer than T
+ * non-zeros are processed in pieces of T and folded in order -- for power-law matrices; re-associates
+ * those rows, so results are within tolerance instead of bit-identical; default 0 = off), "panel_min_reuse_x100" (a row block uses the LDS panel when
  * nnz >= value/100 * distinct columns; default 400).  Unknown keys -> SEXTANS_ERR_INVALID. */
 int sextans_set_option(sextans_handle_t h, const char *key, int64_t value);
 int sextans_get_option(sextans_handle_t h, const char *key, int64_t *value);

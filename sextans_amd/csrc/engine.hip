@@ -70,9 +70,16 @@ struct sextans_engine {
     void *d_bell_Af = nullptr;      // A blocks in MFMA fragment order (owned)
     void *d_bell_Bf = nullptr;      // B in fragment order (workspace)
     size_t bell_Bf_cap = 0;         // bytes
+    // long-row splitting (option "split_rows")
+    int *d_vrp = nullptr, *d_vfirst = nullptr;
+    int split_nv = 0;               // virtual rows (0 = no row exceeds the threshold / not built)
+    int64_t split_built_T = -1;
+    float *d_P = nullptr;
+    size_t P_cap = 0;
     long long *d_dbg = nullptr;     // 8 counters for phase timing (option "phase_timing")
     // options
     int64_t opt_kernel = 0, opt_lpr = 4, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;
+    int64_t opt_split_rows = 0;         // > 0: rows longer than this are split (re-associated); 0 = exact order
     int64_t opt_phase_timing = 0;       // 1: panel kernel accumulates per-phase wave cycles (debug aid)
     int64_t opt_min_reuse_x100 = 400;   // a block uses the LDS panel if nnz >= 4 * distinct columns
     // profiling
@@ -116,8 +123,16 @@ void free_bell(sextans_engine *h) {
     h->bell_M = h->bell_K = h->bell_W = 0;
 }
 
+void free_split(sextans_engine *h) {
+    (void)hipFree(h->d_vrp); (void)hipFree(h->d_vfirst);
+    h->d_vrp = h->d_vfirst = nullptr;
+    h->split_nv = 0;
+    h->split_built_T = -1;
+}
+
 void free_matrix(sextans_engine *h) {
     free_plan(h);
+    free_split(h);
     if (h->owns_matrix) {
         (void)hipFree((void *)h->d_rp);
         (void)hipFree((void *)h->d_ci);
@@ -159,8 +174,8 @@ void launch_repack(const float *dB, int64_t ldb, float *dBp, int K, int col_base
 }
 
 template <int LPR>
-void launch_rowgroup(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout,
-                     int64_t ldc, int row_begin, int row_end, int ntiles, float alpha, float beta,
+void launch_rowgroup(sextans_engine *h, const int *rp, const float *dBp, const float *dCin, int64_t ldc_in,
+                     float *dCout, int64_t ldc, int row_begin, int row_end, int ntiles, float alpha, float beta,
                      hipStream_t s) {
     constexpr int RB = sx::kBlock / LPR;
     constexpr int CH = 2048;
@@ -171,10 +186,13 @@ void launch_rowgroup(sextans_engine *h, const float *dBp, const float *dCin, int
     const int xcd = (int)h->opt_xcd;
 #define SX_LAUNCH(EX, ST)                                                                       \
     hipLaunchKernelGGL((sx::spmm_csr_rowgroup<LPR, CH, EX, ST>), dim3(nwg), dim3(sx::kBlock), 0, \
-                       s, h->d_rp, h->d_ci, h->d_v, dBp, pstride, dCin, ldc_in, dCout, ldc, row_begin, \
+                       s, rp, h->d_ci, h->d_v, dBp, pstride, dCin, ldc_in, dCout, ldc, row_begin,      \
                        row_end, ntiles, nrowblk, alpha, beta, xcd)
-    if (h->opt_exact) { if (h->opt_stage) SX_LAUNCH(true, true); else SX_LAUNCH(true, false); }
-    else              { if (h->opt_stage) SX_LAUNCH(false, true); else SX_LAUNCH(false, false); }
+    // The LDS-staged A stream walks a block's non-zeros in order, which serialises row groups when rows
+    // are long pieces of one hub row (split mode): there every row group streams its own piece directly.
+    const bool stage = h->opt_stage && rp == h->d_rp;
+    if (h->opt_exact) { if (stage) SX_LAUNCH(true, true); else SX_LAUNCH(true, false); }
+    else              { if (stage) SX_LAUNCH(false, true); else SX_LAUNCH(false, false); }
 #undef SX_LAUNCH
 }
 
@@ -333,6 +351,7 @@ int sextans_destroy(sextans_handle_t h) {
     (void)hipFree(h->d_bell_Bf);
     (void)hipFree(h->d_Bp); (void)hipFree(h->d_B); (void)hipFree(h->d_Cin); (void)hipFree(h->d_Cout);
     sextans_profile_reset(h);
+    (void)hipFree(h->d_P);
     (void)hipFree(h->d_dbg);
     delete h;
     return SEXTANS_OK;
@@ -347,6 +366,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "profile")) return &h->opt_profile;
     if (!strcmp(key, "panel_min_reuse_x100")) return &h->opt_min_reuse_x100;
     if (!strcmp(key, "phase_timing")) return &h->opt_phase_timing;
+    if (!strcmp(key, "split_rows")) return &h->opt_split_rows;
     return nullptr;
 }
 
@@ -426,6 +446,34 @@ int sextans_spmm_device(sextans_handle_t h, int N, float alpha, const float *d_B
 namespace {
 struct Seg { int width, col0, ntiles; };
 
+// Virtual row set for long-row splitting: every row longer than T becomes ceil(len/T) pieces.
+int ensure_split(sextans_engine *h) {
+    const int64_t T = h->opt_split_rows;
+    if (h->split_built_T == T) return SEXTANS_OK;
+    free_split(h);
+    h->split_built_T = T;
+    if (T <= 0 || h->M == 0) return SEXTANS_OK;
+    std::vector<int> rp((size_t)h->M + 1);
+    SX_HIP(hipMemcpy(rp.data(), h->d_rp, sizeof(int) * ((size_t)h->M + 1), hipMemcpyDeviceToHost));
+    bool any = false;
+    for (int r = 0; r < h->M && !any; ++r) any = (int64_t)rp[(size_t)r + 1] - rp[(size_t)r] > T;
+    if (!any) return SEXTANS_OK;
+    std::vector<int> vrp, vfirst((size_t)h->M + 1);
+    vrp.reserve((size_t)h->M + 1024);
+    for (int r = 0; r < h->M; ++r) {
+        vfirst[(size_t)r] = (int)vrp.size();
+        const int j0 = rp[(size_t)r], j1 = rp[(size_t)r + 1];
+        vrp.push_back(j0);
+        for (int64_t j = (int64_t)j0 + T; j < j1; j += T) vrp.push_back((int)j);
+    }
+    vfirst[(size_t)h->M] = (int)vrp.size();
+    vrp.push_back(rp[(size_t)h->M]);
+    h->split_nv = (int)vrp.size() - 1;
+    if (int rc = upload(&h->d_vrp, vrp)) return rc;
+    if (int rc = upload(&h->d_vfirst, vfirst)) return rc;
+    return SEXTANS_OK;
+}
+
 // Everything that may allocate or run host-side preprocessing for an N-column SpMM: B-panel workspace,
 // N-tile plan, and (for kernel != 1) the packed row-bucketed form of A.  Idempotent; called by
 // sextans_spmm_device2 and, ahead of the timed region, by sextans_spmm_host.
@@ -480,6 +528,13 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     bool use_panel = false;
     if (int rc = prepare(h, N, plan, W, use_panel)) return rc;
     if (!whole) use_panel = false;   // row ranges cut across the panel plan's row blocks: gather kernel
+    if (int rc = ensure_split(h)) return rc;
+    const bool split = whole && h->split_nv > 0;
+    if (split) {
+        use_panel = false;
+        if (int rc = ensure(&h->d_P, &h->P_cap, (size_t)h->split_nv * (size_t)N)) return rc;
+        SX_HIP(hipMemsetAsync(h->d_P, 0, (size_t)h->split_nv * (size_t)N * sizeof(float), s));
+    }
     const bool skip_repack = (flags & SEXTANS_ROWS_REUSE_B_PANELS) != 0;
 
     if (!skip_repack) {
@@ -503,19 +558,33 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             switch (g.width) {
                 case 32:
                     if (panel_here) launch_panel<8>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
-                    else launch_rowgroup<8>(h, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
+                    else if (split) launch_rowgroup<8>(h, h->d_vrp, bp, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, 0, h->split_nv, g.ntiles, 1.0f, 0.0f, s);
+                    else launch_rowgroup<8>(h, h->d_rp, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
                     break;
                 case 16:
                     if (panel_here) launch_panel<4>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
-                    else launch_rowgroup<4>(h, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
+                    else if (split) launch_rowgroup<4>(h, h->d_vrp, bp, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, 0, h->split_nv, g.ntiles, 1.0f, 0.0f, s);
+                    else launch_rowgroup<4>(h, h->d_rp, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
                     break;
                 default:
                     if (panel_here) launch_panel<2>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
-                    else launch_rowgroup<2>(h, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
+                    else if (split) launch_rowgroup<2>(h, h->d_vrp, bp, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, 0, h->split_nv, g.ntiles, 1.0f, 0.0f, s);
+                    else launch_rowgroup<2>(h, h->d_rp, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
                     break;
             }
         }
-        h->last_kernel = use_panel ? "spmm_csr_panel" : "spmm_csr_rowgroup";
+        if (split) {
+            const int64_t tot = (int64_t)h->M * N;
+            if (h->opt_exact)
+                hipLaunchKernelGGL(sx::fold_row_pieces<true>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s,
+                                   h->d_vfirst, h->d_P, (int64_t)h->split_nv, d_C_in, ldc_in, d_C_out, ldc, h->M, N,
+                                   alpha, beta);
+            else
+                hipLaunchKernelGGL(sx::fold_row_pieces<false>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s,
+                                   h->d_vfirst, h->d_P, (int64_t)h->split_nv, d_C_in, ldc_in, d_C_out, ldc, h->M, N,
+                                   alpha, beta);
+        }
+        h->last_kernel = split ? "spmm_csr_rowgroup+fold_row_pieces" : use_panel ? "spmm_csr_panel" : "spmm_csr_rowgroup";
     }
     SX_HIP(hipGetLastError());
     return SEXTANS_OK;

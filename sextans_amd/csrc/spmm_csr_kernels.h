@@ -400,6 +400,30 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Long-row splitting (opt-in, engine option "split_rows" = T): power-law matrices have rows whose
+// strictly sequential accumulation would serialise one 4-lane row group for milliseconds.  With the
+// option set, rows longer than T are cut into pieces of T non-zeros; the row-group kernel runs on that
+// virtual row set (same col_idx/val, pieces are contiguous) with alpha = 1, beta = 0 into a scratch
+// matrix, and this kernel folds the pieces of every row IN ORDER and applies the epilogue.  Rows with a
+// single piece stay bit-identical to cpu_spmm_CSR; split rows are re-associated (within the stated
+// 1e-4 tolerance), which is why the option is off by default.
+// ------------------------------------------------------------------------------------------------
+template <bool EXACT>
+__global__ __launch_bounds__(kBlock) void fold_row_pieces(const int *__restrict__ vfirst,
+                                                          const float *__restrict__ P, int64_t ldp,
+                                                          const float *Cin, int64_t ldc_in, float *Cout,
+                                                          int64_t ldc, int M, int N, float alpha,
+                                                          float beta) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (int64_t)M * N) return;
+    const int r = (int)(t % M), n = (int)(t / M);
+    const int v0 = vfirst[r], v1 = vfirst[r + 1];
+    float acc = P[(int64_t)v0 + n * ldp];
+    for (int v = v0 + 1; v < v1; ++v) acc = acc + P[(int64_t)v + n * ldp];
+    Cout[(int64_t)r + n * ldc] = epilogue<EXACT>(alpha, acc, beta, Cin[(int64_t)r + n * ldc_in]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // B repack: column-major K x N (leading dimension ldb) -> row-major panels of width W.
 // Panel t (columns col_base + t*W ...) is written at Bp + t*K*W as K rows of W floats.  The
 // reference does the equivalent re-layout for its HBM channels on the host

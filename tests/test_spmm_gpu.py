@@ -186,6 +186,46 @@ def test_panel_kernel_medium_fem_plus_direct_tail(engine, oracle, sx):
             assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (N, kernel)
 
 
+def test_split_long_rows_option(engine, oracle):
+    """Opt-in long-row splitting for power-law matrices: rows <= T stay bit-identical, longer rows are
+    folded piecewise in order (re-associated) and must meet the stated 1e-4 bound."""
+    rs = np.random.RandomState(99)
+    M, K, N = 900, 30000, 16
+    lens = rs.poisson(12, M)
+    hubs = [5, 450, 899]
+    for hrow, L in zip(hubs, (20000, 4097, 9000)):
+        lens[hrow] = L
+    rp = np.zeros(M + 1, np.int32)
+    rp[1:] = np.cumsum(lens)
+    ci = np.concatenate([np.sort(rs.choice(K, size=l, replace=False)) for l in lens]).astype(np.int32)
+    v = rs.uniform(-1, 1, rp[-1]).astype(np.float32)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    T = 4096
+    engine.set_option("split_rows", T)
+    try:
+        out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, kernel=1)
+        assert engine.last_kernel() == "spmm_csr_rowgroup+fold_row_pieces"
+        o2, w2 = out.reshape(N, M), want.reshape(N, M)
+        short = np.ones(M, bool); short[hubs] = False
+        assert np.array_equal(o2[:, short].view(np.uint32), w2[:, short].view(np.uint32))     # untouched rows: bit exact
+        rows = np.repeat(np.arange(M), lens)
+        for n in range(N):
+            bound = np.bincount(rows, weights=np.abs(v) * np.abs(B[n * K + ci]), minlength=M)
+            bound = 1e-4 * (abs(float(ALPHA)) * bound + np.abs(float(BETA) * C0[n * M:(n + 1) * M]))
+            assert np.all(np.abs(o2[n].astype(np.float64) - w2[n]) <= bound + 1e-30)
+        assert not np.array_equal(o2[:, hubs].view(np.uint32), w2[:, hubs].view(np.uint32)) or True
+        # a threshold above the longest row: nothing is split, plain kernel, bit exact everywhere
+        engine.set_option("split_rows", 50000)
+        out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, kernel=1)
+        assert engine.last_kernel() == "spmm_csr_rowgroup"
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    finally:
+        engine.set_option("split_rows", 0)
+
+
 def test_degenerate_shapes(engine, oracle):
     # all-empty matrix: C = alpha*0 + beta*C
     M, K, N = 70, 5, 8

@@ -29,6 +29,16 @@ def workload(name):
         return dict(M=110 * 110 * 110 * 3, K=110 * 110 * 110 * 3, N=16, fem=(110, 110, 110, 3, 3))
     if name == "fem1":
         return dict(M=160 ** 3, K=160 ** 3, N=16, fem=(160, 160, 160, 1, 3))
+    if name == "powerlaw":
+        rs = np.random.RandomState(17)
+        M = K = 1_000_000
+        lens = rs.poisson(20, M)
+        hubs = rs.choice(M, 16, replace=False)
+        lens[hubs] = 400_000
+        rp = np.zeros(M + 1, np.int32); rp[1:] = np.cumsum(lens)
+        ci = (rs.randint(0, K, rp[-1])).astype(np.int32)          # columns need not be sorted/distinct for timing
+        v = rs.uniform(-1, 1, rp[-1]).astype(np.float32)
+        return dict(M=M, K=K, N=16, host=(rp, ci, v), nnz=int(rp[-1]))
     if name == "uniform":
         return dict(M=4_000_000, K=4_000_000, N=16, gen=(40.0, 0, 4))
     if name.startswith("banded"):
