@@ -77,8 +77,12 @@ def main():
         raise SystemExit("bench.py: no MI355X visible; the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SEXTANS_BENCH_FORCE_DIST=1 runs the multi-rank code path (process group, chunked slab, collectives,
+    # unpack) on a 1-rank group: the only way to exercise it on a single-GPU box.
+    multi = world > 1 or os.environ.get("SEXTANS_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     M = K = args.rows
@@ -109,7 +113,7 @@ def main():
     # With --chunks > 1 (default 4) the slab is produced in row chunks and the all-gather of chunk i
     # overlaps the SpMM of chunk i+1 (PipelinedSlabGather).
     sg = pg = None
-    if world > 1:
+    if multi:
         if args.chunks > 1 and M % world == 0:
             pg = sxd.PipelinedSlabGather(M, N, ranges, rank, dev, nchunks=args.chunks)
         else:
@@ -120,7 +124,7 @@ def main():
                              reuse_b_panels=not first, stream=stream)
 
     def compute():
-        if world == 1:
+        if not multi:
             eng.spmm_device(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr, cout_ptr, M, stream)
         elif pg is not None:
             for i, ((c0, c1), S) in enumerate(zip(pg.chunks, pg.S)):
@@ -129,18 +133,18 @@ def main():
             eng.spmm_device2(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr, M, sg.local_ptr(), sg.lmax, stream)
 
     def step():
-        if world == 1:
+        if not multi:
             compute()
         elif pg is not None:
-            pg.run(chunk)
+            pg.run(chunk, _force=(world == 1))
             pg.finish(Cout)
         else:
             compute()
-            sg.gather()
+            sg.gather(_force=(world == 1))
             sg.unpack_into(Cout)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
 
     def timed(fn, iters):
@@ -150,7 +154,7 @@ def main():
             fn()
         torch.cuda.synchronize(); barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -159,10 +163,10 @@ def main():
     for _ in range(args.warmup):
         step()
     dt = timed(step, args.steps)
-    dt_compute = timed(compute, args.steps) if world > 1 else dt
+    dt_compute = timed(compute, args.steps) if multi else dt
 
     nnz_tot = nnz_loc
-    if world > 1:
+    if multi:
         t = torch.tensor([nnz_loc], dtype=torch.int64, device=dev)
         dist.all_reduce(t)
         nnz_tot = int(t.item())
@@ -179,6 +183,10 @@ def main():
     k_ns, k_n, rp_ns = eng.profile_read()
     eng.set_option("profile", 0)
     eng.profile_reset()
+    # at N > 1 a step launches the kernel once per row chunk: k_ns is the mean per launch, so scale to
+    # the whole slab (k_n launches were timed over 10 steps)
+    launches_per_step = max(1, k_n // 10)
+    k_ns *= launches_per_step
     bytes_launch = alg_bytes(m_loc, K, N, nnz_loc)
     achieved = bytes_launch / (k_ns * 1e-9) / 1e9
     # HBM traffic of this kernel comes from separate rocprofv3 --pmc passes of this same command
@@ -192,6 +200,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": eng.last_kernel(), "kernel_us": round(k_ns / 1e3, 2),
                 "alg_bytes_per_launch": bytes_launch, "launches_timed": k_n,
+                "kernel_launches_per_step": launches_per_step,
                 "repack_us": round(rp_ns / 1e3, 2)}
 
     out = {
@@ -208,11 +217,17 @@ def main():
         "roofline": roofline,
     }
     also = {}
-    if world > 1:
+    if multi:
         also["compute_only_ms_per_step"] = round(dt_compute / args.steps * 1e3, 4)
         also["compute_only_gflops"] = round(flops / (dt_compute / args.steps) / 1e9, 2)
 
     if rank == 0 and world == 1:
+        if multi:   # forced single-rank distributed run: check the gathered C against the plain path
+            ref = torch.empty_like(Cout)
+            eng.spmm_device(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr, ref.data_ptr(), M, stream)
+            torch.cuda.synchronize()
+            also["dist_path_matches_plain_path"] = bool(torch.equal(ref, Cout))
+            del ref
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(api, M, K, N, args, Cout, flops_per_row=None)
         del B, Cin, Cout
@@ -233,9 +248,19 @@ def main():
     eng.close()
     for q in (d_rp, d_ci, d_v):
         api.device_free(local_rank, q)
+    # RCCL prints a version banner through C stdio (fully buffered when stdout is a pipe): push it out on
+    # every rank BEFORE the result so that the JSON line is the last thing on stdout.
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if multi:
+        dist.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
