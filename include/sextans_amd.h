@@ -121,6 +121,62 @@ void sextans_packed_free(sextans_packed *p);
 /* Decoder: reconstructs col_idx[nnz], val[nnz] of the CSR matrix with row extents row_ptr. */
 int sextans_unpack_csr(const sextans_packed *p, const int *row_ptr, int *col_idx, float *val);
 
+/* ------------------------------------------------------------------ the accelerator's own buffer formats
+ *
+ * Writer / reader for exactly the buffers the reference host prepares for tapa::invoke(Sextans, ...)
+ * (sextans-host.cpp:114-204), so inputs prepared for the FPGA can be consumed by this engine
+ * (sextans_invoke below) and results produced in the FPGA's C layout.
+ *
+ *   A: scheduled non-zero stream of 64 PEs (row % 64) in 4096-column windows, 10-slot spacing between
+ *      entries of one row inside a window, bubble padding to the window's longest PE list
+ *      (generate_edge_list_for_all_PEs, sparse_helper.h:292-403); packed as 64-bit words
+ *      col14<<50 | row18<<32 | fp32 in 8 channels, PE p at channel p%8, slot bitrev3(p/8) of each
+ *      8-word group (edge_list_64bit, sparse_helper.h:406-473); bubble = 0x3FFFF<<32 (any word with
+ *      row bit 17 set is skipped, sextans.cpp:407).  edge_list_ptr[w+1] = stream length after window w.
+ *   B: NUM_CH_B (4 in sextans.h:8, or 8) float channels, sextans-host.cpp:152-177.
+ *   C: 8 float channels, row m in channel m%8 at colsize*(n/8) + (m/8)*8 + n%8, colsize = round_up(M,16)
+ *      (sextans-host.cpp:179-195 for C_in, :264-270 for C_out). */
+#define SEXTANS_EDGES_NUM_PE 64
+#define SEXTANS_EDGES_NUM_CH 8
+#define SEXTANS_EDGES_WINDOW 4096
+
+typedef struct sextans_edges {
+    int32_t M, K;
+    int32_t num_windows;          /* NUM_ITE   = ceil(K / 4096)               sextans-host.cpp:221 */
+    int32_t num_a_len;            /* NUM_A_LEN = edge_list_ptr[num_windows]   sextans-host.cpp:222 */
+    int64_t nnz;                  /* non-bubble words */
+    int64_t ptr_len;              /* ints in edge_list_ptr, zero padded to a multiple of 1024 (:131-134) */
+    int64_t chan_len;             /* words per channel: round_up(8 * num_a_len, 512) (sparse_helper.h:412-413) */
+    int32_t *edge_list_ptr;
+    uint64_t *channel[SEXTANS_EDGES_NUM_CH];
+} sextans_edges;
+
+/* Writer: CSC (what the reference host feeds its scheduler) -> stream.  M must be <= 64 * 2^17. */
+int sextans_edges_pack_csc(int M, int K, int nnz, const int *col_ptr, const int *row_idx, const float *val,
+                           sextans_edges *out);
+void sextans_edges_free(sextans_edges *e);
+/* Reader: stream -> CSR with each row's entries in stream order (the order the accelerator accumulates
+ * them in; ascending columns for streams written from a CSC matrix).  Arrays are malloc'ed
+ * (sextans_host_free).  SEXTANS_ERR_INDEX if a word addresses a row >= M or a column >= K. */
+int sextans_edges_decode_csr(const int32_t *edge_list_ptr, const uint64_t *const *channel, int num_windows,
+                             int M, int K, int64_t *nnz, int **row_ptr, int **col_idx, float **val);
+/* Container file (little endian): "SXTEDGE1", M, K, num_windows, num_a_len (int32), nnz, ptr_len,
+ * chan_len (int64), edge_list_ptr[ptr_len], channel[8][chan_len]. */
+int sextans_edges_save(const char *path, const sextans_edges *e);
+int sextans_edges_load(const char *path, sextans_edges *out);
+
+/* Dense channel layouts (host side).  N must be a multiple of 8; num_ch_b is 4 or 8.  *_len = floats
+ * per channel (padded to 1024 as the reference allocates them); pack writes only the addressed
+ * positions (callers zero the buffers first, as the reference does). */
+int64_t sextans_chan_b_colsize(int K, int num_ch_b);
+int64_t sextans_chan_b_len(int K, int N, int num_ch_b);
+int64_t sextans_chan_c_colsize(int M);
+int64_t sextans_chan_c_len(int M, int N);
+int sextans_chan_pack_b(int K, int N, int num_ch_b, const float *B, float *const *channel);
+int sextans_chan_unpack_b(int K, int N, int num_ch_b, const float *const *channel, float *B);
+int sextans_chan_pack_c(int M, int N, const float *C, float *const *channel);
+int sextans_chan_unpack_c(int M, int N, const float *const *channel, float *C);
+
 /* ------------------------------------------------------------------ L1: the SpMM engine (HIP) */
 
 typedef struct sextans_engine *sextans_handle_t;
@@ -183,6 +239,23 @@ int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_
 int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
                              float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out,
                              int64_t ldc_out, int row_begin, int row_end, int flags, void *stream);
+
+/* Drop-in for the kernel-invoke call itself: the argument list of
+ *   tapa::invoke(Sextans, bitstream, edge_list_ptr, edge_list_ch[8], mat_B_ch[NUM_CH_B], mat_C_ch_in[8],
+ *                mat_C_ch[8], NUM_ITE, NUM_A_LEN, M, K, P_N, alpha_u, beta_u)
+ * (sextans-host.cpp:237-251, prototype sextans.h:20-26) on the host buffers the reference host prepared.
+ * P_N = (rp_time << 16) | N, alpha_u / beta_u = fp32 bit patterns.  The stream is decoded and uploaded
+ * (edge_list_ptr == NULL: keep the matrix set by the previous sextans_set_matrix_edges / sextans_invoke on
+ * this handle, which must have the same M and K); B and C_in channels are uploaded and converted on the
+ * device; C_out channels receive colsize * N/8 floats each, padded rows included (alpha*0 + beta*0, as the
+ * accelerator writes them).  *elapsed_ns = device time of the layout conversions + all rp_time repeats.
+ * Results are bit-identical to cpu_spmm_CSR on the decoded matrix. */
+int sextans_set_matrix_edges(sextans_handle_t h, const int32_t *edge_list_ptr, const uint64_t *const *edge_list_ch,
+                             int NUM_ITE, int NUM_A_LEN, int M, int K);
+int sextans_invoke(sextans_handle_t h, const int32_t *edge_list_ptr, const uint64_t *const *edge_list_ch,
+                   const float *const *mat_B_ch, int num_ch_b, const float *const *mat_C_ch_in,
+                   float *const *mat_C_ch, int NUM_ITE, int NUM_A_LEN, int M, int K, int P_N, int alpha_u,
+                   int beta_u, double *elapsed_ns);
 
 /* One-shot convenience with exactly cpu_spmm_CSR's argument list (sparse_helper.h:262-272):
  * create + upload + run + download + destroy on device 0. */

@@ -174,6 +174,24 @@ class Ref:
         L.ref_cpu_spmm_csr.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _i32p, _i32p,
                                        _f32p, _f32p, C.c_float, _f32p]
 
+        L.ref_generate_edge_list.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f32p,
+                                             C.POINTER(C.c_int), C.POINTER(C.c_int), pi, pi, pi, pf]
+
+    def generate_edge_list(self, M, K, col_ptr, row_idx, val):
+        """The reference's generate_edge_list_for_all_PEs (64 PEs, window 4096, distance 10).
+        -> (ptr[num_windows+1], row[64, L], col[64, L], val[64, L]); row == -1 marks a bubble."""
+        nw, Ln = C.c_int(), C.c_int()
+        p, r, c, v = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()
+        self.lib.ref_generate_edge_list(M, K, int(len(row_idx)), np.ascontiguousarray(col_ptr, np.int32),
+                                        _pad(np.asarray(row_idx, np.int32)), _pad(np.asarray(val, np.float32)),
+                                        nw, Ln, p, r, c, v)
+        n = 64 * Ln.value
+        out = (_take(p, nw.value + 1, np.int32), _take(r, n, np.int32).reshape(64, Ln.value),
+               _take(c, n, np.int32).reshape(64, Ln.value), _take(v, n, np.float32).reshape(64, Ln.value))
+        for q in (p, r, c, v):
+            self.lib.ref_free(q)
+        return out
+
     @staticmethod
     def available():
         return os.path.exists(os.path.join(_HERE, "_ref", "libsextans_ref.so")) or \

@@ -6,6 +6,9 @@
 //   read_suitsparse_matrix  sparse_helper.h:169-259
 //   CSC_2_CSR               sparse_helper.h:475-509
 //   cpu_spmm_CSR            sparse_helper.h:262-290
+//   generate_edge_list_for_all_PEs  sparse_helper.h:345-403  (the FPGA non-zero scheduler)
+// (edge_list_64bit, sparse_helper.h:406-473, is NOT built: its signature needs tapa::aligned_allocator
+//  from the absent TAPA headers, and oracle/Makefile strips it rather than stand in for TAPA.)
 // The result (oracle/_ref/libsextans_ref.so) is used by tests to pin oracle/sextans_oracle.c
 // and to generate tests/golden/, and by bench.py as the "reference" CPU baseline.
 //
@@ -68,6 +71,34 @@ double ref_cpu_spmm_csr(int M, int N, int K, int nnz, float alpha, const int *ro
     auto t1 = std::chrono::steady_clock::now();
     memcpy(C, c.data(), sizeof(float) * (size_t)M * N);
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// The reference scheduler on caller CSC arrays with the host's constants (64 PEs, window 4096,
+// distance 10: sextans-host.cpp:119-129, sextans.h:7-12).  Returns malloc'ed ptr[num_windows + 1] and,
+// for PE p and slot i < L = ptr[num_windows], row/col/val[p * L + i]; row = -1 marks a bubble.
+int ref_generate_edge_list(int M, int K, int nnz, const int *col_ptr, const int *row_idx, const float *val,
+                           int *num_windows, int *L, int **ptr, int **row, int **col, float **attr) {
+    vector<int> cp(col_ptr, col_ptr + K + 1), ri(row_idx, row_idx + nnz);
+    vector<float> cv(val, val + nnz);
+    vector<vector<edge> > pes;
+    vector<int> p;
+    generate_edge_list_for_all_PEs(cp, ri, cv, 64, M, K, 4096, pes, p, 10);
+    *num_windows = (int)p.size() - 1;
+    *L = p.back();
+    const size_t n = (size_t)64 * (size_t)(*L);
+    *ptr = (int *)malloc(sizeof(int) * p.size());
+    memcpy(*ptr, p.data(), sizeof(int) * p.size());
+    *row = (int *)malloc(sizeof(int) * (n ? n : 1));
+    *col = (int *)malloc(sizeof(int) * (n ? n : 1));
+    *attr = (float *)malloc(sizeof(float) * (n ? n : 1));
+    for (int q = 0; q < 64; ++q)
+        for (int i = 0; i < *L; ++i) {
+            const edge &e = pes[q][i];
+            (*row)[(size_t)q * *L + i] = e.row;
+            (*col)[(size_t)q * *L + i] = e.col;
+            (*attr)[(size_t)q * *L + i] = e.attr;
+        }
+    return 0;
 }
 
 }  // extern "C"

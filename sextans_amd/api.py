@@ -38,6 +38,13 @@ class Packed(C.Structure):
                 ("nnz_in_panel_blocks", C.c_int64)]
 
 
+class Edges(C.Structure):
+    """Mirror of struct sextans_edges (include/sextans_amd.h)."""
+    _fields_ = [("M", C.c_int32), ("K", C.c_int32), ("num_windows", C.c_int32), ("num_a_len", C.c_int32),
+                ("nnz", C.c_int64), ("ptr_len", C.c_int64), ("chan_len", C.c_int64),
+                ("edge_list_ptr", C.POINTER(C.c_int32)), ("channel", C.POINTER(C.c_uint64) * 8)]
+
+
 class SextansError(RuntimeError):
     def __init__(self, code, where=""):
         self.code = code
@@ -85,6 +92,26 @@ def lib():
     L.sextans_packed_free.argtypes = [C.POINTER(Packed)]
     L.sextans_packed_free.restype = None
     L.sextans_unpack_csr.argtypes = [C.POINTER(Packed), _i32p, _i32p, _f32p]
+    pp = C.POINTER(C.c_void_p)
+    L.sextans_edges_pack_csc.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f32p, C.POINTER(Edges)]
+    L.sextans_edges_free.argtypes = [C.POINTER(Edges)]
+    L.sextans_edges_free.restype = None
+    L.sextans_edges_decode_csr.argtypes = [_i32p, pp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), pi, pi, pf]
+    L.sextans_edges_save.argtypes = [C.c_char_p, C.POINTER(Edges)]
+    L.sextans_edges_load.argtypes = [C.c_char_p, C.POINTER(Edges)]
+    for fn in ("sextans_chan_b_colsize", "sextans_chan_b_len", "sextans_chan_c_colsize", "sextans_chan_c_len"):
+        getattr(L, fn).restype = C.c_int64
+    L.sextans_chan_b_colsize.argtypes = [C.c_int, C.c_int]
+    L.sextans_chan_b_len.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.sextans_chan_c_colsize.argtypes = [C.c_int]
+    L.sextans_chan_c_len.argtypes = [C.c_int, C.c_int]
+    L.sextans_chan_pack_b.argtypes = [C.c_int, C.c_int, C.c_int, _f32p, pp]
+    L.sextans_chan_unpack_b.argtypes = [C.c_int, C.c_int, C.c_int, pp, _f32p]
+    L.sextans_chan_pack_c.argtypes = [C.c_int, C.c_int, _f32p, pp]
+    L.sextans_chan_unpack_c.argtypes = [C.c_int, C.c_int, pp, _f32p]
+    L.sextans_set_matrix_edges.argtypes = [C.c_void_p, _i32p, pp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.sextans_invoke.argtypes = [C.c_void_p, C.c_void_p, pp, pp, C.c_int, pp, pp, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     L.sextans_device_count.argtypes = [ip]
     L.sextans_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     L.sextans_destroy.argtypes = [C.c_void_p]
@@ -208,6 +235,108 @@ def pack_csr(M, K, row_ptr, col_idx, val, lanes_per_row=4, min_reuse_x100=400):
         L.sextans_packed_free(C.byref(P))
 
 
+# ---- the accelerator's own buffer formats ----
+
+def _rows(a2d):
+    """(void *)[n] over the rows of a C-contiguous 2-D array (one pointer per channel)."""
+    n = a2d.shape[0]
+    arr = (C.c_void_p * n)()
+    for i in range(n):
+        arr[i] = a2d[i].ctypes.data
+    return arr
+
+
+def _edges_to_dict(E):
+    ch = np.stack([_take(E.channel[c], E.chan_len, np.uint64) if E.chan_len else np.zeros(0, np.uint64)
+                   for c in range(8)])
+    return dict(M=E.M, K=E.K, num_windows=E.num_windows, num_a_len=E.num_a_len, nnz=E.nnz,
+                edge_list_ptr=_take(E.edge_list_ptr, E.ptr_len, np.int32), channels=ch)
+
+
+def edges_pack_csc(M, K, col_ptr, row_idx, val):
+    """generate_edge_list_for_all_PEs + edge_list_64bit + the edge_list_ptr padding
+    (sextans-host.cpp:114-146): -> dict(edge_list_ptr[ptr_len], channels[8, chan_len] uint64, ...)."""
+    L = lib()
+    E = Edges()
+    _check(L.sextans_edges_pack_csc(M, K, int(len(row_idx)), _buf(col_ptr, np.int32), _buf(row_idx, np.int32),
+                                    _buf(val, np.float32), C.byref(E)), "edges_pack_csc")
+    try:
+        return _edges_to_dict(E)
+    finally:
+        L.sextans_edges_free(C.byref(E))
+
+
+def edges_decode_csr(edge_list_ptr, channels, num_windows, M, K):
+    """-> (row_ptr, col_idx, val): each row's entries in stream order."""
+    L = lib()
+    ch = np.ascontiguousarray(channels, np.uint64)
+    if ch.shape[1] == 0:
+        ch = np.zeros((8, 1), np.uint64)
+    nnz = C.c_int64()
+    p, i, v = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()
+    _check(L.sextans_edges_decode_csr(_buf(edge_list_ptr, np.int32), _rows(ch), num_windows, M, K, C.byref(nnz),
+                                      p, i, v), "edges_decode_csr")
+    out = (_take(p, M + 1, np.int32), _take(i, nnz.value, np.int32), _take(v, nnz.value, np.float32))
+    for q in (p, i, v):
+        L.sextans_host_free(q)
+    return out
+
+
+def edges_save(path, e):
+    """Write the container file from a dict as returned by edges_pack_csc."""
+    L = lib()
+    ch = np.ascontiguousarray(e["channels"], np.uint64)
+    ptr = np.ascontiguousarray(e["edge_list_ptr"], np.int32)
+    E = Edges(M=e["M"], K=e["K"], num_windows=e["num_windows"], num_a_len=e["num_a_len"], nnz=e["nnz"],
+              ptr_len=ptr.size, chan_len=ch.shape[1])
+    E.edge_list_ptr = ptr.ctypes.data_as(C.POINTER(C.c_int32))
+    for c in range(8):
+        E.channel[c] = ch[c].ctypes.data_as(C.POINTER(C.c_uint64))
+    _check(L.sextans_edges_save(os.fsencode(path), C.byref(E)), f"edges_save({path})")
+
+
+def edges_load(path):
+    L = lib()
+    E = Edges()
+    _check(L.sextans_edges_load(os.fsencode(path), C.byref(E)), f"edges_load({path})")
+    try:
+        return _edges_to_dict(E)
+    finally:
+        L.sextans_edges_free(C.byref(E))
+
+
+def chan_pack_b(K, N, B, num_ch_b=4):
+    """mat_B_cpu (column major K x N) -> mat_B_fpga_vec[num_ch_b][len] (sextans-host.cpp:152-177)."""
+    L = lib()
+    ch = np.zeros((num_ch_b, L.sextans_chan_b_len(K, N, num_ch_b)), np.float32)
+    _check(L.sextans_chan_pack_b(K, N, num_ch_b, _buf(B, np.float32), _rows(ch)), "chan_pack_b")
+    return ch
+
+
+def chan_unpack_b(K, N, channels):
+    ch = np.ascontiguousarray(channels, np.float32)
+    B = np.zeros(K * N, np.float32)
+    _check(lib().sextans_chan_unpack_b(K, N, ch.shape[0], _rows(ch), _buf(B, np.float32)), "chan_unpack_b")
+    return B
+
+
+def chan_pack_c(M, N, Cm):
+    """mat_C_cpu (column major M x N) -> mat_C_fpga_in[8][len] (sextans-host.cpp:179-195)."""
+    L = lib()
+    ch = np.zeros((8, L.sextans_chan_c_len(M, N)), np.float32)
+    _check(L.sextans_chan_pack_c(M, N, _buf(Cm, np.float32), _rows(ch)), "chan_pack_c")
+    return ch
+
+
+def chan_unpack_c(M, N, channels):
+    """mat_C_fpga_vec[8][len] -> column major M x N (the indexing of sextans-host.cpp:264-270)."""
+    ch = np.ascontiguousarray(channels, np.float32)
+    Cm = np.zeros(M * N, np.float32)
+    out = _buf(Cm, np.float32)
+    _check(lib().sextans_chan_unpack_c(M, N, _rows(ch), out), "chan_unpack_c")
+    return out[:M * N]
+
+
 def init_dense_B(K, N):
     B = np.empty(K * N, np.float32)
     lib().sextans_init_dense_B(K, N, _buf(B, np.float32) if B.size == 0 else B)
@@ -302,6 +431,31 @@ class Engine:
                                        C_inout if C_inout.size else np.zeros(1, np.float32),
                                        rp_time, C.byref(ns)), "spmm_host")
         return ns.value
+
+    def set_matrix_edges(self, edge_list_ptr, channels, NUM_ITE, NUM_A_LEN, M, K):
+        ch = np.ascontiguousarray(channels, np.uint64)
+        _check(lib().sextans_set_matrix_edges(self._h, _buf(edge_list_ptr, np.int32), _rows(ch), NUM_ITE,
+                                              NUM_A_LEN, M, K), "set_matrix_edges")
+        self.M, self.K = M, K
+
+    def invoke(self, edge_list_ptr, edge_list_ch, mat_B_ch, mat_C_ch_in, NUM_ITE, NUM_A_LEN, M, K, P_N,
+               alpha_u, beta_u, mat_C_ch=None):
+        """tapa::invoke(Sextans, ...)'s argument list (sextans-host.cpp:237-251) on numpy buffers.
+        edge_list_ptr=None reuses the matrix already set.  -> (mat_C_ch[8, len], elapsed_ns)."""
+        bch = np.ascontiguousarray(mat_B_ch, np.float32)
+        cin = np.ascontiguousarray(mat_C_ch_in, np.float32)
+        cout = np.zeros_like(cin) if mat_C_ch is None else mat_C_ch
+        ns = C.c_double()
+        if edge_list_ptr is None:
+            ptr, ach = None, (C.c_void_p * 8)()
+        else:
+            ptr_arr = _buf(edge_list_ptr, np.int32)
+            ach_arr = np.ascontiguousarray(edge_list_ch, np.uint64)
+            ptr, ach = ptr_arr.ctypes.data, _rows(ach_arr)
+        _check(lib().sextans_invoke(self._h, ptr, ach, _rows(bch), bch.shape[0], _rows(cin), _rows(cout),
+                                    NUM_ITE, NUM_A_LEN, M, K, P_N, alpha_u, beta_u, C.byref(ns)), "invoke")
+        self.M, self.K = M, K
+        return cout, ns.value
 
     def spmm_device(self, N, alpha, d_B, ldb, beta, d_C_in, d_C_out, ldc, stream=None):
         _check(lib().sextans_spmm_device(self._h, N, alpha, d_B, ldb, beta, d_C_in, d_C_out, ldc,

@@ -17,8 +17,9 @@ BINDIR = os.path.join(ROOT, "sextans_amd", "bin")
 LIB = os.path.join(LIBDIR, "libsextans_amd.so")
 CLI = os.path.join(BINDIR, "sextans")
 
-LIB_SOURCES = ["engine.hip", "synth.hip", "host_mtx.cpp", "panel_plan.cpp", "pack_api.cpp"]
-HEADERS = ["spmm_csr_kernels.h", "bell_kernels.h", "panel_plan.h", os.path.join("..", "..", "include", "sextans_amd.h")]
+LIB_SOURCES = ["engine.hip", "synth.hip", "host_mtx.cpp", "panel_plan.cpp", "pack_api.cpp",
+               "edge_stream.cpp"]
+HEADERS = ["spmm_csr_kernels.h", "bell_kernels.h", "chan_kernels.h", "panel_plan.h", os.path.join("..", "..", "include", "sextans_amd.h")]
 
 # -ffp-contract=off: the EXACT kernels and the CLI golden need "multiply, round, add" (the
 # reference's arithmetic, sparse_helper.h:283); hipcc's default is to contract into FMA.

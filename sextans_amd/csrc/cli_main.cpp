@@ -12,9 +12,15 @@
 // device index.  Without a usable device the command fails loudly (exit 1): there is no CPU path
 // for the product computation.  The CPU golden below exists only for the built-in self check the
 // reference performs (:206-219, :262-289).
+//
+// SEXTANS_FPGA_BUFFERS=1 takes the reference's own data path end to end: A is scheduled and packed into
+// the 8-channel 64-bit edge stream, B and C into their channel layouts (:114-204), the engine is entered
+// through sextans_invoke with tapa::invoke's argument list (:237-251), and the result is read back out of
+// the C channels (:264-270).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <vector>
 
@@ -93,10 +99,50 @@ int main(int argc, char **argv) {
     cout << "done (" << time_cpu * 1000 << " msec)\n";
     cout << "CPU GFLOPS: " << sextans_gflops(M, N, nnz, time_cpu) << "\n";
 
-    cout << "launch kernel\n";
     double elapsed_ns = 0.0;
-    if (int rc = sextans_spmm_host(h, N, alpha, B.data(), beta, C_dev.data(), rp_time, &elapsed_ns))
-        return fail("sextans_spmm_host", rc);
+    const char *fb = getenv("SEXTANS_FPGA_BUFFERS");
+    if (fb && atoi(fb) != 0) {
+        cout << "Preparing sparse A for FPGA ...";
+        std::vector<int> col_ptr((size_t)K + 1), row_idx((size_t)(nnz ? nnz : 1));
+        std::vector<float> cval((size_t)(nnz ? nnz : 1));
+        // CSR -> CSC is CSC -> CSR of the transpose: entries come out ordered by (col, row), as the
+        // reference's CSC read orders them (sparse_helper.h:205-206).
+        if (int rc = sextans_csc_to_csr(K, M, nnz, row_ptr, col_idx, val, col_ptr.data(), row_idx.data(),
+                                        cval.data()))
+            return fail("sextans_csc_to_csr", rc);
+        sextans_edges e;
+        if (int rc = sextans_edges_pack_csc(M, K, nnz, col_ptr.data(), row_idx.data(), cval.data(), &e)) {
+            cout << "\n";
+            return fail("sextans_edges_pack_csc", rc);
+        }
+        cout << "done\n";
+        const int num_ch_b = 4;                                   // NUM_CH_B, sextans.h:8
+        cout << "Preparing dense B for FPGA ...";
+        const int64_t b_len = sextans_chan_b_len(K, N, num_ch_b), c_len = sextans_chan_c_len(M, N);
+        std::vector<std::vector<float>> b_ch(num_ch_b, std::vector<float>((size_t)b_len, 0.f)),
+            c_in(8, std::vector<float>((size_t)c_len, 0.f)), c_out(8, std::vector<float>((size_t)c_len, 0.f));
+        float *bp[8], *cip[8], *cop[8];
+        for (int c = 0; c < num_ch_b; ++c) bp[c] = b_ch[c].data();
+        for (int c = 0; c < 8; ++c) { cip[c] = c_in[c].data(); cop[c] = c_out[c].data(); }
+        sextans_chan_pack_b(K, N, num_ch_b, B.data(), bp);
+        cout << "Preparing dense C for FPGA ...";
+        sextans_chan_pack_c(M, N, C_dev.data(), cip);
+        cout << "done\n";
+        int alpha_u, beta_u;                                      // raw fp32 bits, :225-229
+        memcpy(&alpha_u, &alpha, 4);
+        memcpy(&beta_u, &beta, 4);
+        cout << "launch kernel\n";
+        const int rc = sextans_invoke(h, e.edge_list_ptr, e.channel, bp, num_ch_b, cip, cop, e.num_windows,
+                                      e.num_a_len, M, K, ((rp_time < 1 ? 1 : rp_time) << 16) | N, alpha_u, beta_u,
+                                      &elapsed_ns);
+        sextans_edges_free(&e);
+        if (rc) return fail("sextans_invoke", rc);
+        sextans_chan_unpack_c(M, N, cop, C_dev.data());
+    } else {
+        cout << "launch kernel\n";
+        if (int rc = sextans_spmm_host(h, N, alpha, B.data(), beta, C_dev.data(), rp_time, &elapsed_ns))
+            return fail("sextans_spmm_host", rc);
+    }
     const double time_taken = elapsed_ns * (1e-9 / (rp_time < 1 ? 1 : rp_time));   // :252
     printf("Kernel time is %f ms\n", time_taken * 1000);
     printf("GFLOPS:%f \n", (float)sextans_gflops(M, N, nnz, time_taken));

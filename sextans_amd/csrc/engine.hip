@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "bell_kernels.h"
+#include "chan_kernels.h"
 #include "panel_plan.h"
 #include "sextans_amd.h"
 #include "spmm_csr_kernels.h"
@@ -52,6 +53,8 @@ struct sextans_engine {
     size_t Bp_cap = 0;              // floats
     float *d_B = nullptr, *d_Cin = nullptr, *d_Cout = nullptr;   // host-path staging
     size_t B_cap = 0, C_cap = 0;
+    float *d_chB = nullptr, *d_chC = nullptr;                    // accelerator channel layouts (sextans_invoke)
+    size_t chB_cap = 0, chC_cap = 0;
     // block-dictionary plan for the LDS-panel kernel (built lazily, per lanes_per_row)
     int plan_lpr = 0;               // 0 = no plan
     int64_t plan_min_reuse = -1;
@@ -353,6 +356,7 @@ int sextans_destroy(sextans_handle_t h) {
     sextans_profile_reset(h);
     (void)hipFree(h->d_P);
     (void)hipFree(h->d_dbg);
+    (void)hipFree(h->d_chB); (void)hipFree(h->d_chC);
     delete h;
     return SEXTANS_OK;
 }
@@ -623,6 +627,94 @@ int sextans_spmm_host(sextans_handle_t h, int N, float alpha, const float *B, fl
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (elapsed_ns) *elapsed_ns = (double)ms * 1e6;
     SX_HIP(hipMemcpy(C, h->d_Cout, nC * sizeof(float), hipMemcpyDeviceToHost));
+    return SEXTANS_OK;
+}
+
+int sextans_set_matrix_edges(sextans_handle_t h, const int32_t *edge_list_ptr, const uint64_t *const *edge_list_ch,
+                             int NUM_ITE, int NUM_A_LEN, int M, int K) {
+    if (!h || !edge_list_ptr || !edge_list_ch || NUM_ITE < 0) return SEXTANS_ERR_INVALID;
+    if (edge_list_ptr[NUM_ITE] != NUM_A_LEN) return SEXTANS_ERR_INVALID;
+    int64_t nnz = 0;
+    int *rp = nullptr, *ci = nullptr;
+    float *v = nullptr;
+    if (int rc = sextans_edges_decode_csr(edge_list_ptr, edge_list_ch, NUM_ITE, M, K, &nnz, &rp, &ci, &v))
+        return rc;
+    const int rc = sextans_set_matrix_csr(h, M, K, nnz, rp, ci, v);
+    free(rp); free(ci); free(v);
+    return rc;
+}
+
+int sextans_invoke(sextans_handle_t h, const int32_t *edge_list_ptr, const uint64_t *const *edge_list_ch,
+                   const float *const *mat_B_ch, int num_ch_b, const float *const *mat_C_ch_in,
+                   float *const *mat_C_ch, int NUM_ITE, int NUM_A_LEN, int M, int K, int P_N, int alpha_u,
+                   int beta_u, double *elapsed_ns) {
+    const int N = P_N & 0xFFFF;                      // sextans-host.cpp:223, sextans.cpp:203
+    int rp_time = (int)((unsigned)P_N >> 16);
+    if (rp_time < 1) rp_time = 1;
+    if (!h || !mat_B_ch || !mat_C_ch_in || !mat_C_ch || N <= 0 || (N % 8) || (num_ch_b != 4 && num_ch_b != 8) ||
+        M < 0 || K < 0)
+        return SEXTANS_ERR_INVALID;
+    if (edge_list_ptr) {
+        if (int rc = sextans_set_matrix_edges(h, edge_list_ptr, edge_list_ch, NUM_ITE, NUM_A_LEN, M, K)) return rc;
+    } else if (!h->d_rp) {
+        return SEXTANS_ERR_STATE;
+    } else if (h->M != M || h->K != K) {
+        return SEXTANS_ERR_INVALID;
+    }
+    float alpha, beta;
+    memcpy(&alpha, &alpha_u, 4);                     // raw fp32 bits, sextans-host.cpp:225-229
+    memcpy(&beta, &beta_u, 4);
+    SX_HIP(hipSetDevice(h->device));
+    const int64_t b_cs = sextans_chan_b_colsize(K, num_ch_b), b_len = sextans_chan_b_len(K, N, num_ch_b);
+    const int64_t c_cs = sextans_chan_c_colsize(M), c_len = sextans_chan_c_len(M, N);
+    const int64_t b_used = b_cs * (N / 8), c_used = c_cs * (N / 8);
+    const size_t nB = (size_t)K * (size_t)N, nC = (size_t)M * (size_t)N;
+    if (int rc = ensure(&h->d_chB, &h->chB_cap, (size_t)b_len * num_ch_b)) return rc;
+    if (int rc = ensure(&h->d_chC, &h->chC_cap, (size_t)c_len * 8)) return rc;
+    if (int rc = ensure(&h->d_B, &h->B_cap, nB)) return rc;
+    size_t ccap = h->C_cap;
+    if (int rc = ensure(&h->d_Cin, &ccap, nC)) return rc;
+    if (int rc = ensure(&h->d_Cout, &h->C_cap, nC)) return rc;
+    for (int c = 0; c < num_ch_b; ++c) {
+        if (!mat_B_ch[c]) return SEXTANS_ERR_INVALID;
+        SX_HIP(hipMemcpy(h->d_chB + (size_t)c * b_len, mat_B_ch[c], sizeof(float) * (size_t)b_used,
+                         hipMemcpyHostToDevice));
+    }
+    for (int c = 0; c < 8; ++c) {
+        if (!mat_C_ch_in[c] || !mat_C_ch[c]) return SEXTANS_ERR_INVALID;
+        SX_HIP(hipMemcpy(h->d_chC + (size_t)c * c_len, mat_C_ch_in[c], sizeof(float) * (size_t)c_used,
+                         hipMemcpyHostToDevice));
+    }
+    {
+        std::vector<Seg> plan; int W = 0; bool up = false;
+        if (int rc = prepare(h, N, plan, W, up)) return rc;
+    }
+    hipEvent_t e0, e1;
+    SX_HIP(hipEventCreate(&e0));
+    SX_HIP(hipEventCreate(&e1));
+    SX_HIP(hipEventRecord(e0, nullptr));
+    if (K > 0)
+        sx::chan_unpack_b<<<dim3((unsigned)((K + 255) / 256), (unsigned)N), 256, 0, nullptr>>>(
+            h->d_chB, b_len, b_cs, num_ch_b, K, N, h->d_B);
+    if (M > 0)
+        sx::chan_unpack_c<<<dim3((unsigned)((M + 255) / 256), (unsigned)(N / 8)), 256, 0, nullptr>>>(
+            h->d_chC, c_len, c_cs, M, N, h->d_Cin);
+    for (int r = 0; r < rp_time; ++r)
+        if (int rc = sextans_spmm_device(h, N, alpha, h->d_B, K, beta, h->d_Cin, h->d_Cout, M, nullptr)) return rc;
+    const float pad = alpha * 0.0f + beta * 0.0f;    // what the accelerator writes into rows M .. colsize-1
+    if (c_cs > 0)
+        sx::chan_pack_c<<<dim3((unsigned)((c_cs + 255) / 256), (unsigned)(N / 8)), 256, 0, nullptr>>>(
+            h->d_Cout, M, N, c_len, c_cs, pad, h->d_chC);
+    SX_HIP(hipGetLastError());
+    SX_HIP(hipEventRecord(e1, nullptr));
+    SX_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    SX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (elapsed_ns) *elapsed_ns = (double)ms * 1e6;
+    for (int c = 0; c < 8; ++c)
+        SX_HIP(hipMemcpy(mat_C_ch[c], h->d_chC + (size_t)c * c_len, sizeof(float) * (size_t)c_used,
+                         hipMemcpyDeviceToHost));
     return SEXTANS_OK;
 }
 

@@ -63,3 +63,50 @@ def random_csr(rs, M, K, mean_nnz, empty_frac=0.05, long_rows=0):
             ci[rp[i]:rp[i + 1]] = np.sort(rs.choice(K, size=lens[i], replace=False))
     val = rs.uniform(-1, 1, rp[-1]).astype(np.float32)
     return rp, ci, val
+
+
+# ---- the accelerator's buffer formats, restated in numpy for the tests ----
+
+def bitrev3(x):
+    return ((x & 1) << 2) | (x & 2) | ((x >> 2) & 1)
+
+
+def edge_words(ptr, row, col, val):
+    """edge_list_64bit for 8 channels, restated from sparse_helper.h:406-473: scheduler output
+    (row/col/val[64, L], row == -1 = bubble) -> uint64 channels[8, round_up(8 L, 512)].
+    word = (col & 0x3FFF) << 50 | (row & 0x3FFFF) << 32 | fp32 bits; bubble = 0x3FFFF << 32;
+    PE p -> channel p % 8, slot bitrev3(p / 8) of each 8-word group (:458-464)."""
+    L = int(ptr[-1])
+    ch = np.zeros((8, (8 * L + 511) // 512 * 512), np.uint64)
+    bits = np.ascontiguousarray(val, np.float32).view(np.uint32).astype(np.uint64)
+    w = ((col.astype(np.int64).astype(np.uint64) & np.uint64(0x3FFF)) << np.uint64(50)) | \
+        ((row.astype(np.int64).astype(np.uint64) & np.uint64(0x3FFFF)) << np.uint64(32)) | bits
+    w = np.where(row == -1, np.uint64(0x3FFFF) << np.uint64(32), w)
+    for p in range(64):
+        ch[p % 8, bitrev3(p // 8):8 * L:8] = w[p]
+    return ch
+
+
+def chan_b_ref(K, N, B, num_ch_b):
+    """mat_B_fpga_vec of sextans-host.cpp:152-177, element by element."""
+    cs = (K + 15) // 16 * 16 if num_ch_b == 8 else (K + 7) // 8 * 8 * 2
+    ln = (cs * (N // 8) + 1023) // 1024 * 1024
+    ch = np.zeros((num_ch_b, ln), np.float32)
+    for nn in range(N):
+        for kk in range(K):
+            if num_ch_b == 4:
+                ch[(nn // 2) % 4, (kk // 8) * 16 + (nn % 2) * 8 + kk % 8 + cs * (nn // 8)] = B[kk + K * nn]
+            else:
+                ch[nn % 8, kk + cs * (nn // 8)] = B[kk + K * nn]
+    return ch
+
+
+def chan_c_ref(M, N, Cm):
+    """mat_C_fpga_in of sextans-host.cpp:179-195 (same indexing reads mat_C_fpga_vec, :264-270)."""
+    cs = (M + 15) // 16 * 16
+    ln = (cs * (N // 8) + 1023) // 1024 * 1024
+    ch = np.zeros((8, ln), np.float32)
+    m = np.arange(M)
+    for nn in range(N):
+        ch[m % 8, cs * (nn // 8) + (m // 8) * 8 + nn % 8] = Cm[m + M * nn]
+    return ch
