@@ -62,6 +62,21 @@ int sextans_mtx_read(const char *path, int format, int *M, int *K, int *nnz, int
                      float **val);
 void sextans_host_free(void *p);
 
+/* Loader throughput.  sextans_mtx_read parses with all host cores (env
+ * SEXTANS_LOADER_THREADS overrides).  The binary container holds exactly the arrays it returns:
+ *   64-byte header "SXTCSR01", int32 format, M, K, nnz, int64 src_size, src_mtime_ns, 24 reserved bytes;
+ *   ptr[(format == CSR ? M : K) + 1], idx[nnz], val[nnz]  (little endian).
+ * sextans_mtx_read_cached reads `path` through the container `cache_path` (NULL: path + ".csr.sxbin" /
+ * ".csc.sxbin"): a container written for the same format from a source file of the same size and
+ * mtime is loaded instead of parsing (*cache_hit = 1); otherwise the text is parsed and the container
+ * (re)written, best effort.  Results are identical either way. */
+int sextans_matrix_save(const char *path, int format, int M, int K, int nnz, const int *ptr, const int *idx,
+                        const float *val);
+int sextans_matrix_load(const char *path, int *format, int *M, int *K, int *nnz, int **ptr, int **idx,
+                        float **val);
+int sextans_mtx_read_cached(const char *path, const char *cache_path, int format, int *M, int *K, int *nnz,
+                            int **ptr, int **idx, float **val, int *cache_hit);
+
 /* Replaces CSC_2_CSR (sparse_helper.h:475-509).  Caller provides row_ptr[M+1], col_idx[nnz],
  * csr_val[nnz].  Per-row column order = CSC traversal order (ascending columns). */
 int sextans_csc_to_csr(int M, int K, int nnz, const int *col_ptr, const int *row_idx,

@@ -74,6 +74,9 @@ def lib():
     L.sextans_error_string.argtypes = [C.c_int]
     L.sextans_last_error.restype = C.c_char_p
     L.sextans_mtx_read.argtypes = [C.c_char_p, C.c_int, ip, ip, ip, pi, pi, pf]
+    L.sextans_mtx_read_cached.argtypes = [C.c_char_p, C.c_char_p, C.c_int, ip, ip, ip, pi, pi, pf, ip]
+    L.sextans_matrix_save.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f32p]
+    L.sextans_matrix_load.argtypes = [C.c_char_p, ip, ip, ip, ip, pi, pi, pf]
     L.sextans_host_free.argtypes = [C.c_void_p]
     L.sextans_host_free.restype = None
     L.sextans_csc_to_csr.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f32p, _i32p, _i32p,
@@ -187,15 +190,43 @@ def _take(ptr, n, dtype):
 
 # ------------------------------------------------------------------ L2: host sparse library
 
-def read_suitsparse_matrix(path, fmt=FMT_CSR):
-    """-> (ptr, idx, val, M, K, nnz); raises SextansError where the reference would exit(1)."""
+def read_suitsparse_matrix(path, fmt=FMT_CSR, cache=None):
+    """-> (ptr, idx, val, M, K, nnz); raises SextansError where the reference would exit(1).
+    cache: None = parse the text; True = go through the binary container next to the file
+    (path + ".csr.sxbin" / ".csc.sxbin"); a string = that container path."""
     L = lib()
     M, K, nnz = C.c_int(), C.c_int(), C.c_int()
     p, i, v = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()
-    _check(L.sextans_mtx_read(os.fsencode(path), fmt, M, K, nnz, p, i, v), f"mtx_read({path})")
+    if cache is None:
+        _check(L.sextans_mtx_read(os.fsencode(path), fmt, M, K, nnz, p, i, v), f"mtx_read({path})")
+    else:
+        hit = C.c_int()
+        cpath = None if cache is True else os.fsencode(cache)
+        _check(L.sextans_mtx_read_cached(os.fsencode(path), cpath, fmt, M, K, nnz, p, i, v, C.byref(hit)),
+               f"mtx_read_cached({path})")
+        read_suitsparse_matrix.last_cache_hit = bool(hit.value)
     n_ptr = (M.value if fmt == FMT_CSR else K.value) + 1
     out = (_take(p, n_ptr, np.int32), _take(i, nnz.value, np.int32),
            _take(v, nnz.value, np.float32), M.value, K.value, nnz.value)
+    for q in (p, i, v):
+        L.sextans_host_free(q)
+    return out
+
+
+def matrix_save(path, fmt, M, K, ptr, idx, val):
+    _check(lib().sextans_matrix_save(os.fsencode(path), fmt, M, K, int(len(idx)), _buf(ptr, np.int32),
+                                     _buf(idx, np.int32), _buf(val, np.float32)), f"matrix_save({path})")
+
+
+def matrix_load(path):
+    """-> (fmt, ptr, idx, val, M, K, nnz)"""
+    L = lib()
+    fmt, M, K, nnz = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    p, i, v = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()
+    _check(L.sextans_matrix_load(os.fsencode(path), fmt, M, K, nnz, p, i, v), f"matrix_load({path})")
+    n_ptr = (M.value if fmt.value == FMT_CSR else K.value) + 1
+    out = (fmt.value, _take(p, n_ptr, np.int32), _take(i, nnz.value, np.int32), _take(v, nnz.value, np.float32),
+           M.value, K.value, nnz.value)
     for q in (p, i, v):
         L.sextans_host_free(q)
     return out

@@ -59,7 +59,11 @@ int main(int argc, char **argv) {
     int M = 0, K = 0, nnz = 0;
     int *row_ptr = nullptr, *col_idx = nullptr;
     float *val = nullptr;
-    if (int rc = sextans_mtx_read(path, SEXTANS_FMT_CSR, &M, &K, &nnz, &row_ptr, &col_idx, &val)) {
+    const char *use_cache = getenv("SEXTANS_MTX_CACHE");      // 1: go through <file>.csr.sxbin (written on first use)
+    const int rc_read = (use_cache && atoi(use_cache) != 0)
+                            ? sextans_mtx_read_cached(path, nullptr, SEXTANS_FMT_CSR, &M, &K, &nnz, &row_ptr, &col_idx, &val, nullptr)
+                            : sextans_mtx_read(path, SEXTANS_FMT_CSR, &M, &K, &nnz, &row_ptr, &col_idx, &val);
+    if (int rc = rc_read) {
         cout << "\n";
         if (rc == SEXTANS_ERR_OPEN) cout << "Could not open " << path << std::endl;
         else cout << "Could not read " << path << ": " << sextans_error_string(rc) << std::endl;

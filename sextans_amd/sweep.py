@@ -16,6 +16,7 @@ import glob
 import json
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -24,7 +25,8 @@ from . import api
 HBM_PEAK_GBS = 8000.0
 
 
-def sweep(paths, n_values, rp_time=20, alpha=0.85, beta=-2.06, check=False, device=0, options=None, out=sys.stdout):
+def sweep(paths, n_values, rp_time=20, alpha=0.85, beta=-2.06, check=False, device=0, options=None, out=sys.stdout,
+          cache=False):
     records = []
     with api.Engine(device) as eng:
         for k, v in (options or {}).items():
@@ -32,7 +34,9 @@ def sweep(paths, n_values, rp_time=20, alpha=0.85, beta=-2.06, check=False, devi
         for path in paths:
             name = os.path.splitext(os.path.basename(path))[0]
             try:
-                rp, ci, va, M, K, nnz = api.read_suitsparse_matrix(path)
+                t0 = time.perf_counter()
+                rp, ci, va, M, K, nnz = api.read_suitsparse_matrix(path, cache=True if cache else None)
+                load_s = time.perf_counter() - t0
             except api.SextansError as e:
                 rec = {"matrix": name, "error": str(e)}
                 records.append(rec); print(json.dumps(rec), file=out, flush=True)
@@ -49,7 +53,7 @@ def sweep(paths, n_values, rp_time=20, alpha=0.85, beta=-2.06, check=False, devi
                 sec = ns * 1e-9 / max(rp_time, 1)
                 by = 8 * nnz + 4 * (M + 1) + 4 * K * N + 8 * M * N
                 rec = {"matrix": name, "M": M, "K": K, "nnz": nnz, "N": N, "kernel": eng.last_kernel(),
-                       "ms": round(sec * 1e3, 6), "gflops": round(api.gflops(M, N, nnz, sec), 2),
+                       "load_s": round(load_s, 4), "ms": round(sec * 1e3, 6), "gflops": round(api.gflops(M, N, nnz, sec), 2),
                        "alg_gbs": round(by / sec / 1e9, 2),
                        "roofline_frac": round(by / sec / 1e9 / HBM_PEAK_GBS, 5)}
                 if check:
@@ -73,13 +77,15 @@ def main(argv=None):
     ap.add_argument("--beta", type=float, default=-2.06)
     ap.add_argument("--check", action="store_true", help="compare with the host golden (reference criterion)")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--cache", action="store_true",
+                    help="read each matrix through its binary container (<file>.csr.sxbin), writing it on first use")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value")
     a = ap.parse_args(argv)
     paths = []
     for p in a.paths:
         paths.extend(sorted(glob.glob(p)) or [p])
     opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.opt}
-    sweep(paths, [int(x) for x in a.n.split(",")], a.rp, a.alpha, a.beta, a.check, a.device, opts)
+    sweep(paths, [int(x) for x in a.n.split(",")], a.rp, a.alpha, a.beta, a.check, a.device, opts, cache=a.cache)
 
 
 if __name__ == "__main__":
