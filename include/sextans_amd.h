@@ -121,9 +121,11 @@ typedef struct sextans_packed {
     int *dict_ptr;                /* nblk + 1 offsets into dict; empty range = "direct" block */
     int *dict;                    /* distinct columns of each dictionary block, ascending */
     int *row_off;                 /* M + 1: first stream entry of each row (multiple of 4) */
-    uint16_t *idx16;              /* stream_len: dictionary index per entry (dictionary blocks) */
+    uint16_t *idx16;              /* stream_len: dictionary index per entry (dictionary blocks); 0xFFFF in the
+                                     padding of those rows, whose value is -0.0f: the kernel multiplies such an
+                                     entry with a +1.0f row, and x + (-0.0f) == x bit for bit */
     int *col32;                   /* stream_len: column per entry (direct blocks) */
-    float *val;                   /* stream_len: value per entry (0 in padding) */
+    float *val;                   /* stream_len: value per entry (+-0 in padding) */
     int64_t stream_len;
     int max_dict;                 /* largest dictionary */
     int64_t nnz_in_panel_blocks;  /* non-zeros covered by dictionary blocks */

@@ -58,6 +58,8 @@ struct sextans_engine {
     // block-dictionary plan for the LDS-panel kernel (built lazily, per lanes_per_row)
     int plan_lpr = 0;               // 0 = no plan
     int64_t plan_min_reuse = -1;
+    // d_dict_ptr: entries per block dictionary; d_dict: dictionaries at stride plan_dict_stride;
+    // d_row_off: {first packed entry, entries} per (block, slot)
     int *d_dict_ptr = nullptr, *d_dict = nullptr, *d_blk_row = nullptr, *d_row_off = nullptr;
     int *d_pcol32 = nullptr;
     float *d_pval = nullptr;
@@ -65,6 +67,7 @@ struct sextans_engine {
     unsigned short *d_lidx = nullptr;
     double plan_panel_frac = 0.0;   // share of non-zeros living in dictionary blocks
     int plan_max_dict = 0;          // largest block dictionary (entries)
+    int plan_dict_stride = 0;       // ints per block in d_dict (dictionaries padded to a common stride)
     bool plan_built = false;        // false: only the sampled verdict exists (no packed stream)
     // blocked-ELL bf16 matrix (MFMA path)
     int bell_M = 0, bell_K = 0, bell_W = 0;
@@ -273,10 +276,40 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
     sx::build_panel_plan(h->M, h->K, rp.data(), ci.data(), va.data(), RB, kPanelFloats / (4 * lpr),
                          min_reuse, plan);
     h->plan_nblk = (int)plan.blk_row.size() - 1;
+    // Block-strided headers for the kernel (addresses depend on the block number only): per slot
+    // {first packed entry, entries}; per block its dictionary padded to a common stride with the last
+    // column repeated.
+    const int nblk = h->plan_nblk;
+    int dstride = ((plan.max_dict + RB - 1) / RB) * RB;
+    if (dstride < RB) dstride = RB;
+    if (dstride > 9 * RB) return SEXTANS_ERR_STATE;   // kPanelFloats / (4 * lpr) = 9 * RB by construction
+    std::vector<int> slot_info((size_t)nblk * RB * 2, 0), bdict((size_t)nblk * dstride, 0), dcnt((size_t)nblk);
+    for (int b = 0; b < nblk; ++b) {
+        const int r0 = plan.blk_row[b], r1 = plan.blk_row[b + 1];
+        const int u0 = plan.dict_ptr[b], nu = plan.dict_ptr[b + 1] - u0;
+        for (int r = r0; r < r1; ++r) {
+            // dictionary rows are consumed in whole groups of 4 entries (exact-safe padding, panel_plan.cpp);
+            // direct rows keep their true length (their padding is never multiplied)
+            const int len = rp[(size_t)r + 1] - rp[(size_t)r];
+            slot_info[((size_t)b * RB + (size_t)(r - r0)) * 2] = plan.row_off[r];
+            slot_info[((size_t)b * RB + (size_t)(r - r0)) * 2 + 1] = nu > 0 ? (len + 3) / 4 * 4 : len;
+        }
+        dcnt[(size_t)b] = nu;
+        for (int i = 0; i < dstride; ++i)
+            bdict[(size_t)b * dstride + i] = nu > 0 ? plan.dict[(size_t)u0 + (size_t)(i < nu ? i : nu - 1)] : 0;
+    }
+    h->plan_dict_stride = dstride;
     if (int rc = upload(&h->d_blk_row, plan.blk_row)) return rc;
-    if (int rc = upload(&h->d_dict_ptr, plan.dict_ptr)) return rc;
-    if (int rc = upload(&h->d_dict, plan.dict)) return rc;
-    if (int rc = upload(&h->d_row_off, plan.row_off)) return rc;
+    if (int rc = upload(&h->d_dict_ptr, dcnt)) return rc;
+    if (int rc = upload(&h->d_dict, bdict)) return rc;
+    if (int rc = upload(&h->d_row_off, slot_info)) return rc;
+    // the kernel adds the entry straight to its LDS address: store index * (bytes per panel row)
+    {
+        const unsigned row_bytes = 16u * (unsigned)lpr;
+        const unsigned pad_off = (unsigned)plan.max_dict * row_bytes;   // the +1.0f row sits right after the largest dictionary
+        if (pad_off > 0xffffu) return SEXTANS_ERR_STATE;
+        for (auto &x : plan.idx16) x = (uint16_t)(x == sx::kPadIndex ? pad_off : x * row_bytes);
+    }
     if (int rc = upload(&h->d_lidx, plan.idx16)) return rc;
     if (int rc = upload(&h->d_pcol32, plan.col32)) return rc;
     if (int rc = upload(&h->d_pval, plan.val)) return rc;
@@ -297,19 +330,19 @@ void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_
     const int64_t pstride = (int64_t)h->K * NT;
     const int xcd = (int)h->opt_xcd;
     // LDS = B panel sized for the largest dictionary of this matrix (rounded to 1 KiB) + C tile.
-    int panel_floats = ((h->plan_max_dict * NT + 255) / 256) * 256;
-    if (panel_floats > kPanelFloats) panel_floats = kPanelFloats;
-    const size_t lds = (size_t)(panel_floats + NT * (RB + 1)) * sizeof(int);
+    const int panel_floats = (h->plan_max_dict + 1) * NT;   // dictionary rows + the +1.0f row the padding entries address
+    const int tile_floats = NT * (RB + 1);   // the C tile reuses the panel bytes
+    const size_t lds = (size_t)(panel_floats > tile_floats ? panel_floats : tile_floats) * sizeof(int);
     if (h->opt_exact)
-        hipLaunchKernelGGL((sx::spmm_csr_panel<LPR, true>), dim3(nwg), dim3(sx::kBlock), lds, s, h->d_rp,
-                           h->d_row_off, h->d_lidx, h->d_pcol32, h->d_pval, h->d_blk_row, h->d_dict_ptr,
-                           h->d_dict, dBp, pstride, dCin, ldc_in, dCout, ldc, ntiles, h->plan_nblk, alpha,
-                           beta, xcd, panel_floats, (long long *)h->d_dbg);
+        hipLaunchKernelGGL((sx::spmm_csr_panel<LPR, true>), dim3(nwg), dim3(sx::kBlock), lds, s,
+                           (const int2 *)h->d_row_off, h->d_lidx, h->d_pcol32, h->d_pval, h->d_blk_row,
+                           h->d_dict_ptr, h->d_dict, h->plan_dict_stride, dBp, pstride, dCin, ldc_in, dCout,
+                           ldc, ntiles, h->plan_nblk, alpha, beta, xcd, panel_floats, (long long *)h->d_dbg);
     else
-        hipLaunchKernelGGL((sx::spmm_csr_panel<LPR, false>), dim3(nwg), dim3(sx::kBlock), lds, s, h->d_rp,
-                           h->d_row_off, h->d_lidx, h->d_pcol32, h->d_pval, h->d_blk_row, h->d_dict_ptr,
-                           h->d_dict, dBp, pstride, dCin, ldc_in, dCout, ldc, ntiles, h->plan_nblk, alpha,
-                           beta, xcd, panel_floats, (long long *)h->d_dbg);
+        hipLaunchKernelGGL((sx::spmm_csr_panel<LPR, false>), dim3(nwg), dim3(sx::kBlock), lds, s,
+                           (const int2 *)h->d_row_off, h->d_lidx, h->d_pcol32, h->d_pval, h->d_blk_row,
+                           h->d_dict_ptr, h->d_dict, h->plan_dict_stride, dBp, pstride, dCin, ldc_in, dCout,
+                           ldc, ntiles, h->plan_nblk, alpha, beta, xcd, panel_floats, (long long *)h->d_dbg);
 }
 
 }  // namespace

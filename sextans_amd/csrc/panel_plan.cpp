@@ -70,6 +70,12 @@ void build_part(int K, const int *rp, const int *ci, const float *va, int RB, in
                 if (use_dict) idx16[o] = (uint16_t)local[(size_t)ci[j]];
                 else col32[o] = ci[j];
             }
+            // Padding of dictionary rows is CONSUMED by the kernel (whole groups of 4 entries): value
+            // -0.0f against a panel row of +1.0f gives the product -0.0f, and x + (-0.0f) == x bit for
+            // bit for every x, so the sequential sum is untouched.  kPadIndex is replaced by the
+            // position of that row when the stream is handed to the device.
+            if (use_dict)
+                for (; o < row_off[row + 1]; ++o) { pval[o] = -0.0f; idx16[o] = kPadIndex; }
         }
         ++blk_id;
         r = e;

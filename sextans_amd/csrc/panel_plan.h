@@ -22,6 +22,8 @@
 
 namespace sx {
 
+constexpr uint16_t kPadIndex = 0xFFFF;   // idx16 of padding entries in dictionary rows (value -0.0f)
+
 struct PanelPlan {
     int rows_per_block = 0;
     int max_unique = 0;
@@ -29,9 +31,9 @@ struct PanelPlan {
     std::vector<int> dict_ptr;       // nblk + 1 offsets into dict (empty range = direct block)
     std::vector<int> dict;           // distinct columns per dictionary block, ascending
     std::vector<int> row_off;        // M + 1: first packed entry of each row (multiple of 4); row_off[M] = total
-    std::vector<uint16_t> idx16;     // packed local indices (dictionary rows; 0 elsewhere/padding)
+    std::vector<uint16_t> idx16;     // packed local indices (dictionary rows; kPadIndex in their padding; 0 elsewhere)
     std::vector<int> col32;          // packed 32-bit columns (direct rows; 0 elsewhere/padding)
-    std::vector<float> val;          // packed values (0 in padding)
+    std::vector<float> val;          // packed values (-0.0f in the padding of dictionary rows, 0 elsewhere)
     int64_t nnz_in_panel_blocks = 0;
     int64_t nnz_total = 0;
     int max_dict = 0;

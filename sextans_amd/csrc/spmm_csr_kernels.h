@@ -217,22 +217,25 @@ __device__ __forceinline__ int slot_bcast(int x) {
 
 template <int LPR, bool EXACT>
 __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
-    const int *__restrict__ row_ptr, const int *__restrict__ row_off,
-    const unsigned short *__restrict__ p_idx16, const int *__restrict__ p_col32,
-    const float *__restrict__ p_val, const int *__restrict__ blk_row,
-    const int *__restrict__ dict_ptr, const int *__restrict__ dict, const float *__restrict__ Bp,
-    int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc, int ntiles,
-    int nblk, float alpha, float beta, int use_xcd_remap, int panel_floats, long long *dbg) {
+    const int2 *__restrict__ slot_info, const unsigned short *__restrict__ p_idx16,
+    const int *__restrict__ p_col32, const float *__restrict__ p_val, const int *__restrict__ blk_row,
+    const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
+    const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout,
+    int64_t ldc, int ntiles, int nblk, float alpha, float beta, int use_xcd_remap, int panel_floats,
+    long long *dbg) {
     const long long t0 = dbg ? clock64() : 0;   // dbg: optional phase timing (engine option "phase_timing")
+    const long long w0 = dbg ? wall_clock64() : 0;   // 100 MHz constant clock: calibrates the cycle counts
     constexpr int NT = 4 * LPR;
     constexpr int RB = kBlock / LPR;
     constexpr int TS = RB + 1;
     constexpr int BATCH = 4 * LPR;            // entries a row group holds per fetch (4 per lane)
     constexpr int OPT = (RB * NT) / kBlock;   // outputs per thread
-    // Dynamic LDS: [panel_floats floats of B panel][NT*TS floats of C tile].
+    // Dynamic LDS: max(panel_floats, NT*TS) floats.  The B panel lives there while rows are streamed; the
+    // C tile of the epilogue reuses the same bytes after a barrier (36 KiB per workgroup => 4 per CU;
+    // a separate 4 KiB tile made it 41 024 bytes, 64 too many for the fourth workgroup).
     extern __shared__ __attribute__((aligned(16))) int smem[];
     float *panel = reinterpret_cast<float *>(smem);
-    float *s_c = reinterpret_cast<float *>(smem + panel_floats);
+    float *s_c = reinterpret_cast<float *>(smem);
 
     const unsigned nwg = (unsigned)nblk * (unsigned)ntiles;
     unsigned wg = blockIdx.x;
@@ -243,27 +246,27 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     const int tid = threadIdx.x;
     const int slot = tid / LPR;
     const int q = tid % LPR;
+    // Everything the block needs first sits at addresses that depend on the block NUMBER only (fixed
+    // strides per block), so the scalar block meta, this slot's row extent and its share of the
+    // dictionary are all requested in the same round trip; the entries and the B rows follow in the
+    // second one.  Slots past the block's last row read {0, 0}; dictionary slots past its last entry
+    // repeat the last column (they rewrite the same panel bytes).
+    constexpr int MAXD = 9;   // dictionary capacity = MAXD * RB entries (36 KiB panel)
+    const int2 si = slot_info[(int64_t)blk * RB + slot];      // {first packed entry, entries} of this slot's row
+    int dix[MAXD];
+    {
+        const int *bd = blk_dict + (int64_t)blk * dict_stride;
+#pragma unroll
+        for (int u = 0; u < MAXD; ++u) dix[u] = bd[min(slot + u * RB, dict_stride - 1)];
+    }
     const int row0 = blk_row[blk];
     const int row1 = blk_row[blk + 1];        // row1 - row0 <= RB
-    const int row = row0 + slot;
-    const int u0 = dict_ptr[blk];
-    const int nu = dict_ptr[blk + 1] - u0;
+    const int nu = dict_cnt[blk];
     const bool use_dict = nu > 0;
 
-    // Dictionary indices of this slot's panel rows (slot, slot+RB, ...; clamped): requested FIRST, they
-    // depend only on the scalar block meta, so their latency overlaps the row-extent round trip instead
-    // of following it.
-    constexpr int MAXD = 9;   // 576-entry dictionary / 64 slots (N tile 16); larger ones take the loop below
-    int dix[MAXD];
-    if (use_dict) {
-#pragma unroll
-        for (int u = 0; u < MAXD; ++u) dix[u] = dict[u0 + min(slot + u * RB, nu - 1)];
-    }
-
     const float *bq = Bp + (int64_t)tile * panel_stride + 4 * q;
-    int len = 0;
-    int64_t off = 0;
-    if (row < row1) { len = row_ptr[row + 1] - row_ptr[row]; off = row_off[row]; }
+    const int len = si.y;
+    const int64_t off = si.x;
 
     // this lane's 4 entries of a batch: indices (unpacked to int) and values
     auto fetch = [&](int pos, int (&oi)[4], float (&ov)[4]) {
@@ -271,6 +274,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
         const f32x4 v = *reinterpret_cast<const f32x4 *>(p_val + o);
         ov[0] = v.x; ov[1] = v.y; ov[2] = v.z; ov[3] = v.w;
         if (use_dict) {
+            // dictionary entries carry the BYTE offset of their B row in the panel (index * NT * 4 < 64 Ki)
             const uint2 w = *reinterpret_cast<const uint2 *>(p_idx16 + o);
             oi[0] = (int)(w.x & 0xffffu); oi[1] = (int)(w.x >> 16);
             oi[2] = (int)(w.y & 0xffffu); oi[3] = (int)(w.y >> 16);
@@ -308,11 +312,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
                 if (h0 + u < MAXD)
                     *reinterpret_cast<f32x4 *>(panel + min(slot + (h0 + u) * RB, nu - 1) * NT + 4 * q) = v[u];
         }
-        // dictionaries beyond MAXD*RB entries (other N-tile widths): plain loop
-        for (int i = slot + MAXD * RB; i < nu; i += RB) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(bq + (int64_t)dict[u0 + i] * NT);
-            *reinterpret_cast<f32x4 *>(panel + i * NT + 4 * q) = v;
-        }
+        if (tid < NT) panel[panel_floats - NT + tid] = 1.0f;   // the row padding entries (value -0.0f) point at
         __syncthreads();
     }
 
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
 // entries held by lane (k/4) of the row group, issue all B-row reads (BROW: LDS panel or global
 // gather -- kept as two separate code paths so the LDS reads stay ds_read_b128, not flat loads), then
 // accumulate in order.
-#define SX_BROW_LDS(idx) (*reinterpret_cast<const float4 *>(pq + (idx) * NT))
+#define SX_BROW_LDS(idx) (*reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(pq) + (idx)))
 #define SX_BROW_GLB(idx) (*reinterpret_cast<const float4 *>(bq + (int64_t)(idx) * NT))
 #define SX_STEP_DECL(k) int i##k = 0; float a##k = 0.f; float4 b##k = make_float4(0.f, 0.f, 0.f, 0.f);
 #define SX_STEP_LOAD(BROW, k, base, live)                                                            \
@@ -348,7 +348,24 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
         SX_STEP_MAC(4, base, (base) + 4 < (cnt)) SX_STEP_MAC(5, base, (base) + 5 < (cnt))               \
         SX_STEP_MAC(6, base, (base) + 6 < (cnt)) SX_STEP_MAC(7, base, (base) + 7 < (cnt))               \
     }
-#define SX_ROW_LOOP(BROW)                                                                      \
+// Tail of a dictionary row: its remaining entries come in whole groups of 4 (one lane's fetch), the
+// padding inside the last group is exact-safe, so the predicate is per group, not per entry.
+#define SX_QUAD(BROW, j, cnt)                                                                            \
+    if constexpr ((j) < LPR - 1) {                                                                       \
+        if (4 * (j) < (cnt)) {                                                                           \
+            SX_STEP_DECL(0) SX_STEP_DECL(1) SX_STEP_DECL(2) SX_STEP_DECL(3)                              \
+            SX_STEP_LOAD(BROW, 0, 4 * (j), true) SX_STEP_LOAD(BROW, 1, 4 * (j), true)                    \
+            SX_STEP_LOAD(BROW, 2, 4 * (j), true) SX_STEP_LOAD(BROW, 3, 4 * (j), true)                    \
+            SX_STEP_MAC(0, 4 * (j), true) SX_STEP_MAC(1, 4 * (j), true)                                  \
+            SX_STEP_MAC(2, 4 * (j), true) SX_STEP_MAC(3, 4 * (j), true)                                  \
+        }                                                                                                \
+    }
+#define SX_TAIL_ENTRIES(BROW, cnt) \
+    { SX_SUB(BROW, 0, cnt) SX_SUB(BROW, 8, cnt) SX_SUB(BROW, 16, cnt) SX_SUB(BROW, 24, cnt) }
+#define SX_TAIL_QUADS(BROW, cnt)                                                                  \
+    { SX_QUAD(BROW, 0, cnt) SX_QUAD(BROW, 1, cnt) SX_QUAD(BROW, 2, cnt) SX_QUAD(BROW, 3, cnt)     \
+      SX_QUAD(BROW, 4, cnt) SX_QUAD(BROW, 5, cnt) SX_QUAD(BROW, 6, cnt) }
+#define SX_ROW_LOOP(BROW, TAIL)                                                                \
     {                                                                                          \
         int pos = 0;                                                                           \
         /* full batches: every entry is live, no per-entry predicate */                        \
@@ -361,11 +378,14 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
         /* tail: fewer than BATCH entries left, predicated per entry */                        \
         if (pos < len) {                                                                       \
             const int cnt = len - pos;                                                         \
-            SX_SUB(BROW, 0, cnt) SX_SUB(BROW, 8, cnt) SX_SUB(BROW, 16, cnt) SX_SUB(BROW, 24, cnt) \
+            TAIL(BROW, cnt)                                                                    \
         }                                                                                      \
     }
-    if (use_dict) SX_ROW_LOOP(SX_BROW_LDS) else SX_ROW_LOOP(SX_BROW_GLB)
+    if (use_dict) SX_ROW_LOOP(SX_BROW_LDS, SX_TAIL_QUADS) else SX_ROW_LOOP(SX_BROW_GLB, SX_TAIL_ENTRIES)
 #undef SX_ROW_LOOP
+#undef SX_TAIL_QUADS
+#undef SX_TAIL_ENTRIES
+#undef SX_QUAD
 #undef SX_SUB
 #undef SX_STEP_MAC
 #undef SX_STEP_LOAD
@@ -374,6 +394,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
 #undef SX_BROW_LDS
 
     const long long t3 = dbg ? clock64() : 0;
+    __syncthreads();                          // every wave is done reading the panel: reuse it as the C tile
     s_c[(4 * q + 0) * TS + slot] = acc.x;
     s_c[(4 * q + 1) * TS + slot] = acc.y;
     s_c[(4 * q + 2) * TS + slot] = acc.z;
@@ -396,6 +417,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
         atomicAdd((unsigned long long *)&dbg[2], (unsigned long long)(t3 - t2));   // row streaming / compute
         atomicAdd((unsigned long long *)&dbg[3], (unsigned long long)(t4 - t3));   // C tile + epilogue
         atomicAdd((unsigned long long *)&dbg[4], 1ull);
+        atomicAdd((unsigned long long *)&dbg[5], (unsigned long long)(wall_clock64() - w0));   // same span, 10 ns ticks
     }
 }
 

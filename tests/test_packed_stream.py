@@ -30,11 +30,18 @@ def check_invariants(P, M, K, rp, ci, v, lanes, min_reuse):
     assert covered == P["nnz_in_panel_blocks"]
     # the decoder gives back the CSR arrays bit for bit
     assert np.array_equal(P["decoded_col_idx"], ci) and np.array_equal(P["decoded_val"].view(np.uint32), v.view(np.uint32))
-    # padding entries carry value 0
+    # padding: value zero everywhere; inside dictionary rows it is -0.0f with index 0xFFFF (the kernel
+    # multiplies it with a +1.0f panel row: x + (-0.0f) == x bit for bit), elsewhere +0.0f / index 0
     mask = np.ones(P["stream_len"], bool)
-    for r in range(M):
-        mask[ro[r]:ro[r] + lens[r]] = False
+    dict_pad = np.zeros(P["stream_len"], bool)
+    for b in range(len(br) - 1):
+        for r in range(br[b], br[b + 1]):
+            mask[ro[r]:ro[r] + lens[r]] = False
+            if dp[b + 1] > dp[b]:
+                dict_pad[ro[r] + lens[r]:ro[r + 1]] = True
     assert np.all(P["val"][mask] == 0)
+    assert np.all(np.signbit(P["val"][dict_pad])) and np.all(P["idx16"][dict_pad] == 0xFFFF)
+    assert not np.any(np.signbit(P["val"][mask & ~dict_pad])) and not np.any(P["idx16"][mask & ~dict_pad])
 
 
 @pytest.mark.parametrize("lanes", [2, 4, 8])

@@ -44,4 +44,5 @@ by = alg_bytes(M, K, N, nnz)
 if opts.get("phase_timing") == "1":
     pt = e.phase_timing_read()
     print("  phase cycles/wave: prologue %.0f staging %.0f stream %.0f epilogue %.0f (sampled waves %d)" % tuple([x / max(pt[4], 1) for x in pt[:4]] + [pt[4]]))
+    print("  wave lifetime %.2f us (100 MHz clock) => clock64 rate %.0f MHz" % (pt[5] / max(pt[4], 1) / 100.0, sum(pt[:4]) / max(pt[5], 1) * 100.0))
 print(f"{name} {opts} kernel={e.last_kernel()} {k_ns/1e3:.2f} us repack {r_ns/1e3:.2f} us alg {by/(k_ns*1e-9)/1e9:.1f} GB/s nnz={nnz}")
