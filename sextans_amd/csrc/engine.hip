@@ -68,6 +68,7 @@ struct sextans_engine {
     double plan_panel_frac = 0.0;   // share of non-zeros living in dictionary blocks
     int plan_max_dict = 0;          // largest block dictionary (entries)
     int plan_dict_stride = 0;       // ints per block in d_dict (dictionaries padded to a common stride)
+    bool plan_mixed = false;        // some block with non-zeros has no dictionary (global-gather path needed)
     bool plan_built = false;        // false: only the sampled verdict exists (no packed stream)
     // blocked-ELL bf16 matrix (MFMA path)
     int bell_M = 0, bell_K = 0, bell_W = 0;
@@ -283,6 +284,7 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
     int dstride = ((plan.max_dict + RB - 1) / RB) * RB;
     if (dstride < RB) dstride = RB;
     if (dstride > 9 * RB) return SEXTANS_ERR_STATE;   // kPanelFloats / (4 * lpr) = 9 * RB by construction
+    bool mixed = false;
     std::vector<int> slot_info((size_t)nblk * RB * 2, 0), bdict((size_t)nblk * dstride, 0), dcnt((size_t)nblk);
     for (int b = 0; b < nblk; ++b) {
         const int r0 = plan.blk_row[b], r1 = plan.blk_row[b + 1];
@@ -295,10 +297,12 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
             slot_info[((size_t)b * RB + (size_t)(r - r0)) * 2 + 1] = nu > 0 ? (len + 3) / 4 * 4 : len;
         }
         dcnt[(size_t)b] = nu;
+        if (nu == 0 && rp[(size_t)r1] > rp[(size_t)r0]) mixed = true;
         for (int i = 0; i < dstride; ++i)
             bdict[(size_t)b * dstride + i] = nu > 0 ? plan.dict[(size_t)u0 + (size_t)(i < nu ? i : nu - 1)] : 0;
     }
     h->plan_dict_stride = dstride;
+    h->plan_mixed = mixed;
     if (int rc = upload(&h->d_blk_row, plan.blk_row)) return rc;
     if (int rc = upload(&h->d_dict_ptr, dcnt)) return rc;
     if (int rc = upload(&h->d_dict, bdict)) return rc;
@@ -333,16 +337,19 @@ void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_
     const int panel_floats = (h->plan_max_dict + 1) * NT;   // dictionary rows + the +1.0f row the padding entries address
     const int tile_floats = NT * (RB + 1);   // the C tile reuses the panel bytes
     const size_t lds = (size_t)(panel_floats > tile_floats ? panel_floats : tile_floats) * sizeof(int);
-    if (h->opt_exact)
-        hipLaunchKernelGGL((sx::spmm_csr_panel<LPR, true>), dim3(nwg), dim3(sx::kBlock), lds, s,
-                           (const int2 *)h->d_row_off, h->d_lidx, h->d_pcol32, h->d_pval, h->d_blk_row,
-                           h->d_dict_ptr, h->d_dict, h->plan_dict_stride, dBp, pstride, dCin, ldc_in, dCout,
-                           ldc, ntiles, h->plan_nblk, alpha, beta, xcd, panel_floats, (long long *)h->d_dbg);
-    else
-        hipLaunchKernelGGL((sx::spmm_csr_panel<LPR, false>), dim3(nwg), dim3(sx::kBlock), lds, s,
-                           (const int2 *)h->d_row_off, h->d_lidx, h->d_pcol32, h->d_pval, h->d_blk_row,
-                           h->d_dict_ptr, h->d_dict, h->plan_dict_stride, dBp, pstride, dCin, ldc_in, dCout,
-                           ldc, ntiles, h->plan_nblk, alpha, beta, xcd, panel_floats, (long long *)h->d_dbg);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(sx::kBlock), lds, s, (const int2 *)h->d_row_off, h->d_lidx,
+                           h->d_pcol32, h->d_pval, h->d_blk_row, h->d_dict_ptr, h->d_dict, h->plan_dict_stride, dBp,
+                           pstride, dCin, ldc_in, dCout, ldc, ntiles, h->plan_nblk, alpha, beta, xcd, panel_floats,
+                           (long long *)h->d_dbg);
+    };
+    if (h->plan_mixed) {
+        if (h->opt_exact) go(sx::spmm_csr_panel<LPR, true, true>);
+        else go(sx::spmm_csr_panel<LPR, false, true>);
+    } else {
+        if (h->opt_exact) go(sx::spmm_csr_panel<LPR, true, false>);
+        else go(sx::spmm_csr_panel<LPR, false, false>);
+    }
 }
 
 }  // namespace

@@ -215,7 +215,10 @@ __device__ __forceinline__ int slot_bcast(int x) {
     }
 }
 
-template <int LPR, bool EXACT>
+// MIXED = the plan also has "direct" blocks (no dictionary: 32-bit columns, B rows gathered from global
+// memory).  Matrices whose every block has reuse run the MIXED = false instantiation: no second code path,
+// so no control-flow joins at which the waitcnt insertion has to drain all outstanding loads.
+template <int LPR, bool EXACT, bool MIXED>
 __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     const int2 *__restrict__ slot_info, const unsigned short *__restrict__ p_idx16,
     const int *__restrict__ p_col32, const float *__restrict__ p_val, const int *__restrict__ blk_row,
@@ -252,17 +255,19 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     // second one.  Slots past the block's last row read {0, 0}; dictionary slots past its last entry
     // repeat the last column (they rewrite the same panel bytes).
     constexpr int MAXD = 9;   // dictionary capacity = MAXD * RB entries (36 KiB panel)
-    const int2 si = slot_info[(int64_t)blk * RB + slot];      // {first packed entry, entries} of this slot's row
-    int dix[MAXD];
-    {
-        const int *bd = blk_dict + (int64_t)blk * dict_stride;
-#pragma unroll
-        for (int u = 0; u < MAXD; ++u) dix[u] = bd[min(slot + u * RB, dict_stride - 1)];
-    }
     const int row0 = blk_row[blk];
     const int row1 = blk_row[blk + 1];        // row1 - row0 <= RB
     const int nu = dict_cnt[blk];
-    const bool use_dict = nu > 0;
+    const bool use_dict = MIXED ? nu > 0 : true;
+    const int2 si = slot_info[(int64_t)blk * RB + slot];      // {first packed entry, entries} of this slot's row
+    int dix[MAXD];
+    {
+        // dict_stride is a multiple of RB: the clamp is on the uniform part of the address only (branch-free:
+        // all loads stay in one basic block and in flight together)
+        const int *bd = blk_dict + (int64_t)blk * dict_stride + slot;
+#pragma unroll
+        for (int u = 0; u < MAXD; ++u) dix[u] = bd[min(u * RB, dict_stride - RB)];
+    }
 
     const float *bq = Bp + (int64_t)tile * panel_stride + 4 * q;
     const int len = si.y;
@@ -300,7 +305,8 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     const long long t1 = dbg ? clock64() : 0;
     if (use_dict) {
         // Stage the block's distinct B rows: slot s copies dictionary entries s, s+RB, ... (indices were
-        // requested at kernel entry; clamped duplicates rewrite the same bytes).
+        // requested at kernel entry; chunks past the stride repeat the last chunk and entries past the
+        // dictionary repeat its last column, so duplicates rewrite the same bytes).
 #pragma unroll
         for (int h0 = 0; h0 < MAXD; h0 += 5) {
             f32x4 v[5];
@@ -310,7 +316,8 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
 #pragma unroll
             for (int u = 0; u < 5; ++u)
                 if (h0 + u < MAXD)
-                    *reinterpret_cast<f32x4 *>(panel + min(slot + (h0 + u) * RB, nu - 1) * NT + 4 * q) = v[u];
+                    *reinterpret_cast<f32x4 *>(
+                        panel + max(min(slot + min((h0 + u) * RB, dict_stride - RB), nu - 1), 0) * NT + 4 * q) = v[u];
         }
         if (tid < NT) panel[panel_floats - NT + tid] = 1.0f;   // the row padding entries (value -0.0f) point at
         __syncthreads();
