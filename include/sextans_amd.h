@@ -230,7 +230,8 @@ int sextans_set_matrix_csr_device(sextans_handle_t h, int M, int K, int64_t nnz,
  * place, column major, ld = K for B and M for C.  The kernel runs rp_time (>=1) times, every
  * repeat from the same C input (the reference reads C_in and writes a separate C_out), and
  * *elapsed_ns receives the device time of ALL repeats (tapa::invoke returns the same;
- * sextans-host.cpp:252 divides by rp_time).  Host<->device copies are outside *elapsed_ns. */
+ * sextans-host.cpp:252 divides by rp_time).  Host<->device copies are outside *elapsed_ns.  B is laid
+ * out in panels once (first repeat); the repeats are replayed as one hipGraph. */
 int sextans_spmm_host(sextans_handle_t h, int N, float alpha, const float *B, float beta, float *C,
                       int rp_time, double *elapsed_ns);
 
