@@ -288,20 +288,41 @@ def cpu_baseline(api, M, K, N, args, Cout, flops_per_row):
             sec = ref.spmm(R, N, K, np.float32(ALPHA), rp, ci, v, Bh, np.float32(BETA), Cs)
         else:
             sec = o.time_spmm_rows(0, R, R, N, K, np.float32(ALPHA), rp, ci, v, Bh, np.float32(BETA), Cs)
-        return sec, int(rp[-1]), Cs
+        return sec, int(rp[-1]), Cs, (rp, ci, v)
 
     R = min(M, 50_000)
-    sec, nnz_s, Cs = run(R)
+    sec, nnz_s, Cs, csr = run(R)
     if sec < args.cpu_seconds / 4 and R < M:
         R = int(min(M, max(R, R * args.cpu_seconds / max(sec, 1e-3))))
-        sec, nnz_s, Cs = run(R)
+        sec, nnz_s, Cs, csr = run(R)
     gf = 2.0 * N * (nnz_s + R) / sec / 1e9
     got = Cout.view(N, M)[:, :R].cpu().numpy().reshape(-1)
     match = bool(np.array_equal(got.view(np.uint32), Cs.view(np.uint32)))
-    return {"value": round(gf, 3), "unit": "GFLOP/s", "cores": cores, "kind": kind,
-            "sample": f"rows [0,{R}) of the same matrix ({nnz_s} nnz), same B and C_in, "
-                      f"{sec:.2f} s single thread; host has {os.cpu_count()} logical cores",
-            "gpu_matches_cpu_bitwise_on_sample": match}
+    out = {"value": round(gf, 3), "unit": "GFLOP/s", "cores": cores, "kind": kind,
+           "sample": f"rows [0,{R}) of the same matrix ({nnz_s} nnz), same B and C_in, "
+                     f"{sec:.2f} s single thread; host has {os.cpu_count()} logical cores",
+           "gpu_matches_cpu_bitwise_on_sample": match}
+    # Same loop nest, row-parallel on the host's cores (SURVEY.md 8d baseline 2): the C restatement on
+    # nnz-balanced row ranges, one thread per range (ctypes releases the GIL), same sample.
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        from sextans_amd import dist as sxd
+        rp, ci, v = csr
+        T = max(1, min(os.cpu_count() or 1, 64))
+        ranges = [r for r in sxd.partition_rows_by_nnz(rp, T) if r[1] > r[0]]
+        Cs2 = np.ascontiguousarray(Cin_h.reshape(N, M)[:, :R]).reshape(-1)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(len(ranges)) as ex:
+            list(ex.map(lambda r: o.spmm_rows(r[0], r[1], R, N, K, np.float32(ALPHA), rp, ci, v, Bh,
+                                              np.float32(BETA), Cs2), ranges))
+        sec2 = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(2.0 * N * (nnz_s + R) / sec2 / 1e9, 3), "unit": "GFLOP/s",
+                            "cores": len(ranges), "kind": "port", "seconds": round(sec2, 3),
+                            "matches_single_thread_bitwise": bool(np.array_equal(Cs2.view(np.uint32),
+                                                                                  Cs.view(np.uint32)))}
+    except Exception as e:   # extra information only
+        out["all_cores"] = {"error": str(e)}
+    return out
 
 
 def _measure(api, torch, e, M, K, N, nnz, dev, stream, iters):
