@@ -9,7 +9,7 @@ namespace sx {
 namespace {
 
 constexpr int kPad = 4;       // entries; every row of the packed stream starts on this boundary
-constexpr int kTailPad = 64;  // extra zero entries at the end (prefetch of the last batch)
+constexpr int kTailPad = 256; // extra zero entries at the end (the kernel keeps up to 4 batches of 32 ahead in flight)
 
 struct Part {
     std::vector<int> blk_row;   // first rows of the blocks of this part (without the final end)

@@ -290,7 +290,36 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     };
     int ix[4], nx[4];
     float vx[4], nv[4];
+    // Dictionary-only instantiation: the B-row loads of the panel (mostly L2 hits) are issued BEFORE the
+    // row-stream loads (always HBM): vmcnt retires in order, so the LDS writes of the panel would otherwise
+    // wait for the slower stream loads queued ahead of them.
+    constexpr int MAXD_ = 9;
+    f32x4 bv[MIXED ? 1 : MAXD_];
+    if constexpr (!MIXED) {
+#pragma unroll
+        for (int u = 0; u < MAXD_; ++u) bv[u] = *reinterpret_cast<const f32x4 *>(bq + (int64_t)dix[u] * NT);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     fetch(0, ix, vx);
+    // Dictionary-only instantiation: PFT further batches of the row stay in flight as raw loads (6
+    // registers each); see the row loop below.
+    constexpr int PFT = MIXED ? 0 : 3;
+    f32x4 rv[PFT > 0 ? PFT : 1];
+    uint2 rw[PFT > 0 ? PFT : 1];
+    auto fetch_raw = [&](int pos, f32x4 &v, uint2 &w) {
+        const int64_t o = off + pos + 4 * q;
+        v = *reinterpret_cast<const f32x4 *>(p_val + o);
+        w = *reinterpret_cast<const uint2 *>(p_idx16 + o);
+    };
+    auto unpack_raw = [&](const f32x4 &v, const uint2 &w) {
+        vx[0] = v.x; vx[1] = v.y; vx[2] = v.z; vx[3] = v.w;
+        ix[0] = (int)(w.x & 0xffffu); ix[1] = (int)(w.x >> 16);
+        ix[2] = (int)(w.y & 0xffffu); ix[3] = (int)(w.y >> 16);
+    };
+    if constexpr (PFT > 0) {
+#pragma unroll
+        for (int d = 0; d < PFT; ++d) fetch_raw((d + 1) * BATCH, rv[d], rw[d]);
+    }
 
     // C_in for this thread's outputs: issued now, consumed in the epilogue (clamped addresses).
     const int64_t col0 = (int64_t)tile * NT;
@@ -303,7 +332,15 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     }
 
     const long long t1 = dbg ? clock64() : 0;
-    if (use_dict) {
+    if constexpr (!MIXED) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < MAXD_; ++u)
+            *reinterpret_cast<f32x4 *>(panel + max(min(slot + min(u * RB, dict_stride - RB), nu - 1), 0) * NT + 4 * q) =
+                bv[u];
+        if (tid < NT) panel[panel_floats - NT + tid] = 1.0f;   // the row padding entries (value -0.0f) point at
+        __syncthreads();
+    } else if (use_dict) {
         // Stage the block's distinct B rows: slot s copies dictionary entries s, s+RB, ... (indices were
         // requested at kernel entry; chunks past the stride repeat the last chunk and entries past the
         // dictionary repeat its last column, so duplicates rewrite the same bytes).
@@ -388,7 +425,37 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
             TAIL(BROW, cnt)                                                                    \
         }                                                                                      \
     }
-    if (use_dict) SX_ROW_LOOP(SX_BROW_LDS, SX_TAIL_QUADS) else SX_ROW_LOOP(SX_BROW_GLB, SX_TAIL_ENTRIES)
+    if constexpr (!MIXED) {
+        // Ring of PFT batches ahead.  The steady-state body has no branches, so the compiler can wait for
+        // exactly the oldest fetch (vmcnt(2 * (PFT - 1))) instead of draining everything at a join.
+        int pos = 0;
+        while (pos + PFT * BATCH <= len) {
+#pragma unroll
+            for (int d = 0; d < PFT; ++d) {
+                SX_SUB(SX_BROW_LDS, 0, BATCH) SX_SUB(SX_BROW_LDS, 8, BATCH)
+                SX_SUB(SX_BROW_LDS, 16, BATCH) SX_SUB(SX_BROW_LDS, 24, BATCH)
+                unpack_raw(rv[d], rw[d]);
+                fetch_raw(pos + (PFT + 1) * BATCH, rv[d], rw[d]);
+                pos += BATCH;
+            }
+        }
+        // fewer than PFT full batches left: they are already in the ring, nothing new is requested
+#pragma unroll
+        for (int d = 0; d < PFT - 1; ++d) {
+            if (pos + BATCH <= len) {
+                SX_SUB(SX_BROW_LDS, 0, BATCH) SX_SUB(SX_BROW_LDS, 8, BATCH)
+                SX_SUB(SX_BROW_LDS, 16, BATCH) SX_SUB(SX_BROW_LDS, 24, BATCH)
+                unpack_raw(rv[d], rw[d]);
+                pos += BATCH;
+            }
+        }
+        if (pos < len) {
+            const int cnt = len - pos;
+            SX_TAIL_QUADS(SX_BROW_LDS, cnt)
+        }
+    } else {
+        if (use_dict) SX_ROW_LOOP(SX_BROW_LDS, SX_TAIL_QUADS) else SX_ROW_LOOP(SX_BROW_GLB, SX_TAIL_ENTRIES)
+    }
 #undef SX_ROW_LOOP
 #undef SX_TAIL_QUADS
 #undef SX_TAIL_ENTRIES
