@@ -211,7 +211,8 @@ int sextans_destroy(sextans_handle_t h);
  * (0/1), "exact" (1 = no FMA, reference rounding; 0 = allow FMA), "profile" (0/1 hipEvent
  * per-kernel timing), "phase_timing" (0/1, see sextans_phase_timing_read), "split_rows" (T > 0: rows longer than T
  * non-zeros are processed in pieces of T and folded in order -- for power-law matrices; re-associates
- * those rows, so results are within tolerance instead of bit-identical; default 0 = off), "panel_min_reuse_x100" (a row block uses the LDS panel when
+ * those rows, so results are within tolerance instead of bit-identical; default 0 = off), "fuse_b" (1 = the panel kernel may stage B straight from column-major B when B is <= 16 MiB and every row block has a dictionary, saving the
+ * repack launch; default 1), "panel_min_reuse_x100" (a row block uses the LDS panel when
  * nnz >= value/100 * distinct columns; default 400).  Unknown keys -> SEXTANS_ERR_INVALID. */
 int sextans_set_option(sextans_handle_t h, const char *key, int64_t value);
 int sextans_get_option(sextans_handle_t h, const char *key, int64_t *value);

@@ -88,6 +88,7 @@ struct sextans_engine {
     long long *d_dbg = nullptr;     // 8 counters for phase timing (option "phase_timing")
     // options
     int64_t opt_kernel = 0, opt_lpr = 4, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;
+    int64_t opt_fuse_b = 1;             // panel kernel may stage from column-major B (small matrices: no repack launch)
     int64_t opt_split_rows = 0;         // > 0: rows longer than this are split (re-associated); 0 = exact order
     int64_t opt_phase_timing = 0;       // 1: panel kernel accumulates per-phase wave cycles (debug aid)
     int64_t opt_min_reuse_x100 = 400;   // a block uses the LDS panel if nnz >= 4 * distinct columns
@@ -327,13 +328,15 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
     return SEXTANS_OK;
 }
 
+// dBp: repacked panel (bcol_ld == 0) or the caller's column-major B at this segment's first column with its
+// leading dimension bcol_ld (dictionary-only plans, small B: no repack launch).
 template <int LPR>
 void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout,
-                  int64_t ldc, int ntiles, float alpha, float beta, hipStream_t s) {
+                  int64_t ldc, int ntiles, float alpha, float beta, hipStream_t s, int64_t bcol_ld = 0) {
     constexpr int RB = sx::kBlock / LPR;
     constexpr int NT = 4 * LPR;
     const unsigned nwg = (unsigned)h->plan_nblk * (unsigned)ntiles;
-    const int64_t pstride = (int64_t)h->K * NT;
+    const int64_t pstride = bcol_ld > 0 ? bcol_ld : (int64_t)h->K * NT;
     const int xcd = (int)h->opt_xcd;
     // LDS = B panel sized for the largest dictionary of this matrix (rounded to 1 KiB) + C tile.
     const int panel_floats = (h->plan_max_dict + 1) * NT;   // dictionary rows + the +1.0f row the padding entries address
@@ -348,6 +351,9 @@ void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_
     if (h->plan_mixed) {
         if (h->opt_exact) go(sx::spmm_csr_panel<LPR, true, true>);
         else go(sx::spmm_csr_panel<LPR, false, true>);
+    } else if (bcol_ld > 0) {
+        if (h->opt_exact) go(sx::spmm_csr_panel<LPR, true, false, true>);
+        else go(sx::spmm_csr_panel<LPR, false, false, true>);
     } else {
         if (h->opt_exact) go(sx::spmm_csr_panel<LPR, true, false>);
         else go(sx::spmm_csr_panel<LPR, false, false>);
@@ -420,6 +426,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "panel_min_reuse_x100")) return &h->opt_min_reuse_x100;
     if (!strcmp(key, "phase_timing")) return &h->opt_phase_timing;
     if (!strcmp(key, "split_rows")) return &h->opt_split_rows;
+    if (!strcmp(key, "fuse_b")) return &h->opt_fuse_b;
     return nullptr;
 }
 
@@ -588,7 +595,11 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         if (int rc = ensure(&h->d_P, &h->P_cap, (size_t)h->split_nv * (size_t)N)) return rc;
         SX_HIP(hipMemsetAsync(h->d_P, 0, (size_t)h->split_nv * (size_t)N * sizeof(float), s));
     }
-    const bool skip_repack = (flags & SEXTANS_ROWS_REUSE_B_PANELS) != 0;
+    // Small B (fits the L2s), dictionary-only plan, one N segment: the panel kernel stages straight from the
+    // caller's column-major B and the repack launch disappears.
+    const bool fuse_b = use_panel && !h->plan_mixed && h->opt_fuse_b && plan.size() == 1 && plan[0].width == W &&
+                        (size_t)h->K * (size_t)N * sizeof(float) <= ((size_t)16 << 20);
+    const bool skip_repack = fuse_b || (flags & SEXTANS_ROWS_REUSE_B_PANELS) != 0;
 
     if (!skip_repack) {
         Prof p(h, &h->ev_repack, s);
@@ -610,17 +621,17 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             const bool panel_here = use_panel && g.width == W;   // the plan is built for width W
             switch (g.width) {
                 case 32:
-                    if (panel_here) launch_panel<8>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
+                    if (panel_here) launch_panel<8>(h, fuse_b ? d_B + (int64_t)g.col0 * ldb : bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, fuse_b ? ldb : 0);
                     else if (split) launch_rowgroup<8>(h, h->d_vrp, bp, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, 0, h->split_nv, g.ntiles, 1.0f, 0.0f, s);
                     else launch_rowgroup<8>(h, h->d_rp, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
                     break;
                 case 16:
-                    if (panel_here) launch_panel<4>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
+                    if (panel_here) launch_panel<4>(h, fuse_b ? d_B + (int64_t)g.col0 * ldb : bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, fuse_b ? ldb : 0);
                     else if (split) launch_rowgroup<4>(h, h->d_vrp, bp, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, 0, h->split_nv, g.ntiles, 1.0f, 0.0f, s);
                     else launch_rowgroup<4>(h, h->d_rp, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
                     break;
                 default:
-                    if (panel_here) launch_panel<2>(h, bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s);
+                    if (panel_here) launch_panel<2>(h, fuse_b ? d_B + (int64_t)g.col0 * ldb : bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, fuse_b ? ldb : 0);
                     else if (split) launch_rowgroup<2>(h, h->d_vrp, bp, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, 0, h->split_nv, g.ntiles, 1.0f, 0.0f, s);
                     else launch_rowgroup<2>(h, h->d_rp, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
                     break;

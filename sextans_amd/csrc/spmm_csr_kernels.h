@@ -218,7 +218,11 @@ __device__ __forceinline__ int slot_bcast(int x) {
 // MIXED = the plan also has "direct" blocks (no dictionary: 32-bit columns, B rows gathered from global
 // memory).  Matrices whose every block has reuse run the MIXED = false instantiation: no second code path,
 // so no control-flow joins at which the waitcnt insertion has to drain all outstanding loads.
-template <int LPR, bool EXACT, bool MIXED>
+// BCOL (dictionary-only): Bp is the caller's COLUMN-MAJOR B (panel_stride = its leading dimension) and the
+// panel is staged from it with four 4-byte loads per B row and lane instead of one 16-byte load from the
+// repacked panel.  For matrices whose B fits the L2s this saves the repack launch, which is a third of a
+// step when the whole SpMM is a few microseconds (nasa4704).
+template <int LPR, bool EXACT, bool MIXED, bool BCOL = false>
 __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     const int2 *__restrict__ slot_info, const unsigned short *__restrict__ p_idx16,
     const int *__restrict__ p_col32, const float *__restrict__ p_val, const int *__restrict__ blk_row,
@@ -228,6 +232,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     long long *dbg) {
     const long long t0 = dbg ? clock64() : 0;   // dbg: optional phase timing (engine option "phase_timing")
     const long long w0 = dbg ? wall_clock64() : 0;   // 100 MHz constant clock: calibrates the cycle counts
+    static_assert(!(MIXED && BCOL), "the column-major staging exists for dictionary-only plans");
     constexpr int NT = 4 * LPR;
     constexpr int RB = kBlock / LPR;
     constexpr int TS = RB + 1;
@@ -297,7 +302,15 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     f32x4 bv[MIXED ? 1 : MAXD_];
     if constexpr (!MIXED) {
 #pragma unroll
-        for (int u = 0; u < MAXD_; ++u) bv[u] = *reinterpret_cast<const f32x4 *>(bq + (int64_t)dix[u] * NT);
+        for (int u = 0; u < MAXD_; ++u) {
+            if constexpr (BCOL) {
+                const float *bc = Bp + ((int64_t)tile * NT + 4 * q) * panel_stride + dix[u];
+                bv[u].x = bc[0]; bv[u].y = bc[panel_stride]; bv[u].z = bc[2 * panel_stride];
+                bv[u].w = bc[3 * panel_stride];
+            } else {
+                bv[u] = *reinterpret_cast<const f32x4 *>(bq + (int64_t)dix[u] * NT);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     fetch(0, ix, vx);

@@ -57,11 +57,14 @@ def test_structure_sweep(engine, oracle, seed, kind, M, K, mean, N, lpr, min_reu
     alpha, beta = np.float32(rs.choice([0.85, -1.5, 1.0])), np.float32(rs.choice([-2.06, 0.0, 1.0]))
     want = C0.copy()
     oracle.spmm(M, N, K, alpha, rp, ci, v, B, beta, want)
-    for kernel in (1, 2):
-        for k, val in dict(lanes_per_row=lpr, stage_a=1, xcd_remap=1, exact=1, kernel=kernel,
+    # kernel 1 = row-group gather; kernel 2 = panel, staging B from the repacked panel (fuse_b 0) or straight
+    # from the caller's column-major B (fuse_b 1, the default for small matrices)
+    for kernel, fuse_b in ((1, 1), (2, 0), (2, 1)):
+        for k, val in dict(lanes_per_row=lpr, stage_a=1, xcd_remap=1, exact=1, kernel=kernel, fuse_b=fuse_b,
                            panel_min_reuse_x100=min_reuse, split_rows=0).items():
             engine.set_option(k, val)
         engine.set_matrix_csr(M, K, rp, ci, v)
         out = C0.copy()
         engine.spmm(N, float(alpha), B, float(beta), out, rp_time=int(rs.choice([1, 2])))
-        assert bits_equal(out, want), (kernel, engine.last_kernel())
+        assert bits_equal(out, want), (kernel, fuse_b, engine.last_kernel())
+    engine.set_option("fuse_b", 1)

@@ -18,7 +18,7 @@ MANIFEST = json.load(open(os.path.join(CASES, "manifest.json")))
 
 
 def run(engine, M, K, rp, ci, v, N, alpha, B, beta, C0, **opts):
-    defaults = dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0, panel_min_reuse_x100=400)
+    defaults = dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0, panel_min_reuse_x100=400, fuse_b=1)
     defaults.update(opts)
     for k, val in defaults.items():
         engine.set_option(k, val)
