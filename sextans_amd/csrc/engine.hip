@@ -673,46 +673,52 @@ int run_repeats(sextans_engine *h, int N, float alpha, float beta, int rp_time, 
         SX_HIP(hipStreamSynchronize(h->host_stream));
     }
     hipStream_t cs = h->host_stream;
-    auto enqueue = [&]() -> int {
-        // many repeats on the same B: one repack, then the (slightly faster) panel-staged kernel every time
-        const int nofuse = rp_time >= 4 ? kRowsNoFuseB : 0;
-        for (int r = 0; r < rp_time; ++r)
+    // `count` repeats; the first one lays B out in panels, the others reuse them.  Loops of four or more
+    // repeats always use the panel-staged kernel (one repack amortised) instead of the column-major staging.
+    const int nofuse = rp_time >= 4 ? kRowsNoFuseB : 0;
+    auto enqueue = [&](int count) -> int {
+        for (int r = 0; r < count; ++r)
             if (int rc = sextans_spmm_device_rows(h, N, alpha, h->d_B, h->K, beta, h->d_Cin, h->M, h->d_Cout, h->M,
                                                   0, h->M, (r ? SEXTANS_ROWS_REUSE_B_PANELS : 0) | nofuse, (void *)cs))
                 return rc;
         return SEXTANS_OK;
     };
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
+    struct Cleanup {   // released on every exit path
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Cleanup() {
+            if (exec) (void)hipGraphExecDestroy(exec);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } c;
     const bool use_graph = !h->opt_profile && !h->opt_phase_timing && h->opt_split_rows == 0;
+    const int per_graph = rp_time < 128 ? rp_time : 128;   // bound the graph; long loops replay it
     if (use_graph) {
         // relaxed mode: the enqueue path calls hipSetDevice / hipGetLastError, which thread-local capture rejects
         SX_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
-        const int rc = enqueue();
-        const hipError_t ce = hipStreamEndCapture(cs, &graph);
-        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        const int rc = enqueue(per_graph);
+        const hipError_t ce = hipStreamEndCapture(cs, &c.graph);
+        if (rc) return rc;
         SX_HIP(ce);
-        SX_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        SX_HIP(hipGraphInstantiate(&c.exec, c.graph, nullptr, nullptr, 0));
     }
-    hipEvent_t e0, e1;
-    SX_HIP(hipEventCreate(&e0));
-    SX_HIP(hipEventCreate(&e1));
-    SX_HIP(hipEventRecord(e0, cs));
+    SX_HIP(hipEventCreate(&c.e0));
+    SX_HIP(hipEventCreate(&c.e1));
+    SX_HIP(hipEventRecord(c.e0, cs));
     if constexpr (!std::is_same<Pre, std::nullptr_t>::value) pre(cs);
     if (use_graph) {
-        SX_HIP(hipGraphLaunch(exec, cs));
-    } else if (int rc = enqueue()) {
+        for (int done = 0; done + per_graph <= rp_time; done += per_graph) SX_HIP(hipGraphLaunch(c.exec, cs));
+        if (int rc = enqueue(rp_time % per_graph)) return rc;
+    } else if (int rc = enqueue(rp_time)) {
         return rc;
     }
     if constexpr (!std::is_same<Post, std::nullptr_t>::value) post(cs);
     SX_HIP(hipGetLastError());
-    SX_HIP(hipEventRecord(e1, cs));
-    SX_HIP(hipEventSynchronize(e1));
+    SX_HIP(hipEventRecord(c.e1, cs));
+    SX_HIP(hipEventSynchronize(c.e1));
     float ms = 0.f;
-    SX_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (exec) (void)hipGraphExecDestroy(exec);
-    if (graph) (void)hipGraphDestroy(graph);
+    SX_HIP(hipEventElapsedTime(&ms, c.e0, c.e1));
     *ns = (double)ms * 1e6;
     return SEXTANS_OK;
 }
