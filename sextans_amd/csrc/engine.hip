@@ -277,6 +277,17 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
         SX_HIP(hipMemcpy(ci.data(), h->d_ci, sizeof(int) * (size_t)h->nnz, hipMemcpyDeviceToHost));
         SX_HIP(hipMemcpy(va.data(), h->d_v, sizeof(float) * (size_t)h->nnz, hipMemcpyDeviceToHost));
     }
+    {   // the packed stream is addressed with 32-bit entry offsets: rows padded to 4 entries must fit
+        int64_t padded = 0;
+        for (int r = 0; r < h->M; ++r) padded += ((int64_t)(rp[(size_t)r + 1] - rp[(size_t)r]) + 3) / 4 * 4;
+        if (padded > 0x7fffffffLL - 4096) {
+            h->plan_lpr = lpr;
+            h->plan_min_reuse = h->opt_min_reuse_x100;
+            h->plan_panel_frac = 0.0;
+            h->plan_built = false;
+            return SEXTANS_OK;   // row-group kernel only
+        }
+    }
     sx::PanelPlan plan;
     sx::build_panel_plan(h->M, h->K, rp.data(), ci.data(), va.data(), RB, kPanelFloats / (4 * lpr),
                          min_reuse, plan);
