@@ -66,6 +66,9 @@ class Oracle:
         L.orc_bell_spmm.restype = None
         L.orc_bell_spmm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _i32p, u16p, u16p, C.c_float,
                                     C.c_float, _f32p, f64p]
+        L.orc_edge_stream.restype = C.c_int
+        L.orc_edge_stream.argtypes = [C.c_int, C.c_int, _i32p, _i32p, _f32p, C.POINTER(C.POINTER(C.c_int)),
+                                      C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_long)]
         L.orc_gflops.restype = C.c_double
         L.orc_gflops.argtypes = [C.c_int, C.c_int, C.c_long, C.c_double]
 
@@ -123,6 +126,21 @@ class Oracle:
                                np.ascontiguousarray(block_val, np.uint16),
                                np.ascontiguousarray(B_bf16, np.uint16), alpha, beta, C_inout, asum)
         return asum
+
+    def edge_stream(self, M, K, col_ptr, row_idx, val):
+        """Restatement of generate_edge_list_for_all_PEs + edge_list_64bit: -> (ptr[num_windows+1],
+        channels[8, chan_len] uint64)."""
+        p, ch, n = C.POINTER(C.c_int)(), C.POINTER(C.c_uint64)(), C.c_long()
+        err = self.lib.orc_edge_stream(M, K, np.ascontiguousarray(col_ptr, np.int32), _pad(np.asarray(row_idx, np.int32)),
+                                       _pad(np.asarray(val, np.float32)), p, ch, n)
+        if err:
+            raise RuntimeError(f"orc_edge_stream error {err}")
+        nwin = (K + 4095) // 4096
+        out = (_take(p, nwin + 1, np.int32),
+               (_take(ch, 8 * n.value, np.uint64) if n.value else np.zeros(0, np.uint64)).reshape(8, n.value))
+        self.lib.orc_free(p)
+        self.lib.orc_free(ch)
+        return out
 
     def init_B(self, K, N):
         B = np.empty(K * N, np.float32)

@@ -293,6 +293,86 @@ double orc_time_spmm_rows(int r0, int r1, int M, int N, int K, float alpha, cons
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
+/* ---- The accelerator's scheduled non-zero stream.
+ * generate_edge_list_for_one_PE / _all_PEs, sparse_helper.h:292-403: per 4096-column window, the CSC entries
+ * of the window are dealt to PE = row % 64 in CSC order; inside a PE every entry takes the first free slot
+ * at or after (slot of the previous entry of the same row in this window) + 10, probing linearly (:315-327);
+ * after each window all 64 lists are padded with bubbles to the longest (:390-397) and
+ * edge_list_ptr[w + 1] = that length (:400).
+ * edge_list_64bit, sparse_helper.h:406-473 (8 channels): word = (col & 0x3FFF) << 50 | (row & 0x3FFFF) << 32 |
+ * fp32 bits, bubble = 0x3FFFF << 32 (:427-443); PE p = j + 8*cc is stored in channel j = p % 8 at slot
+ * ((p/8 & 1) * 4 + (p/8 & 2) + (p/8 & 4) / 4) of 8-word group i (:458-464); every channel is
+ * round_up(8 * length, 512) words, zero filled (:412-417).
+ * Returns 0 and malloc'ed *ptr_out (num_windows + 1 ints) and *chan_out (8 * *chan_len words, channel c at
+ * c * *chan_len).  Parity: tests/test_edge_stream.py checks the slot assignment against the reference's own
+ * generate_edge_list_for_all_PEs (oracle/_ref and tests/golden/edges/); the word layout has no executable
+ * reference here (edge_list_64bit needs TAPA's allocator type) and is pinned by hand-computed words. */
+int orc_edge_stream(int M, int K, const int *col_ptr, const int *row_idx, const float *val, int **ptr_out,
+                    uint64_t **chan_out, long *chan_len) {
+    enum { NPE = 64, WIN = 4096, DIST = 10 };
+    const int nwin = (K + WIN - 1) / WIN;
+    int *ptr = (int *)calloc((size_t)nwin + 1, sizeof(int));
+    uint64_t *pe[NPE];
+    size_t cap[NPE], len[NPE];
+    int *last = (int *)malloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
+    if (!ptr || !last) return ORC_ERR_ALLOC;
+    for (int p = 0; p < NPE; ++p) { pe[p] = NULL; cap[p] = len[p] = 0; }
+    const uint64_t bubble = (uint64_t)0x3FFFF << 32;
+    for (int w = 0; w < nwin; ++w) {
+        const int c0 = w * WIN, c1 = (c0 + WIN < K) ? c0 + WIN : K;
+        size_t start[NPE], used[NPE];
+        for (int p = 0; p < NPE; ++p) { start[p] = len[p]; used[p] = 0; }
+        for (int r = 0; r < M; ++r) last[r] = -DIST;                       /* cycles_rows, :308 */
+        for (int c = c0; c < c1; ++c)
+            for (int j = col_ptr[c]; j < col_ptr[c + 1]; ++j) {
+                const int r = row_idx[j], p = r % NPE;
+                size_t cyc = (size_t)(last[r] + DIST);
+                for (;;) {                                                  /* :318-327 */
+                    if (cyc >= used[p]) {
+                        const size_t need = start[p] + cyc + 1;
+                        if (need > cap[p]) {
+                            cap[p] = need * 2 + 64;
+                            pe[p] = (uint64_t *)realloc(pe[p], cap[p] * sizeof(uint64_t));
+                            if (!pe[p]) return ORC_ERR_ALLOC;
+                        }
+                        for (size_t t = used[p]; t <= cyc; ++t) pe[p][start[p] + t] = bubble;
+                        used[p] = cyc + 1;
+                    }
+                    if (pe[p][start[p] + cyc] != bubble) ++cyc; else break;
+                }
+                uint32_t bits;
+                memcpy(&bits, &val[j], 4);
+                pe[p][start[p] + cyc] = ((uint64_t)((c - c0) & 0x3FFF) << 50) |
+                                        ((uint64_t)((r / NPE) & 0x3FFFF) << 32) | bits;
+                last[r] = (int)cyc;
+            }
+        size_t longest = 0;
+        for (int p = 0; p < NPE; ++p) { len[p] = start[p] + used[p]; if (len[p] > longest) longest = len[p]; }
+        for (int p = 0; p < NPE; ++p) {
+            if (longest > cap[p]) {
+                cap[p] = longest + 64;
+                pe[p] = (uint64_t *)realloc(pe[p], cap[p] * sizeof(uint64_t));
+                if (!pe[p]) return ORC_ERR_ALLOC;
+            }
+            for (size_t t = len[p]; t < longest; ++t) pe[p][t] = bubble;
+            len[p] = longest;
+        }
+        ptr[w + 1] = (int)longest;
+    }
+    const long L = nwin ? ptr[nwin] : 0;
+    const long clen = (8 * L + 511) / 512 * 512;
+    uint64_t *ch = (uint64_t *)calloc((size_t)(clen > 0 ? clen * 8 : 1), sizeof(uint64_t));
+    if (!ch) return ORC_ERR_ALLOC;
+    for (int p = 0; p < NPE; ++p) {
+        const int g = p / 8, slot = ((g & 1) ? 4 : 0) + ((g & 2) ? 2 : 0) + ((g & 4) ? 1 : 0);
+        for (long i = 0; i < L; ++i) ch[(long)(p % 8) * clen + i * 8 + slot] = pe[p][i];
+        free(pe[p]);
+    }
+    free(last);
+    *ptr_out = ptr; *chan_out = ch; *chan_len = clen;
+    return ORC_OK;
+}
+
 /* ---- Blocked-ELL bf16 SpMM (BASELINE config 5).  NO reference analogue: parity for this path is
  * UNPINNED by the reference; this is our own fp32 CPU restatement on bf16 inputs:
  * every bf16 x bf16 product is exact in fp32; products are accumulated in fp32 in slot order, k

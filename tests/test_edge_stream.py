@@ -235,3 +235,30 @@ def test_channel_lengths_follow_the_host():
     assert L.sextans_chan_c_len(4704, 16) == (4704 * 2 + 1023) // 1024 * 1024
     with pytest.raises(sx.SextansError):
         sx.chan_pack_b(4, 12, np.zeros(48, np.float32), 4)                 # N not a multiple of 8
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_oracle_restatement_matches_reference_scheduler_fixture(oracle, path):
+    """oracle/sextans_oracle.c:orc_edge_stream (linear probing, as the reference) against the committed outputs
+    of the reference's scheduler; the product's writer (union-find) against the oracle."""
+    f = load_fixture(path)
+    M, K = int(f["M"]), int(f["K"])
+    ptr, ch = oracle.edge_stream(M, K, f["csc_ptr"], f["csc_idx"], f["csc_val"])
+    assert np.array_equal(ptr, f["ptr"])
+    assert np.array_equal(ch, edge_words(f["ptr"], f["row"], f["col"], f["val"]))
+    e = sx.edges_pack_csc(M, K, f["csc_ptr"], f["csc_idx"], f["csc_val"])
+    assert np.array_equal(e["channels"], ch)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_writer_matches_oracle_on_random_matrices(oracle, seed):
+    rs = np.random.RandomState(100 + seed)
+    M, K = int(rs.choice([3, 64, 200, 1500])), int(rs.choice([1, 70, 4096, 9000]))
+    mask = rs.rand(K, M) < rs.choice([0.002, 0.02, 0.3])
+    cp = np.zeros(K + 1, np.int32)
+    cp[1:] = np.cumsum(mask.sum(1))
+    ri = np.nonzero(mask)[1].astype(np.int32)
+    cv = rs.uniform(-1, 1, ri.size).astype(np.float32)
+    ptr, ch = oracle.edge_stream(M, K, cp, ri, cv)
+    e = sx.edges_pack_csc(M, K, cp, ri, cv)
+    assert np.array_equal(e["edge_list_ptr"][:len(ptr)], ptr) and np.array_equal(e["channels"], ch)
