@@ -236,7 +236,7 @@ def main():
                         ("config3_pcrystk02_surrogate_N128",
                          lambda: fem_secondary(api, torch, dev, stream, (35, 19, 7, 3), 128, 300)),
                         ("suitesparse_like_fem_4M_N16",
-                         lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 10)),
+                         lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 100)),
                         ("config5_blocked_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream))):
             try:
                 also[key] = fn()
