@@ -1,8 +1,10 @@
 #!/bin/bash
 # tools/power_probe.sh <workload> [engine options...] -- sample rocm-smi power / clocks while one workload loops
-python tools/run_one.py "$@" iters=3000 > /tmp/pp_run.log 2>&1 &
+python tools/run_one.py "$@" iters=6000 > /tmp/pp_run.log 2>&1 &
 PID=$!
-sleep 6
-for i in 1 2 3 4 5; do rocm-smi --showpower --showclocks --showuse 2>/dev/null | grep -E "Power|sclk|mclk|GPU use|fclk" | tr '\n' ';'; echo; sleep 1; done
+for i in $(seq 1 24); do
+  rocm-smi --showpower --showclocks --showuse 2>/dev/null | grep -E "Package Power|sclk|GPU use" | sed 's/.*: //' | tr '\n' ' '; echo
+  sleep 0.5
+done
 wait $PID
 tail -1 /tmp/pp_run.log
