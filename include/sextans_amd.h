@@ -138,6 +138,27 @@ void sextans_packed_free(sextans_packed *p);
 /* Decoder: reconstructs col_idx[nnz], val[nnz] of the CSR matrix with row extents row_ptr. */
 int sextans_unpack_csr(const sextans_packed *p, const int *row_ptr, int *col_idx, float *val);
 
+/* K-windowed stream of A for the accumulator-resident kernel ("kernel" = 3; the reference's own dataflow:
+ * B window on chip, partial sums resident, non-zeros pre-bucketed per (PE, window) -- sextans.cpp:337,353-381,
+ * 462-570; sparse_helper.h:345-403).  Wavefront g owns rows [g*rows_per_wave, (g+1)*rows_per_wave); its
+ * stream is steps [wave_step0[g], wave_step0[g+1]) of 32 entries each (a multiple of 24 steps), ordered by
+ * (K window, rank of the entry inside its (row, window), row) so that a row's entries keep their CSR order;
+ * no step holds a row twice; padding entries carry the local row `rows_per_wave` (a dummy accumulator).
+ * Entry (little endian 64 bit): low word = fp32 value bits, high word = local_row << 23 | column.
+ * K must be <= 2^23, rows_per_wave <= 510.  The arrays are what sextans_set_matrix_* builds internally. */
+typedef struct sextans_window_packed {
+    int M, K;
+    int64_t nnz;
+    int rows_per_wave, window_cols, nwaves;
+    int64_t steps;                /* total steps (stream holds steps * 32 entries + a zero tail of 32 steps) */
+    int64_t padded_lower_bound;   /* the dispatcher's cheap estimate of steps * 32 */
+    int *wave_step0;              /* nwaves + 1 */
+    uint64_t *stream;
+} sextans_window_packed;
+int sextans_window_pack_csr(int M, int K, const int *row_ptr, const int *col_idx, const float *val,
+                            int rows_per_wave, int window_cols, sextans_window_packed *out);
+void sextans_window_packed_free(sextans_window_packed *p);
+
 /* ------------------------------------------------------------------ the accelerator's own buffer formats
  *
  * Writer / reader for exactly the buffers the reference host prepares for tapa::invoke(Sextans, ...)
@@ -206,7 +227,9 @@ int sextans_device_count(int *count);
 int sextans_create(sextans_handle_t *h, int device);
 int sextans_destroy(sextans_handle_t h);
 
-/* Tunables.  key: "kernel" (0 auto, 1 row-group gather, 2 LDS panel), "lanes_per_row"
+/* Tunables.  key: "kernel" (0 auto, 1 row-group gather, 2 LDS panel, 3 K-windowed accumulator-resident
+ * sweep), "window_rows" (rows per wavefront of kernel 3, default 319), "window_cols" (columns per K window,
+ * default 65536), "window_unroll" (4 or 8 steps in flight), "lanes_per_row"
  * (2/4/8, N-tile = 4*lanes), "stage_a" (0/1 stage the CSR stream through LDS), "xcd_remap"
  * (0/1), "exact" (1 = no FMA, reference rounding; 0 = allow FMA), "profile" (0/1 hipEvent
  * per-kernel timing), "phase_timing" (0/1, see sextans_phase_timing_read), "split_rows" (T > 0: rows longer than T
@@ -216,6 +239,11 @@ int sextans_destroy(sextans_handle_t h);
  * nnz >= value/100 * distinct columns; default 400).  Unknown keys -> SEXTANS_ERR_INVALID. */
 int sextans_set_option(sextans_handle_t h, const char *key, int64_t value);
 int sextans_get_option(sextans_handle_t h, const char *key, int64_t *value);
+/* Read-only figures about the matrix currently set.  key: "plan_build_s" (host seconds spent so far
+ * building packed forms of A -- read back from the device, pack on all cores, upload; outside every timed
+ * region like the reference's scheduling/packing, sextans-host.cpp:114-148), "window_padded_entries",
+ * "window_state" (0 not evaluated, 1 built, -1 rejected), "panel_fraction", "panel_blocks". */
+int sextans_get_stat(sextans_handle_t h, const char *key, double *value);
 
 /* Upload a CSR matrix (host pointers) once; later spmm calls reuse the device copy.  This is
  * the analogue of the reference's FPGA-side preparation (generate_edge_list_for_all_PEs +
@@ -253,11 +281,18 @@ int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_
  * their row 0 (ldc_in, ldc_out >= row_end - row_begin).  Used to pipeline a rank's slab in chunks so the
  * all-gather of chunk i overlaps the SpMM of chunk i+1.  flags: SEXTANS_ROWS_REUSE_B_PANELS = the B
  * panels repacked by the previous call on this handle are still valid (same B, same N): skip the repack.
- * Row ranges always use the row-group gather kernel. */
+ * A range that starts and ends on sextans_align_row boundaries (or at 0 / M) keeps the whole-matrix kernel;
+ * any other range uses the row-group gather kernel. */
 #define SEXTANS_ROWS_REUSE_B_PANELS 1
 int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
                              float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out,
                              int64_t ldc_out, int row_begin, int row_end, int flags, void *stream);
+
+/* Largest row <= `row` at which a row-range call of an N-column SpMM on this matrix can be cut without losing
+ * the kernel the dispatcher would use for the whole matrix (a wavefront boundary of the window kernel, a row
+ * block boundary of the LDS-panel kernel; any row for the gather kernel).  row == M is returned unchanged.
+ * Builds the packed forms of A if they do not exist yet. */
+int sextans_align_row(sextans_handle_t h, int N, int row, int *aligned);
 
 /* Drop-in for the kernel-invoke call itself: the argument list of
  *   tapa::invoke(Sextans, bitstream, edge_list_ptr, edge_list_ch[8], mat_B_ch[NUM_CH_B], mat_C_ch_in[8],

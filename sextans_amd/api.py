@@ -38,6 +38,14 @@ class Packed(C.Structure):
                 ("nnz_in_panel_blocks", C.c_int64)]
 
 
+class WindowPacked(C.Structure):
+    """Mirror of struct sextans_window_packed (include/sextans_amd.h)."""
+    _fields_ = [("M", C.c_int), ("K", C.c_int), ("nnz", C.c_int64), ("rows_per_wave", C.c_int),
+                ("window_cols", C.c_int), ("nwaves", C.c_int), ("steps", C.c_int64),
+                ("padded_lower_bound", C.c_int64), ("wave_step0", C.POINTER(C.c_int)),
+                ("stream", C.POINTER(C.c_uint64))]
+
+
 class Edges(C.Structure):
     """Mirror of struct sextans_edges (include/sextans_amd.h)."""
     _fields_ = [("M", C.c_int32), ("K", C.c_int32), ("num_windows", C.c_int32), ("num_a_len", C.c_int32),
@@ -95,6 +103,12 @@ def lib():
     L.sextans_packed_free.argtypes = [C.POINTER(Packed)]
     L.sextans_packed_free.restype = None
     L.sextans_unpack_csr.argtypes = [C.POINTER(Packed), _i32p, _i32p, _f32p]
+    L.sextans_window_pack_csr.argtypes = [C.c_int, C.c_int, _i32p, _i32p, _f32p, C.c_int, C.c_int,
+                                          C.POINTER(WindowPacked)]
+    L.sextans_window_packed_free.argtypes = [C.POINTER(WindowPacked)]
+    L.sextans_window_packed_free.restype = None
+    L.sextans_get_stat.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
+    L.sextans_align_row.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
     pp = C.POINTER(C.c_void_p)
     L.sextans_edges_pack_csc.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f32p, C.POINTER(Edges)]
     L.sextans_edges_free.argtypes = [C.POINTER(Edges)]
@@ -266,6 +280,28 @@ def pack_csr(M, K, row_ptr, col_idx, val, lanes_per_row=4, min_reuse_x100=400):
         L.sextans_packed_free(C.byref(P))
 
 
+def window_pack_csr(M, K, row_ptr, col_idx, val, rows_per_wave=319, window_cols=65536):
+    """Build the K-windowed stream of the accumulator-resident kernel (host); returns a dict:
+    wave_step0[nwaves+1], val[steps*32] (float32), row[steps*32] (local row; == rows_per_wave for padding),
+    col[steps*32]."""
+    L = lib()
+    P = WindowPacked()
+    _check(L.sextans_window_pack_csr(M, K, _buf(row_ptr, np.int32), _buf(col_idx, np.int32),
+                                     _buf(val, np.float32), rows_per_wave, window_cols, C.byref(P)),
+           "window_pack_csr")
+    try:
+        n = int(P.steps) * 32
+        words = _take(P.stream, n, np.uint64)
+        hi = (words >> np.uint64(32)).astype(np.uint32)
+        return dict(M=P.M, K=P.K, nnz=P.nnz, rows_per_wave=P.rows_per_wave, window_cols=P.window_cols,
+                    nwaves=P.nwaves, steps=int(P.steps), padded_lower_bound=int(P.padded_lower_bound),
+                    wave_step0=_take(P.wave_step0, P.nwaves + 1, np.int32),
+                    val=(words & np.uint64(0xffffffff)).astype(np.uint32).view(np.float32),
+                    row=(hi >> np.uint32(23)).astype(np.int32), col=(hi & np.uint32(0x7fffff)).astype(np.int32))
+    finally:
+        L.sextans_window_packed_free(C.byref(P))
+
+
 # ---- the accelerator's own buffer formats (SURVEY 8f row 2) ----
 
 def _rows(a2d):
@@ -430,6 +466,17 @@ class Engine:
 
     def set_option(self, key, value):
         _check(lib().sextans_set_option(self._h, key.encode(), int(value)), f"set_option({key})")
+
+    def align_row(self, N, row):
+        """Largest row <= `row` where a row-range call keeps the whole-matrix kernel (sextans_align_row)."""
+        out = C.c_int()
+        _check(lib().sextans_align_row(self._h, N, int(row), C.byref(out)), "align_row")
+        return out.value
+
+    def get_stat(self, key):
+        v = C.c_double()
+        _check(lib().sextans_get_stat(self._h, key.encode(), C.byref(v)), f"get_stat({key})")
+        return v.value
 
     def get_option(self, key):
         v = C.c_int64()

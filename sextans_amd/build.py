@@ -17,9 +17,11 @@ BINDIR = os.path.join(ROOT, "sextans_amd", "bin")
 LIB = os.path.join(LIBDIR, "libsextans_amd.so")
 CLI = os.path.join(BINDIR, "sextans")
 
-LIB_SOURCES = ["engine.hip", "synth.hip", "host_mtx.cpp", "panel_plan.cpp", "pack_api.cpp",
+LIB_SOURCES = ["engine.hip", "synth.hip", "host_mtx.cpp", "panel_plan.cpp", "window_plan.cpp", "pack_api.cpp",
                "edge_stream.cpp"]
-HEADERS = ["spmm_csr_kernels.h", "bell_kernels.h", "chan_kernels.h", "panel_plan.h", os.path.join("..", "..", "include", "sextans_amd.h")]
+HEADERS = ["spmm_csr_kernels.h", "spmm_window_kernel.h", "bell_kernels.h", "chan_kernels.h", "panel_plan.h",
+           "window_plan.h", os.path.join("..", "..", "include", "sextans_amd.h")]
+OBJDIR = os.path.join(LIBDIR, "obj")
 
 # -ffp-contract=off: the EXACT kernels and the CLI golden need "multiply, round, add" (the
 # reference's arithmetic, sparse_helper.h:283); hipcc's default is to contract into FMA.
@@ -42,21 +44,38 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
+    """One object per source (rebuilt only when it or a header changed, compiled in parallel), then link."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(BINDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    if force or _stale(LIB, deps):
-        cmd = [hipcc()] + FLAGS + ["-shared", "-o", LIB] + srcs
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+
+    def compile_one(name):
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(OBJDIR, name + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [hipcc()] + FLAGS + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            return obj, True
+        return obj, False
+
+    with ThreadPoolExecutor(len(LIB_SOURCES)) as ex:
+        res = list(ex.map(compile_one, LIB_SOURCES))
+    objs = [o for o, _ in res]
+    if force or any(ch for _, ch in res) or _stale(LIB, objs):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
     cli_src = os.path.join(CSRC, "cli_main.cpp")
     if force or _stale(CLI, [cli_src, LIB]):
         cmd = [hipcc()] + FLAGS + ["-o", CLI, cli_src, "-L", LIBDIR, "-lsextans_amd",
                                    "-Wl,-rpath,$ORIGIN/../lib"]
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
     return LIB, CLI
 

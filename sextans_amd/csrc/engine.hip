@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -19,6 +20,8 @@
 #include "panel_plan.h"
 #include "sextans_amd.h"
 #include "spmm_csr_kernels.h"
+#include "spmm_window_kernel.h"
+#include "window_plan.h"
 
 namespace {
 
@@ -53,6 +56,7 @@ struct sextans_engine {
     // workspaces
     float *d_Bp = nullptr;
     size_t Bp_cap = 0;              // floats
+    int bp_layout = 0;              // main panel width of the last repack into d_Bp (0 = none)
     float *d_B = nullptr, *d_Cin = nullptr, *d_Cout = nullptr;   // host-path staging
     size_t B_cap = 0, C_cap = 0;
     hipStream_t host_stream = nullptr;                           // stream of the host-buffer entry points
@@ -67,12 +71,21 @@ struct sextans_engine {
     int *d_pcol32 = nullptr;
     float *d_pval = nullptr;
     int plan_nblk = 0;
+    std::vector<int> h_blk_row;     // host copy of the plan's block boundaries (row-range calls, sextans_align_row)
     unsigned short *d_lidx = nullptr;
     double plan_panel_frac = 0.0;   // share of non-zeros living in dictionary blocks
     int plan_max_dict = 0;          // largest block dictionary (entries)
     int plan_dict_stride = 0;       // ints per block in d_dict (dictionaries padded to a common stride)
     bool plan_mixed = false;        // some block with non-zeros has no dictionary (global-gather path needed)
     bool plan_built = false;        // false: only the sampled verdict exists (no packed stream)
+    // K-windowed accumulator-resident plan (spmm_csr_window; built lazily)
+    uint2 *d_wstream = nullptr;
+    int *d_wstep0 = nullptr;
+    int win_nwaves = 0, win_rw = 0;
+    int64_t win_padded = 0;         // stream entries including padding
+    int win_state = 0;              // 0 = not evaluated, 1 = built, -1 = rejected (skewed rows / K too large)
+    int64_t win_built_rows = -1, win_built_cols = -1;
+    double plan_build_s = 0.0;      // host seconds spent building packed forms of A for the current matrix
     // blocked-ELL bf16 matrix (MFMA path)
     int bell_M = 0, bell_K = 0, bell_W = 0;
     const int *d_bell_col = nullptr;
@@ -93,6 +106,9 @@ struct sextans_engine {
     int64_t opt_split_rows = 0;         // > 0: rows longer than this are split (re-associated); 0 = exact order
     int64_t opt_phase_timing = 0;       // 1: panel kernel accumulates per-phase wave cycles (debug aid)
     int64_t opt_min_reuse_x100 = 400;   // a block uses the LDS panel if nnz >= 4 * distinct columns
+    int64_t opt_win_rows = 319;         // rows per wavefront of the window kernel (+1 dummy row: 4 x 320 x 32 B = 40 KiB)
+    int64_t opt_win_cols = 65536;       // columns per K window (x 32 B = 2 MiB of the 8-column panel: half an XCD's L2)
+    int64_t opt_win_unroll = 8;         // steps in flight per ring (4 or 8)
     // profiling
     std::vector<EventPair> ev_kernel, ev_repack;
     const char *last_kernel = "none";
@@ -122,10 +138,20 @@ void free_plan(sextans_engine *h) {
     h->d_dict_ptr = h->d_dict = h->d_blk_row = h->d_row_off = h->d_pcol32 = nullptr;
     h->d_pval = nullptr;
     h->plan_nblk = 0;
+    h->h_blk_row.clear();
     h->d_lidx = nullptr;
     h->plan_lpr = 0;
     h->plan_panel_frac = 0.0;
     h->plan_built = false;
+}
+
+void free_window(sextans_engine *h) {
+    (void)hipFree(h->d_wstream); (void)hipFree(h->d_wstep0);
+    h->d_wstream = nullptr; h->d_wstep0 = nullptr;
+    h->win_nwaves = h->win_rw = 0;
+    h->win_padded = 0;
+    h->win_state = 0;
+    h->win_built_rows = h->win_built_cols = -1;
 }
 
 void free_bell(sextans_engine *h) {
@@ -144,6 +170,8 @@ void free_split(sextans_engine *h) {
 void free_matrix(sextans_engine *h) {
     free_plan(h);
     free_split(h);
+    free_window(h);
+    h->plan_build_s = 0.0;
     if (h->owns_matrix) {
         (void)hipFree((void *)h->d_rp);
         (void)hipFree((void *)h->d_ci);
@@ -216,6 +244,36 @@ int upload(T **dst, const std::vector<T> &src) {
     return SEXTANS_OK;
 }
 
+struct PlanTimer {   // accumulates host seconds spent packing A (reported by sextans_get_stat "plan_build_s")
+    sextans_engine *h; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit PlanTimer(sextans_engine *h_) : h(h_) {}
+    ~PlanTimer() { h->plan_build_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// Device copy of the CSR arrays -> host, validated: the host-side plan builders index arrays of size K with
+// the column indices and trust row_ptr to be monotonic (a matrix handed over with
+// sextans_set_matrix_csr_device has not been looked at by anybody yet).
+int read_back_row_ptr(sextans_engine *h, std::vector<int> &rp) {
+    rp.resize((size_t)h->M + 1);
+    SX_HIP(hipMemcpy(rp.data(), h->d_rp, sizeof(int) * ((size_t)h->M + 1), hipMemcpyDeviceToHost));
+    if (rp[0] != 0 || (int64_t)rp[(size_t)h->M] != h->nnz) return SEXTANS_ERR_INVALID;
+    for (int r = 0; r < h->M; ++r)
+        if (rp[(size_t)r + 1] < rp[(size_t)r]) return SEXTANS_ERR_INVALID;
+    return SEXTANS_OK;
+}
+int read_back_entries(sextans_engine *h, std::vector<int> &ci, std::vector<float> &va) {
+    const size_t n1 = (size_t)(h->nnz ? h->nnz : 1);
+    ci.assign(n1, 0); va.assign(n1, 0.f);
+    if (h->nnz) {
+        SX_HIP(hipMemcpy(ci.data(), h->d_ci, sizeof(int) * (size_t)h->nnz, hipMemcpyDeviceToHost));
+        SX_HIP(hipMemcpy(va.data(), h->d_v, sizeof(float) * (size_t)h->nnz, hipMemcpyDeviceToHost));
+    }
+    const unsigned K = (unsigned)h->K;
+    unsigned bad = 0;
+    for (int64_t j = 0; j < h->nnz; ++j) bad |= (unsigned)((unsigned)ci[(size_t)j] >= K);
+    return bad ? SEXTANS_ERR_INDEX : SEXTANS_OK;
+}
+
 // Build (or reuse) the packed row-bucketed form of A for `lpr` lanes per row.  The CSR arrays are read
 // back from the device copy, so this works for host- and device-provided matrices alike; it runs once
 // per matrix ("upload once"), outside any timed region, like the reference's host-side scheduling
@@ -226,8 +284,8 @@ int upload(T **dst, const std::vector<T> &src) {
 int sample_reuse(sextans_engine *h, int RB, int max_unique, double min_reuse, double *frac) {
     const int nblk = (h->M + RB - 1) / RB;
     const int nsample = std::min(nblk, 512);
-    std::vector<int> rp((size_t)h->M + 1);
-    SX_HIP(hipMemcpy(rp.data(), h->d_rp, sizeof(int) * ((size_t)h->M + 1), hipMemcpyDeviceToHost));
+    std::vector<int> rp;
+    if (int rc = read_back_row_ptr(h, rp)) return rc;
     int64_t tot = 0, good = 0;
     std::vector<int> cols;
     for (int sidx = 0; sidx < nsample; ++sidx) {
@@ -256,6 +314,7 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
     if (h->plan_lpr == lpr && h->plan_min_reuse == h->opt_min_reuse_x100 && (h->plan_built || !force))
         return SEXTANS_OK;
     free_plan(h);
+    PlanTimer timer(h);
     const int RB = sx::kBlock / lpr;
     const double min_reuse = (double)h->opt_min_reuse_x100 / 100.0;
     if (!force) {
@@ -269,14 +328,10 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
             return SEXTANS_OK;
         }
     }
-    const size_t n1 = (size_t)(h->nnz ? h->nnz : 1);
-    std::vector<int> rp((size_t)h->M + 1), ci(n1);
-    std::vector<float> va(n1);
-    SX_HIP(hipMemcpy(rp.data(), h->d_rp, sizeof(int) * ((size_t)h->M + 1), hipMemcpyDeviceToHost));
-    if (h->nnz) {
-        SX_HIP(hipMemcpy(ci.data(), h->d_ci, sizeof(int) * (size_t)h->nnz, hipMemcpyDeviceToHost));
-        SX_HIP(hipMemcpy(va.data(), h->d_v, sizeof(float) * (size_t)h->nnz, hipMemcpyDeviceToHost));
-    }
+    std::vector<int> rp, ci;
+    std::vector<float> va;
+    if (int rc = read_back_row_ptr(h, rp)) return rc;
+    if (int rc = read_back_entries(h, ci, va)) return rc;
     {   // the packed stream is addressed with 32-bit entry offsets: rows padded to 4 entries must fit
         int64_t padded = 0;
         for (int r = 0; r < h->M; ++r) padded += ((int64_t)(rp[(size_t)r + 1] - rp[(size_t)r]) + 3) / 4 * 4;
@@ -319,6 +374,7 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
     h->plan_dict_stride = dstride;
     h->plan_mixed = mixed;
     if (int rc = upload(&h->d_blk_row, plan.blk_row)) return rc;
+    h->h_blk_row = plan.blk_row;
     if (int rc = upload(&h->d_dict_ptr, dcnt)) return rc;
     if (int rc = upload(&h->d_dict, bdict)) return rc;
     if (int rc = upload(&h->d_row_off, slot_info)) return rc;
@@ -370,6 +426,77 @@ void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_
         if (h->opt_exact) go(sx::spmm_csr_panel<LPR, true, false>);
         else go(sx::spmm_csr_panel<LPR, false, false>);
     }
+}
+
+// Traffic model behind the automatic choice between the gather kernel and the window kernel for matrices
+// without B-row reuse (bytes crossing the L2 <-> memory fabric per SpMM):
+//   gather: every non-zero pulls max(128, 4 * tile width) bytes of B (a 64-byte B row still costs a
+//           128-byte line) + the 8-byte CSR entry per N tile;
+//   window: every XCD streams the whole 8-column panel once per sweep, sweeps = rows / rows whose partial
+//           sums the chip holds in LDS at once (at least 1), + the 8-byte stream entry, per 8-column tile.
+bool window_pays(const sextans_engine *h, int N, int64_t padded) {
+    if (N > 24 || h->nnz == 0) return false;
+    const double K = (double)h->K, nnz = (double)h->nnz, M = (double)h->M;
+    if (K * N * 4.0 <= 48.0 * 1048576.0) return false;   // B (nearly) fits the L2s: gathers stay on chip
+    double gather = 0.0;
+    int rest = N;
+    for (int w : {16, 8}) { const int nt = rest / w; gather += nt * nnz * (std::max(128.0, 4.0 * w) + 8.0); rest -= nt * w; }
+    const double live = (double)h->num_cus * 16.0 * (double)h->opt_win_rows;
+    const double sweeps = std::max(1.0, M / live);
+    const double window = (N / 8) * (sweeps * 8.0 * K * 32.0 + 8.0 * (double)padded);
+    return window < 0.75 * gather;
+}
+
+// Build (or reuse) the K-windowed stream of A.  force: "kernel" = 3 (no pay-off / skew test).
+int ensure_window(sextans_engine *h, bool force) {
+    if (h->win_state != 0 && h->win_built_rows == h->opt_win_rows && h->win_built_cols == h->opt_win_cols &&
+        (h->win_state == 1 || !force))
+        return SEXTANS_OK;
+    free_window(h);
+    PlanTimer timer(h);
+    h->win_built_rows = h->opt_win_rows;
+    h->win_built_cols = h->opt_win_cols;
+    h->win_state = -1;
+    const int RW = (int)h->opt_win_rows;
+    if (RW < 1 || RW > sx::kWinMaxRowsPerWave || h->opt_win_cols < 1 || h->opt_win_cols > 0x7fffffff ||
+        (int64_t)h->K > ((int64_t)1 << sx::kWinColBits) || h->nnz == 0)
+        return SEXTANS_OK;
+    std::vector<int> rp, ci;
+    std::vector<float> va;
+    if (int rc = read_back_row_ptr(h, rp)) return rc;
+    if (!force && (double)sx::window_plan_padded_lower_bound(h->M, rp.data(), RW) > 1.3 * (double)h->nnz)
+        return SEXTANS_OK;   // skewed rows: one row per step would be mostly padding
+    if (int rc = read_back_entries(h, ci, va)) return rc;
+    sx::WindowPlan plan;
+    if (!sx::build_window_plan(h->M, h->K, rp.data(), ci.data(), va.data(), RW, (int)h->opt_win_cols, plan))
+        return SEXTANS_OK;
+    if (!force && (double)plan.padded > 1.35 * (double)h->nnz) return SEXTANS_OK;
+    static_assert(sizeof(sx::WinEntry) == sizeof(uint2), "stream entries are loaded as uint2");
+    SX_HIP(hipMalloc((void **)&h->d_wstream, sizeof(uint2) * plan.stream.size()));
+    SX_HIP(hipMemcpy(h->d_wstream, plan.stream.data(), sizeof(uint2) * plan.stream.size(), hipMemcpyHostToDevice));
+    if (int rc = upload(&h->d_wstep0, plan.wave_step0)) return rc;
+    h->win_nwaves = plan.nwaves;
+    h->win_rw = RW;
+    h->win_padded = plan.padded;
+    h->win_state = 1;
+    return SEXTANS_OK;
+}
+
+// dBp8: N/8 row-major K x 8 panels.  Rows [wave_begin * RW, min(M, wave_end * RW)); the C pointers address
+// row `row_base` as their row 0.
+void launch_window(sextans_engine *h, const float *dBp8, const float *dCin, int64_t ldc_in, float *dCout,
+                   int64_t ldc, int ntiles, int wave_begin, int wave_end, int row_base, float alpha, float beta,
+                   hipStream_t s) {
+    const int nwg = (wave_end - wave_begin + sx::kWinWaves - 1) / sx::kWinWaves;
+    if (nwg <= 0) return;
+    const size_t lds = (size_t)sx::kWinWaves * (size_t)(h->win_rw + 1) * sx::kWinNT * sizeof(float);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg * (unsigned)ntiles), dim3(sx::kWinWaves * 64), lds, s,
+                           (const sx::u32x2 *)h->d_wstream, (const int *)h->d_wstep0, dBp8, (int64_t)h->K * sx::kWinNT, dCin,
+                           ldc_in, dCout, ldc, h->M, h->win_rw, wave_begin, wave_end, nwg, row_base, alpha, beta);
+    };
+    if (h->opt_win_unroll == 4) { if (h->opt_exact) go(sx::spmm_csr_window<true, 4>); else go(sx::spmm_csr_window<false, 4>); }
+    else                        { if (h->opt_exact) go(sx::spmm_csr_window<true, 8>); else go(sx::spmm_csr_window<false, 8>); }
 }
 
 }  // namespace
@@ -439,6 +566,9 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "phase_timing")) return &h->opt_phase_timing;
     if (!strcmp(key, "split_rows")) return &h->opt_split_rows;
     if (!strcmp(key, "fuse_b")) return &h->opt_fuse_b;
+    if (!strcmp(key, "window_rows")) return &h->opt_win_rows;
+    if (!strcmp(key, "window_cols")) return &h->opt_win_cols;
+    if (!strcmp(key, "window_unroll")) return &h->opt_win_unroll;
     return nullptr;
 }
 
@@ -447,6 +577,13 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
     int64_t *slot = option_slot(h, key);
     if (!slot) return SEXTANS_ERR_INVALID;
     if (slot == &h->opt_lpr && value != 2 && value != 4 && value != 8) return SEXTANS_ERR_INVALID;
+    if (slot == &h->opt_win_rows && (value < 1 || value > sx::kWinMaxRowsPerWave)) return SEXTANS_ERR_INVALID;
+    if (slot == &h->opt_win_cols && (value < 1 || value > 0x7fffffff)) return SEXTANS_ERR_INVALID;
+    if (slot == &h->opt_win_unroll && value != 4 && value != 8) return SEXTANS_ERR_INVALID;
+    if ((slot == &h->opt_win_rows || slot == &h->opt_win_cols) && *slot != value) {
+        (void)hipSetDevice(h->device);
+        free_window(h);   // the stream is built for one (rows per wavefront, window) pair
+    }
     *slot = value;
     if (slot == &h->opt_phase_timing) {
         (void)hipSetDevice(h->device);
@@ -465,6 +602,17 @@ int sextans_phase_timing_read(sextans_handle_t h, int64_t out[8]) {
     return SEXTANS_OK;
 }
 
+int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
+    if (!h || !key || !value) return SEXTANS_ERR_INVALID;
+    if (!strcmp(key, "plan_build_s")) *value = h->plan_build_s;
+    else if (!strcmp(key, "window_padded_entries")) *value = (double)h->win_padded;
+    else if (!strcmp(key, "window_state")) *value = (double)h->win_state;
+    else if (!strcmp(key, "panel_fraction")) *value = h->plan_panel_frac;
+    else if (!strcmp(key, "panel_blocks")) *value = (double)h->plan_nblk;
+    else return SEXTANS_ERR_INVALID;
+    return SEXTANS_OK;
+}
+
 int sextans_get_option(sextans_handle_t h, const char *key, int64_t *value) {
     if (!h || !key || !value) return SEXTANS_ERR_INVALID;
     int64_t *slot = option_slot(h, key);
@@ -479,6 +627,14 @@ int sextans_set_matrix_csr(sextans_handle_t h, int M, int K, int64_t nnz, const 
         return SEXTANS_ERR_INVALID;
     if (nnz > 0x7fffffffLL) return SEXTANS_ERR_INVALID;   // 32-bit row_ptr like the reference
     if (row_ptr[0] != 0 || row_ptr[M] != (int)nnz) return SEXTANS_ERR_INVALID;
+    // the kernels gather B rows by column index and the plan builders index host arrays of size K with them
+    for (int r = 0; r < M; ++r)
+        if (row_ptr[r + 1] < row_ptr[r]) return SEXTANS_ERR_INVALID;
+    {
+        unsigned bad = 0;
+        for (int64_t j = 0; j < nnz; ++j) bad |= (unsigned)((unsigned)col_idx[j] >= (unsigned)K);
+        if (bad) return SEXTANS_ERR_INDEX;
+    }
     SX_HIP(hipSetDevice(h->device));
     free_matrix(h);
     int *rp = nullptr, *ci = nullptr;
@@ -549,7 +705,8 @@ int ensure_split(sextans_engine *h) {
 // Everything that may allocate or run host-side preprocessing for an N-column SpMM: B-panel workspace,
 // N-tile plan, and (for kernel != 1) the packed row-bucketed form of A.  Idempotent; called by
 // sextans_spmm_device2 and, ahead of the timed region, by sextans_spmm_host.
-int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_panel) {
+int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_panel, bool &use_window) {
+    if (h->Bp_cap < (size_t)h->K * (size_t)N || !h->d_Bp) h->bp_layout = 0;   // new workspace: nothing to reuse
     if (int rc = ensure(&h->d_Bp, &h->Bp_cap, (size_t)h->K * (size_t)N)) return rc;
     // main tile width: 4*lanes_per_row, but never wider than N itself (N = 8 -> 2 lanes per row); then
     // 16- and 8-wide tiles for the remainder (N is a multiple of 8, the reference's N-tile
@@ -571,9 +728,35 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
         if (int rc = ensure_plan(h, lpr, h->opt_kernel == 2)) return rc;
         use_panel = h->plan_built && ((h->opt_kernel == 2) || h->plan_panel_frac >= 0.5);
     }
+    // "kernel" 3 = K-windowed accumulator-resident kernel; auto picks it for matrices without B-row reuse
+    // whose B does not fit the L2s when the traffic model says the sweep moves fewer bytes than the gather.
+    use_window = false;
+    if (h->nnz > 0 && (h->opt_kernel == 3 || (h->opt_kernel == 0 && !use_panel))) {
+        const bool force = h->opt_kernel == 3;
+        if (force || (h->win_state >= 0 && window_pays(h, N, h->win_state == 1 ? h->win_padded : h->nnz))) {
+            if (int rc = ensure_window(h, force)) return rc;
+            use_window = h->win_state == 1 && (force || window_pays(h, N, h->win_padded));
+        }
+    }
     return SEXTANS_OK;
 }
 }  // namespace
+
+int sextans_align_row(sextans_handle_t h, int N, int row, int *aligned) {
+    if (!h || !aligned || N <= 0 || (N % 8) != 0 || row < 0 || row > h->M) return SEXTANS_ERR_INVALID;
+    if (!h->d_rp) return SEXTANS_ERR_STATE;
+    SX_HIP(hipSetDevice(h->device));
+    std::vector<Seg> plan;
+    int W = 0;
+    bool use_panel = false, use_window = false;
+    if (int rc = prepare(h, N, plan, W, use_panel, use_window)) return rc;
+    *aligned = row;
+    if (row == h->M) return SEXTANS_OK;
+    if (use_window) *aligned = row / h->win_rw * h->win_rw;
+    else if (use_panel && !h->h_blk_row.empty())
+        *aligned = *(std::upper_bound(h->h_blk_row.begin(), h->h_blk_row.end(), row) - 1);
+    return SEXTANS_OK;
+}
 
 int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
                          float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out, int64_t ldc,
@@ -597,11 +780,29 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     if (nrows == 0) return SEXTANS_OK;
     std::vector<Seg> plan;
     int W = 0;
-    bool use_panel = false;
-    if (int rc = prepare(h, N, plan, W, use_panel)) return rc;
+    bool use_panel = false, use_window = false;
+    if (int rc = prepare(h, N, plan, W, use_panel, use_window)) return rc;
     if (!whole) use_panel = false;   // row ranges cut across the panel plan's row blocks: gather kernel
+    // a row range can use the window kernel when it starts and ends on wavefront (rows-per-wave) boundaries
+    if (use_window && (row_begin % h->win_rw != 0 || (row_end % h->win_rw != 0 && row_end != h->M))) use_window = false;
     if (int rc = ensure_split(h)) return rc;
-    const bool split = whole && h->split_nv > 0;
+    const bool split = whole && h->split_nv > 0 && !use_window;
+    if (use_window) {
+        // B in 8-column panels (the reference's N tile), then one tile-major launch
+        if (!(flags & SEXTANS_ROWS_REUSE_B_PANELS) || h->bp_layout != 8) {
+            Prof p(h, &h->ev_repack, s);
+            launch_repack<8>(d_B, ldb, h->d_Bp, h->K, 0, N / 8, s);
+            h->bp_layout = 8;
+        }
+        {
+            Prof p(h, &h->ev_kernel, s);
+            const int w0 = row_begin / h->win_rw, w1 = (row_end + h->win_rw - 1) / h->win_rw;
+            launch_window(h, h->d_Bp, d_C_in, ldc_in, d_C_out, ldc, N / 8, w0, w1, row_begin, alpha, beta, s);
+            h->last_kernel = "spmm_csr_window";
+        }
+        SX_HIP(hipGetLastError());
+        return SEXTANS_OK;
+    }
     if (split) {
         use_panel = false;
         if (int rc = ensure(&h->d_P, &h->P_cap, (size_t)h->split_nv * (size_t)N)) return rc;
@@ -612,9 +813,12 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     const bool fuse_b = use_panel && !h->plan_mixed && h->opt_fuse_b && !(flags & kRowsNoFuseB) && plan.size() == 1 &&
                         plan[0].width == W &&
                         (size_t)h->K * (size_t)N * sizeof(float) <= ((size_t)16 << 20);
-    const bool skip_repack = fuse_b || (flags & SEXTANS_ROWS_REUSE_B_PANELS) != 0;
+    // (a reuse request is honoured only if the panels in the workspace have this layout: row-range calls of
+    // one pipelined SpMM may alternate between the window kernel's 8-column panels and these)
+    const bool skip_repack = fuse_b || ((flags & SEXTANS_ROWS_REUSE_B_PANELS) != 0 && h->bp_layout == W);
 
     if (!skip_repack) {
+        h->bp_layout = W;
         Prof p(h, &h->ev_repack, s);
         for (const Seg &g : plan) {
             float *dst = h->d_Bp + (size_t)h->K * (size_t)g.col0;
@@ -750,8 +954,8 @@ int sextans_spmm_host(sextans_handle_t h, int N, float alpha, const float *B, fl
     SX_HIP(hipMemcpy(h->d_B, B, nB * sizeof(float), hipMemcpyHostToDevice));
     SX_HIP(hipMemcpy(h->d_Cin, C, nC * sizeof(float), hipMemcpyHostToDevice));
     {   // allocations and the one-time packing of A stay outside the timed region
-        std::vector<Seg> plan; int W = 0; bool up = false;
-        if (int rc = prepare(h, N, plan, W, up)) return rc;
+        std::vector<Seg> plan; int W = 0; bool up = false, uw = false;
+        if (int rc = prepare(h, N, plan, W, up, uw)) return rc;
     }
     double ns = 0.0;
     if (int rc = run_repeats(h, N, alpha, beta, rp_time, nullptr, nullptr, &ns)) return rc;
@@ -762,7 +966,9 @@ int sextans_spmm_host(sextans_handle_t h, int N, float alpha, const float *B, fl
 
 int sextans_set_matrix_edges(sextans_handle_t h, const int32_t *edge_list_ptr, const uint64_t *const *edge_list_ch,
                              int NUM_ITE, int NUM_A_LEN, int M, int K) {
-    if (!h || !edge_list_ptr || !edge_list_ch || NUM_ITE < 0) return SEXTANS_ERR_INVALID;
+    if (!h || !edge_list_ptr || !edge_list_ch || NUM_ITE < 0 || M < 0 || K < 0) return SEXTANS_ERR_INVALID;
+    // NUM_ITE = ceil(K / 4096) (sextans-host.cpp:221): checked BEFORE edge_list_ptr[NUM_ITE] is read
+    if ((int64_t)NUM_ITE != ((int64_t)K + SEXTANS_EDGES_WINDOW - 1) / SEXTANS_EDGES_WINDOW) return SEXTANS_ERR_INVALID;
     if (edge_list_ptr[NUM_ITE] != NUM_A_LEN) return SEXTANS_ERR_INVALID;
     int64_t nnz = 0;
     int *rp = nullptr, *ci = nullptr;
@@ -816,8 +1022,8 @@ int sextans_invoke(sextans_handle_t h, const int32_t *edge_list_ptr, const uint6
                          hipMemcpyHostToDevice));
     }
     {
-        std::vector<Seg> plan; int W = 0; bool up = false;
-        if (int rc = prepare(h, N, plan, W, up)) return rc;
+        std::vector<Seg> plan; int W = 0; bool up = false, uw = false;
+        if (int rc = prepare(h, N, plan, W, up, uw)) return rc;
     }
     const float pad = alpha * 0.0f + beta * 0.0f;    // what the accelerator writes into rows M .. colsize-1
     auto pre = [&](hipStream_t cs) {

@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "panel_plan.h"
+#include "window_plan.h"
 #include "sextans_amd.h"
 
 namespace {
@@ -75,6 +76,38 @@ int sextans_unpack_csr(const sextans_packed *p, const int *row_ptr, int *col_idx
         }
     }
     return SEXTANS_OK;
+}
+
+int sextans_window_pack_csr(int M, int K, const int *row_ptr, const int *col_idx, const float *val,
+                            int rows_per_wave, int window_cols, sextans_window_packed *out) {
+    if (!out || M < 0 || K < 0 || !row_ptr) return SEXTANS_ERR_INVALID;
+    if (row_ptr[0] != 0) return SEXTANS_ERR_INVALID;
+    for (int r = 0; r < M; ++r)
+        if (row_ptr[r + 1] < row_ptr[r]) return SEXTANS_ERR_INVALID;
+    const int64_t nnz = M > 0 ? row_ptr[M] : 0;
+    for (int64_t j = 0; j < nnz; ++j)
+        if (col_idx[j] < 0 || col_idx[j] >= K) return SEXTANS_ERR_INDEX;
+    sx::WindowPlan p;
+    if (!sx::build_window_plan(M, K, row_ptr, col_idx, val, rows_per_wave, window_cols, p)) return SEXTANS_ERR_INVALID;
+    memset(out, 0, sizeof *out);
+    out->M = M; out->K = K; out->nnz = nnz;
+    out->rows_per_wave = p.rows_per_wave;
+    out->window_cols = p.window_cols;
+    out->nwaves = p.nwaves;
+    out->steps = p.padded / sx::kWinStep;
+    out->padded_lower_bound = sx::window_plan_padded_lower_bound(M, row_ptr, rows_per_wave);
+    out->wave_step0 = dup(p.wave_step0);
+    static_assert(sizeof(sx::WinEntry) == 8, "entry = {fp32 value, row << 23 | column}");
+    out->stream = (uint64_t *)malloc(sizeof(uint64_t) * (p.stream.empty() ? 1 : p.stream.size()));
+    if (!out->wave_step0 || !out->stream) { sextans_window_packed_free(out); return SEXTANS_ERR_ALLOC; }
+    if (!p.stream.empty()) memcpy(out->stream, p.stream.data(), sizeof(uint64_t) * p.stream.size());
+    return SEXTANS_OK;
+}
+
+void sextans_window_packed_free(sextans_window_packed *p) {
+    if (!p) return;
+    free(p->wave_step0); free(p->stream);
+    memset(p, 0, sizeof *p);
 }
 
 }  // extern "C"

@@ -144,37 +144,64 @@ class SlabGather:
 class PipelinedSlabGather:
     """SlabGather with compute/communication overlap: the rank's slab is produced in `nchunks` row
     chunks; as soon as chunk c is computed its all-gather starts (async, on RCCL's stream) while the
-    SpMM of chunk c+1 runs.  Requires equal row counts per rank (the synthetic config 4); per chunk
-    one in-place all_gather_into_tensor of 4*N*chunk_rows bytes per rank.
+    SpMM of chunk c+1 runs.  Per chunk one in-place all_gather_into_tensor of 4*N*(longest chunk c of any
+    rank) bytes per rank.  Row ranges may be unequal (nnz-balanced): chunk c of every rank is padded to the
+    longest chunk c.  `align(row) -> row' <= row` lets the caller snap this rank's interior cut positions to
+    boundaries its kernels like (Engine.align_row: wavefront / row-block boundaries, so every chunk keeps the
+    best kernel); the cut positions of all ranks are then exchanged once, here.
 
-        pg = PipelinedSlabGather(M, N, ranges, rank, device, nchunks=4)
+        pg = PipelinedSlabGather(M, N, ranges, rank, device, nchunks=4, align=lambda r: eng.align_row(N, r))
         pg.run(lambda c0, c1, out_ptr, ld_out, first: engine.spmm_device_rows(..., row_begin=c0, row_end=c1,
                                                                             reuse_b_panels=not first, ...))
         pg.finish(C_full)      # waits for the collectives, writes column-major C
     """
 
-    def __init__(self, M, N, ranges, rank, device, nchunks=4, dtype=None):
+    def __init__(self, M, N, ranges, rank, device, nchunks=4, dtype=None, align=None, group=None):
         import torch
         self.M, self.N, self.ranges, self.rank = M, N, list(ranges), rank
         self.world = len(self.ranges)
-        lens = {b - a for a, b in self.ranges}
-        if len(lens) != 1 or next(iter(lens)) * self.world != M:
-            raise ValueError("PipelinedSlabGather needs equal row counts per rank")
-        self.L = next(iter(lens))
-        nchunks = max(1, min(nchunks, self.L))
-        cuts = [self.L * c // nchunks for c in range(nchunks + 1)]
-        self.chunks = [(cuts[c], cuts[c + 1]) for c in range(nchunks) if cuts[c + 1] > cuts[c]]
-        self.S = [torch.zeros((self.world, N, c1 - c0), dtype=dtype or torch.float32, device=device)
-                  for c0, c1 in self.chunks]
+        lens = [b - a for a, b in self.ranges]
+        if sum(lens) != M or any(self.ranges[g][1] != self.ranges[g + 1][0] for g in range(self.world - 1)):
+            raise ValueError("ranges must tile [0, M) in rank order")
+        nchunks = max(1, min(nchunks, max(max(lens), 1)))
+
+        def cuts_of(L, snap=None):
+            c = [L * i // nchunks for i in range(nchunks + 1)]
+            if snap is not None:
+                for i in range(1, nchunks):
+                    c[i] = min(max(int(snap(c[i])), c[i - 1]), L)
+            return c
+        all_cuts = [cuts_of(L) for L in lens]
+        if align is not None:
+            mine = cuts_of(lens[rank], align)
+            if self.world > 1:
+                import torch.distributed as dist
+                t = torch.tensor(mine, dtype=torch.int64, device=device)
+                buf = torch.empty(self.world * (nchunks + 1), dtype=torch.int64, device=device)
+                dist.all_gather_into_tensor(buf, t, group=group)
+                all_cuts = buf.view(self.world, nchunks + 1).cpu().tolist()
+            else:
+                all_cuts[rank] = mine
+        self.cuts = all_cuts                                     # [rank][chunk] local row offsets
+        self.chunks = [(all_cuts[rank][c], all_cuts[rank][c + 1]) for c in range(nchunks)]
+        self.lmax = [max(max(all_cuts[g][c + 1] - all_cuts[g][c] for g in range(self.world)), 1)
+                     for c in range(nchunks)]
+        self.even = len(set(lens)) == 1 and all(all_cuts[g] == all_cuts[0] for g in range(self.world))
+        self.L = lens[0] if self.even else None
+        self.S = [torch.zeros((self.world, N, self.lmax[c]), dtype=dtype or torch.float32, device=device)
+                  for c in range(nchunks)]
         self.works = []
 
     def run(self, compute_chunk, group=None, _force=False):
-        """compute_chunk(c0, c1, out_ptr, ld_out, first) must enqueue the SpMM of local rows [c0, c1) writing
-        a packed column-major (c1-c0) x N slab at out_ptr."""
+        """compute_chunk(c0, c1, out_ptr, ld_out, first) must enqueue the SpMM of local rows [c0, c1) writing a
+        column-major (c1-c0) x N slab with leading dimension ld_out at out_ptr."""
         import torch.distributed as dist
         self.works = []
-        for i, ((c0, c1), S) in enumerate(zip(self.chunks, self.S)):
-            compute_chunk(c0, c1, S[self.rank].data_ptr(), c1 - c0, i == 0)
+        first = True
+        for (c0, c1), S, lmax in zip(self.chunks, self.S, self.lmax):
+            if c1 > c0:
+                compute_chunk(c0, c1, S[self.rank].data_ptr(), lmax, first)
+                first = False
             if self.world > 1 or _force:
                 self.works.append(dist.all_gather_into_tensor(S.view(-1), S[self.rank].reshape(-1),
                                                               group=group, async_op=True))
@@ -183,6 +210,15 @@ class PipelinedSlabGather:
         for w in self.works:
             w.wait()
         self.works = []
-        cols = C_full.view(self.N, self.world, self.L)
-        for (c0, c1), S in zip(self.chunks, self.S):
-            cols[:, :, c0:c1].copy_(S.permute(1, 0, 2))
+        if self.even:
+            cols = C_full.view(self.N, self.world, self.L)
+            for (c0, c1), S in zip(self.chunks, self.S):
+                if c1 > c0:
+                    cols[:, :, c0:c1].copy_(S.permute(1, 0, 2))
+            return
+        cols = C_full.view(self.N, self.M)
+        for g, (a, _) in enumerate(self.ranges):
+            for c, S in enumerate(self.S):
+                c0, c1 = self.cuts[g][c], self.cuts[g][c + 1]
+                if c1 > c0:
+                    cols[:, a + c0:a + c1] = S[g, :, :c1 - c0]

@@ -26,7 +26,9 @@ HBM_PEAK_GBS = 8000.0
 
 
 def sweep(paths, n_values, rp_time=20, alpha=0.85, beta=-2.06, check=False, device=0, options=None, out=sys.stdout,
-          cache=False):
+          cache=False, inspect=None):
+    """inspect(record, M, K, N, row_ptr, col_idx, val, B, C_in, C_out): optional hook called with every result
+    (the tests compare C_out with the oracle there)."""
     records = []
     with api.Engine(device) as eng:
         for k, v in (options or {}).items():
@@ -63,6 +65,8 @@ def sweep(paths, n_values, rp_time=20, alpha=0.85, beta=-2.06, check=False, devi
                     mism, pct = api.verify(M, N, gold, C)
                     rec.update(mismatch=int(mism), mismatch_pct=round(float(pct), 4), passed=bool(rc == 0 and pct < 2.0),
                                bit_identical=bool(np.array_equal(gold.view(np.uint32), C.view(np.uint32))))
+                if inspect is not None:
+                    inspect(rec, M, K, N, rp, ci, va, B, C0, C)
                 records.append(rec)
                 print(json.dumps(rec), file=out, flush=True)
     return records

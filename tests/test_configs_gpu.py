@@ -1,0 +1,169 @@
+"""BASELINE.json configurations at their stated sizes, under -m gpu:
+
+  config 3  pcrystk02.mtx, N=128 (file absent from the mount: its labelled stand-in, a 35x19x7 3-dof FEM grid,
+            13 965 rows, 968 715 nnz vs the real 968 583) -- every kernel and lane count, bit-exact vs the oracle;
+  config 4  synthetic CSR 4 000 000 x 4 000 000, Poisson(40), seed 4, N=16 -- too large for the oracle as a
+            whole: linearity in B, the alpha = 0 identity and >= 1 000 sampled rows recomputed by the oracle's
+            cpu_spmm_CSR restatement from the HOST generator (also pins host/device generator agreement);
+  config 5  blocked-ELL 1 048 576^2, 32x32 bf16 blocks, width 328, N=256 -- sampled block rows against the
+            oracle's blocked-ELL restatement with the stated condition-aware bound; this is where the fp32
+            accumulation error of a 10 496-term sum is actually measured.
+The 8-GPU row split of config 4 is exercised for real by test_dist_gpu.py::test_rccl_two_ranks when the box has
+two GPUs, and by gloo world-2/3 tests on CPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import ALPHA, BETA
+
+pytestmark = pytest.mark.gpu
+
+
+def _set(engine, **opts):
+    d = dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0, panel_min_reuse_x100=400, fuse_b=1,
+             split_rows=0, window_rows=319, window_cols=65536, window_unroll=8)
+    d.update(opts)
+    for k, v in d.items():
+        engine.set_option(k, v)
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
+@pytest.mark.parametrize("lpr", [2, 4, 8])
+def test_config3_pcrystk02_standin_n128(engine, oracle, kernel, lpr):
+    from sextans_amd import api
+    rp, ci, v = api.gen_fem3d_host(35, 19, 7, 3, 2)
+    M = K = 35 * 19 * 7 * 3
+    assert M == 13965 and rp[-1] == 968715
+    N = 128
+    rs = np.random.RandomState(3)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    _set(engine, kernel=kernel, lanes_per_row=lpr)
+    engine.set_matrix_csr(M, K, rp, ci, v)
+    out = C0.copy()
+    engine.spmm(N, ALPHA, B, BETA, out, rp_time=2)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), engine.last_kernel()
+    if kernel in (0, 2):
+        assert engine.last_kernel() == "spmm_csr_panel"
+    _set(engine)
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_config4_full_size(engine, oracle, kernel):
+    """kernel 0 = what the dispatcher picks for this matrix (the K-windowed kernel), 1 = the gather kernel."""
+    import torch
+    from sextans_amd import api
+    M = K = 4_000_000
+    N = 16
+    st = torch.cuda.current_stream().cuda_stream
+    p, i, v, nnz = api.gen_csr_device(0, M, K, 40.0, 4)
+    try:
+        _set(engine, kernel=kernel)
+        engine.set_matrix_csr_device(M, K, nnz, p, i, v)
+        assert 159_000_000 < nnz < 161_000_000
+        B1 = torch.empty(K * N, device="cuda"); B2 = torch.empty(K * N, device="cuda")
+        Cin = torch.empty(M * N, device="cuda")
+        api.gen_uniform_device(0, B1.data_ptr(), K * N, 41, st)
+        api.gen_uniform_device(0, B2.data_ptr(), K * N, 43, st)
+        api.gen_uniform_device(0, Cin.data_ptr(), M * N, 42, st)
+        Z = torch.zeros(M * N, device="cuda")
+        outs = []
+        for Bx in (B1, B2, B1 + B2):
+            o = torch.empty(M * N, device="cuda")
+            engine.spmm_device(N, 1.0, Bx.data_ptr(), K, 0.0, Z.data_ptr(), o.data_ptr(), M, st)
+            outs.append(o)
+        torch.cuda.synchronize()
+        if kernel == 0:
+            assert engine.last_kernel() == "spmm_csr_window"
+        # linearity: A(B1 + B2) = A B1 + A B2 up to fp32 rounding of ~40-term sums
+        err = (outs[0] + outs[1] - outs[2]).abs().max().item()
+        scale = outs[2].abs().max().item()
+        assert err <= 1e-4 * scale and scale > 1.0
+        del outs[1:], B2, Z
+        # alpha = 0: C_out = 0 * psum + beta * C_in exactly
+        o = torch.empty(M * N, device="cuda")
+        engine.spmm_device(N, 0.0, B1.data_ptr(), K, -2.0, Cin.data_ptr(), o.data_ptr(), M, st)
+        torch.cuda.synchronize()
+        assert torch.equal(o, -2.0 * Cin)
+        # the real thing, default alpha/beta, then >= 1000 sampled rows through the oracle
+        engine.spmm_device(N, float(ALPHA), B1.data_ptr(), K, float(BETA), Cin.data_ptr(), o.data_ptr(), M, st)
+        torch.cuda.synchronize()
+        rs = np.random.RandomState(4)
+        rows = np.unique(np.concatenate([[0, 1, 318, 319, 320, M - 1], rs.randint(0, M, 1100)]))
+        assert len(rows) >= 1000
+        parts = [api.gen_csr_host(M, K, 40.0, 4, int(r), int(r) + 1) for r in rows]
+        srp = np.zeros(len(rows) + 1, np.int32)
+        srp[1:] = np.cumsum([len(c) for _, c, _ in parts])
+        sci = np.concatenate([c for _, c, _ in parts]).astype(np.int32)
+        sv = np.concatenate([x for _, _, x in parts]).astype(np.float32)
+        Bh = api.gen_uniform_host(K * N, 41)
+        idx = torch.from_numpy(rows.astype(np.int64)).cuda()
+        c_s = Cin.view(N, M)[:, idx].cpu().numpy().reshape(-1).copy()      # column-major len(rows) x N
+        oracle.spmm(len(rows), N, K, ALPHA, srp, sci, sv, Bh, BETA, c_s)
+        got = o.view(N, M)[:, idx].cpu().numpy().reshape(-1)
+        assert np.array_equal(got.view(np.uint32), c_s.view(np.uint32))
+    finally:
+        engine.set_matrix_csr(1, 1, np.array([0, 0], np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
+        _set(engine)
+        for q in (p, i, v):
+            api.device_free(0, q)
+        torch.cuda.empty_cache()
+
+
+def test_config5_full_size(engine, oracle):
+    import torch
+    from sextans_amd import api
+    M = K = 1_048_576
+    W, N = 328, 256
+    st = torch.cuda.current_stream().cuda_stream
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    dc, dv = api.gen_bell_device(0, M, K, W, 5)
+    try:
+        rs = np.random.RandomState(5)
+        brs = np.unique(np.concatenate([[0, M // 32 - 1], rs.randint(0, M // 32, 10)]))
+        cols, vals = [], []
+        for br in brs:                                       # the sampled block rows' slots, straight from HBM
+            tc = torch.empty(W, dtype=torch.int32, device="cuda")
+            tv = torch.empty(W * 1024, dtype=torch.int16, device="cuda")
+            assert hip.hipMemcpy(tc.data_ptr(), dc + int(br) * W * 4, W * 4, 3) == 0
+            assert hip.hipMemcpy(tv.data_ptr(), dv + int(br) * W * 2048, W * 2048, 3) == 0
+            cols.append(tc.cpu().numpy()); vals.append(tv.cpu().numpy().view(np.uint16))
+        engine.set_matrix_bell_device(M, K, W, dc, dv)
+        api.device_free(0, dv); dv = None                    # the engine keeps its own fragment-order copy
+        B = torch.empty(K * N, dtype=torch.int16, device="cuda")
+        Cin = torch.empty(M * N, device="cuda")
+        Cout = torch.empty(M * N, device="cuda")
+        api.gen_uniform_bf16_device(0, B.data_ptr(), K * N, 51, st)
+        api.gen_uniform_device(0, Cin.data_ptr(), M * N, 52, st)
+        engine.spmm_bell_device(N, float(ALPHA), B.data_ptr(), K, float(BETA), Cin.data_ptr(), Cout.data_ptr(), M, st)
+        torch.cuda.synchronize()
+        assert engine.last_kernel().startswith("spmm_bell")
+        Bh = B.cpu().numpy().view(np.uint16)
+        worst = 0.0
+        for br, bc, bv in zip(brs, cols, vals):
+            assert np.all(np.diff(bc) > 0) and bc.min() >= 0 and bc.max() < K // 32
+            c0 = Cin.view(N, M)[:, br * 32:(br + 1) * 32].cpu().numpy().reshape(-1).copy()     # 32 x N column-major
+            want = c0.copy()
+            asum = oracle.bell_spmm(32, K, N, W, bc, bv, Bh, ALPHA, BETA, want)
+            got = Cout.view(N, M)[:, br * 32:(br + 1) * 32].cpu().numpy().reshape(-1).astype(np.float64)
+            tol = 4e-6 * asum + 1e-6 * np.abs(float(BETA) * c0) + 1e-30
+            worst = max(worst, float(np.max(np.abs(got - want) / tol)))
+            rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+            assert rel < 1e-6, (br, rel)
+        print(f"config 5 full size: worst |gpu - fp32 oracle| / (4e-6 * sum|a*b| + 1e-6*|beta*c|) = {worst:.3f} "
+              f"over {len(brs)} block rows (10 496-term fp32 sums)")
+        assert worst <= 1.0
+    finally:
+        if dv is not None:
+            api.device_free(0, dv)
+        # drop the 22 GB fragment copy before the next test
+        try:
+            bc1, bv1 = api.gen_bell_host(32, 32, 1, 1)
+            engine.set_matrix_bell(32, 32, 1, bc1, bv1)
+        finally:
+            api.device_free(0, dc)
+            torch.cuda.empty_cache()

@@ -56,23 +56,27 @@ def _worker(rank, world, port, mode, q):
         t2 = torch.full((M * N,), float("nan"))
         sg.unpack_into(t2)
         ok = ok and np.array_equal(t2.numpy().view(np.uint32), want.view(np.uint32))
-        if mode == "even":
-            # pipelined form: chunked compute (oracle here) with async all-gathers in flight
-            pg = sxd.PipelinedSlabGather(M, N, ranges, rank, torch.device("cpu"), nchunks=3)
-            keep = []
+        # pipelined form: chunked compute (oracle here) with async all-gathers in flight; nnz-balanced (unequal)
+        # ranges pad every chunk to the longest chunk of any rank, and `align` snaps this rank's cut positions
+        # (the engine snaps them to its kernels' row-block boundaries) -- exchanged between ranks at set-up
+        align = None if mode == "even" else (lambda r: r // 7 * 7)
+        pg = sxd.PipelinedSlabGather(M, N, ranges, rank, torch.device("cpu"), nchunks=3, align=align)
+        keep = []
 
-            def chunk(c0, c1, out_ptr, ld_out, first):
-                part = np.ascontiguousarray(C0.reshape(N, M)[:, r0 + c0:r0 + c1]).reshape(-1)
-                crp, cci, cv = sxd.slice_csr(rp, ci, v, r0 + c0, r0 + c1)
-                o.spmm(c1 - c0, N, K, ALPHA, crp, cci, cv, B, BETA, part)
-                idx = [i for i, ch in enumerate(pg.chunks) if ch == (c0, c1)][0]
-                assert pg.S[idx][rank].data_ptr() == out_ptr and ld_out == c1 - c0
-                pg.S[idx][rank].copy_(torch.from_numpy(part.reshape(N, c1 - c0)))
-                keep.append(first)
-            pg.run(chunk)
-            t3 = torch.full((M * N,), float("nan"))
-            pg.finish(t3)
-            ok = ok and keep == [True, False, False] and np.array_equal(t3.numpy().view(np.uint32), want.view(np.uint32))
+        def chunk(c0, c1, out_ptr, ld_out, first):
+            part = np.ascontiguousarray(C0.reshape(N, M)[:, r0 + c0:r0 + c1]).reshape(-1)
+            crp, cci, cv = sxd.slice_csr(rp, ci, v, r0 + c0, r0 + c1)
+            o.spmm(c1 - c0, N, K, ALPHA, crp, cci, cv, B, BETA, part)
+            idx = [i for i, ch in enumerate(pg.chunks) if ch == (c0, c1)][0]
+            assert pg.S[idx][rank].data_ptr() == out_ptr and ld_out == pg.lmax[idx] >= c1 - c0
+            assert align is None or c0 % 7 == 0
+            pg.S[idx][rank][:, :c1 - c0].copy_(torch.from_numpy(part.reshape(N, c1 - c0)))
+            keep.append(first)
+        pg.run(chunk)
+        t3 = torch.full((M * N,), float("nan"))
+        pg.finish(t3)
+        ok = ok and keep[0] is True and not any(keep[1:]) and np.array_equal(t3.numpy().view(np.uint32), want.view(np.uint32))
+        assert pg.even == (mode == "even")
         q.put((rank, ok, ranges))
     finally:
         dist.destroy_process_group()

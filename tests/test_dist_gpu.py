@@ -70,3 +70,84 @@ def test_nccl_allgather_paths_single_rank(engine, oracle):
         assert np.array_equal(got.view(np.uint32), want.reshape(N, M)[:, r0:r1].copy().view(np.uint32))
     finally:
         dist.destroy_process_group()
+
+
+def _rccl_worker(rank, world, port, q):
+    """One rank of a real multi-GPU run: its own GPU, its own engine on its row range of A, B replicated,
+    RCCL all-gather of the C slabs (single-collective and pipelined forms)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    import torch.distributed as dist
+    from oracle.bindings import Oracle
+    from sextans_amd import api, dist as sxd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ok = {}
+    try:
+        o = Oracle()
+        rs = np.random.RandomState(123)
+        M, K, N = 6400, 5000, 16
+        rp, ci, v = random_csr(rs, M, K, 12, long_rows=1)
+        B = rs.uniform(-1, 1, K * N).astype(np.float32)
+        C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+        want = C0.copy()
+        o.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+        st = torch.cuda.current_stream().cuda_stream
+        dB = torch.from_numpy(B).to(dev); dCin = torch.from_numpy(C0).to(dev)
+        with api.Engine(rank) as e:
+            for mode in ("even", "nnz"):
+                ranges = sxd.partition_rows_even(M, world) if mode == "even" else sxd.partition_rows_by_nnz(rp, world)
+                r0, r1 = ranges[rank]
+                lrp, lci, lv = sxd.slice_csr(rp, ci, v, r0, r1)
+                e.set_matrix_csr(r1 - r0, K, lrp, lci, lv)
+                sg = sxd.SlabGather(M, N, ranges, rank, dev)
+                e.spmm_device2(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr() + 4 * r0, M, sg.local_ptr(), sg.lmax, st)
+                sg.gather()
+                out = torch.full((M * N,), float("nan"), device=dev)
+                sg.unpack_into(out)
+                torch.cuda.synchronize()
+                ok["slab_" + mode] = bool(np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)))
+                pg = sxd.PipelinedSlabGather(M, N, ranges, rank, dev, nchunks=3)
+
+                def chunk(c0, c1, out_ptr, ld_out, first):
+                    e.spmm_device_rows(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr() + 4 * (r0 + c0), M, out_ptr,
+                                       ld_out, c0, c1, reuse_b_panels=not first, stream=st)
+                pg.run(chunk)
+                out = torch.full((M * N,), float("nan"), device=dev)
+                pg.finish(out)
+                torch.cuda.synchronize()
+                ok["pipelined_" + mode] = bool(np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two MI355X on one node (runs as soon as the box has them)")
+def test_rccl_two_ranks():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok in res:
+        assert ok and all(ok.values()), (rank, ok)

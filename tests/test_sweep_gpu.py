@@ -12,11 +12,24 @@ from util import CASES, NASA
 pytestmark = pytest.mark.gpu
 
 
-def test_sweep_all_fixtures(sx):
+def test_sweep_all_fixtures(sx, oracle):
+    import numpy as np
     from sextans_amd import sweep
     paths = sorted(glob.glob(os.path.join(CASES, "*.mtx"))) + [NASA]
     buf = io.StringIO()
-    recs = sweep.sweep(paths, [8, 16, 40], rp_time=3, check=True, out=buf)
+    checked = []
+
+    def against_oracle(rec, M, K, N, rp, ci, va, B, C0, C):
+        """Every (matrix, N) result against the oracle's cpu_spmm_CSR restatement, bit for bit."""
+        want = C0.copy()
+        oracle.spmm(M, N, K, np.float32(0.85), rp, ci, va, B, np.float32(-2.06), want)
+        nan = np.isnan(want)
+        assert np.array_equal(nan, np.isnan(C)), rec
+        assert np.array_equal(want.view(np.uint32)[~nan], C.view(np.uint32)[~nan]), rec
+        checked.append((rec["matrix"], N))
+
+    recs = sweep.sweep(paths, [8, 16, 40], rp_time=3, check=True, out=buf, inspect=against_oracle)
+    assert len(checked) == len(recs)
     lines = [json.loads(l) for l in buf.getvalue().splitlines()]
     assert len(lines) == len(recs) and len(recs) >= 3 * (len(paths) - 1)
     for r in recs:
