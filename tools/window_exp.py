@@ -16,6 +16,8 @@ from sextans_amd import api  # noqa: E402
 M = K = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 variants = sys.argv[3] if len(sys.argv) > 3 else "full"
+if len(sys.argv) > 4:
+    K = int(sys.argv[4])                # K < M: probe with a B panel that fits the L2s (every gather hits)
 dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream().cuda_stream
 p, i, v, nnz = api.gen_csr_device(0, M, K, 40.0, 4)
@@ -43,14 +45,14 @@ def timed(reps=10):
 
 e.set_option("kernel", 1)
 ref, k_ns, r_ns = timed()
-print(f"M={M} N={N} nnz={nnz} alg={by/1e9:.3f} GB")
+print(f"M={M} K={K} N={N} nnz={nnz} alg={by/1e9:.3f} GB")
 print(f"gather  : {e.last_kernel():18s} kernel {k_ns/1e3:9.1f} us repack {r_ns/1e3:6.1f} us  frac {by/(k_ns*1e-9)/8e12:.4f}", flush=True)
 e.set_option("kernel", 3)
 if variants == "full":
     combos = [(319, 65536, 8), (319, 65536, 4), (319, 32768, 8), (319, 131072, 8), (319, 16384, 8), (255, 65536, 8),
               (159, 65536, 8), (319, 4_000_000 if K <= 4_000_000 else 8_000_000, 8)]
 else:
-    combos = [(319, 65536, 8)]
+    combos = [(319, 65536, 8), (319, 65536, 4)]
 for rows, cols, unroll in combos:
     e.set_option("window_rows", rows); e.set_option("window_cols", cols); e.set_option("window_unroll", unroll)
     t0 = time.perf_counter()
