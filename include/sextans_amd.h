@@ -229,7 +229,9 @@ int sextans_destroy(sextans_handle_t h);
 
 /* Tunables.  key: "kernel" (0 auto, 1 row-group gather, 2 LDS panel, 3 K-windowed accumulator-resident
  * sweep), "window_rows" (rows per wavefront of kernel 3, default 319), "window_cols" (columns per K window,
- * default 65536), "window_unroll" (4 or 8 steps in flight), "lanes_per_row"
+ * default 65536), "window_unroll" (4 or 8 steps in flight), "window_auto" (1: kernel 0 may choose kernel 3 from
+ * its fabric-traffic model; default 0 because the sweep never beat the gather kernel on MI355X),
+ * "lanes_per_row"
  * (2/4/8, N-tile = 4*lanes), "stage_a" (0/1 stage the CSR stream through LDS), "xcd_remap"
  * (0/1), "exact" (1 = no FMA, reference rounding; 0 = allow FMA), "profile" (0/1 hipEvent
  * per-kernel timing), "phase_timing" (0/1, see sextans_phase_timing_read), "split_rows" (T > 0: rows longer than T
@@ -310,6 +312,31 @@ int sextans_invoke(sextans_handle_t h, const int32_t *edge_list_ptr, const uint6
                    const float *const *mat_B_ch, int num_ch_b, const float *const *mat_C_ch_in,
                    float *const *mat_C_ch, int NUM_ITE, int NUM_A_LEN, int M, int K, int P_N, int alpha_u,
                    int beta_u, double *elapsed_ns);
+
+/* ---- Multi-GPU form behind the C ABI (north_star: A row-range partitioned across the GPUs of one node, B
+ * replicated, RCCL all-gather of C panels over xGMI).  The reference is single-device; its only
+ * sharding is rows -> PEs with B broadcast (sparse_helper.h:370, sextans.cpp:916-927), the same independence of
+ * output rows used here.  One process (or thread) per GPU; RCCL is bound at run time (librccl.so.1, or the
+ * library named by SEXTANS_RCCL_PATH), so single-GPU callers never need it.
+ *
+ *   sextans_dist_unique_id   rank 0 creates the 128-byte RCCL id and hands it to the other ranks by its own
+ *                            means (MPI_Bcast, a file, a socket);
+ *   sextans_dist_comm_init   every rank: communicator of `world` ranks on HIP device `device`;
+ *   sextans_dist_spmm        the engine holds THIS rank's rows [row_ranges[2*rank], row_ranges[2*rank+1]) of the
+ *                            M_total x K matrix (ranges tile [0, M_total) in rank order, unequal lengths allowed:
+ *                            nnz-balanced splits); d_B is the full K x N matrix, d_C_in / d_C_out the full
+ *                            column-major M_total x N matrices on this rank's device.  The rank's slab is
+ *                            computed in `nchunks` row chunks into a staging buffer; the all-gather of chunk i
+ *                            (ncclAllGather on the engine's communication stream) overlaps the SpMM of chunk
+ *                            i+1; a final pass writes every rank's rows into d_C_out.  Enqueued on `stream`,
+ *                            returns without synchronising (one short host sync for the row tables).  d_C_out
+ *                            holds C = alpha*A*B + beta*C_in for ALL rows on every rank. */
+int sextans_dist_unique_id(char id[128]);
+int sextans_dist_comm_init(void **comm, int device, int world, int rank, const char id[128]);
+int sextans_dist_comm_destroy(void *comm);
+int sextans_dist_spmm(sextans_handle_t h, void *comm, int world, int rank, const int *row_ranges, int N, float alpha,
+                      const float *d_B, int64_t ldb, float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out,
+                      int64_t ldc, int nchunks, void *stream);
 
 /* One-shot convenience with exactly cpu_spmm_CSR's argument list (sparse_helper.h:262-272):
  * create + upload + run + download + destroy on device 0. */

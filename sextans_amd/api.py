@@ -109,6 +109,12 @@ def lib():
     L.sextans_window_packed_free.restype = None
     L.sextans_get_stat.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
     L.sextans_align_row.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.sextans_dist_unique_id.argtypes = [C.c_char_p]
+    L.sextans_dist_comm_init.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_char_p]
+    L.sextans_dist_comm_destroy.argtypes = [C.c_void_p]
+    L.sextans_dist_spmm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i32p, C.c_int, C.c_float, C.c_void_p,
+                                    C.c_int64, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
+                                    C.c_void_p]
     pp = C.POINTER(C.c_void_p)
     L.sextans_edges_pack_csc.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f32p, C.POINTER(Edges)]
     L.sextans_edges_free.argtypes = [C.POINTER(Edges)]
@@ -467,6 +473,13 @@ class Engine:
     def set_option(self, key, value):
         _check(lib().sextans_set_option(self._h, key.encode(), int(value)), f"set_option({key})")
 
+    def dist_spmm(self, comm, world, rank, ranges, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out, ldc, nchunks=4,
+                  stream=None):
+        """Native multi-GPU SpMM (sextans_dist_spmm): this engine holds rows ranges[rank] of the matrix."""
+        rr = np.ascontiguousarray(np.asarray(ranges, np.int32).reshape(-1))
+        _check(lib().sextans_dist_spmm(self._h, comm, world, rank, rr, N, alpha, d_B, ldb, beta, d_C_in, ldc_in,
+                                       d_C_out, ldc, nchunks, stream), "dist_spmm")
+
     def align_row(self, N, row):
         """Largest row <= `row` where a row-range call keeps the whole-matrix kernel (sextans_align_row)."""
         out = C.c_int()
@@ -669,6 +682,23 @@ def gen_uniform_host(n, seed):
 
 def gen_uniform_device(device, d_ptr, n, seed, stream=None):
     _check(lib().sextans_gen_uniform_device(device, d_ptr, n, seed, stream), "gen_uniform_device")
+
+
+def dist_unique_id():
+    """128-byte RCCL id (rank 0 creates it, the other ranks receive it by the caller's own means)."""
+    buf = C.create_string_buffer(128)
+    _check(lib().sextans_dist_unique_id(buf), "dist_unique_id")
+    return buf.raw
+
+
+def dist_comm_init(device, world, rank, uid):
+    comm = C.c_void_p()
+    _check(lib().sextans_dist_comm_init(C.byref(comm), device, world, rank, uid), "dist_comm_init")
+    return comm
+
+
+def dist_comm_destroy(comm):
+    _check(lib().sextans_dist_comm_destroy(comm), "dist_comm_destroy")
 
 
 def device_free(device, d_ptr):

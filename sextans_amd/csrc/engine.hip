@@ -7,6 +7,8 @@
 // There is NO CPU fallback anywhere in this file: no device => SEXTANS_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -100,6 +102,11 @@ struct sextans_engine {
     float *d_P = nullptr;
     size_t P_cap = 0;
     long long *d_dbg = nullptr;     // 8 counters for phase timing (option "phase_timing")
+    // native multi-GPU form (sextans_dist_spmm): slab staging S[chunk][world][N][lmax_chunk], communication stream
+    float *d_stage = nullptr;
+    size_t stage_cap = 0;
+    hipStream_t comm_stream = nullptr;
+    std::vector<hipEvent_t> dist_events;
     // options
     int64_t opt_kernel = 0, opt_lpr = 4, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;
     int64_t opt_fuse_b = 1;             // panel kernel may stage from column-major B (small matrices: no repack launch)
@@ -109,6 +116,7 @@ struct sextans_engine {
     int64_t opt_win_rows = 319;         // rows per wavefront of the window kernel (+1 dummy row: 4 x 320 x 32 B = 40 KiB)
     int64_t opt_win_cols = 65536;       // columns per K window (x 32 B = 2 MiB of the 8-column panel: half an XCD's L2)
     int64_t opt_win_unroll = 8;         // steps in flight per ring (4 or 8)
+    int64_t opt_win_auto = 0;           // 1: "kernel" 0 may pick the window kernel from the fabric-byte model
     // profiling
     std::vector<EventPair> ev_kernel, ev_repack;
     const char *last_kernel = "none";
@@ -400,10 +408,13 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
 // leading dimension bcol_ld (dictionary-only plans, small B: no repack launch).
 template <int LPR>
 void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout,
-                  int64_t ldc, int ntiles, float alpha, float beta, hipStream_t s, int64_t bcol_ld = 0) {
+                  int64_t ldc, int ntiles, float alpha, float beta, hipStream_t s, int64_t bcol_ld, int blk_begin,
+                  int blk_end, int row_base) {
     constexpr int RB = sx::kBlock / LPR;
     constexpr int NT = 4 * LPR;
-    const unsigned nwg = (unsigned)h->plan_nblk * (unsigned)ntiles;
+    const int nblk = blk_end - blk_begin;
+    if (nblk <= 0) return;
+    const unsigned nwg = (unsigned)nblk * (unsigned)ntiles;
     const int64_t pstride = bcol_ld > 0 ? bcol_ld : (int64_t)h->K * NT;
     const int xcd = (int)h->opt_xcd;
     // LDS = B panel sized for the largest dictionary of this matrix (rounded to 1 KiB) + C tile.
@@ -413,8 +424,8 @@ void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(nwg), dim3(sx::kBlock), lds, s, (const int2 *)h->d_row_off, h->d_lidx,
                            h->d_pcol32, h->d_pval, h->d_blk_row, h->d_dict_ptr, h->d_dict, h->plan_dict_stride, dBp,
-                           pstride, dCin, ldc_in, dCout, ldc, ntiles, h->plan_nblk, alpha, beta, xcd, panel_floats,
-                           (long long *)h->d_dbg);
+                           pstride, dCin, ldc_in, dCout, ldc, ntiles, nblk, alpha, beta, xcd, panel_floats,
+                           (long long *)h->d_dbg, blk_begin, row_base);
     };
     if (h->plan_mixed) {
         if (h->opt_exact) go(sx::spmm_csr_panel<LPR, true, true>);
@@ -435,6 +446,12 @@ void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_
 //   window: every XCD streams the whole 8-column panel once per sweep, sweeps = rows / rows whose partial
 //           sums the chip holds in LDS at once (at least 1), + the 8-byte stream entry, per 8-column tile.
 bool window_pays(const sextans_engine *h, int N, int64_t padded) {
+    // Measured on MI355X (profiles/r02_window_kernel_*.txt): the model below counts fabric BYTES, but both
+    // kernels are bound by line REQUESTS (~57 G/s beyond L2, ~135 G/s from L2), the sweep issues two 32-byte
+    // row reads per non-zero at N = 16 where the gather issues one 64-byte read, and without a chip-wide
+    // window barrier the wavefronts drift apart by more than the 4 MiB L2 holds (L2 hit rate 20 %).  The
+    // window kernel never won a measurement, so "auto" only considers it when option "window_auto" is set.
+    if (!h->opt_win_auto) return false;
     if (N > 24 || h->nnz == 0) return false;
     const double K = (double)h->K, nnz = (double)h->nnz, M = (double)h->M;
     if (K * N * 4.0 <= 48.0 * 1048576.0) return false;   // B (nearly) fits the L2s: gathers stay on chip
@@ -550,6 +567,9 @@ int sextans_destroy(sextans_handle_t h) {
     (void)hipFree(h->d_P);
     (void)hipFree(h->d_dbg);
     (void)hipFree(h->d_chB); (void)hipFree(h->d_chC);
+    (void)hipFree(h->d_stage);
+    for (hipEvent_t e : h->dist_events) (void)hipEventDestroy(e);
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
     delete h;
     return SEXTANS_OK;
@@ -569,6 +589,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "window_rows")) return &h->opt_win_rows;
     if (!strcmp(key, "window_cols")) return &h->opt_win_cols;
     if (!strcmp(key, "window_unroll")) return &h->opt_win_unroll;
+    if (!strcmp(key, "window_auto")) return &h->opt_win_auto;
     return nullptr;
 }
 
@@ -782,7 +803,14 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     int W = 0;
     bool use_panel = false, use_window = false;
     if (int rc = prepare(h, N, plan, W, use_panel, use_window)) return rc;
-    if (!whole) use_panel = false;   // row ranges cut across the panel plan's row blocks: gather kernel
+    // a row range keeps the panel kernel when it starts and ends on row-block boundaries of the plan
+    int blk0 = 0, blk1 = h->plan_nblk;
+    if (use_panel && !whole) {
+        const auto &br = h->h_blk_row;
+        const auto i0 = std::lower_bound(br.begin(), br.end(), row_begin), i1 = std::lower_bound(br.begin(), br.end(), row_end);
+        if (i0 == br.end() || *i0 != row_begin || i1 == br.end() || *i1 != row_end) use_panel = false;
+        else { blk0 = (int)(i0 - br.begin()); blk1 = (int)(i1 - br.begin()); }
+    }
     // a row range can use the window kernel when it starts and ends on wavefront (rows-per-wave) boundaries
     if (use_window && (row_begin % h->win_rw != 0 || (row_end % h->win_rw != 0 && row_end != h->M))) use_window = false;
     if (int rc = ensure_split(h)) return rc;
@@ -838,17 +866,17 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             const bool panel_here = use_panel && g.width == W;   // the plan is built for width W
             switch (g.width) {
                 case 32:
-                    if (panel_here) launch_panel<8>(h, fuse_b ? d_B + (int64_t)g.col0 * ldb : bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, fuse_b ? ldb : 0);
+                    if (panel_here) launch_panel<8>(h, fuse_b ? d_B + (int64_t)g.col0 * ldb : bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, fuse_b ? ldb : 0, blk0, blk1, row_begin);
                     else if (split) launch_rowgroup<8>(h, h->d_vrp, bp, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, 0, h->split_nv, g.ntiles, 1.0f, 0.0f, s);
                     else launch_rowgroup<8>(h, h->d_rp, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
                     break;
                 case 16:
-                    if (panel_here) launch_panel<4>(h, fuse_b ? d_B + (int64_t)g.col0 * ldb : bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, fuse_b ? ldb : 0);
+                    if (panel_here) launch_panel<4>(h, fuse_b ? d_B + (int64_t)g.col0 * ldb : bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, fuse_b ? ldb : 0, blk0, blk1, row_begin);
                     else if (split) launch_rowgroup<4>(h, h->d_vrp, bp, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, 0, h->split_nv, g.ntiles, 1.0f, 0.0f, s);
                     else launch_rowgroup<4>(h, h->d_rp, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
                     break;
                 default:
-                    if (panel_here) launch_panel<2>(h, fuse_b ? d_B + (int64_t)g.col0 * ldb : bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, fuse_b ? ldb : 0);
+                    if (panel_here) launch_panel<2>(h, fuse_b ? d_B + (int64_t)g.col0 * ldb : bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, fuse_b ? ldb : 0, blk0, blk1, row_begin);
                     else if (split) launch_rowgroup<2>(h, h->d_vrp, bp, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, 0, h->split_nv, g.ntiles, 1.0f, 0.0f, s);
                     else launch_rowgroup<2>(h, h->d_rp, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
                     break;
@@ -1135,6 +1163,168 @@ int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint1
         if (ntiles % 4 == 0) SX_BELL(4) else if (ntiles % 2 == 0) SX_BELL(2) else SX_BELL(1)
 #undef SX_BELL
         h->last_kernel = "spmm_bell_mfma";
+    }
+    SX_HIP(hipGetLastError());
+    return SEXTANS_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Native multi-GPU form (north_star: "A row-range partitioned across the GPUs of one node, B replicated,
+// RCCL all-gather of C panels over xGMI") behind the C ABI, for callers that have no torch.distributed.
+// RCCL is bound at run time (dlopen "librccl.so.1"): the single-GPU entry points never need it.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Id128 { char b[128]; };   // ncclUniqueId, passed to ncclCommInitRank BY VALUE
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl *rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.lib ? &r : nullptr;
+    tried = true;
+    const char *env = getenv("SEXTANS_RCCL_PATH");
+    for (const char *name : {env, "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+        if (!name || !*name) continue;
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) { g_last_error = std::string("RCCL not found: ") + dlerror(); return nullptr; }
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) {
+        g_last_error = "RCCL library lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllGather";
+        dlclose(r.lib); r.lib = nullptr;
+        return nullptr;
+    }
+    return &r;
+}
+int rccl_check(int rc, const char *what) {
+    if (rc == 0) return SEXTANS_OK;
+    Rccl *r = rccl();
+    g_last_error = std::string(what) + " failed: " + (r && r->GetErrorString ? r->GetErrorString(rc) : "RCCL error");
+    return SEXTANS_ERR_HIP;
+}
+
+// S[g][n][0 .. len_g) -> C[(row0_g + i) + n * ldc]: one thread per staged element; `meta` = {row0, len} per rank.
+__global__ __launch_bounds__(256) void dist_unpack_slabs(const float *__restrict__ S, int64_t lmax, int N,
+                                                         const int2 *__restrict__ meta, float *C, int64_t ldc) {
+    const int g = blockIdx.z, n = blockIdx.y;
+    const int2 m = meta[g];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < m.y) C[(int64_t)m.x + i + (int64_t)n * ldc] = S[((int64_t)g * N + n) * lmax + i];
+}
+}  // namespace
+
+extern "C" {
+
+int sextans_dist_unique_id(char id[128]) {
+    if (!id) return SEXTANS_ERR_INVALID;
+    Rccl *r = rccl();
+    if (!r) return SEXTANS_ERR_STATE;
+    return rccl_check(r->GetUniqueId(id), "ncclGetUniqueId");
+}
+
+int sextans_dist_comm_init(void **comm, int device, int world, int rank, const char id[128]) {
+    if (!comm || !id || world < 1 || rank < 0 || rank >= world) return SEXTANS_ERR_INVALID;
+    if (int rc = check_device(device)) return rc;
+    Rccl *r = rccl();
+    if (!r) return SEXTANS_ERR_STATE;
+    SX_HIP(hipSetDevice(device));
+    Id128 u;
+    memcpy(u.b, id, 128);
+    return rccl_check(r->CommInitRank(comm, world, u, rank), "ncclCommInitRank");
+}
+
+int sextans_dist_comm_destroy(void *comm) {
+    Rccl *r = rccl();
+    if (!r || !comm) return SEXTANS_ERR_INVALID;
+    return rccl_check(r->CommDestroy(comm), "ncclCommDestroy");
+}
+
+int sextans_dist_spmm(sextans_handle_t h, void *comm, int world, int rank, const int *row_ranges, int N, float alpha,
+                      const float *d_B, int64_t ldb, float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out,
+                      int64_t ldc, int nchunks, void *stream) {
+    if (!h || !comm || world < 1 || rank < 0 || rank >= world || !row_ranges || N <= 0 || (N % 8) || !d_B || !d_C_in ||
+        !d_C_out)
+        return SEXTANS_ERR_INVALID;
+    if (!h->d_rp) return SEXTANS_ERR_STATE;
+    Rccl *r = rccl();
+    if (!r) return SEXTANS_ERR_STATE;
+    // ranges must tile [0, M_total) in rank order and this rank's range must be the engine's matrix
+    int64_t M_total = 0;
+    for (int g = 0; g < world; ++g) {
+        if (row_ranges[2 * g] != (int)M_total || row_ranges[2 * g + 1] < row_ranges[2 * g]) return SEXTANS_ERR_INVALID;
+        M_total = row_ranges[2 * g + 1];
+    }
+    const int row0 = row_ranges[2 * rank], m_loc = row_ranges[2 * rank + 1] - row0;
+    if (m_loc != h->M || ldc < M_total || ldc_in < M_total || ldb < h->K) return SEXTANS_ERR_INVALID;
+    SX_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (nchunks < 1) nchunks = 1;
+    if (nchunks > 16) nchunks = 16;
+    // Chunk c of rank g = rows [len_g * c / nchunks, len_g * (c+1) / nchunks) of its range -- computable by every
+    // rank for every rank.  This rank's own interior cuts are NOT snapped to kernel-friendly boundaries here
+    // (that would need an exchange); sextans_spmm_device_rows falls back to the gather kernel on unaligned cuts.
+    auto cut = [&](int g, int c) { return (int)((int64_t)(row_ranges[2 * g + 1] - row_ranges[2 * g]) * c / nchunks); };
+    std::vector<int64_t> lmax((size_t)nchunks, 1), off((size_t)nchunks + 1, 0);
+    for (int c = 0; c < nchunks; ++c) {
+        for (int g = 0; g < world; ++g) lmax[(size_t)c] = std::max<int64_t>(lmax[(size_t)c], cut(g, c + 1) - cut(g, c));
+        off[(size_t)c + 1] = off[(size_t)c] + (int64_t)world * N * lmax[(size_t)c];
+    }
+    // staging + per-chunk {row0, len} tables (ints, kept behind the float staging area)
+    const size_t meta_floats = (size_t)nchunks * (size_t)world * 2;
+    if (int rc = ensure(&h->d_stage, &h->stage_cap, (size_t)off[(size_t)nchunks] + meta_floats)) return rc;
+    if (!h->comm_stream) SX_HIP(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    while (h->dist_events.size() < (size_t)nchunks + 1) {
+        hipEvent_t e;
+        SX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->dist_events.push_back(e);
+    }
+    std::vector<int> meta(meta_floats);
+    for (int c = 0; c < nchunks; ++c)
+        for (int g = 0; g < world; ++g) {
+            meta[((size_t)c * world + g) * 2] = row_ranges[2 * g] + cut(g, c);
+            meta[((size_t)c * world + g) * 2 + 1] = cut(g, c + 1) - cut(g, c);
+        }
+    int *d_meta = reinterpret_cast<int *>(h->d_stage + off[(size_t)nchunks]);
+    SX_HIP(hipMemcpyAsync(d_meta, meta.data(), sizeof(int) * meta.size(), hipMemcpyHostToDevice, s));
+    SX_HIP(hipStreamSynchronize(s));   // `meta` is a host temporary
+    bool first = true;
+    for (int c = 0; c < nchunks; ++c) {
+        float *S = h->d_stage + off[(size_t)c];
+        const int c0 = cut(rank, c), c1 = cut(rank, c + 1);
+        float *mine = S + (size_t)rank * N * lmax[(size_t)c];
+        if (c1 > c0) {
+            if (int rc = sextans_spmm_device_rows(h, N, alpha, d_B, ldb, beta, d_C_in + row0 + c0, ldc_in, mine,
+                                                  lmax[(size_t)c], c0, c1, first ? 0 : SEXTANS_ROWS_REUSE_B_PANELS, stream))
+                return rc;
+            first = false;
+        }
+        // the all-gather of chunk c runs on the communication stream while the SpMM of chunk c+1 runs on `stream`
+        SX_HIP(hipEventRecord(h->dist_events[(size_t)c], s));
+        SX_HIP(hipStreamWaitEvent(h->comm_stream, h->dist_events[(size_t)c], 0));
+        if (int rc = rccl_check(r->AllGather(mine, S, (size_t)N * (size_t)lmax[(size_t)c], 7 /* ncclFloat */, comm,
+                                             h->comm_stream), "ncclAllGather"))
+            return rc;
+    }
+    SX_HIP(hipEventRecord(h->dist_events[(size_t)nchunks], h->comm_stream));
+    SX_HIP(hipStreamWaitEvent(s, h->dist_events[(size_t)nchunks], 0));
+    for (int c = 0; c < nchunks; ++c) {
+        const unsigned gx = (unsigned)((lmax[(size_t)c] + 255) / 256);
+        hipLaunchKernelGGL(dist_unpack_slabs, dim3(gx, (unsigned)N, (unsigned)world), dim3(256), 0, s,
+                           h->d_stage + off[(size_t)c], lmax[(size_t)c], N, reinterpret_cast<const int2 *>(d_meta) + (size_t)c * world,
+                           d_C_out, ldc);
     }
     SX_HIP(hipGetLastError());
     return SEXTANS_OK;

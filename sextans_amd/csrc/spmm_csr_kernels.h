@@ -229,7 +229,9 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
     const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout,
     int64_t ldc, int ntiles, int nblk, float alpha, float beta, int use_xcd_remap, int panel_floats,
-    long long *dbg) {
+    long long *dbg, int blk_begin, int row_base) {
+    // Blocks [blk_begin, blk_begin + nblk) of the plan are processed (row-range calls of the multi-GPU pipeline
+    // cut at block boundaries); the C pointers address row `row_base` as their row 0.
     const long long t0 = dbg ? clock64() : 0;   // dbg: optional phase timing (engine option "phase_timing")
     const long long w0 = dbg ? wall_clock64() : 0;   // 100 MHz constant clock: calibrates the cycle counts
     static_assert(!(MIXED && BCOL), "the column-major staging exists for dictionary-only plans");
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     const unsigned nwg = (unsigned)nblk * (unsigned)ntiles;
     unsigned wg = blockIdx.x;
     if (use_xcd_remap) wg = xcd_remap(wg, nwg);
-    const int blk = (int)(wg / (unsigned)ntiles);
+    const int blk = blk_begin + (int)(wg / (unsigned)ntiles);
     const int tile = (int)(wg % (unsigned)ntiles);
 
     const int tid = threadIdx.x;
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     for (int i = 0; i < OPT; ++i) {
         const int e = tid + i * kBlock;
         const int n = e / RB, r = e % RB;
-        cin[i] = Cin[(int64_t)min(row0 + r, row1 - 1) + (col0 + n) * ldc_in];
+        cin[i] = Cin[(int64_t)(min(row0 + r, row1 - 1) - row_base) + (col0 + n) * ldc_in];
     }
 
     const long long t1 = dbg ? clock64() : 0;
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
         const int n = e / RB, r = e % RB;
         const int orow = row0 + r;
         if (orow < row1) {
-            const int64_t o = (int64_t)orow + (col0 + n) * ldc;
+            const int64_t o = (int64_t)(orow - row_base) + (col0 + n) * ldc;
             Cout[o] = epilogue<EXACT>(alpha, s_c[n * TS + r], beta, cin[i]);
         }
     }

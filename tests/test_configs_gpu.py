@@ -51,9 +51,10 @@ def test_config3_pcrystk02_standin_n128(engine, oracle, kernel, lpr):
     _set(engine)
 
 
-@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("kernel", [0, 3])
 def test_config4_full_size(engine, oracle, kernel):
-    """kernel 0 = what the dispatcher picks for this matrix (the K-windowed kernel), 1 = the gather kernel."""
+    """kernel 0 = what the dispatcher picks for this matrix (the gather kernel: no B-row reuse), 3 = the
+    K-windowed accumulator-resident kernel at full size."""
     import torch
     from sextans_amd import api
     M = K = 4_000_000
@@ -76,8 +77,7 @@ def test_config4_full_size(engine, oracle, kernel):
             engine.spmm_device(N, 1.0, Bx.data_ptr(), K, 0.0, Z.data_ptr(), o.data_ptr(), M, st)
             outs.append(o)
         torch.cuda.synchronize()
-        if kernel == 0:
-            assert engine.last_kernel() == "spmm_csr_window"
+        assert engine.last_kernel() == ("spmm_csr_window" if kernel == 3 else "spmm_csr_rowgroup")
         # linearity: A(B1 + B2) = A B1 + A B2 up to fp32 rounding of ~40-term sums
         err = (outs[0] + outs[1] - outs[2]).abs().max().item()
         scale = outs[2].abs().max().item()

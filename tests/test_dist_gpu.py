@@ -72,6 +72,64 @@ def test_nccl_allgather_paths_single_rank(engine, oracle):
         dist.destroy_process_group()
 
 
+def test_native_dist_spmm_single_rank(engine, oracle, sx):
+    """sextans_dist_spmm (RCCL called from the C ABI, no torch.distributed) on a 1-rank communicator: chunked
+    slab, ncclAllGather on the engine's communication stream, unpack -- and the LDS-panel kernel on
+    block-aligned row chunks (FEM matrix)."""
+    import torch
+    from sextans_amd import api
+    comm = api.dist_comm_init(0, 1, 0, api.dist_unique_id())
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        rs = np.random.RandomState(4)
+        for name in ("random", "fem"):
+            if name == "random":
+                M, K, N = 2000, 1500, 16
+                rp, ci, v = random_csr(rs, M, K, 9, long_rows=1)
+            else:
+                rp, ci, v = api.gen_fem3d_host(12, 11, 10, 3, 7)
+                M = K = 12 * 11 * 10 * 3
+                N = 24
+            B = rs.uniform(-1, 1, K * N).astype(np.float32)
+            C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+            want = C0.copy()
+            oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+            for k, val in dict(kernel=0, lanes_per_row=4, exact=1, split_rows=0).items():
+                engine.set_option(k, val)
+            engine.set_matrix_csr(M, K, rp, ci, v)
+            dB = torch.from_numpy(B).cuda(); dCin = torch.from_numpy(C0).cuda()
+            for nchunks in (1, 3):
+                out = torch.full((M * N,), float("nan"), device="cuda")
+                engine.dist_spmm(comm, 1, 0, [(0, M)], N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr(), M, out.data_ptr(), M,
+                                 nchunks=nchunks, stream=st)
+                torch.cuda.synchronize()
+                assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (name, nchunks)
+            if name == "fem":
+                # row-range calls cut at sextans_align_row boundaries keep the LDS-panel kernel
+                cuts = [0, engine.align_row(N, M // 3), engine.align_row(N, 2 * M // 3), M]
+                assert cuts[1] > 0 and cuts[2] > cuts[1]
+                out = torch.full((M * N,), float("nan"), device="cuda")
+                for i in range(3):
+                    c0, c1 = cuts[i], cuts[i + 1]
+                    slab = torch.full(((c1 - c0) * N,), float("nan"), device="cuda")
+                    engine.spmm_device_rows(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr() + 4 * c0, M, slab.data_ptr(),
+                                            c1 - c0, c0, c1, reuse_b_panels=i > 0, stream=st)
+                    assert engine.last_kernel() == "spmm_csr_panel"
+                    out.view(N, M)[:, c0:c1] = slab.view(N, c1 - c0)
+                torch.cuda.synchronize()
+                assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+                # an unaligned cut falls back to the gather kernel, same bits
+                slab = torch.full(((M - 5) * N,), float("nan"), device="cuda")
+                engine.spmm_device_rows(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr() + 4 * 5, M, slab.data_ptr(), M - 5, 5, M,
+                                        stream=st)
+                torch.cuda.synchronize()
+                assert engine.last_kernel() == "spmm_csr_rowgroup"
+                assert np.array_equal(slab.cpu().numpy().reshape(N, M - 5).view(np.uint32),
+                                      want.reshape(N, M)[:, 5:].copy().view(np.uint32))
+    finally:
+        api.dist_comm_destroy(comm)
+
+
 def _rccl_worker(rank, world, port, q):
     """One rank of a real multi-GPU run: its own GPU, its own engine on its row range of A, B replicated,
     RCCL all-gather of the C slabs (single-collective and pipelined forms)."""
@@ -123,6 +181,16 @@ def _rccl_worker(rank, world, port, q):
                 pg.finish(out)
                 torch.cuda.synchronize()
                 ok["pipelined_" + mode] = bool(np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)))
+                # the native form: RCCL from the C ABI; the id travels through the torch store
+                ids = [api.dist_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                comm = api.dist_comm_init(rank, world, rank, ids[0])
+                out = torch.full((M * N,), float("nan"), device=dev)
+                e.dist_spmm(comm, world, rank, ranges, N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr(), M, out.data_ptr(), M,
+                            nchunks=3, stream=st)
+                torch.cuda.synchronize()
+                ok["native_" + mode] = bool(np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)))
+                api.dist_comm_destroy(comm)
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
