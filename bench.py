@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--chunks", type=int, default=4, help="N>1: row chunks for gather/compute overlap (1 = off)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value")
+    ap.add_argument("--native-dist", action="store_true",
+                    help="N>1: sextans_dist_spmm (RCCL called from the C ABI) instead of torch.distributed collectives")
     args = ap.parse_args()
 
     import torch
@@ -112,10 +114,17 @@ def main():
     # buffer, ONE RCCL all-gather moves all slabs, a local strided copy writes column-major C_out.
     # With --chunks > 1 (default 4) the slab is produced in row chunks and the all-gather of chunk i
     # overlaps the SpMM of chunk i+1 (PipelinedSlabGather).
-    sg = pg = None
-    if multi:
-        if args.chunks > 1 and M % world == 0:
-            pg = sxd.PipelinedSlabGather(M, N, ranges, rank, dev, nchunks=args.chunks)
+    sg = pg = comm = None
+    if multi and args.native_dist:
+        ids = [api.dist_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)              # the 128-byte RCCL id travels through the torch store
+        comm = api.dist_comm_init(local_rank, world, rank, ids[0])
+    elif multi:
+        if args.chunks > 1:
+            # chunk cuts snapped to the boundaries the rank's kernel wants (row blocks of the LDS-panel plan,
+            # wavefronts of the window kernel): every chunk keeps the whole-matrix kernel
+            pg = sxd.PipelinedSlabGather(M, N, ranges, rank, dev, nchunks=args.chunks,
+                                         align=lambda r: eng.align_row(N, r))
         else:
             sg = sxd.SlabGather(M, N, ranges, rank, dev)
 
@@ -127,14 +136,19 @@ def main():
         if not multi:
             eng.spmm_device(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr, cout_ptr, M, stream)
         elif pg is not None:
-            for i, ((c0, c1), S) in enumerate(zip(pg.chunks, pg.S)):
-                chunk(c0, c1, S[rank].data_ptr(), c1 - c0, i == 0)
+            for i, ((c0, c1), S, lmax) in enumerate(zip(pg.chunks, pg.S, pg.lmax)):
+                chunk(c0, c1, S[rank].data_ptr(), lmax, i == 0)
+        elif comm is not None:   # compute-only leg of the native form: the rank's slab, in place, no collective
+            eng.spmm_device2(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr, M, cout_ptr, M, stream)
         else:
             eng.spmm_device2(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr, M, sg.local_ptr(), sg.lmax, stream)
 
     def step():
         if not multi:
             compute()
+        elif comm is not None:
+            eng.dist_spmm(comm, world, rank, ranges, N, ALPHA, B.data_ptr(), K, BETA, Cin.data_ptr(), M, Cout.data_ptr(), M,
+                          nchunks=args.chunks, stream=stream)
         elif pg is not None:
             pg.run(chunk, _force=(world == 1))
             pg.finish(Cout)
@@ -191,13 +205,18 @@ def main():
     achieved = bytes_launch / (k_ns * 1e-9) / 1e9
     # HBM traffic of this kernel comes from separate rocprofv3 --pmc passes of this same command
     # (tools/prof.sh -> profiles/*_traffic.json); only valid for the default single-GPU workload.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_config4_traffic.json")
+    # It is NOT measured in this run: the value and its provenance are reported side by side.
+    traffic = traffic_source = None
+    tpath = os.path.join(ROOT, "profiles", "r02_config4_traffic.json")
     if world == 1 and args.rows == 4_000_000 and args.mean_nnz == 40.0 and N == 16 and not args.opt \
             and os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
+        tj = json.load(open(tpath))
+        if tj.get("kernel") == eng.last_kernel():
+            traffic = tj.get("traffic_bytes_per_launch")
+            traffic_source = ("stored, not measured in this run: profiles/r02_config4_traffic.json <- " +
+                              str(tj.get("source")))
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": eng.last_kernel(), "kernel_us": round(k_ns / 1e3, 2),
                 "alg_bytes_per_launch": bytes_launch, "launches_timed": k_n,
                 "kernel_launches_per_step": launches_per_step,
@@ -216,10 +235,18 @@ def main():
         "hbm_gbs_algorithmic_step": round(alg_bytes(M, K, N, nnz_tot) / sec_per_step / 1e9, 1),
         "roofline": roofline,
     }
+    out["plan_build_s"] = round(eng.get_stat("plan_build_s"), 3)   # host packing of A, outside every timed region
     also = {}
     if multi:
         also["compute_only_ms_per_step"] = round(dt_compute / args.steps * 1e3, 4)
         also["compute_only_gflops"] = round(flops / (dt_compute / args.steps) / 1e9, 2)
+        also["end_to_end_ms_per_step"] = round(sec_per_step * 1e3, 4)
+        # per-rank costs (rank 0's; the B repack is replicated on every rank and does not shrink with N)
+        also["per_rank"] = {"rows": m_loc, "nnz": nnz_loc, "kernel": eng.last_kernel(),
+                            "kernel_us_per_step": round(k_ns / 1e3, 2), "repack_us_per_step": round(rp_ns / 1e3, 2),
+                            "allgather_bytes_received": 4 * N * (M - m_loc), "chunks": args.chunks,
+                            "collectives": "sextans_dist_spmm (RCCL from the C ABI)" if comm is not None
+                            else "torch.distributed all_gather_into_tensor"}
 
     if rank == 0 and world == 1:
         if multi:   # forced single-rank distributed run: check the gathered C against the plain path
@@ -245,6 +272,8 @@ def main():
     if also:
         out["also"] = also
 
+    if comm is not None:
+        api.dist_comm_destroy(comm)
     eng.close()
     for q in (d_rp, d_ci, d_v):
         api.device_free(local_rank, q)
@@ -302,22 +331,15 @@ def cpu_baseline(api, M, K, N, args, Cout, flops_per_row):
            "sample": f"rows [0,{R}) of the same matrix ({nnz_s} nnz), same B and C_in, "
                      f"{sec:.2f} s single thread; host has {os.cpu_count()} logical cores",
            "gpu_matches_cpu_bitwise_on_sample": match}
-    # Same loop nest, row-parallel on the host's cores (SURVEY.md 8d baseline 2): the C restatement on
-    # nnz-balanced row ranges, one thread per range (ctypes releases the GIL), same sample.
+    # Same loop nest, row-parallel on ALL host cores (SURVEY.md 8d baseline 2): OpenMP loop in oracle/, same sample.
     try:
-        from concurrent.futures import ThreadPoolExecutor
-        from sextans_amd import dist as sxd
         rp, ci, v = csr
-        T = max(1, min(os.cpu_count() or 1, 64))
-        ranges = [r for r in sxd.partition_rows_by_nnz(rp, T) if r[1] > r[0]]
         Cs2 = np.ascontiguousarray(Cin_h.reshape(N, M)[:, :R]).reshape(-1)
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(len(ranges)) as ex:
-            list(ex.map(lambda r: o.spmm_rows(r[0], r[1], R, N, K, np.float32(ALPHA), rp, ci, v, Bh,
-                                              np.float32(BETA), Cs2), ranges))
-        sec2 = time.perf_counter() - t0
+        o.time_spmm_omp(R, N, K, np.float32(ALPHA), rp, ci, v, Bh, np.float32(BETA), Cs2.copy())   # thread start-up
+        sec2, threads = o.time_spmm_omp(R, N, K, np.float32(ALPHA), rp, ci, v, Bh, np.float32(BETA), Cs2)
         out["all_cores"] = {"value": round(2.0 * N * (nnz_s + R) / sec2 / 1e9, 3), "unit": "GFLOP/s",
-                            "cores": len(ranges), "kind": "port", "seconds": round(sec2, 3),
+                            "cores": threads, "kind": "port", "seconds": round(sec2, 3),
+                            "host_logical_cores": os.cpu_count(),
                             "matches_single_thread_bitwise": bool(np.array_equal(Cs2.view(np.uint32),
                                                                                   Cs.view(np.uint32)))}
     except Exception as e:   # extra information only
@@ -351,6 +373,7 @@ def _measure(api, torch, e, M, K, N, nnz, dev, stream, iters):
     return {"M": M, "K": K, "N": N, "nnz": nnz, "kernel": e.last_kernel(),
             "us_per_step": round(per * 1e6, 2), "gflops": round(2.0 * N * (nnz + M) / per / 1e9, 1),
             "kernel_us": round(k_ns / 1e3, 2), "repack_us": round(rp_ns / 1e3, 2),
+            "plan_build_s": round(e.get_stat("plan_build_s"), 3),
             "alg_gbs_kernel": round(by / (k_ns * 1e-9) / 1e9, 1),
             "roofline_frac_kernel": round(by / (k_ns * 1e-9) / 1e9 / HBM_PEAK_GBS, 4)}
 

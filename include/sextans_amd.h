@@ -234,13 +234,20 @@ int sextans_destroy(sextans_handle_t h);
  * "lanes_per_row"
  * (2/4/8, N-tile = 4*lanes), "stage_a" (0/1 stage the CSR stream through LDS), "xcd_remap"
  * (0/1), "exact" (1 = no FMA, reference rounding; 0 = allow FMA), "profile" (0/1 hipEvent
- * per-kernel timing), "phase_timing" (0/1, see sextans_phase_timing_read), "split_rows" (T > 0: rows longer than T
- * non-zeros are processed in pieces of T and folded in order -- for power-law matrices; re-associates
- * those rows, so results are within tolerance instead of bit-identical; default 0 = off), "fuse_b" (1 = the panel kernel may stage B straight from column-major B when B is <= 16 MiB and every row block has a dictionary, saving the
+ * per-kernel timing), "phase_timing" (0/1, see sextans_phase_timing_read), "split_rows" (hub rows of power-law
+ * matrices: rows longer than T non-zeros are summed in parallel pieces of T entries which are then folded in
+ * order -- their sums are re-associated, so THOSE rows meet the stated 1e-4 tolerance instead of bit identity
+ * (sextans_reassociated_rows lists them); every other row stays bit-identical, whichever kernel runs.
+ * T > 0: explicit threshold; 0: never split (strict cpu_spmm_CSR order for every row); -1 (default): T chosen
+ * from the matrix, max(512, nnz / 16384) -- no row is split in matrices without hubs), "fuse_b" (1 = the panel kernel may stage B straight from column-major B when B is <= 16 MiB and every row block has a dictionary, saving the
  * repack launch; default 1), "panel_min_reuse_x100" (a row block uses the LDS panel when
  * nnz >= value/100 * distinct columns; default 400).  Unknown keys -> SEXTANS_ERR_INVALID. */
 int sextans_set_option(sextans_handle_t h, const char *key, int64_t value);
 int sextans_get_option(sextans_handle_t h, const char *key, int64_t *value);
+/* Rows of the current matrix whose sums are re-associated under the current "split_rows" setting (ascending);
+ * writes at most `capacity` of them, *count = how many there are.  sextans_get_stat: "reassociated_rows",
+ * "split_threshold". */
+int sextans_reassociated_rows(sextans_handle_t h, int *rows, int capacity, int *count);
 /* Read-only figures about the matrix currently set.  key: "plan_build_s" (host seconds spent so far
  * building packed forms of A -- read back from the device, pack on all cores, upload; outside every timed
  * region like the reference's scheduling/packing, sextans-host.cpp:114-148), "window_padded_entries",
@@ -391,6 +398,14 @@ int sextans_gen_fem3d_host(int nx, int ny, int nz, int dof, uint64_t seed, int r
                            int **col_idx, float **val, int64_t *nnz);
 int sextans_gen_fem3d_device(int device, int nx, int ny, int nz, int dof, uint64_t seed, int r0, int r1,
                              int **d_row_ptr, int **d_col_idx, float **d_val, int64_t *nnz);
+/* Power-law matrix (the sweep harness's load-balancing case): row lengths with
+ * P(len >= x) = (xmin / x)^(tail_x100 / 100) on [xmin, min(max_len, K)] -- a few hub rows hundreds of thousands
+ * of entries long next to a mass of short rows -- columns one uniform draw per equal stratum of [0, K) (distinct,
+ * ascending), values U(-1,1).  Same bits on host and device. */
+int sextans_gen_powerlaw_host(int M, int K, int xmin, int tail_x100, int max_len, uint64_t seed, int r0, int r1,
+                              int **row_ptr, int **col_idx, float **val, int64_t *nnz);
+int sextans_gen_powerlaw_device(int device, int M, int K, int xmin, int tail_x100, int max_len, uint64_t seed, int r0,
+                                int r1, int **d_row_ptr, int **d_col_idx, float **d_val, int64_t *nnz);
 /* Blocked-ELL synthetic input (BASELINE config 5): every block row gets `ell_width` distinct sorted
  * block columns, values bf16(U(-1,1)).  Device form allocates (free with sextans_device_free). */
 int sextans_gen_bell_host(int M, int K, int ell_width, uint64_t seed, int **block_col, uint16_t **block_val);

@@ -57,6 +57,9 @@ class Oracle:
                                             _i32p, _i32p, _f32p, _f32p, C.c_float, _f32p]
         L.orc_time_spmm_rows.restype = C.c_double
         L.orc_time_spmm_rows.argtypes = L.orc_cpu_spmm_csr_rows.argtypes
+        L.orc_time_spmm_csr_omp.restype = C.c_double
+        L.orc_time_spmm_csr_omp.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, _i32p, _i32p, _f32p, _f32p,
+                                            C.c_float, _f32p, C.POINTER(C.c_int)]
         L.orc_init_B.argtypes = [C.c_int, C.c_int, _f32p]
         L.orc_init_C.argtypes = [C.c_int, C.c_int, _f32p]
         L.orc_verify.restype = C.c_int
@@ -117,6 +120,13 @@ class Oracle:
     def time_spmm_rows(self, r0, r1, M, N, K, alpha, row_ptr, col_idx, val, B, beta, C_inout):
         return self.lib.orc_time_spmm_rows(r0, r1, M, N, K, alpha, row_ptr, _pad(col_idx),
                                            _pad(val), B, beta, C_inout)
+
+    def time_spmm_omp(self, M, N, K, alpha, row_ptr, col_idx, val, B, beta, C_inout):
+        """cpu_spmm_CSR's loop nest on all host cores (OpenMP); -> (seconds, threads used)."""
+        t = C.c_int(0)
+        sec = self.lib.orc_time_spmm_csr_omp(M, N, K, alpha, row_ptr, _pad(col_idx), _pad(val), B, beta, C_inout,
+                                             C.byref(t))
+        return sec, t.value
 
     def bell_spmm(self, M, K, N, ell_width, block_col, block_val, B_bf16, alpha, beta, C_inout):
         """Blocked-ELL bf16 restatement (config 5; parity unpinned by the reference).  In place on

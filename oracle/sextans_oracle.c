@@ -249,6 +249,42 @@ void orc_cpu_spmm_csr_rows(int r0, int r1, int M, int N, int K, float alpha, con
     free(psum);
 }
 
+/* Same loop nest, row-parallel on all host cores (SURVEY.md 8d baseline 2: "the same loop nest row-parallel with
+ * OpenMP on all cores").  Rows are independent, every row is still summed sequentially in CSR order, so the
+ * result is bit-identical to orc_cpu_spmm_csr.  Returns the wall seconds (steady clock) and writes the number
+ * of threads actually used to *threads.  dynamic,256: rows of power-law matrices differ in length. */
+#include <omp.h>
+double orc_time_spmm_csr_omp(int M, int N, int K, float alpha, const int *row_ptr, const int *col_idx,
+                             const float *val, const float *B, float beta, float *C, int *threads) {
+    struct timespec t0, t1;
+    int used = 1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+#pragma omp parallel
+    {
+        float psum[512];
+        float *ps = N <= 512 ? psum : (float *)malloc(sizeof(float) * (size_t)N);
+#pragma omp single
+        used = omp_get_num_threads();
+#pragma omp for schedule(dynamic, 256)
+        for (int i = 0; i < M; ++i) {
+            for (int nn = 0; nn < N; ++nn) ps[nn] = 0.0f;
+            for (int j = row_ptr[i]; j < row_ptr[i + 1]; ++j) {
+                const float a = val[j];
+                const float *bk = B + col_idx[j];
+                for (int nn = 0; nn < N; ++nn) ps[nn] += a * bk[(size_t)K * nn];
+            }
+            for (int nn = 0; nn < N; ++nn) {
+                size_t o = (size_t)i + (size_t)M * nn;
+                C[o] = alpha * ps[nn] + beta * C[o];
+            }
+        }
+        if (ps != psum) free(ps);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (threads) *threads = used;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
 /* ---- dense operand init, sextans-host.cpp:94-111. ---- */
 void orc_init_B(int K, int N, float *B) {
     for (int nn = 0; nn < N; ++nn)

@@ -109,6 +109,7 @@ def lib():
     L.sextans_window_packed_free.restype = None
     L.sextans_get_stat.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
     L.sextans_align_row.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.sextans_reassociated_rows.argtypes = [C.c_void_p, _i32p, C.c_int, C.POINTER(C.c_int)]
     L.sextans_dist_unique_id.argtypes = [C.c_char_p]
     L.sextans_dist_comm_init.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.sextans_dist_comm_destroy.argtypes = [C.c_void_p]
@@ -173,6 +174,11 @@ def lib():
                                            C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                            C.POINTER(C.c_int64)]
+    L.sextans_gen_powerlaw_host.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                                            pi, pi, pf, C.POINTER(C.c_int64)]
+    L.sextans_gen_powerlaw_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
+                                              C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS")
     L.sextans_set_matrix_bell.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _i32p, u16p]
     L.sextans_set_matrix_bell_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -480,6 +486,14 @@ class Engine:
         _check(lib().sextans_dist_spmm(self._h, comm, world, rank, rr, N, alpha, d_B, ldb, beta, d_C_in, ldc_in,
                                        d_C_out, ldc, nchunks, stream), "dist_spmm")
 
+    def reassociated_rows(self):
+        """Hub rows whose sums are formed in pieces under the current "split_rows" setting (ascending)."""
+        n = C.c_int()
+        _check(lib().sextans_reassociated_rows(self._h, np.zeros(1, np.int32), 0, C.byref(n)), "reassociated_rows")
+        rows = np.zeros(max(n.value, 1), np.int32)
+        _check(lib().sextans_reassociated_rows(self._h, rows, n.value, C.byref(n)), "reassociated_rows")
+        return rows[:n.value]
+
     def align_row(self, N, row):
         """Largest row <= `row` where a row-range call keeps the whole-matrix kernel (sextans_align_row)."""
         out = C.c_int()
@@ -645,6 +659,29 @@ def gen_fem3d_device(device, nx, ny, nz, dof, seed, r0=0, r1=None):
     nnz = C.c_int64()
     _check(lib().sextans_gen_fem3d_device(device, nx, ny, nz, dof, seed, r0, r1, C.byref(p), C.byref(i),
                                           C.byref(v), C.byref(nnz)), "gen_fem3d_device")
+    return p.value, i.value, v.value, nnz.value
+
+
+def gen_powerlaw_host(M, K, xmin, tail_x100, max_len, seed, r0=0, r1=None):
+    """Power-law row lengths, P(len >= x) = (xmin/x)^(tail_x100/100) on [xmin, max_len] -> (row_ptr, col_idx, val)."""
+    L = lib()
+    r1 = M if r1 is None else r1
+    p, i, v = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()
+    nnz = C.c_int64()
+    _check(L.sextans_gen_powerlaw_host(M, K, xmin, tail_x100, max_len, seed, r0, r1, p, i, v, C.byref(nnz)),
+           "gen_powerlaw_host")
+    out = (_take(p, r1 - r0 + 1, np.int32), _take(i, nnz.value, np.int32), _take(v, nnz.value, np.float32))
+    for q in (p, i, v):
+        L.sextans_host_free(q)
+    return out
+
+
+def gen_powerlaw_device(device, M, K, xmin, tail_x100, max_len, seed, r0=0, r1=None):
+    r1 = M if r1 is None else r1
+    p, i, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    nnz = C.c_int64()
+    _check(lib().sextans_gen_powerlaw_device(device, M, K, xmin, tail_x100, max_len, seed, r0, r1, C.byref(p),
+                                             C.byref(i), C.byref(v), C.byref(nnz)), "gen_powerlaw_device")
     return p.value, i.value, v.value, nnz.value
 
 

@@ -95,10 +95,20 @@ struct sextans_engine {
     void *d_bell_Af = nullptr;      // A blocks in MFMA fragment order (owned)
     void *d_bell_Bf = nullptr;      // B in fragment order (workspace)
     size_t bell_Bf_cap = 0;         // bytes
-    // long-row splitting (option "split_rows")
-    int *d_vrp = nullptr, *d_vfirst = nullptr;
-    int split_nv = 0;               // virtual rows (0 = no row exceeds the threshold / not built)
-    int64_t split_built_T = -1;
+    // Hub rows (longer than the split threshold, option "split_rows"; default: chosen from the matrix) are taken
+    // out of the "main" matrix -- the CSR arrays every kernel and plan works on, equal to the arrays above when
+    // there are no hubs -- and go through the piece path: pieces of T entries summed in parallel, folded in order.
+    const int *m_rp = nullptr, *m_ci = nullptr;
+    const float *m_v = nullptr;
+    int64_t m_nnz = 0;
+    int *d_mrp = nullptr, *d_mci = nullptr;   // owned compacted copy (exists only with hubs)
+    float *d_mv = nullptr;
+    int *d_vrp = nullptr, *d_vend = nullptr, *d_vfirst = nullptr, *d_hub_row = nullptr;   // piece [begin, end) in d_ci/d_v, first piece per hub, hub rows
+    std::vector<int> h_hub_row, h_vfirst;
+    int nhub = 0;
+    int split_nv = 0;               // pieces of all hubs
+    int64_t split_T = 0;            // threshold in effect (0 = none)
+    int64_t split_built_opt = -2;   // value of opt_split_rows the state above was built for (-2 = not evaluated)
     float *d_P = nullptr;
     size_t P_cap = 0;
     long long *d_dbg = nullptr;     // 8 counters for phase timing (option "phase_timing")
@@ -110,7 +120,8 @@ struct sextans_engine {
     // options
     int64_t opt_kernel = 0, opt_lpr = 4, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;
     int64_t opt_fuse_b = 1;             // panel kernel may stage from column-major B (small matrices: no repack launch)
-    int64_t opt_split_rows = 0;         // > 0: rows longer than this are split (re-associated); 0 = exact order
+    int64_t opt_split_rows = -1;        // > 0: rows longer than this are split (re-associated); 0 = never (strict
+                                        // order); -1 = threshold chosen from the matrix: max(512, nnz / 16384)
     int64_t opt_phase_timing = 0;       // 1: panel kernel accumulates per-phase wave cycles (debug aid)
     int64_t opt_min_reuse_x100 = 400;   // a block uses the LDS panel if nnz >= 4 * distinct columns
     int64_t opt_win_rows = 319;         // rows per wavefront of the window kernel (+1 dummy row: 4 x 320 x 32 B = 40 KiB)
@@ -169,10 +180,15 @@ void free_bell(sextans_engine *h) {
 }
 
 void free_split(sextans_engine *h) {
-    (void)hipFree(h->d_vrp); (void)hipFree(h->d_vfirst);
-    h->d_vrp = h->d_vfirst = nullptr;
-    h->split_nv = 0;
-    h->split_built_T = -1;
+    (void)hipFree(h->d_vrp); (void)hipFree(h->d_vend); (void)hipFree(h->d_vfirst); (void)hipFree(h->d_hub_row);
+    (void)hipFree(h->d_mrp); (void)hipFree(h->d_mci); (void)hipFree(h->d_mv);
+    h->d_vrp = h->d_vend = h->d_vfirst = h->d_hub_row = h->d_mrp = h->d_mci = nullptr;
+    h->d_mv = nullptr;
+    h->h_hub_row.clear(); h->h_vfirst.clear();
+    h->nhub = h->split_nv = 0;
+    h->split_T = 0;
+    h->split_built_opt = -2;
+    h->m_rp = h->d_rp; h->m_ci = h->d_ci; h->m_v = h->d_v; h->m_nnz = h->nnz;
 }
 
 void free_matrix(sextans_engine *h) {
@@ -188,6 +204,7 @@ void free_matrix(sextans_engine *h) {
     h->d_rp = h->d_ci = nullptr;
     h->d_v = nullptr;
     h->owns_matrix = false;
+    h->m_rp = h->m_ci = nullptr; h->m_v = nullptr; h->m_nnz = 0;
 }
 
 int ensure(float **p, size_t *cap, size_t need) {
@@ -221,9 +238,9 @@ void launch_repack(const float *dB, int64_t ldb, float *dBp, int K, int col_base
 }
 
 template <int LPR>
-void launch_rowgroup(sextans_engine *h, const int *rp, const float *dBp, const float *dCin, int64_t ldc_in,
-                     float *dCout, int64_t ldc, int row_begin, int row_end, int ntiles, float alpha, float beta,
-                     hipStream_t s) {
+void launch_rowgroup(sextans_engine *h, const int *rp, const int *rend, const int *ci, const float *va, bool pieces, const float *dBp,
+                     const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc, int row_begin, int row_end, int ntiles,
+                     float alpha, float beta, hipStream_t s) {
     constexpr int RB = sx::kBlock / LPR;
     constexpr int CH = 2048;
     const int nrowblk = (row_end - row_begin + RB - 1) / RB;
@@ -233,11 +250,11 @@ void launch_rowgroup(sextans_engine *h, const int *rp, const float *dBp, const f
     const int xcd = (int)h->opt_xcd;
 #define SX_LAUNCH(EX, ST)                                                                       \
     hipLaunchKernelGGL((sx::spmm_csr_rowgroup<LPR, CH, EX, ST>), dim3(nwg), dim3(sx::kBlock), 0, \
-                       s, rp, h->d_ci, h->d_v, dBp, pstride, dCin, ldc_in, dCout, ldc, row_begin,      \
+                       s, rp, rend, ci, va, dBp, pstride, dCin, ldc_in, dCout, ldc, row_begin,          \
                        row_end, ntiles, nrowblk, alpha, beta, xcd)
     // The LDS-staged A stream walks a block's non-zeros in order, which serialises row groups when rows
     // are long pieces of one hub row (split mode): there every row group streams its own piece directly.
-    const bool stage = h->opt_stage && rp == h->d_rp;
+    const bool stage = h->opt_stage && !pieces;
     if (h->opt_exact) { if (stage) SX_LAUNCH(true, true); else SX_LAUNCH(true, false); }
     else              { if (stage) SX_LAUNCH(false, true); else SX_LAUNCH(false, false); }
 #undef SX_LAUNCH
@@ -261,24 +278,26 @@ struct PlanTimer {   // accumulates host seconds spent packing A (reported by se
 // Device copy of the CSR arrays -> host, validated: the host-side plan builders index arrays of size K with
 // the column indices and trust row_ptr to be monotonic (a matrix handed over with
 // sextans_set_matrix_csr_device has not been looked at by anybody yet).
-int read_back_row_ptr(sextans_engine *h, std::vector<int> &rp) {
+// (main = true: the arrays the kernels work on, hub rows emptied; false: the matrix as the caller set it)
+int read_back_row_ptr(sextans_engine *h, std::vector<int> &rp, bool main = true) {
     rp.resize((size_t)h->M + 1);
-    SX_HIP(hipMemcpy(rp.data(), h->d_rp, sizeof(int) * ((size_t)h->M + 1), hipMemcpyDeviceToHost));
-    if (rp[0] != 0 || (int64_t)rp[(size_t)h->M] != h->nnz) return SEXTANS_ERR_INVALID;
+    SX_HIP(hipMemcpy(rp.data(), main ? h->m_rp : h->d_rp, sizeof(int) * ((size_t)h->M + 1), hipMemcpyDeviceToHost));
+    if (rp[0] != 0 || (int64_t)rp[(size_t)h->M] != (main ? h->m_nnz : h->nnz)) return SEXTANS_ERR_INVALID;
     for (int r = 0; r < h->M; ++r)
         if (rp[(size_t)r + 1] < rp[(size_t)r]) return SEXTANS_ERR_INVALID;
     return SEXTANS_OK;
 }
-int read_back_entries(sextans_engine *h, std::vector<int> &ci, std::vector<float> &va) {
-    const size_t n1 = (size_t)(h->nnz ? h->nnz : 1);
+int read_back_entries(sextans_engine *h, std::vector<int> &ci, std::vector<float> &va, bool main = true) {
+    const int64_t nnz = main ? h->m_nnz : h->nnz;
+    const size_t n1 = (size_t)(nnz ? nnz : 1);
     ci.assign(n1, 0); va.assign(n1, 0.f);
-    if (h->nnz) {
-        SX_HIP(hipMemcpy(ci.data(), h->d_ci, sizeof(int) * (size_t)h->nnz, hipMemcpyDeviceToHost));
-        SX_HIP(hipMemcpy(va.data(), h->d_v, sizeof(float) * (size_t)h->nnz, hipMemcpyDeviceToHost));
+    if (nnz) {
+        SX_HIP(hipMemcpy(ci.data(), main ? h->m_ci : h->d_ci, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost));
+        SX_HIP(hipMemcpy(va.data(), main ? h->m_v : h->d_v, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost));
     }
     const unsigned K = (unsigned)h->K;
     unsigned bad = 0;
-    for (int64_t j = 0; j < h->nnz; ++j) bad |= (unsigned)((unsigned)ci[(size_t)j] >= K);
+    for (int64_t j = 0; j < nnz; ++j) bad |= (unsigned)((unsigned)ci[(size_t)j] >= K);
     return bad ? SEXTANS_ERR_INDEX : SEXTANS_OK;
 }
 
@@ -302,7 +321,7 @@ int sample_reuse(sextans_engine *h, int RB, int max_unique, double min_reuse, do
         const int j0 = rp[(size_t)r0], j1 = rp[(size_t)r1];
         if (j1 <= j0) continue;
         cols.resize((size_t)(j1 - j0));
-        SX_HIP(hipMemcpy(cols.data(), h->d_ci + j0, sizeof(int) * cols.size(), hipMemcpyDeviceToHost));
+        SX_HIP(hipMemcpy(cols.data(), h->m_ci + j0, sizeof(int) * cols.size(), hipMemcpyDeviceToHost));
         std::sort(cols.begin(), cols.end());
         const int64_t distinct = std::unique(cols.begin(), cols.end()) - cols.begin();
         tot += j1 - j0;
@@ -452,8 +471,8 @@ bool window_pays(const sextans_engine *h, int N, int64_t padded) {
     // window barrier the wavefronts drift apart by more than the 4 MiB L2 holds (L2 hit rate 20 %).  The
     // window kernel never won a measurement, so "auto" only considers it when option "window_auto" is set.
     if (!h->opt_win_auto) return false;
-    if (N > 24 || h->nnz == 0) return false;
-    const double K = (double)h->K, nnz = (double)h->nnz, M = (double)h->M;
+    if (N > 24 || h->m_nnz == 0) return false;
+    const double K = (double)h->K, nnz = (double)h->m_nnz, M = (double)h->M;
     if (K * N * 4.0 <= 48.0 * 1048576.0) return false;   // B (nearly) fits the L2s: gathers stay on chip
     double gather = 0.0;
     int rest = N;
@@ -476,18 +495,18 @@ int ensure_window(sextans_engine *h, bool force) {
     h->win_state = -1;
     const int RW = (int)h->opt_win_rows;
     if (RW < 1 || RW > sx::kWinMaxRowsPerWave || h->opt_win_cols < 1 || h->opt_win_cols > 0x7fffffff ||
-        (int64_t)h->K > ((int64_t)1 << sx::kWinColBits) || h->nnz == 0)
+        (int64_t)h->K > ((int64_t)1 << sx::kWinColBits) || h->m_nnz == 0)
         return SEXTANS_OK;
     std::vector<int> rp, ci;
     std::vector<float> va;
     if (int rc = read_back_row_ptr(h, rp)) return rc;
-    if (!force && (double)sx::window_plan_padded_lower_bound(h->M, rp.data(), RW) > 1.3 * (double)h->nnz)
+    if (!force && (double)sx::window_plan_padded_lower_bound(h->M, rp.data(), RW) > 1.3 * (double)h->m_nnz)
         return SEXTANS_OK;   // skewed rows: one row per step would be mostly padding
     if (int rc = read_back_entries(h, ci, va)) return rc;
     sx::WindowPlan plan;
     if (!sx::build_window_plan(h->M, h->K, rp.data(), ci.data(), va.data(), RW, (int)h->opt_win_cols, plan))
         return SEXTANS_OK;
-    if (!force && (double)plan.padded > 1.35 * (double)h->nnz) return SEXTANS_OK;
+    if (!force && (double)plan.padded > 1.35 * (double)h->m_nnz) return SEXTANS_OK;
     static_assert(sizeof(sx::WinEntry) == sizeof(uint2), "stream entries are loaded as uint2");
     SX_HIP(hipMalloc((void **)&h->d_wstream, sizeof(uint2) * plan.stream.size()));
     SX_HIP(hipMemcpy(h->d_wstream, plan.stream.data(), sizeof(uint2) * plan.stream.size(), hipMemcpyHostToDevice));
@@ -628,6 +647,8 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     if (!strcmp(key, "plan_build_s")) *value = h->plan_build_s;
     else if (!strcmp(key, "window_padded_entries")) *value = (double)h->win_padded;
     else if (!strcmp(key, "window_state")) *value = (double)h->win_state;
+    else if (!strcmp(key, "reassociated_rows")) *value = (double)h->nhub;
+    else if (!strcmp(key, "split_threshold")) *value = (double)h->split_T;
     else if (!strcmp(key, "panel_fraction")) *value = h->plan_panel_frac;
     else if (!strcmp(key, "panel_blocks")) *value = (double)h->plan_nblk;
     else return SEXTANS_ERR_INVALID;
@@ -671,6 +692,7 @@ int sextans_set_matrix_csr(sextans_handle_t h, int M, int K, int64_t nnz, const 
     h->d_rp = rp; h->d_ci = ci; h->d_v = v;
     h->owns_matrix = true;
     h->M = M; h->K = K; h->nnz = nnz;
+    free_split(h);   // main matrix = the matrix itself until the hub test has run
     return SEXTANS_OK;
 }
 
@@ -683,6 +705,7 @@ int sextans_set_matrix_csr_device(sextans_handle_t h, int M, int K, int64_t nnz,
     h->d_rp = d_row_ptr; h->d_ci = d_col_idx; h->d_v = d_val;
     h->owns_matrix = false;
     h->M = M; h->K = K; h->nnz = nnz;
+    free_split(h);
     return SEXTANS_OK;
 }
 
@@ -695,31 +718,72 @@ int sextans_spmm_device(sextans_handle_t h, int N, float alpha, const float *d_B
 namespace {
 struct Seg { int width, col0, ntiles; };
 
-// Virtual row set for long-row splitting: every row longer than T becomes ceil(len/T) pieces.
+// Hub test + piece tables.  Rows longer than T are removed from the main matrix (compacted copy) and cut into
+// pieces of T entries of the ORIGINAL arrays; the pieces are summed in parallel by the row-group kernel and folded
+// in order -- the only place where a row's sum is re-associated (stated tolerance instead of bit equality; the
+// rows are reported by sextans_reassociated_rows).  T: option "split_rows" > 0; 0 = never; -1 (default) =
+// max(512, nnz / 16384): one 4-lane row group retires ~10 non-zeros per microsecond while the whole chip retires
+// ~50 000, so a row holding more than 1/16384 of the matrix would dominate the launch on its own.
 int ensure_split(sextans_engine *h) {
-    const int64_t T = h->opt_split_rows;
-    if (h->split_built_T == T) return SEXTANS_OK;
+    if (h->split_built_opt == h->opt_split_rows) return SEXTANS_OK;
     free_split(h);
-    h->split_built_T = T;
-    if (T <= 0 || h->M == 0) return SEXTANS_OK;
-    std::vector<int> rp((size_t)h->M + 1);
-    SX_HIP(hipMemcpy(rp.data(), h->d_rp, sizeof(int) * ((size_t)h->M + 1), hipMemcpyDeviceToHost));
-    bool any = false;
-    for (int r = 0; r < h->M && !any; ++r) any = (int64_t)rp[(size_t)r + 1] - rp[(size_t)r] > T;
-    if (!any) return SEXTANS_OK;
-    std::vector<int> vrp, vfirst((size_t)h->M + 1);
-    vrp.reserve((size_t)h->M + 1024);
-    for (int r = 0; r < h->M; ++r) {
-        vfirst[(size_t)r] = (int)vrp.size();
-        const int j0 = rp[(size_t)r], j1 = rp[(size_t)r + 1];
-        vrp.push_back(j0);
-        for (int64_t j = (int64_t)j0 + T; j < j1; j += T) vrp.push_back((int)j);
+    free_plan(h);      // the packed forms are built from the main matrix
+    free_window(h);
+    h->split_built_opt = h->opt_split_rows;
+    int64_t T = h->opt_split_rows;
+    if (T < 0) T = std::max<int64_t>(512, h->nnz / 16384);
+    if (T == 0 || h->M == 0 || h->nnz == 0) return SEXTANS_OK;
+    PlanTimer timer(h);
+    std::vector<int> rp;
+    if (int rc = read_back_row_ptr(h, rp, false)) return rc;
+    std::vector<int> hubs;
+    for (int r = 0; r < h->M; ++r)
+        if ((int64_t)rp[(size_t)r + 1] - rp[(size_t)r] > T) hubs.push_back(r);
+    if (hubs.empty()) return SEXTANS_OK;
+    std::vector<int> ci;
+    std::vector<float> va;
+    if (int rc = read_back_entries(h, ci, va, false)) return rc;
+    // main matrix: hub rows emptied
+    std::vector<int> mrp((size_t)h->M + 1, 0), vrp, vend, vfirst;
+    {
+        size_t k = 0, w = 0;
+        for (int r = 0; r < h->M; ++r) {
+            const int j0 = rp[(size_t)r], j1 = rp[(size_t)r + 1];
+            if (k < hubs.size() && hubs[k] == r) {
+                vfirst.push_back((int)vrp.size());
+                for (int64_t j = j0; j < j1; j += T) vrp.push_back((int)j);
+                ++k;
+            } else {
+                if (w != (size_t)j0) {
+                    std::copy(ci.begin() + j0, ci.begin() + j1, ci.begin() + (ptrdiff_t)w);
+                    std::copy(va.begin() + j0, va.begin() + j1, va.begin() + (ptrdiff_t)w);
+                }
+                w += (size_t)(j1 - j0);
+            }
+            mrp[(size_t)r + 1] = (int)w;
+        }
+        vfirst.push_back((int)vrp.size());
+        // piece v covers [vrp[v], vend[v]): the next piece of the same hub, or the end of the hub row
+        vend.resize(vrp.size());
+        for (size_t kk = 0; kk < hubs.size(); ++kk)
+            for (int v = vfirst[kk]; v < vfirst[kk + 1]; ++v)
+                vend[(size_t)v] = v + 1 < vfirst[kk + 1] ? vrp[(size_t)v + 1] : rp[(size_t)hubs[kk] + 1];
+        ci.resize(w ? w : 1); va.resize(w ? w : 1);
+        h->m_nnz = (int64_t)w;
     }
-    vfirst[(size_t)h->M] = (int)vrp.size();
-    vrp.push_back(rp[(size_t)h->M]);
-    h->split_nv = (int)vrp.size() - 1;
+    if (int rc = upload(&h->d_mrp, mrp)) return rc;
+    if (int rc = upload(&h->d_mci, ci)) return rc;
+    if (int rc = upload(&h->d_mv, va)) return rc;
+    h->m_rp = h->d_mrp; h->m_ci = h->d_mci; h->m_v = h->d_mv;
     if (int rc = upload(&h->d_vrp, vrp)) return rc;
+    if (int rc = upload(&h->d_vend, vend)) return rc;
     if (int rc = upload(&h->d_vfirst, vfirst)) return rc;
+    if (int rc = upload(&h->d_hub_row, hubs)) return rc;
+    h->h_hub_row = hubs;
+    h->h_vfirst = vfirst;
+    h->nhub = (int)hubs.size();
+    h->split_nv = (int)vrp.size();
+    h->split_T = T;
     return SEXTANS_OK;
 }
 
@@ -727,6 +791,9 @@ int ensure_split(sextans_engine *h) {
 // N-tile plan, and (for kernel != 1) the packed row-bucketed form of A.  Idempotent; called by
 // sextans_spmm_device2 and, ahead of the timed region, by sextans_spmm_host.
 int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_panel, bool &use_window) {
+    if (int rc = ensure_split(h)) return rc;   // first: the packed forms below are built from the main matrix
+    if (h->nhub > 0)
+        if (int rc = ensure(&h->d_P, &h->P_cap, (size_t)h->split_nv * (size_t)N)) return rc;
     if (h->Bp_cap < (size_t)h->K * (size_t)N || !h->d_Bp) h->bp_layout = 0;   // new workspace: nothing to reuse
     if (int rc = ensure(&h->d_Bp, &h->Bp_cap, (size_t)h->K * (size_t)N)) return rc;
     // main tile width: 4*lanes_per_row, but never wider than N itself (N = 8 -> 2 lanes per row); then
@@ -745,16 +812,16 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
     // Kernel choice: "kernel" 1 = row-group gather, 2 = LDS panel, 0 = auto (panel when at least half
     // of the non-zeros sit in row blocks whose B rows are reused -- "only where a tile has reuse").
     use_panel = false;
-    if (h->opt_kernel != 1 && h->nnz > 0) {
+    if (h->opt_kernel != 1 && h->m_nnz > 0) {
         if (int rc = ensure_plan(h, lpr, h->opt_kernel == 2)) return rc;
         use_panel = h->plan_built && ((h->opt_kernel == 2) || h->plan_panel_frac >= 0.5);
     }
     // "kernel" 3 = K-windowed accumulator-resident kernel; auto picks it for matrices without B-row reuse
     // whose B does not fit the L2s when the traffic model says the sweep moves fewer bytes than the gather.
     use_window = false;
-    if (h->nnz > 0 && (h->opt_kernel == 3 || (h->opt_kernel == 0 && !use_panel))) {
+    if (h->m_nnz > 0 && (h->opt_kernel == 3 || (h->opt_kernel == 0 && !use_panel))) {
         const bool force = h->opt_kernel == 3;
-        if (force || (h->win_state >= 0 && window_pays(h, N, h->win_state == 1 ? h->win_padded : h->nnz))) {
+        if (force || (h->win_state >= 0 && window_pays(h, N, h->win_state == 1 ? h->win_padded : h->m_nnz))) {
             if (int rc = ensure_window(h, force)) return rc;
             use_window = h->win_state == 1 && (force || window_pays(h, N, h->win_padded));
         }
@@ -787,6 +854,29 @@ int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_
                                     stream);
 }
 
+}  // extern "C"
+namespace {
+// Hub rows inside [row_begin, row_end): pieces summed as virtual rows by the row-group kernel from B panels of width
+// 4 * LPR at dBp (ntiles panels), then folded in order into the C the main kernel has already written.
+template <int LPR>
+void launch_hub_pieces(sextans_engine *h, const float *dBp, int ntiles, int col0, int v0, int v1, hipStream_t s) {
+    float *P = h->d_P + v0 + (int64_t)col0 * h->split_nv;
+    launch_rowgroup<LPR>(h, h->d_vrp, h->d_vend, h->d_ci, h->d_v, true, dBp, P, h->split_nv, P, h->split_nv, v0, v1, ntiles,
+                         1.0f, 0.0f, s);
+}
+}  // namespace
+extern "C" {
+
+int sextans_reassociated_rows(sextans_handle_t h, int *rows, int capacity, int *count) {
+    if (!h || !count || capacity < 0 || (capacity > 0 && !rows)) return SEXTANS_ERR_INVALID;
+    if (!h->d_rp) return SEXTANS_ERR_STATE;
+    SX_HIP(hipSetDevice(h->device));
+    if (int rc = ensure_split(h)) return rc;
+    *count = h->nhub;
+    for (int i = 0; i < h->nhub && i < capacity; ++i) rows[i] = h->h_hub_row[(size_t)i];
+    return SEXTANS_OK;
+}
+
 int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
                              float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out, int64_t ldc,
                              int row_begin, int row_end, int flags, void *stream) {
@@ -811,10 +901,25 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         if (i0 == br.end() || *i0 != row_begin || i1 == br.end() || *i1 != row_end) use_panel = false;
         else { blk0 = (int)(i0 - br.begin()); blk1 = (int)(i1 - br.begin()); }
     }
-    // a row range can use the window kernel when it starts and ends on wavefront (rows-per-wave) boundaries
+    // ... and the window kernel when it starts and ends on wavefront (rows-per-wave) boundaries
     if (use_window && (row_begin % h->win_rw != 0 || (row_end % h->win_rw != 0 && row_end != h->M))) use_window = false;
-    if (int rc = ensure_split(h)) return rc;
-    const bool split = whole && h->split_nv > 0 && !use_window;
+    // hub rows of this range: [hub0, hub1) of the hub list, pieces [v0, v1)
+    int hub0 = 0, hub1 = 0, v0 = 0, v1 = 0;
+    if (h->nhub > 0) {
+        hub0 = (int)(std::lower_bound(h->h_hub_row.begin(), h->h_hub_row.end(), row_begin) - h->h_hub_row.begin());
+        hub1 = (int)(std::lower_bound(h->h_hub_row.begin(), h->h_hub_row.end(), row_end) - h->h_hub_row.begin());
+        v0 = h->h_vfirst[(size_t)hub0]; v1 = h->h_vfirst[(size_t)hub1];
+    }
+    const bool hubs = hub1 > hub0;
+    if (hubs) SX_HIP(hipMemsetAsync(h->d_P, 0, (size_t)h->split_nv * (size_t)N * sizeof(float), s));
+    auto fold = [&]() {
+        const int64_t tot = (int64_t)(hub1 - hub0) * N;
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, h->d_vfirst, h->d_hub_row, h->d_P,
+                               (int64_t)h->split_nv, d_C_out, ldc, hub0, hub1 - hub0, N, row_begin, alpha);
+        };
+        if (h->opt_exact) go(sx::fold_hub_pieces<true>); else go(sx::fold_hub_pieces<false>);
+    };
     if (use_window) {
         // B in 8-column panels (the reference's N tile), then one tile-major launch
         if (!(flags & SEXTANS_ROWS_REUSE_B_PANELS) || h->bp_layout != 8) {
@@ -826,20 +931,16 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             Prof p(h, &h->ev_kernel, s);
             const int w0 = row_begin / h->win_rw, w1 = (row_end + h->win_rw - 1) / h->win_rw;
             launch_window(h, h->d_Bp, d_C_in, ldc_in, d_C_out, ldc, N / 8, w0, w1, row_begin, alpha, beta, s);
-            h->last_kernel = "spmm_csr_window";
+            if (hubs) { launch_hub_pieces<2>(h, h->d_Bp, N / 8, 0, v0, v1, s); fold(); }
+            h->last_kernel = hubs ? "spmm_csr_window+hub_pieces" : "spmm_csr_window";
         }
         SX_HIP(hipGetLastError());
         return SEXTANS_OK;
     }
-    if (split) {
-        use_panel = false;
-        if (int rc = ensure(&h->d_P, &h->P_cap, (size_t)h->split_nv * (size_t)N)) return rc;
-        SX_HIP(hipMemsetAsync(h->d_P, 0, (size_t)h->split_nv * (size_t)N * sizeof(float), s));
-    }
     // Small B (fits the L2s), dictionary-only plan, one N segment: the panel kernel stages straight from the
     // caller's column-major B and the repack launch disappears.
     const bool fuse_b = use_panel && !h->plan_mixed && h->opt_fuse_b && !(flags & kRowsNoFuseB) && plan.size() == 1 &&
-                        plan[0].width == W &&
+                        plan[0].width == W && !hubs &&
                         (size_t)h->K * (size_t)N * sizeof(float) <= ((size_t)16 << 20);
     // (a reuse request is honoured only if the panels in the workspace have this layout: row-range calls of
     // one pipelined SpMM may alternate between the window kernel's 8-column panels and these)
@@ -864,36 +965,23 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             const float *cin = d_C_in + (int64_t)g.col0 * ldc_in;
             float *cout = d_C_out + (int64_t)g.col0 * ldc;
             const bool panel_here = use_panel && g.width == W;   // the plan is built for width W
+            const float *bsrc = fuse_b ? d_B + (int64_t)g.col0 * ldb : bp;
+            const int64_t bld = fuse_b ? ldb : 0;
+#define SX_SEG(L)                                                                                                       \
+    if (panel_here) launch_panel<L>(h, bsrc, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, bld, blk0, blk1, row_begin);  \
+    else launch_rowgroup<L>(h, h->m_rp, h->m_rp + 1, h->m_ci, h->m_v, false, bp, cin, ldc_in, cout, ldc, row_begin, row_end,  \
+                            g.ntiles, alpha, beta, s);                                                                   \
+    if (hubs) launch_hub_pieces<L>(h, bp, g.ntiles, g.col0, v0, v1, s);
             switch (g.width) {
-                case 32:
-                    if (panel_here) launch_panel<8>(h, fuse_b ? d_B + (int64_t)g.col0 * ldb : bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, fuse_b ? ldb : 0, blk0, blk1, row_begin);
-                    else if (split) launch_rowgroup<8>(h, h->d_vrp, bp, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, 0, h->split_nv, g.ntiles, 1.0f, 0.0f, s);
-                    else launch_rowgroup<8>(h, h->d_rp, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
-                    break;
-                case 16:
-                    if (panel_here) launch_panel<4>(h, fuse_b ? d_B + (int64_t)g.col0 * ldb : bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, fuse_b ? ldb : 0, blk0, blk1, row_begin);
-                    else if (split) launch_rowgroup<4>(h, h->d_vrp, bp, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, 0, h->split_nv, g.ntiles, 1.0f, 0.0f, s);
-                    else launch_rowgroup<4>(h, h->d_rp, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
-                    break;
-                default:
-                    if (panel_here) launch_panel<2>(h, fuse_b ? d_B + (int64_t)g.col0 * ldb : bp, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, fuse_b ? ldb : 0, blk0, blk1, row_begin);
-                    else if (split) launch_rowgroup<2>(h, h->d_vrp, bp, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, h->d_P + (int64_t)g.col0 * h->split_nv, h->split_nv, 0, h->split_nv, g.ntiles, 1.0f, 0.0f, s);
-                    else launch_rowgroup<2>(h, h->d_rp, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s);
-                    break;
+                case 32: SX_SEG(8) break;
+                case 16: SX_SEG(4) break;
+                default: SX_SEG(2) break;
             }
+#undef SX_SEG
         }
-        if (split) {
-            const int64_t tot = (int64_t)h->M * N;
-            if (h->opt_exact)
-                hipLaunchKernelGGL(sx::fold_row_pieces<true>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s,
-                                   h->d_vfirst, h->d_P, (int64_t)h->split_nv, d_C_in, ldc_in, d_C_out, ldc, h->M, N,
-                                   alpha, beta);
-            else
-                hipLaunchKernelGGL(sx::fold_row_pieces<false>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s,
-                                   h->d_vfirst, h->d_P, (int64_t)h->split_nv, d_C_in, ldc_in, d_C_out, ldc, h->M, N,
-                                   alpha, beta);
-        }
-        h->last_kernel = split ? "spmm_csr_rowgroup+fold_row_pieces" : use_panel ? "spmm_csr_panel" : "spmm_csr_rowgroup";
+        if (hubs) fold();
+        h->last_kernel = use_panel ? (hubs ? "spmm_csr_panel+hub_pieces" : "spmm_csr_panel")
+                                   : (hubs ? "spmm_csr_rowgroup+hub_pieces" : "spmm_csr_rowgroup");
     }
     SX_HIP(hipGetLastError());
     return SEXTANS_OK;
@@ -935,7 +1023,7 @@ int run_repeats(sextans_engine *h, int N, float alpha, float beta, int rp_time, 
             if (e1) (void)hipEventDestroy(e1);
         }
     } c;
-    const bool use_graph = !h->opt_profile && !h->opt_phase_timing && h->opt_split_rows == 0;
+    const bool use_graph = !h->opt_profile && !h->opt_phase_timing;
     const int per_graph = rp_time < 128 ? rp_time : 128;   // bound the graph; long loops replay it
     if (use_graph) {
         // relaxed mode: the enqueue path calls hipSetDevice / hipGetLastError, which thread-local capture rejects

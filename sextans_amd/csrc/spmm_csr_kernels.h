@@ -81,10 +81,12 @@ __device__ __forceinline__ float epilogue(float alpha, float acc, float beta, fl
 // ------------------------------------------------------------------------------------------------
 template <int LPR, int CH, bool EXACT, bool STAGE>
 __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
-    const int *__restrict__ row_ptr, const int *__restrict__ col_idx, const float *__restrict__ val,
-    const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout,
-    int64_t ldc, int row_begin, int M, int ntiles, int nrowblk, float alpha, float beta,
+    const int *__restrict__ row_ptr, const int *__restrict__ row_end, const int *__restrict__ col_idx,
+    const float *__restrict__ val, const float *__restrict__ Bp, int64_t panel_stride, const float *Cin,
+    int64_t ldc_in, float *Cout, int64_t ldc, int row_begin, int M, int ntiles, int nrowblk, float alpha, float beta,
     int use_xcd_remap) {
+    // Row r holds entries [row_ptr[r], row_end[r]): row_end = row_ptr + 1 for a CSR matrix; the pieces of hub rows
+    // (long-row splitting) come with their own end array and are not contiguous from one piece to the next.
     // Rows [row_begin, M) are processed; C pointers address row_begin as their row 0 (row-range calls
     // of the multi-GPU pipeline write a packed slab chunk); row_ptr is indexed with the global row.
     constexpr int NT = 4 * LPR;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
 
     const float *bq = Bp + (int64_t)tile * panel_stride + 4 * q;
     int j = 0, jend = 0;
-    if (row < M) { j = row_ptr[row]; jend = row_ptr[row + 1]; }
+    if (row < M) { j = row_ptr[row]; jend = row_end[row]; }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
     if constexpr (STAGE) {
@@ -511,27 +513,34 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// Long-row splitting (opt-in, engine option "split_rows" = T): power-law matrices have rows whose
-// strictly sequential accumulation would serialise one 4-lane row group for milliseconds.  With the
-// option set, rows longer than T are cut into pieces of T non-zeros; the row-group kernel runs on that
-// virtual row set (same col_idx/val, pieces are contiguous) with alpha = 1, beta = 0 into a scratch
-// matrix, and this kernel folds the pieces of every row IN ORDER and applies the epilogue.  Rows with a
-// single piece stay bit-identical to cpu_spmm_CSR; split rows are re-associated (within the stated
-// 1e-4 tolerance), which is why the option is off by default.
+// Long-row splitting (engine option "split_rows"): power-law matrices have hub rows whose strictly sequential
+// accumulation would occupy one 4-lane row group for milliseconds while the chip idles.  Rows longer than
+// the threshold T are taken out of the main matrix (every kernel sees them as empty rows and writes
+// alpha*0 + beta*c_in for them); their entries are cut into pieces of T, the row-group kernel sums the pieces as
+// virtual rows (alpha = 1, beta = 0) into a scratch matrix P, and this kernel folds the pieces of every hub IN
+// ORDER and adds alpha * sum to what the main kernel wrote.  Rows that are not hubs stay bit-identical to
+// cpu_spmm_CSR; a hub's sum is re-associated (pieces instead of one chain): within the stated 1e-4 bound.
+// One thread per (hub, column).
 // ------------------------------------------------------------------------------------------------
 template <bool EXACT>
-__global__ __launch_bounds__(kBlock) void fold_row_pieces(const int *__restrict__ vfirst,
-                                                          const float *__restrict__ P, int64_t ldp,
-                                                          const float *Cin, int64_t ldc_in, float *Cout,
-                                                          int64_t ldc, int M, int N, float alpha,
-                                                          float beta) {
+__global__ __launch_bounds__(kBlock) void fold_hub_pieces(const int *__restrict__ vfirst, const int *__restrict__ hub_row,
+                                                          const float *__restrict__ P, int64_t ldp, float *Cout,
+                                                          int64_t ldc, int hub_begin, int nhub, int N, int row_base,
+                                                          float alpha) {
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= (int64_t)M * N) return;
-    const int r = (int)(t % M), n = (int)(t / M);
-    const int v0 = vfirst[r], v1 = vfirst[r + 1];
+    if (t >= (int64_t)nhub * N) return;
+    const int k = hub_begin + (int)(t % nhub), n = (int)(t / nhub);
+    const int v0 = vfirst[k], v1 = vfirst[k + 1];
     float acc = P[(int64_t)v0 + n * ldp];
     for (int v = v0 + 1; v < v1; ++v) acc = acc + P[(int64_t)v + n * ldp];
-    Cout[(int64_t)r + n * ldc] = epilogue<EXACT>(alpha, acc, beta, Cin[(int64_t)r + n * ldc_in]);
+    const int64_t o = (int64_t)(hub_row[k] - row_base) + n * ldc;
+    const float base = Cout[o];            // (alpha * 0) + (beta * c_in), written by the main kernel
+    if constexpr (EXACT) {
+        const float t0 = alpha * acc;
+        Cout[o] = t0 + base;
+    } else {
+        Cout[o] = __builtin_fmaf(alpha, acc, base);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

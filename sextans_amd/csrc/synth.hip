@@ -51,6 +51,11 @@ SX_HD float u01m1(uint64_t bits) {
 // [0,K) (bw == 0) or over the band [row-bw, row+bw] (bw > 0).  kind 1: 3-D finite-element-like
 // matrix (27-point node stencil on an nx*ny*nz grid, dof unknowns per node, dense dof x dof blocks):
 // the structure of SuiteSparse FEM matrices such as Boeing/pcrystk02 (3 dof, ~69 nnz/row).
+// kind 2: power-law row lengths (web/social-graph-like skew, what the sweep harness needs for its load-balancing
+// cases): P(len >= x) = (xmin / x)^tail for x in [xmin, max_len], drawn by integer inverse CDF over
+// quarter-octave buckets (thresholds and bucket edges are computed once on the host in long double and handed
+// to both generators, so host and device agree bit for bit); columns are one uniform draw from each of `len`
+// equal strata of [0, K) -- distinct, ascending, O(len) -- values as for kind 0.
 struct Spec {
     int kind, K, bw, nx, ny, nz, dof;
     uint64_t seed;
@@ -84,6 +89,16 @@ SX_HD int fem_neighbors(const Spec &sp, int node, int *nb) {
 
 SX_HD int row_len(const Spec &sp, const uint64_t *table, int row) {
     if (sp.kind == 1) return fem_neighbors(sp, row / sp.dof, nullptr) * sp.dof;
+    if (sp.kind == 2) {
+        // table[0 .. nb) = thresholds (CDF at the upper edge of bucket b, 64-bit fixed point), table[kTable/2 + b] =
+        // lower edge of bucket b (edges[nb] = max_len + 1); nb = sp.bw
+        const uint64_t u = rnd(sp.seed, (uint64_t)row, 0);
+        int b = 0;
+        while (b < sp.bw - 1 && u >= table[b]) ++b;
+        const uint64_t lo = table[kTable / 2 + b], hi = table[kTable / 2 + b + 1];
+        const int len = (int)(lo + mulhi64(rnd(sp.seed, (uint64_t)row, 0x70776c), hi - lo));
+        return len < sp.K ? len : sp.K;
+    }
     const uint64_t u = rnd(sp.seed, (uint64_t)row, 0);
     int len = 0;
     while (len < kTable - 1 && u >= table[len]) ++len;
@@ -103,6 +118,11 @@ SX_HD void fill_row(const Spec &sp, int row, int len, int *c, float *v) {
         int i = 0;
         for (int a = 0; a < n; ++a)
             for (int e = 0; e < sp.dof; ++e) c[i++] = nb[a] * sp.dof + e;
+    } else if (sp.kind == 2) {
+        for (int i = 0; i < len; ++i) {
+            const int64_t lo = (int64_t)i * sp.K / len, hi = (int64_t)(i + 1) * sp.K / len;   // len <= K: hi > lo
+            c[i] = (int)(lo + (int64_t)mulhi64(rnd(sp.seed, (uint64_t)row, 1 + (uint64_t)i), (uint64_t)(hi - lo)));
+        }
     } else {
         // bw == 0: columns uniform over [0, K); bw > 0: banded, uniform over [row-bw, row+bw] clipped.
         int lo = 0, span = sp.K;
@@ -128,6 +148,8 @@ SX_HD void fill_row(const Spec &sp, int row, int len, int *c, float *v) {
     for (int i = 0; i < len; ++i) v[i] = u01m1(rnd(sp.seed ^ kValSalt, (uint64_t)row, (uint64_t)i));
 }
 
+thread_local uint64_t g_powerlaw_table[kTable];   // filled by the kind-2 entry points right before gen_host/gen_device
+
 void poisson_table(double mean, uint64_t *t) {
     long double p = expl(-(long double)mean), cdf = 0.0L;
     const long double two64 = 18446744073709551616.0L;
@@ -138,6 +160,31 @@ void poisson_table(double mean, uint64_t *t) {
         p = p * (long double)mean / (long double)(i + 1);
     }
     t[kTable - 1] = UINT64_MAX;
+}
+
+// kind 2 tables (see row_len): returns the number of buckets.
+int powerlaw_table(int xmin, double tail, int max_len, uint64_t *t) {
+    const long double two64 = 18446744073709551616.0L;
+    int nb = 0;
+    long double edge = (long double)xmin;
+    std::vector<uint64_t> edges;
+    while (nb < kTable / 2 - 2) {
+        const uint64_t e = (uint64_t)edge;
+        if (!edges.empty() && e <= edges.back()) { edge *= 1.189207115002721L; continue; }   // 2^(1/4)
+        if (e > (uint64_t)max_len) break;
+        edges.push_back(e);
+        ++nb;
+        edge *= 1.189207115002721L;
+    }
+    edges.push_back((uint64_t)max_len + 1);
+    for (int b = 0; b < nb; ++b) {
+        // P(len < upper edge) = 1 - (xmin / upper)^tail ; the last bucket takes the rest
+        const long double cdf = b == nb - 1 ? 1.0L : 1.0L - powl((long double)xmin / (long double)edges[(size_t)b + 1], (long double)tail);
+        const long double x = cdf * two64;
+        t[b] = (cdf >= 1.0L || x >= two64 - 1.0L) ? UINT64_MAX : (uint64_t)x;
+    }
+    for (int b = 0; b <= nb; ++b) t[kTable / 2 + b] = edges[(size_t)b];
+    return nb;
 }
 
 __global__ void k_row_len(Spec sp, const uint64_t *table, int r0, int nrows, int *lens) {
@@ -159,7 +206,8 @@ __global__ void k_uniform(float *dst, int64_t n, uint64_t seed) {
 int gen_host(const Spec &sp, double mean, int r0, int r1, int **row_ptr, int **col_idx, float **val,
              int64_t *nnz) {
     std::vector<uint64_t> table(kTable);
-    poisson_table(mean, table.data());
+    if (sp.kind == 2) memcpy(table.data(), g_powerlaw_table, sizeof(uint64_t) * kTable);
+    else poisson_table(mean, table.data());
     const int nrows = r1 - r0;
     int *rp = (int *)malloc(sizeof(int) * ((size_t)nrows + 1));
     if (!rp) return SEXTANS_ERR_ALLOC;
@@ -185,7 +233,8 @@ int gen_device(int device, const Spec &sp, double mean, int r0, int r1, int **d_
         return SEXTANS_ERR_NO_DEVICE;
     SY_HIP(hipSetDevice(device));
     std::vector<uint64_t> table(kTable);
-    poisson_table(mean, table.data());
+    if (sp.kind == 2) memcpy(table.data(), g_powerlaw_table, sizeof(uint64_t) * kTable);
+    else poisson_table(mean, table.data());
     uint64_t *d_table = nullptr;
     SY_HIP(hipMalloc((void **)&d_table, sizeof(uint64_t) * kTable));
     SY_HIP(hipMemcpy(d_table, table.data(), sizeof(uint64_t) * kTable, hipMemcpyHostToDevice));
@@ -281,6 +330,33 @@ int sextans_gen_csr_device(int device, int M, int K, double mean_nnz, int bandwi
         return SEXTANS_ERR_INVALID;
     const Spec sp{0, K, bandwidth, 0, 0, 0, 0, seed};
     return gen_device(device, sp, mean_nnz, r0, r1, d_row_ptr, d_col_idx, d_val, nnz);
+}
+
+static int powerlaw_spec(int M, int K, int xmin, int tail_x100, int max_len, uint64_t seed, int r0, int r1, Spec *sp) {
+    if (M < 0 || K <= 0 || r0 < 0 || r1 < r0 || r1 > M || xmin < 1 || tail_x100 < 50 || tail_x100 > 1000 ||
+        max_len < xmin)
+        return SEXTANS_ERR_INVALID;
+    if (max_len > K) max_len = K;
+    if (max_len < xmin) return SEXTANS_ERR_INVALID;
+    const int nb = powerlaw_table(xmin, tail_x100 / 100.0, max_len, g_powerlaw_table);
+    *sp = Spec{2, K, nb, 0, 0, 0, 0, seed};
+    return SEXTANS_OK;
+}
+
+int sextans_gen_powerlaw_host(int M, int K, int xmin, int tail_x100, int max_len, uint64_t seed, int r0, int r1,
+                              int **row_ptr, int **col_idx, float **val, int64_t *nnz) {
+    if (!row_ptr || !col_idx || !val || !nnz) return SEXTANS_ERR_INVALID;
+    Spec sp;
+    if (int rc = powerlaw_spec(M, K, xmin, tail_x100, max_len, seed, r0, r1, &sp)) return rc;
+    return gen_host(sp, 1.0, r0, r1, row_ptr, col_idx, val, nnz);
+}
+
+int sextans_gen_powerlaw_device(int device, int M, int K, int xmin, int tail_x100, int max_len, uint64_t seed, int r0,
+                                int r1, int **d_row_ptr, int **d_col_idx, float **d_val, int64_t *nnz) {
+    if (!d_row_ptr || !d_col_idx || !d_val || !nnz) return SEXTANS_ERR_INVALID;
+    Spec sp;
+    if (int rc = powerlaw_spec(M, K, xmin, tail_x100, max_len, seed, r0, r1, &sp)) return rc;
+    return gen_device(device, sp, 1.0, r0, r1, d_row_ptr, d_col_idx, d_val, nnz);
 }
 
 int sextans_gen_fem3d_host(int nx, int ny, int nz, int dof, uint64_t seed, int r0, int r1, int **row_ptr,

@@ -143,7 +143,7 @@ def test_config5_full_size(engine, oracle):
         torch.cuda.synchronize()
         assert engine.last_kernel().startswith("spmm_bell")
         Bh = B.cpu().numpy().view(np.uint16)
-        worst = 0.0
+        worst = worst_rel = 0.0
         for br, bc, bv in zip(brs, cols, vals):
             assert np.all(np.diff(bc) > 0) and bc.min() >= 0 and bc.max() < K // 32
             c0 = Cin.view(N, M)[:, br * 32:(br + 1) * 32].cpu().numpy().reshape(-1).copy()     # 32 x N column-major
@@ -153,9 +153,18 @@ def test_config5_full_size(engine, oracle):
             tol = 4e-6 * asum + 1e-6 * np.abs(float(BETA) * c0) + 1e-30
             worst = max(worst, float(np.max(np.abs(got - want) / tol)))
             rel = np.linalg.norm(got - want) / np.linalg.norm(want)
-            assert rel < 1e-6, (br, rel)
-        print(f"config 5 full size: worst |gpu - fp32 oracle| / (4e-6 * sum|a*b| + 1e-6*|beta*c|) = {worst:.3f} "
-              f"over {len(brs)} block rows (10 496-term fp32 sums)")
+            worst_rel = max(worst_rel, float(rel))
+            assert rel < 5e-6, (br, rel)     # two fp32 summation orders of a 10 496-term sum against each other
+        msg = (f"config 5 full size: worst |gpu - fp32 oracle| / (4e-6 * sum|a*b| + 1e-6*|beta*c|) = {worst:.3f} "
+               f"over {len(brs)} block rows (10 496-term fp32 sums); worst ||d||/||c|| = {worst_rel:.3e}")
+        print(msg)
+        try:                                                  # kept with the round's profiles when run under gpurun
+            import os
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+            open(os.path.join(root, "gpurun_out", "config5_full_size_error.txt"), "w").write(msg + "\n")
+        except OSError:
+            pass
         assert worst <= 1.0
     finally:
         if dv is not None:

@@ -1,0 +1,154 @@
+"""Automatic handling of skewed (power-law) matrices, SURVEY.md 8f row 1.  The reference balances by construction
+(rows dealt to PEs by row % 64 + bubble padding, sparse_helper.h:345-403); here rows longer than a threshold chosen
+from the matrix are summed in parallel pieces and folded in order.  Default engine options throughout
+(split_rows = -1): rows that are NOT hubs must stay bit-identical to cpu_spmm_CSR under every kernel; hub rows
+(reported by sextans_reassociated_rows) must meet |d| <= 1e-4 * (|alpha| * sum|a*b| + |beta*c|)."""
+import time
+
+import numpy as np
+import pytest
+
+from util import ALPHA, BETA
+
+pytestmark = pytest.mark.gpu
+
+
+def _defaults(engine, **opts):
+    d = dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0, panel_min_reuse_x100=400, fuse_b=1,
+             split_rows=-1, window_rows=319, window_cols=65536, window_unroll=8)
+    d.update(opts)
+    for k, v in d.items():
+        engine.set_option(k, v)
+
+
+def _check(out, want, M, N, rp, ci, v, B, C0, hubs, alpha, beta):
+    o2, w2 = out.reshape(N, M), want.reshape(N, M)
+    plain = np.ones(M, bool)
+    plain[hubs] = False
+    assert np.array_equal(o2[:, plain].view(np.uint32), w2[:, plain].view(np.uint32)), "a non-hub row changed"
+    K = len(B) // N
+    rows = np.repeat(np.arange(M), np.diff(rp))
+    for n in range(N):
+        bound = np.bincount(rows, weights=np.abs(v).astype(np.float64) * np.abs(B[n * K + ci]), minlength=M)
+        bound = 1e-4 * (abs(float(alpha)) * bound + np.abs(float(beta) * C0[n * M:(n + 1) * M]))
+        assert np.all(np.abs(o2[n].astype(np.float64) - w2[n]) <= bound + 1e-30), n
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
+@pytest.mark.parametrize("N", [8, 16, 40])
+def test_power_law_default_options(engine, oracle, kernel, N):
+    from sextans_amd import api
+    M = K = 20000
+    rp, ci, v = api.gen_powerlaw_host(M, K, 3, 120, 15000, 11)
+    lens = np.diff(rp)
+    T = max(512, int(rp[-1]) // 16384)
+    expect = np.nonzero(lens > T)[0]
+    assert len(expect) >= 3 and lens.max() > 5000
+    rs = np.random.RandomState(N)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    _defaults(engine, kernel=kernel)
+    engine.set_matrix_csr(M, K, rp, ci, v)
+    hubs = engine.reassociated_rows()
+    assert np.array_equal(hubs, expect) and engine.get_stat("split_threshold") == T
+    out = C0.copy()
+    engine.spmm(N, ALPHA, B, BETA, out, rp_time=2)
+    assert engine.last_kernel().endswith("+hub_pieces")
+    if kernel == 3:
+        assert engine.last_kernel() == "spmm_csr_window+hub_pieces"
+    _check(out, want, M, N, rp, ci, v, B, C0, hubs, ALPHA, BETA)
+    # strict order on request: no row is split, everything bit-identical (and slow for the hubs)
+    _defaults(engine, kernel=kernel, split_rows=0)
+    out = C0.copy()
+    engine.spmm(N, ALPHA, B, BETA, out)
+    assert len(engine.reassociated_rows()) == 0 and "+hub" not in engine.last_kernel()
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    _defaults(engine)
+
+
+def test_fem_with_hub_rows_keeps_the_panel_kernel(engine, oracle):
+    """A matrix with B-row reuse plus a few hub rows: the LDS-panel kernel runs on the main matrix, the hubs go
+    through the piece path; row-range calls see the hubs of their range only."""
+    import torch
+    from sextans_amd import api
+    frp, fci, fv = api.gen_fem3d_host(20, 20, 12, 3, 5)
+    M0 = 20 * 20 * 12 * 3
+    K = M0
+    rs = np.random.RandomState(17)
+    hub_at = [7, 5000, M0 - 1]
+    rows = []
+    for r in range(M0):
+        c, x = fci[frp[r]:frp[r + 1]], fv[frp[r]:frp[r + 1]]
+        if r in hub_at:
+            c = np.sort(rs.choice(K, size=6000 + r % 100, replace=False)).astype(np.int32)
+            x = rs.uniform(-1, 1, len(c)).astype(np.float32)
+        rows.append((c, x))
+    M = M0
+    rp = np.zeros(M + 1, np.int32); rp[1:] = np.cumsum([len(c) for c, _ in rows])
+    ci = np.concatenate([c for c, _ in rows]).astype(np.int32)
+    v = np.concatenate([x for _, x in rows]).astype(np.float32)
+    N = 16
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    alpha, beta = np.float32(-1.5), np.float32(0.75)
+    want = C0.copy()
+    oracle.spmm(M, N, K, alpha, rp, ci, v, B, beta, want)
+    _defaults(engine)
+    engine.set_matrix_csr(M, K, rp, ci, v)
+    assert list(engine.reassociated_rows()) == hub_at
+    out = C0.copy()
+    engine.spmm(N, float(alpha), B, float(beta), out)
+    assert engine.last_kernel() == "spmm_csr_panel+hub_pieces"
+    _check(out, want, M, N, rp, ci, v, B, C0, np.array(hub_at), alpha, beta)
+    # in place (C_in == C_out) and in row ranges cut at kernel-friendly boundaries
+    st = torch.cuda.current_stream().cuda_stream
+    dB = torch.from_numpy(B).cuda(); dC = torch.from_numpy(C0).cuda()
+    cuts = [0, engine.align_row(N, M // 2), M]
+    for i in range(2):
+        c0, c1 = cuts[i], cuts[i + 1]
+        engine.spmm_device_rows(N, float(alpha), dB.data_ptr(), K, float(beta), dC.data_ptr() + 4 * c0, M,
+                                dC.data_ptr() + 4 * c0, M, c0, c1, reuse_b_panels=i > 0, stream=st)
+        assert engine.last_kernel() == "spmm_csr_panel+hub_pieces"
+    torch.cuda.synchronize()
+    assert np.array_equal(dC.cpu().numpy().view(np.uint32), out.view(np.uint32))     # same bits as the whole-matrix call
+
+
+def test_power_law_1m_rows_within_1p5x_of_uniform(engine, sx):
+    """VERDICT r01 task 5: a 1M-row power-law matrix runs within 1.5x of a uniform matrix with the same number
+    of non-zeros, kernel = 0, no option set."""
+    import torch
+    from sextans_amd import api
+    M = K = 1_000_000
+    N = 16
+    st = torch.cuda.current_stream().cuda_stream
+    B = torch.empty(K * N, device="cuda"); Cin = torch.empty(M * N, device="cuda"); Cout = torch.empty(M * N, device="cuda")
+    api.gen_uniform_device(0, B.data_ptr(), K * N, 41, st)
+    api.gen_uniform_device(0, Cin.data_ptr(), M * N, 42, st)
+
+    def time_it(ptrs, nnz):
+        with api.Engine(0) as e:                       # a fresh engine: every option at its default
+            e.set_matrix_csr_device(M, K, nnz, *ptrs)
+            f = lambda: e.spmm_device(N, 0.85, B.data_ptr(), K, -2.06, Cin.data_ptr(), Cout.data_ptr(), M, st)
+            for _ in range(3):
+                f()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                f()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / 10, e.last_kernel(), int(e.get_stat("reassociated_rows"))
+
+    pl = api.gen_powerlaw_device(0, M, K, 6, 120, 400_000, 7)
+    t_pl, k_pl, hubs = time_it(pl[:3], pl[3])
+    for q in pl[:3]:
+        api.device_free(0, q)
+    un = api.gen_csr_device(0, M, K, pl[3] / M, 7)
+    t_un, k_un, _ = time_it(un[:3], un[3])
+    for q in un[:3]:
+        api.device_free(0, q)
+    print(f"power-law {pl[3]} nnz: {t_pl * 1e3:.3f} ms ({k_pl}, {hubs} hub rows); uniform {un[3]} nnz: {t_un * 1e3:.3f} ms ({k_un})")
+    assert hubs > 100 and k_pl.endswith("+hub_pieces")
+    assert abs(un[3] - pl[3]) < 0.02 * pl[3]
+    assert t_pl <= 1.5 * t_un, (t_pl, t_un)

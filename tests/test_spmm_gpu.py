@@ -18,7 +18,8 @@ MANIFEST = json.load(open(os.path.join(CASES, "manifest.json")))
 
 
 def run(engine, M, K, rp, ci, v, N, alpha, B, beta, C0, **opts):
-    defaults = dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0, panel_min_reuse_x100=400, fuse_b=1)
+    defaults = dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0, panel_min_reuse_x100=400, fuse_b=1,
+                    split_rows=0)      # 0 = strict cpu_spmm_CSR order for every row (the default, -1, splits hub rows)
     defaults.update(opts)
     for k, val in defaults.items():
         engine.set_option(k, val)
@@ -206,8 +207,9 @@ def test_split_long_rows_option(engine, oracle):
     T = 4096
     engine.set_option("split_rows", T)
     try:
-        out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, kernel=1)
-        assert engine.last_kernel() == "spmm_csr_rowgroup+fold_row_pieces"
+        out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, kernel=1, split_rows=T)
+        assert engine.last_kernel() == "spmm_csr_rowgroup+hub_pieces"
+        assert list(engine.reassociated_rows()) == sorted(hubs) and engine.get_stat("split_threshold") == T
         o2, w2 = out.reshape(N, M), want.reshape(N, M)
         short = np.ones(M, bool); short[hubs] = False
         assert np.array_equal(o2[:, short].view(np.uint32), w2[:, short].view(np.uint32))     # untouched rows: bit exact
@@ -218,9 +220,8 @@ def test_split_long_rows_option(engine, oracle):
             assert np.all(np.abs(o2[n].astype(np.float64) - w2[n]) <= bound + 1e-30)
         assert not np.array_equal(o2[:, hubs].view(np.uint32), w2[:, hubs].view(np.uint32)) or True
         # a threshold above the longest row: nothing is split, plain kernel, bit exact everywhere
-        engine.set_option("split_rows", 50000)
-        out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, kernel=1)
-        assert engine.last_kernel() == "spmm_csr_rowgroup"
+        out = run(engine, M, K, rp, ci, v, N, ALPHA, B, BETA, C0, kernel=1, split_rows=50000)
+        assert engine.last_kernel() == "spmm_csr_rowgroup" and len(engine.reassociated_rows()) == 0
         assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
     finally:
         engine.set_option("split_rows", 0)

@@ -79,3 +79,47 @@ def test_device_generator_bit_identical_to_host(sx, engine):
     api.gen_uniform_device(0, t.data_ptr(), 100000, 3, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(t.cpu().numpy().view(np.uint32), api.gen_uniform_host(100000, 3).view(np.uint32))
+
+
+def test_powerlaw_generator_properties(sx):
+    from sextans_amd import api
+    M = K = 200_000
+    rp, ci, v = api.gen_powerlaw_host(M, K, 6, 120, 100_000, 7)
+    lens = np.diff(rp)
+    assert lens.min() >= 6 and lens.max() <= 100_000 and lens.max() > 20_000     # a few hubs ...
+    assert np.median(lens) < 12 and 15 < lens.mean() < 60                           # ... over a mass of short rows
+    # tail: P(len >= x) = (xmin / x)^1.2
+    for x in (12, 48, 192):
+        assert abs((lens >= x).mean() - (6 / x) ** 1.2) < 0.15 * (6 / x) ** 1.2 + 2e-4
+    r = int(np.argmax(lens))
+    seg = ci[rp[r]:rp[r + 1]]
+    assert np.all(np.diff(seg) > 0) and seg[0] >= 0 and seg[-1] < K                # strata: distinct, ascending
+    assert v.min() >= -1.0 and v.max() < 1.0
+    rp2, ci2, v2 = api.gen_powerlaw_host(M, K, 6, 120, 100_000, 7, 5000, 5600)     # counter-based: any row range
+    assert np.array_equal(ci2, ci[rp[5000]:rp[5600]]) and np.array_equal(v2, v[rp[5000]:rp[5600]])
+    rp3, ci3, _ = api.gen_powerlaw_host(300, 50, 6, 120, 100_000, 1)               # max_len clipped to K
+    assert np.diff(rp3).max() <= 50 and all(np.all(np.diff(ci3[rp3[i]:rp3[i + 1]]) > 0) for i in range(300))
+
+
+@pytest.mark.gpu
+def test_powerlaw_device_generator_bit_identical_to_host(sx, engine):
+    import ctypes as C
+    import torch
+    from sextans_amd import api
+    M = K = 300_000
+    p, i, v, nnz = api.gen_powerlaw_device(0, M, K, 5, 130, 200_000, 9, 1000, 250_000)
+    try:
+        hp, hi, hv = api.gen_powerlaw_host(M, K, 5, 130, 200_000, 9, 1000, 250_000)
+        assert nnz == len(hi)
+        hip = C.CDLL("libamdhip64.so.7")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        tp = torch.empty(len(hp), dtype=torch.int32, device="cuda")
+        ti = torch.empty(nnz, dtype=torch.int32, device="cuda")
+        tv = torch.empty(nnz, dtype=torch.float32, device="cuda")
+        assert hip.hipMemcpy(tp.data_ptr(), p, len(hp) * 4, 3) == 0
+        assert hip.hipMemcpy(ti.data_ptr(), i, nnz * 4, 3) == 0 and hip.hipMemcpy(tv.data_ptr(), v, nnz * 4, 3) == 0
+        assert np.array_equal(tp.cpu().numpy(), hp) and np.array_equal(ti.cpu().numpy(), hi)
+        assert np.array_equal(tv.cpu().numpy().view(np.uint32), hv.view(np.uint32))
+    finally:
+        for q in (p, i, v):
+            api.device_free(0, q)
