@@ -95,20 +95,29 @@ struct sextans_engine {
     void *d_bell_Af = nullptr;      // A blocks in MFMA fragment order (owned)
     void *d_bell_Bf = nullptr;      // B in fragment order (workspace)
     size_t bell_Bf_cap = 0;         // bytes
-    // Hub rows (longer than the split threshold, option "split_rows"; default: chosen from the matrix) are taken
-    // out of the "main" matrix -- the CSR arrays every kernel and plan works on, equal to the arrays above when
-    // there are no hubs -- and go through the piece path: pieces of T entries summed in parallel, folded in order.
+    // Long rows leave the "main" matrix -- the CSR arrays every kernel and plan works on, equal to the arrays
+    // above when there are none -- and go through the piece path (rows sorted by length, one row group per piece):
+    //   bucketed rows (longer than the bucket threshold L0, option "bucket_rows"): ONE piece, summed in order =
+    //     still bit-identical to cpu_spmm_CSR; they only leave so that a workgroup of the main kernel never waits
+    //     for one long row among 63 short ones;
+    //   hub rows (longer than the split threshold T, option "split_rows"): pieces of T entries summed in parallel
+    //     and folded in order = re-associated (stated tolerance), reported by sextans_reassociated_rows.
     const int *m_rp = nullptr, *m_ci = nullptr;
     const float *m_v = nullptr;
     int64_t m_nnz = 0;
-    int *d_mrp = nullptr, *d_mci = nullptr;   // owned compacted copy (exists only with hubs)
+    int *d_mrp = nullptr, *d_mci = nullptr;   // owned compacted copy (exists only when rows left)
     float *d_mv = nullptr;
-    int *d_vrp = nullptr, *d_vend = nullptr, *d_vfirst = nullptr, *d_hub_row = nullptr;   // piece [begin, end) in d_ci/d_v, first piece per hub, hub rows
-    std::vector<int> h_hub_row, h_vfirst;
-    int nhub = 0;
-    int split_nv = 0;               // pieces of all hubs
-    int64_t split_T = 0;            // threshold in effect (0 = none)
-    int64_t split_built_opt = -2;   // value of opt_split_rows the state above was built for (-2 = not evaluated)
+    unsigned char *d_skip = nullptr;          // 1 = the row's C is written by the piece path, not by the main kernel
+    struct PieceTable {                       // pieces [begin, end) in d_ci / d_v, first piece per long row, the rows
+        int *d_vrp = nullptr, *d_vend = nullptr, *d_vfirst = nullptr, *d_row = nullptr;
+        std::vector<int> h_row, h_vfirst;
+    };
+    PieceTable by_len, by_row;                // sorted by length (whole-matrix calls: balanced workgroups) / by row (row ranges)
+    std::vector<int> h_split_rows;            // ascending: rows cut into more than one piece
+    int nhub = 0;                             // long rows (bucketed + split)
+    int split_nv = 0;                         // pieces of all long rows
+    int64_t split_T = 0, bucket_L0 = 0;       // thresholds in effect (0 = none)
+    int64_t split_built_opt = -2, bucket_built_opt = -2;   // option values the state above was built for
     float *d_P = nullptr;
     size_t P_cap = 0;
     long long *d_dbg = nullptr;     // 8 counters for phase timing (option "phase_timing")
@@ -122,6 +131,8 @@ struct sextans_engine {
     int64_t opt_fuse_b = 1;             // panel kernel may stage from column-major B (small matrices: no repack launch)
     int64_t opt_split_rows = -1;        // > 0: rows longer than this are split (re-associated); 0 = never (strict
                                         // order); -1 = threshold chosen from the matrix: max(512, nnz / 16384)
+    int64_t opt_bucket_rows = -1;       // > 0: rows longer than this take the piece path unsplit (still exact); 0 = off;
+                                        // -1 = max(32, 2 * mean row length)
     int64_t opt_phase_timing = 0;       // 1: panel kernel accumulates per-phase wave cycles (debug aid)
     int64_t opt_min_reuse_x100 = 400;   // a block uses the LDS panel if nnz >= 4 * distinct columns
     int64_t opt_win_rows = 319;         // rows per wavefront of the window kernel (+1 dummy row: 4 x 320 x 32 B = 40 KiB)
@@ -180,14 +191,18 @@ void free_bell(sextans_engine *h) {
 }
 
 void free_split(sextans_engine *h) {
-    (void)hipFree(h->d_vrp); (void)hipFree(h->d_vend); (void)hipFree(h->d_vfirst); (void)hipFree(h->d_hub_row);
-    (void)hipFree(h->d_mrp); (void)hipFree(h->d_mci); (void)hipFree(h->d_mv);
-    h->d_vrp = h->d_vend = h->d_vfirst = h->d_hub_row = h->d_mrp = h->d_mci = nullptr;
+    for (auto *t : {&h->by_len, &h->by_row}) {
+        (void)hipFree(t->d_vrp); (void)hipFree(t->d_vend); (void)hipFree(t->d_vfirst); (void)hipFree(t->d_row);
+        *t = sextans_engine::PieceTable();
+    }
+    (void)hipFree(h->d_mrp); (void)hipFree(h->d_mci); (void)hipFree(h->d_mv); (void)hipFree(h->d_skip);
+    h->d_mrp = h->d_mci = nullptr;
     h->d_mv = nullptr;
-    h->h_hub_row.clear(); h->h_vfirst.clear();
+    h->d_skip = nullptr;
+    h->h_split_rows.clear();
     h->nhub = h->split_nv = 0;
-    h->split_T = 0;
-    h->split_built_opt = -2;
+    h->split_T = h->bucket_L0 = 0;
+    h->split_built_opt = h->bucket_built_opt = -2;
     h->m_rp = h->d_rp; h->m_ci = h->d_ci; h->m_v = h->d_v; h->m_nnz = h->nnz;
 }
 
@@ -238,7 +253,8 @@ void launch_repack(const float *dB, int64_t ldb, float *dBp, int K, int col_base
 }
 
 template <int LPR>
-void launch_rowgroup(sextans_engine *h, const int *rp, const int *rend, const int *ci, const float *va, bool pieces, const float *dBp,
+void launch_rowgroup(sextans_engine *h, const int *rp, const int *rend, const int *ci, const float *va, bool pieces,
+                     const unsigned char *skip, const float *dBp,
                      const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc, int row_begin, int row_end, int ntiles,
                      float alpha, float beta, hipStream_t s) {
     constexpr int RB = sx::kBlock / LPR;
@@ -251,7 +267,7 @@ void launch_rowgroup(sextans_engine *h, const int *rp, const int *rend, const in
 #define SX_LAUNCH(EX, ST)                                                                       \
     hipLaunchKernelGGL((sx::spmm_csr_rowgroup<LPR, CH, EX, ST>), dim3(nwg), dim3(sx::kBlock), 0, \
                        s, rp, rend, ci, va, dBp, pstride, dCin, ldc_in, dCout, ldc, row_begin,          \
-                       row_end, ntiles, nrowblk, alpha, beta, xcd)
+                       row_end, ntiles, nrowblk, alpha, beta, xcd, skip)
     // The LDS-staged A stream walks a block's non-zeros in order, which serialises row groups when rows
     // are long pieces of one hub row (split mode): there every row group streams its own piece directly.
     const bool stage = h->opt_stage && !pieces;
@@ -444,7 +460,7 @@ void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_
         hipLaunchKernelGGL(kern, dim3(nwg), dim3(sx::kBlock), lds, s, (const int2 *)h->d_row_off, h->d_lidx,
                            h->d_pcol32, h->d_pval, h->d_blk_row, h->d_dict_ptr, h->d_dict, h->plan_dict_stride, dBp,
                            pstride, dCin, ldc_in, dCout, ldc, ntiles, nblk, alpha, beta, xcd, panel_floats,
-                           (long long *)h->d_dbg, blk_begin, row_base);
+                           (long long *)h->d_dbg, blk_begin, row_base, (const unsigned char *)h->d_skip);
     };
     if (h->plan_mixed) {
         if (h->opt_exact) go(sx::spmm_csr_panel<LPR, true, true>);
@@ -529,7 +545,8 @@ void launch_window(sextans_engine *h, const float *dBp8, const float *dCin, int6
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3((unsigned)nwg * (unsigned)ntiles), dim3(sx::kWinWaves * 64), lds, s,
                            (const sx::u32x2 *)h->d_wstream, (const int *)h->d_wstep0, dBp8, (int64_t)h->K * sx::kWinNT, dCin,
-                           ldc_in, dCout, ldc, h->M, h->win_rw, wave_begin, wave_end, nwg, row_base, alpha, beta);
+                           ldc_in, dCout, ldc, h->M, h->win_rw, wave_begin, wave_end, nwg, row_base, alpha, beta,
+                           (const unsigned char *)h->d_skip);
     };
     if (h->opt_win_unroll == 4) { if (h->opt_exact) go(sx::spmm_csr_window<true, 4>); else go(sx::spmm_csr_window<false, 4>); }
     else                        { if (h->opt_exact) go(sx::spmm_csr_window<true, 8>); else go(sx::spmm_csr_window<false, 8>); }
@@ -604,6 +621,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "panel_min_reuse_x100")) return &h->opt_min_reuse_x100;
     if (!strcmp(key, "phase_timing")) return &h->opt_phase_timing;
     if (!strcmp(key, "split_rows")) return &h->opt_split_rows;
+    if (!strcmp(key, "bucket_rows")) return &h->opt_bucket_rows;
     if (!strcmp(key, "fuse_b")) return &h->opt_fuse_b;
     if (!strcmp(key, "window_rows")) return &h->opt_win_rows;
     if (!strcmp(key, "window_cols")) return &h->opt_win_cols;
@@ -647,8 +665,10 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     if (!strcmp(key, "plan_build_s")) *value = h->plan_build_s;
     else if (!strcmp(key, "window_padded_entries")) *value = (double)h->win_padded;
     else if (!strcmp(key, "window_state")) *value = (double)h->win_state;
-    else if (!strcmp(key, "reassociated_rows")) *value = (double)h->nhub;
+    else if (!strcmp(key, "reassociated_rows")) *value = (double)h->h_split_rows.size();
+    else if (!strcmp(key, "piece_path_rows")) *value = (double)h->nhub;
     else if (!strcmp(key, "split_threshold")) *value = (double)h->split_T;
+    else if (!strcmp(key, "bucket_threshold")) *value = (double)h->bucket_L0;
     else if (!strcmp(key, "panel_fraction")) *value = h->plan_panel_frac;
     else if (!strcmp(key, "panel_blocks")) *value = (double)h->plan_nblk;
     else return SEXTANS_ERR_INVALID;
@@ -718,40 +738,73 @@ int sextans_spmm_device(sextans_handle_t h, int N, float alpha, const float *d_B
 namespace {
 struct Seg { int width, col0, ntiles; };
 
-// Hub test + piece tables.  Rows longer than T are removed from the main matrix (compacted copy) and cut into
-// pieces of T entries of the ORIGINAL arrays; the pieces are summed in parallel by the row-group kernel and folded
-// in order -- the only place where a row's sum is re-associated (stated tolerance instead of bit equality; the
-// rows are reported by sextans_reassociated_rows).  T: option "split_rows" > 0; 0 = never; -1 (default) =
-// max(512, nnz / 16384): one 4-lane row group retires ~10 non-zeros per microsecond while the whole chip retires
-// ~50 000, so a row holding more than 1/16384 of the matrix would dominate the launch on its own.
+// Long-row test + piece tables (see the engine struct).  Thresholds:
+//   L0 ("bucket_rows"; -1 = max(32, 2 * mean row length)): a workgroup of the row-group / panel kernels owns 32-128
+//     consecutive rows and lives as long as its longest row, so one 100-entry row among 15-entry rows wastes 85 % of
+//     the workgroup; rows above L0 are processed in a second launch in order of length instead.  Regular matrices
+//     (Poisson, FEM, nasa4704) have no such rows and take none of this path.
+//   T ("split_rows"; -1 = max(512, nnz / 16384); 0 = never): one 4-lane row group retires ~10 non-zeros per
+//     microsecond while the chip retires ~50 000, so a row holding more than 1/16384 of the matrix would dominate
+//     the launch on its own: it is cut into pieces of T entries (re-associated).
 int ensure_split(sextans_engine *h) {
-    if (h->split_built_opt == h->opt_split_rows) return SEXTANS_OK;
+    if (h->split_built_opt == h->opt_split_rows && h->bucket_built_opt == h->opt_bucket_rows) return SEXTANS_OK;
     free_split(h);
     free_plan(h);      // the packed forms are built from the main matrix
     free_window(h);
     h->split_built_opt = h->opt_split_rows;
-    int64_t T = h->opt_split_rows;
+    h->bucket_built_opt = h->opt_bucket_rows;
+    if (h->M == 0 || h->nnz == 0) return SEXTANS_OK;
+    int64_t T = h->opt_split_rows, L0 = h->opt_bucket_rows;
     if (T < 0) T = std::max<int64_t>(512, h->nnz / 16384);
-    if (T == 0 || h->M == 0 || h->nnz == 0) return SEXTANS_OK;
+    if (L0 < 0) L0 = std::max<int64_t>(32, 2 * (h->nnz / h->M));
+    if (T == 0) T = INT64_MAX;                 // never split
+    if (L0 == 0) L0 = T;                       // no bucketing: only rows that must be split leave
+    if (L0 > T) L0 = T;
+    if (L0 == INT64_MAX) return SEXTANS_OK;
     PlanTimer timer(h);
     std::vector<int> rp;
     if (int rc = read_back_row_ptr(h, rp, false)) return rc;
-    std::vector<int> hubs;
+    std::vector<int> rows;                     // ascending
     for (int r = 0; r < h->M; ++r)
-        if ((int64_t)rp[(size_t)r + 1] - rp[(size_t)r] > T) hubs.push_back(r);
-    if (hubs.empty()) return SEXTANS_OK;
+        if ((int64_t)rp[(size_t)r + 1] - rp[(size_t)r] > L0) rows.push_back(r);
+    if (rows.empty()) return SEXTANS_OK;
     std::vector<int> ci;
     std::vector<float> va;
     if (int rc = read_back_entries(h, ci, va, false)) return rc;
-    // main matrix: hub rows emptied
-    std::vector<int> mrp((size_t)h->M + 1, 0), vrp, vend, vfirst;
+    // piece tables in two row orders
+    auto build = [&](const std::vector<int> &order, sextans_engine::PieceTable &t) -> int {
+        std::vector<int> vrp, vend, vfirst;
+        for (int r : order) {
+            vfirst.push_back((int)vrp.size());
+            const int64_t j0 = rp[(size_t)r], j1 = rp[(size_t)r + 1];
+            const int64_t step = (j1 - j0 > T) ? T : (j1 - j0);
+            for (int64_t j = j0; j < j1; j += step) { vrp.push_back((int)j); vend.push_back((int)std::min(j + step, j1)); }
+        }
+        vfirst.push_back((int)vrp.size());
+        if (int rc = upload(&t.d_vrp, vrp)) return rc;
+        if (int rc = upload(&t.d_vend, vend)) return rc;
+        if (int rc = upload(&t.d_vfirst, vfirst)) return rc;
+        if (int rc = upload(&t.d_row, order)) return rc;
+        t.h_row = order;
+        t.h_vfirst = vfirst;
+        return SEXTANS_OK;
+    };
+    std::vector<int> by_len = rows;
+    std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b) {
+        return rp[(size_t)a + 1] - rp[(size_t)a] > rp[(size_t)b + 1] - rp[(size_t)b];
+    });
+    if (int rc = build(by_len, h->by_len)) return rc;
+    if (int rc = build(rows, h->by_row)) return rc;
+    // main matrix: long rows emptied; skip flags
+    std::vector<int> mrp((size_t)h->M + 1, 0);
+    std::vector<unsigned char> skip((size_t)h->M, 0);
     {
         size_t k = 0, w = 0;
         for (int r = 0; r < h->M; ++r) {
             const int j0 = rp[(size_t)r], j1 = rp[(size_t)r + 1];
-            if (k < hubs.size() && hubs[k] == r) {
-                vfirst.push_back((int)vrp.size());
-                for (int64_t j = j0; j < j1; j += T) vrp.push_back((int)j);
+            if (k < rows.size() && rows[k] == r) {
+                skip[(size_t)r] = 1;
+                if ((int64_t)j1 - j0 > T) h->h_split_rows.push_back(r);
                 ++k;
             } else {
                 if (w != (size_t)j0) {
@@ -762,28 +815,18 @@ int ensure_split(sextans_engine *h) {
             }
             mrp[(size_t)r + 1] = (int)w;
         }
-        vfirst.push_back((int)vrp.size());
-        // piece v covers [vrp[v], vend[v]): the next piece of the same hub, or the end of the hub row
-        vend.resize(vrp.size());
-        for (size_t kk = 0; kk < hubs.size(); ++kk)
-            for (int v = vfirst[kk]; v < vfirst[kk + 1]; ++v)
-                vend[(size_t)v] = v + 1 < vfirst[kk + 1] ? vrp[(size_t)v + 1] : rp[(size_t)hubs[kk] + 1];
         ci.resize(w ? w : 1); va.resize(w ? w : 1);
         h->m_nnz = (int64_t)w;
     }
     if (int rc = upload(&h->d_mrp, mrp)) return rc;
     if (int rc = upload(&h->d_mci, ci)) return rc;
     if (int rc = upload(&h->d_mv, va)) return rc;
+    if (int rc = upload(&h->d_skip, skip)) return rc;
     h->m_rp = h->d_mrp; h->m_ci = h->d_mci; h->m_v = h->d_mv;
-    if (int rc = upload(&h->d_vrp, vrp)) return rc;
-    if (int rc = upload(&h->d_vend, vend)) return rc;
-    if (int rc = upload(&h->d_vfirst, vfirst)) return rc;
-    if (int rc = upload(&h->d_hub_row, hubs)) return rc;
-    h->h_hub_row = hubs;
-    h->h_vfirst = vfirst;
-    h->nhub = (int)hubs.size();
-    h->split_nv = (int)vrp.size();
-    h->split_T = T;
+    h->nhub = (int)rows.size();
+    h->split_nv = h->by_len.h_vfirst.back();
+    h->split_T = T == INT64_MAX ? 0 : T;
+    h->bucket_L0 = L0;
     return SEXTANS_OK;
 }
 
@@ -859,10 +902,11 @@ namespace {
 // Hub rows inside [row_begin, row_end): pieces summed as virtual rows by the row-group kernel from B panels of width
 // 4 * LPR at dBp (ntiles panels), then folded in order into the C the main kernel has already written.
 template <int LPR>
-void launch_hub_pieces(sextans_engine *h, const float *dBp, int ntiles, int col0, int v0, int v1, hipStream_t s) {
+void launch_hub_pieces(sextans_engine *h, const sextans_engine::PieceTable &t, const float *dBp, int ntiles, int col0,
+                       int v0, int v1, hipStream_t s) {
     float *P = h->d_P + v0 + (int64_t)col0 * h->split_nv;
-    launch_rowgroup<LPR>(h, h->d_vrp, h->d_vend, h->d_ci, h->d_v, true, dBp, P, h->split_nv, P, h->split_nv, v0, v1, ntiles,
-                         1.0f, 0.0f, s);
+    launch_rowgroup<LPR>(h, t.d_vrp, t.d_vend, h->d_ci, h->d_v, true, nullptr, dBp, P, h->split_nv, P, h->split_nv, v0, v1,
+                         ntiles, 1.0f, 0.0f, s);
 }
 }  // namespace
 extern "C" {
@@ -872,8 +916,8 @@ int sextans_reassociated_rows(sextans_handle_t h, int *rows, int capacity, int *
     if (!h->d_rp) return SEXTANS_ERR_STATE;
     SX_HIP(hipSetDevice(h->device));
     if (int rc = ensure_split(h)) return rc;
-    *count = h->nhub;
-    for (int i = 0; i < h->nhub && i < capacity; ++i) rows[i] = h->h_hub_row[(size_t)i];
+    *count = (int)h->h_split_rows.size();
+    for (int i = 0; i < *count && i < capacity; ++i) rows[i] = h->h_split_rows[(size_t)i];
     return SEXTANS_OK;
 }
 
@@ -903,20 +947,25 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     }
     // ... and the window kernel when it starts and ends on wavefront (rows-per-wave) boundaries
     if (use_window && (row_begin % h->win_rw != 0 || (row_end % h->win_rw != 0 && row_end != h->M))) use_window = false;
-    // hub rows of this range: [hub0, hub1) of the hub list, pieces [v0, v1)
+    // long rows of this range: entries [hub0, hub1) of a piece table, pieces [v0, v1).  Whole-matrix calls walk the
+    // table sorted by length (workgroups of equally long pieces), row ranges the one sorted by row.
+    const sextans_engine::PieceTable &pt = whole ? h->by_len : h->by_row;
     int hub0 = 0, hub1 = 0, v0 = 0, v1 = 0;
     if (h->nhub > 0) {
-        hub0 = (int)(std::lower_bound(h->h_hub_row.begin(), h->h_hub_row.end(), row_begin) - h->h_hub_row.begin());
-        hub1 = (int)(std::lower_bound(h->h_hub_row.begin(), h->h_hub_row.end(), row_end) - h->h_hub_row.begin());
-        v0 = h->h_vfirst[(size_t)hub0]; v1 = h->h_vfirst[(size_t)hub1];
+        if (whole) { hub1 = h->nhub; }
+        else {
+            hub0 = (int)(std::lower_bound(pt.h_row.begin(), pt.h_row.end(), row_begin) - pt.h_row.begin());
+            hub1 = (int)(std::lower_bound(pt.h_row.begin(), pt.h_row.end(), row_end) - pt.h_row.begin());
+        }
+        v0 = pt.h_vfirst[(size_t)hub0]; v1 = pt.h_vfirst[(size_t)hub1];
     }
     const bool hubs = hub1 > hub0;
     if (hubs) SX_HIP(hipMemsetAsync(h->d_P, 0, (size_t)h->split_nv * (size_t)N * sizeof(float), s));
     auto fold = [&]() {
         const int64_t tot = (int64_t)(hub1 - hub0) * N;
         auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, h->d_vfirst, h->d_hub_row, h->d_P,
-                               (int64_t)h->split_nv, d_C_out, ldc, hub0, hub1 - hub0, N, row_begin, alpha);
+            hipLaunchKernelGGL(kern, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, pt.d_vfirst, pt.d_row, h->d_P,
+                               (int64_t)h->split_nv, d_C_in, ldc_in, d_C_out, ldc, hub0, hub1 - hub0, N, row_begin, alpha, beta);
         };
         if (h->opt_exact) go(sx::fold_hub_pieces<true>); else go(sx::fold_hub_pieces<false>);
     };
@@ -931,7 +980,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             Prof p(h, &h->ev_kernel, s);
             const int w0 = row_begin / h->win_rw, w1 = (row_end + h->win_rw - 1) / h->win_rw;
             launch_window(h, h->d_Bp, d_C_in, ldc_in, d_C_out, ldc, N / 8, w0, w1, row_begin, alpha, beta, s);
-            if (hubs) { launch_hub_pieces<2>(h, h->d_Bp, N / 8, 0, v0, v1, s); fold(); }
+            if (hubs) { launch_hub_pieces<2>(h, pt, h->d_Bp, N / 8, 0, v0, v1, s); fold(); }
             h->last_kernel = hubs ? "spmm_csr_window+hub_pieces" : "spmm_csr_window";
         }
         SX_HIP(hipGetLastError());
@@ -969,9 +1018,9 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             const int64_t bld = fuse_b ? ldb : 0;
 #define SX_SEG(L)                                                                                                       \
     if (panel_here) launch_panel<L>(h, bsrc, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, bld, blk0, blk1, row_begin);  \
-    else launch_rowgroup<L>(h, h->m_rp, h->m_rp + 1, h->m_ci, h->m_v, false, bp, cin, ldc_in, cout, ldc, row_begin, row_end,  \
+    else launch_rowgroup<L>(h, h->m_rp, h->m_rp + 1, h->m_ci, h->m_v, false, h->d_skip, bp, cin, ldc_in, cout, ldc, row_begin, row_end, \
                             g.ntiles, alpha, beta, s);                                                                   \
-    if (hubs) launch_hub_pieces<L>(h, bp, g.ntiles, g.col0, v0, v1, s);
+    if (hubs) launch_hub_pieces<L>(h, pt, bp, g.ntiles, g.col0, v0, v1, s);
             switch (g.width) {
                 case 32: SX_SEG(8) break;
                 case 16: SX_SEG(4) break;

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
     const int *__restrict__ row_ptr, const int *__restrict__ row_end, const int *__restrict__ col_idx,
     const float *__restrict__ val, const float *__restrict__ Bp, int64_t panel_stride, const float *Cin,
     int64_t ldc_in, float *Cout, int64_t ldc, int row_begin, int M, int ntiles, int nrowblk, float alpha, float beta,
-    int use_xcd_remap) {
+    int use_xcd_remap, const unsigned char *__restrict__ skip) {
+    // skip (may be null): rows whose C is produced by the piece path (long rows taken out of the main matrix).
     // Row r holds entries [row_ptr[r], row_end[r]): row_end = row_ptr + 1 for a CSR matrix; the pieces of hub rows
     // (long-row splitting) come with their own end array and are not contiguous from one piece to the next.
     // Rows [row_begin, M) are processed; C pointers address row_begin as their row 0 (row-range calls
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
         const int e = tid + i * kBlock;
         const int n = e / RB, r = e % RB;
         const int orow = row0 + r;
-        if (orow < M) {
+        if (orow < M && !(skip && skip[orow])) {
             const int64_t lr = (int64_t)(orow - row_begin);
             Cout[lr + (col0 + n) * ldc] = epilogue<EXACT>(alpha, s_c[n * TS + r], beta, Cin[lr + (col0 + n) * ldc_in]);
         }
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
     const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout,
     int64_t ldc, int ntiles, int nblk, float alpha, float beta, int use_xcd_remap, int panel_floats,
-    long long *dbg, int blk_begin, int row_base) {
+    long long *dbg, int blk_begin, int row_base, const unsigned char *__restrict__ skip) {
     // Blocks [blk_begin, blk_begin + nblk) of the plan are processed (row-range calls of the multi-GPU pipeline
     // cut at block boundaries); the C pointers address row `row_base` as their row 0.
     const long long t0 = dbg ? clock64() : 0;   // dbg: optional phase timing (engine option "phase_timing")
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
         const int e = tid + i * kBlock;
         const int n = e / RB, r = e % RB;
         const int orow = row0 + r;
-        if (orow < row1) {
+        if (orow < row1 && !(skip && skip[orow])) {   // skip: rows whose C is produced by the piece path
             const int64_t o = (int64_t)(orow - row_base) + (col0 + n) * ldc;
             Cout[o] = epilogue<EXACT>(alpha, s_c[n * TS + r], beta, cin[i]);
         }
@@ -513,34 +514,26 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// Long-row splitting (engine option "split_rows"): power-law matrices have hub rows whose strictly sequential
-// accumulation would occupy one 4-lane row group for milliseconds while the chip idles.  Rows longer than
-// the threshold T are taken out of the main matrix (every kernel sees them as empty rows and writes
-// alpha*0 + beta*c_in for them); their entries are cut into pieces of T, the row-group kernel sums the pieces as
-// virtual rows (alpha = 1, beta = 0) into a scratch matrix P, and this kernel folds the pieces of every hub IN
-// ORDER and adds alpha * sum to what the main kernel wrote.  Rows that are not hubs stay bit-identical to
-// cpu_spmm_CSR; a hub's sum is re-associated (pieces instead of one chain): within the stated 1e-4 bound.
-// One thread per (hub, column).
+// Piece path for long rows (engine options "bucket_rows" / "split_rows").  Long rows are taken out of the main
+// matrix (the main kernels see them as empty and, told by `skip`, do not write their C); their entries form
+// pieces -- the whole row (bucketed rows) or chunks of T entries (hub rows of power-law matrices) -- which the
+// row-group kernel sums as virtual rows (alpha = 1, beta = 0) into the scratch matrix P; this kernel folds the
+// pieces of each long row IN ORDER and applies the epilogue from C_in.  A one-piece row is bit-identical to
+// cpu_spmm_CSR; a split row's sum is re-associated (within the stated 1e-4 bound).  One thread per (row, column).
 // ------------------------------------------------------------------------------------------------
 template <bool EXACT>
 __global__ __launch_bounds__(kBlock) void fold_hub_pieces(const int *__restrict__ vfirst, const int *__restrict__ hub_row,
-                                                          const float *__restrict__ P, int64_t ldp, float *Cout,
-                                                          int64_t ldc, int hub_begin, int nhub, int N, int row_base,
-                                                          float alpha) {
+                                                          const float *__restrict__ P, int64_t ldp, const float *Cin,
+                                                          int64_t ldc_in, float *Cout, int64_t ldc, int hub_begin, int nhub,
+                                                          int N, int row_base, float alpha, float beta) {
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= (int64_t)nhub * N) return;
     const int k = hub_begin + (int)(t % nhub), n = (int)(t / nhub);
     const int v0 = vfirst[k], v1 = vfirst[k + 1];
     float acc = P[(int64_t)v0 + n * ldp];
     for (int v = v0 + 1; v < v1; ++v) acc = acc + P[(int64_t)v + n * ldp];
-    const int64_t o = (int64_t)(hub_row[k] - row_base) + n * ldc;
-    const float base = Cout[o];            // (alpha * 0) + (beta * c_in), written by the main kernel
-    if constexpr (EXACT) {
-        const float t0 = alpha * acc;
-        Cout[o] = t0 + base;
-    } else {
-        Cout[o] = __builtin_fmaf(alpha, acc, base);
-    }
+    const int64_t r = (int64_t)(hub_row[k] - row_base);
+    Cout[r + n * ldc] = epilogue<EXACT>(alpha, acc, beta, Cin[r + n * ldc_in]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -36,7 +36,8 @@ template <bool EXACT, int UNROLL>
 __global__ __launch_bounds__(kWinWaves * 64, 4) void spmm_csr_window(
     const u32x2 *__restrict__ stream, const int *__restrict__ wave_step0, const float *__restrict__ Bp,
     int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc, int M, int RW,
-    int wave_begin, int wave_end, int nwg_per_tile, int row_base, float alpha, float beta) {
+    int wave_begin, int wave_end, int nwg_per_tile, int row_base, float alpha, float beta,
+    const unsigned char *__restrict__ skip) {
     extern __shared__ __attribute__((aligned(16))) float lds_acc[];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(kWinWaves * 64, 4) void spmm_csr_window(
     const int nrows = min(RW, M - row0);
     const int64_t col0 = (int64_t)tile * kWinNT;
     for (int r = lane; r < nrows; r += 64) {
+        if (skip && skip[row0 + r]) continue;   // this row's C comes from the piece path (long rows)
         const f32x4 lo = *reinterpret_cast<const f32x4 *>(acc + r * kWinNT);
         const f32x4 hi = *reinterpret_cast<const f32x4 *>(acc + r * kWinNT + 4);
         const float a8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};

@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 
 def _set(engine, **opts):
     d = dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0, panel_min_reuse_x100=400, fuse_b=1,
-             split_rows=0, window_rows=319, window_cols=65536, window_unroll=8)
+             split_rows=0, bucket_rows=0, window_rows=319, window_cols=65536, window_unroll=8)
     d.update(opts)
     for k, v in d.items():
         engine.set_option(k, v)

@@ -28,7 +28,8 @@ def test_nccl_allgather_paths_single_rank(engine, oracle):
         C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
         want = C0.copy()
         oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
-        engine.set_option("kernel", 0)
+        for k, val in dict(kernel=0, split_rows=0, bucket_rows=0).items():
+            engine.set_option(k, val)
         engine.set_matrix_csr(M, K, rp, ci, v)
         dB = torch.from_numpy(B).cuda(); dCin = torch.from_numpy(C0).cuda(); dC = torch.zeros(M * N, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
@@ -94,7 +95,7 @@ def test_native_dist_spmm_single_rank(engine, oracle, sx):
             C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
             want = C0.copy()
             oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
-            for k, val in dict(kernel=0, lanes_per_row=4, exact=1, split_rows=0).items():
+            for k, val in dict(kernel=0, lanes_per_row=4, exact=1, split_rows=0, bucket_rows=0).items():
                 engine.set_option(k, val)
             engine.set_matrix_csr(M, K, rp, ci, v)
             dB = torch.from_numpy(B).cuda(); dCin = torch.from_numpy(C0).cuda()

@@ -61,7 +61,7 @@ def test_structure_sweep(engine, oracle, seed, kind, M, K, mean, N, lpr, min_reu
     # from the caller's column-major B (fuse_b 1, the default for small matrices)
     for kernel, fuse_b in ((1, 1), (2, 0), (2, 1)):
         for k, val in dict(lanes_per_row=lpr, stage_a=1, xcd_remap=1, exact=1, kernel=kernel, fuse_b=fuse_b,
-                           panel_min_reuse_x100=min_reuse, split_rows=0).items():
+                           panel_min_reuse_x100=min_reuse, split_rows=0, bucket_rows=int(rs.choice([0, -1]))).items():
             engine.set_option(k, val)
         engine.set_matrix_csr(M, K, rp, ci, v)
         out = C0.copy()

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def _defaults(engine, **opts):
     d = dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0, panel_min_reuse_x100=400, fuse_b=1,
-             split_rows=-1, window_rows=319, window_cols=65536, window_unroll=8)
+             split_rows=-1, bucket_rows=-1, window_rows=319, window_cols=65536, window_unroll=8)
     d.update(opts)
     for k, v in d.items():
         engine.set_option(k, v)
@@ -53,17 +53,25 @@ def test_power_law_default_options(engine, oracle, kernel, N):
     engine.set_matrix_csr(M, K, rp, ci, v)
     hubs = engine.reassociated_rows()
     assert np.array_equal(hubs, expect) and engine.get_stat("split_threshold") == T
+    L0 = max(32, 2 * (int(rp[-1]) // M))
+    assert engine.get_stat("bucket_threshold") == L0 and engine.get_stat("piece_path_rows") == (lens > L0).sum() > 10 * len(hubs)
     out = C0.copy()
     engine.spmm(N, ALPHA, B, BETA, out, rp_time=2)
     assert engine.last_kernel().endswith("+hub_pieces")
     if kernel == 3:
         assert engine.last_kernel() == "spmm_csr_window+hub_pieces"
     _check(out, want, M, N, rp, ci, v, B, C0, hubs, ALPHA, BETA)
-    # strict order on request: no row is split, everything bit-identical (and slow for the hubs)
+    # strict order on request: no row is split, everything bit-identical (and slow for the hubs); the long rows
+    # still take the piece path, one piece each
     _defaults(engine, kernel=kernel, split_rows=0)
     out = C0.copy()
     engine.spmm(N, ALPHA, B, BETA, out)
-    assert len(engine.reassociated_rows()) == 0 and "+hub" not in engine.last_kernel()
+    assert len(engine.reassociated_rows()) == 0 and engine.last_kernel().endswith("+hub_pieces")
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    _defaults(engine, kernel=kernel, split_rows=0, bucket_rows=0)          # ... or nothing leaves the main kernel
+    out = C0.copy()
+    engine.spmm(N, ALPHA, B, BETA, out)
+    assert "+hub" not in engine.last_kernel() and engine.get_stat("piece_path_rows") == 0
     assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
     _defaults(engine)
 
@@ -95,7 +103,7 @@ def test_fem_with_hub_rows_keeps_the_panel_kernel(engine, oracle):
     alpha, beta = np.float32(-1.5), np.float32(0.75)
     want = C0.copy()
     oracle.spmm(M, N, K, alpha, rp, ci, v, B, beta, want)
-    _defaults(engine)
+    _defaults(engine, bucket_rows=0)
     engine.set_matrix_csr(M, K, rp, ci, v)
     assert list(engine.reassociated_rows()) == hub_at
     out = C0.copy()

@@ -19,7 +19,8 @@ MANIFEST = json.load(open(os.path.join(CASES, "manifest.json")))
 
 def run(engine, M, K, rp, ci, v, N, alpha, B, beta, C0, **opts):
     defaults = dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0, panel_min_reuse_x100=400, fuse_b=1,
-                    split_rows=0)      # 0 = strict cpu_spmm_CSR order for every row (the default, -1, splits hub rows)
+                    split_rows=0, bucket_rows=0)   # strict: no row leaves the main kernel (defaults are -1 = chosen from
+                                                   # the matrix; tests/test_skew_gpu.py covers them)
     defaults.update(opts)
     for k, val in defaults.items():
         engine.set_option(k, val)
@@ -281,7 +282,7 @@ def test_rp_time_repeats_read_same_c_in(engine, oracle):
     C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
     want = C0.copy()
     oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
-    for k, val in dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0).items():
+    for k, val in dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0, split_rows=0, bucket_rows=0).items():
         engine.set_option(k, val)
     engine.set_matrix_csr(M, K, rp, ci, v)
     out = C0.copy()
@@ -318,7 +319,7 @@ def test_device_resident_strided_and_aliased(engine, oracle):
     oracle.spmm(M, N, K, ALPHA, rp, ci, v, Bc, BETA, want)
     dB = torch.from_numpy(Bfull).cuda()
     dC = torch.from_numpy(Cfull).cuda()
-    for k, val in dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0).items():
+    for k, val in dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=0, split_rows=0, bucket_rows=0).items():
         engine.set_option(k, val)
     engine.set_matrix_csr(M, K, rp, ci, v)
     st = torch.cuda.current_stream().cuda_stream

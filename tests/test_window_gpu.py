@@ -11,7 +11,7 @@ from util import ALPHA, BETA, NASA, bits_equal, random_csr
 pytestmark = pytest.mark.gpu
 
 DEFAULTS = dict(lanes_per_row=4, stage_a=1, xcd_remap=1, exact=1, kernel=3, panel_min_reuse_x100=400, fuse_b=1,
-                split_rows=0, window_rows=319, window_cols=65536, window_unroll=8)
+                split_rows=0, bucket_rows=0, window_rows=319, window_cols=65536, window_unroll=8)
 
 
 def run(engine, M, K, rp, ci, v, N, alpha, B, beta, C0, rp_time=1, **opts):
