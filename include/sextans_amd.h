@@ -234,12 +234,14 @@ int sextans_destroy(sextans_handle_t h);
  * "lanes_per_row"
  * (2/4/8, N-tile = 4*lanes), "stage_a" (0/1 stage the CSR stream through LDS), "xcd_remap"
  * (0/1), "exact" (1 = no FMA, reference rounding; 0 = allow FMA), "profile" (0/1 hipEvent
- * per-kernel timing), "phase_timing" (0/1, see sextans_phase_timing_read), "split_rows" (hub rows of power-law
- * matrices: rows longer than T non-zeros are summed in parallel pieces of T entries which are then folded in
- * order -- their sums are re-associated, so THOSE rows meet the stated 1e-4 tolerance instead of bit identity
- * (sextans_reassociated_rows lists them); every other row stays bit-identical, whichever kernel runs.
- * T > 0: explicit threshold; 0: never split (strict cpu_spmm_CSR order for every row); -1 (default): T chosen
- * from the matrix, max(512, nnz / 16384) -- no row is split in matrices without hubs), "fuse_b" (1 = the panel kernel may stage B straight from column-major B when B is <= 16 MiB and every row block has a dictionary, saving the
+ * per-kernel timing), "phase_timing" (0/1, see sextans_phase_timing_read), "bucket_rows" / "split_rows" (long
+ * rows, the load-balancing the reference gets from dealing rows to PEs by row % 64: rows longer than L0 =
+ * "bucket_rows" leave the main kernel and are processed in a second launch in order of length, still summed in
+ * CSR order = bit-identical; rows longer than T = "split_rows" are cut into pieces of T entries that are summed in
+ * parallel and folded in order -- THOSE rows are re-associated and meet the stated 1e-4 tolerance instead of bit
+ * identity; sextans_reassociated_rows lists them.  Values: > 0 explicit, 0 off, -1 (default) chosen from the
+ * matrix: L0 = max(32, 2 * mean row length), T = 512; matrices without long rows take none of this path),
+ * "fuse_b" (1 = the panel kernel may stage B straight from column-major B when B is <= 16 MiB and every row block has a dictionary, saving the
  * repack launch; default 1), "panel_min_reuse_x100" (a row block uses the LDS panel when
  * nnz >= value/100 * distinct columns; default 400).  Unknown keys -> SEXTANS_ERR_INVALID. */
 int sextans_set_option(sextans_handle_t h, const char *key, int64_t value);

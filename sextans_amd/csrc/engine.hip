@@ -130,7 +130,7 @@ struct sextans_engine {
     int64_t opt_kernel = 0, opt_lpr = 4, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;
     int64_t opt_fuse_b = 1;             // panel kernel may stage from column-major B (small matrices: no repack launch)
     int64_t opt_split_rows = -1;        // > 0: rows longer than this are split (re-associated); 0 = never (strict
-                                        // order); -1 = threshold chosen from the matrix: max(512, nnz / 16384)
+                                        // order); -1 = 512
     int64_t opt_bucket_rows = -1;       // > 0: rows longer than this take the piece path unsplit (still exact); 0 = off;
                                         // -1 = max(32, 2 * mean row length)
     int64_t opt_phase_timing = 0;       // 1: panel kernel accumulates per-phase wave cycles (debug aid)
@@ -743,9 +743,10 @@ struct Seg { int width, col0, ntiles; };
 //     consecutive rows and lives as long as its longest row, so one 100-entry row among 15-entry rows wastes 85 % of
 //     the workgroup; rows above L0 are processed in a second launch in order of length instead.  Regular matrices
 //     (Poisson, FEM, nasa4704) have no such rows and take none of this path.
-//   T ("split_rows"; -1 = max(512, nnz / 16384); 0 = never): one 4-lane row group retires ~10 non-zeros per
-//     microsecond while the chip retires ~50 000, so a row holding more than 1/16384 of the matrix would dominate
-//     the launch on its own: it is cut into pieces of T entries (re-associated).
+//   T ("split_rows"; -1 = 512; 0 = never): the adds of one row are a serial chain and its B rows arrive at best
+//     ~16 per memory round trip, i.e. ~0.1 us per entry: a 400 000-entry hub row would hold one row group for
+//     40 ms.  Rows above T are cut into pieces of T entries (<= 50 us each) that are summed in parallel and folded
+//     in order (re-associated).
 int ensure_split(sextans_engine *h) {
     if (h->split_built_opt == h->opt_split_rows && h->bucket_built_opt == h->opt_bucket_rows) return SEXTANS_OK;
     free_split(h);
@@ -755,7 +756,7 @@ int ensure_split(sextans_engine *h) {
     h->bucket_built_opt = h->opt_bucket_rows;
     if (h->M == 0 || h->nnz == 0) return SEXTANS_OK;
     int64_t T = h->opt_split_rows, L0 = h->opt_bucket_rows;
-    if (T < 0) T = std::max<int64_t>(512, h->nnz / 16384);
+    if (T < 0) T = 512;
     if (L0 < 0) L0 = std::max<int64_t>(32, 2 * (h->nnz / h->M));
     if (T == 0) T = INT64_MAX;                 // never split
     if (L0 == 0) L0 = T;                       // no bucketing: only rows that must be split leave
@@ -904,9 +905,15 @@ namespace {
 template <int LPR>
 void launch_hub_pieces(sextans_engine *h, const sextans_engine::PieceTable &t, const float *dBp, int ntiles, int col0,
                        int v0, int v1, hipStream_t s) {
-    float *P = h->d_P + v0 + (int64_t)col0 * h->split_nv;
-    launch_rowgroup<LPR>(h, t.d_vrp, t.d_vend, h->d_ci, h->d_v, true, nullptr, dBp, P, h->split_nv, P, h->split_nv, v0, v1,
-                         ntiles, 1.0f, 0.0f, s);
+    constexpr int RB = sx::kBlock / LPR;
+    const int nblk = (v1 - v0 + RB - 1) / RB;
+    if (nblk <= 0) return;
+    float *P = h->d_P + (int64_t)col0 * h->split_nv;
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ntiles), dim3(sx::kBlock), 0, s, t.d_vrp, t.d_vend, h->d_ci,
+                           h->d_v, dBp, (int64_t)h->K * 4 * LPR, P, (int64_t)h->split_nv, v0, v1, ntiles);
+    };
+    if (h->opt_exact) go(sx::spmm_csr_pieces<LPR, true>); else go(sx::spmm_csr_pieces<LPR, false>);
 }
 }  // namespace
 extern "C" {
@@ -960,7 +967,6 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         v0 = pt.h_vfirst[(size_t)hub0]; v1 = pt.h_vfirst[(size_t)hub1];
     }
     const bool hubs = hub1 > hub0;
-    if (hubs) SX_HIP(hipMemsetAsync(h->d_P, 0, (size_t)h->split_nv * (size_t)N * sizeof(float), s));
     auto fold = [&]() {
         const int64_t tot = (int64_t)(hub1 - hub0) * N;
         auto go = [&](auto kern) {

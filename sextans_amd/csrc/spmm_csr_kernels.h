@@ -514,6 +514,94 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Piece kernel: one row group (LPR lanes x 4 columns) per piece [vbeg[v], vend[v]) of a long row, raw sums into
+// the scratch matrix P (no epilogue).  Pieces arrive sorted by length, so the row groups of a workgroup finish
+// together; what matters inside a piece is memory-level parallelism, because the adds of one row are a serial
+// chain anyway: every lane fetches 2 entries per batch (one 8-byte load each for columns and values), the
+// 2 * LPR B-row gathers of batch k + 1 are issued before the multiply-adds of batch k (two register sets, loop
+// unrolled by two), and the entries of batch k + 3 are requested before those of batch k + 1 are used.
+// Order inside a piece = CSR order; one lane per output element (exact).
+// ------------------------------------------------------------------------------------------------
+template <int LPR, bool EXACT>
+__global__ __launch_bounds__(kBlock) void spmm_csr_pieces(const int *__restrict__ vbeg, const int *__restrict__ vend,
+                                                          const int *__restrict__ col_idx, const float *__restrict__ val,
+                                                          const float *__restrict__ Bp, int64_t panel_stride, float *P,
+                                                          int64_t ldp, int v_begin, int v_end, int ntiles) {
+    constexpr int NT = 4 * LPR;
+    constexpr int RB = kBlock / LPR;
+    constexpr int BATCH = 2 * LPR;
+    const int blk = (int)(blockIdx.x / (unsigned)ntiles), tile = (int)(blockIdx.x % (unsigned)ntiles);
+    const int tid = threadIdx.x, slot = tid / LPR, q = tid % LPR;
+    const int v = v_begin + blk * RB + slot;
+    int j = 0, jend = 0;
+    if (v < v_end) { j = vbeg[v]; jend = vend[v]; }
+    const float *bq = Bp + (int64_t)tile * panel_stride + 4 * q;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // this lane's two entries of the batch starting at p (clamped inside the piece: never out of bounds; entries
+    // past the end are never multiplied)
+    auto fetch = [&](int p, int2 &c, float2 &a) {
+        const int i0 = min(p + 2 * q, jend - 1), i1 = min(p + 2 * q + 1, jend - 1);
+        c = make_int2(col_idx[max(i0, 0)], col_idx[max(i1, 0)]);
+        a = make_float2(val[max(i0, 0)], val[max(i1, 0)]);
+    };
+    auto gather = [&](const int2 &c, float4 (&b)[BATCH]) {
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int cu = __shfl((u & 1) ? c.y : c.x, u >> 1, LPR);
+            b[u] = *reinterpret_cast<const float4 *>(bq + (int64_t)cu * NT);
+        }
+    };
+    auto macs = [&](const float2 &a, const float4 (&b)[BATCH], int cnt) {
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const float au = __shfl((u & 1) ? a.y : a.x, u >> 1, LPR);
+            if (u < cnt) mac4<EXACT>(acc, au, b[u]);
+        }
+    };
+    if (j < jend) {
+        int2 c0, c1, c2;
+        float2 a0, a1, a2;
+        float4 bA[BATCH], bB[BATCH];
+        fetch(j, c0, a0); fetch(j + BATCH, c1, a1); fetch(j + 2 * BATCH, c2, a2);
+        gather(c0, bA);
+        int pos = j;
+        while (pos < jend) {
+            // batch at pos: rows in bA, values a0; next batch: entries c1/a1
+            gather(c1, bB);
+            { int2 t; float2 ta; fetch(pos + 3 * BATCH, t, ta); macs(a0, bA, jend - pos); c0 = t; a0 = ta; }
+            pos += BATCH;
+            if (pos >= jend) break;
+            // batch at pos: rows in bB, values a1; next batch: entries c2/a2
+            gather(c2, bA);
+            { int2 t; float2 ta; fetch(pos + 3 * BATCH, t, ta); macs(a1, bB, jend - pos); c1 = t; a1 = ta; }
+            pos += BATCH;
+            if (pos >= jend) break;
+            // third phase of the entry rotation: rows in bA, values a2; next batch: entries c0/a0
+            gather(c0, bB);
+            { int2 t; float2 ta; fetch(pos + 3 * BATCH, t, ta); macs(a2, bA, jend - pos); c2 = t; a2 = ta; }
+            pos += BATCH;
+            if (pos >= jend) break;
+            gather(c1, bA);
+            { int2 t; float2 ta; fetch(pos + 3 * BATCH, t, ta); macs(a0, bB, jend - pos); c0 = t; a0 = ta; }
+            pos += BATCH;
+            if (pos >= jend) break;
+            gather(c2, bB);
+            { int2 t; float2 ta; fetch(pos + 3 * BATCH, t, ta); macs(a1, bA, jend - pos); c1 = t; a1 = ta; }
+            pos += BATCH;
+            if (pos >= jend) break;
+            gather(c0, bA);
+            { int2 t; float2 ta; fetch(pos + 3 * BATCH, t, ta); macs(a2, bB, jend - pos); c2 = t; a2 = ta; }
+            pos += BATCH;
+        }
+    }
+    if (v < v_end) {
+        float *o = P + (int64_t)v + (int64_t)(tile * NT + 4 * q) * ldp;
+        o[0] = acc.x; o[ldp] = acc.y; o[2 * ldp] = acc.z; o[3 * ldp] = acc.w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Piece path for long rows (engine options "bucket_rows" / "split_rows").  Long rows are taken out of the main
 // matrix (the main kernels see them as empty and, told by `skip`, do not write their C); their entries form
 // pieces -- the whole row (bucketed rows) or chunks of T entries (hub rows of power-law matrices) -- which the
