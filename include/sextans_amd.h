@@ -240,10 +240,18 @@ int sextans_destroy(sextans_handle_t h);
  * CSR order = bit-identical; rows longer than T = "split_rows" are cut into pieces of T entries that are summed in
  * parallel and folded in order -- THOSE rows are re-associated and meet the stated 1e-4 tolerance instead of bit
  * identity; sextans_reassociated_rows lists them.  Values: > 0 explicit, 0 off, -1 (default) chosen from the
- * matrix: L0 = max(32, 2 * mean row length), T = 512; matrices without long rows take none of this path),
+ * matrix: L0 = max(32, 2 * mean row length), T = max(1024, nnz / 16384); matrices without long rows take none of
+ * this path),
  * "fuse_b" (1 = the panel kernel may stage B straight from column-major B when B is <= 16 MiB and every row block has a dictionary, saving the
  * repack launch; default 1), "panel_min_reuse_x100" (a row block uses the LDS panel when
  * nnz >= value/100 * distinct columns; default 400).  Unknown keys -> SEXTANS_ERR_INVALID. */
+/* "mfma_dense_tiles" / "dense_tile_fill_x100": north_star's "MFMA only where a tile is actually dense".  The engine
+ * always counts the 32x32 tiles of A whose fill reaches dense_tile_fill_x100 % (default 50) -- sextans_get_stat
+ * "dense_tiles", "dense_tile_fraction" (share of the non-zeros in such tiles).  With mfma_dense_tiles = 1 the caller
+ * opts into bf16 for them: those tiles (values rounded to bf16) times bf16(B) run on v_mfma_f32_32x32x16_bf16 with
+ * fp32 accumulation, the rest of A stays on the fp32 CSR kernels, whose epilogue adds the two parts; results then
+ * meet the blocked-ELL tolerance (tests/test_dense_tiles_gpu.py), not bit identity.  Needs N % 32 == 0 and
+ * whole-matrix calls.  Default 0: fp32 everywhere, bit-identical to cpu_spmm_CSR. */
 int sextans_set_option(sextans_handle_t h, const char *key, int64_t value);
 int sextans_get_option(sextans_handle_t h, const char *key, int64_t *value);
 /* Rows of the current matrix whose sums are re-associated under the current "split_rows" setting (ascending);
@@ -253,7 +261,9 @@ int sextans_reassociated_rows(sextans_handle_t h, int *rows, int capacity, int *
 /* Read-only figures about the matrix currently set.  key: "plan_build_s" (host seconds spent so far
  * building packed forms of A -- read back from the device, pack on all cores, upload; outside every timed
  * region like the reference's scheduling/packing, sextans-host.cpp:114-148), "window_padded_entries",
- * "window_state" (0 not evaluated, 1 built, -1 rejected), "panel_fraction", "panel_blocks". */
+ * "window_state" (0 not evaluated, 1 built, -1 rejected), "panel_fraction", "panel_blocks", "piece_path_rows",
+ * "reassociated_rows", "bucket_threshold", "split_threshold", "dense_tiles", "dense_tile_fraction",
+ * "dense_tiles_on_mfma". */
 int sextans_get_stat(sextans_handle_t h, const char *key, double *value);
 
 /* Upload a CSR matrix (host pointers) once; later spmm calls reuse the device copy.  This is

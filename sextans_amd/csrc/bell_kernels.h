@@ -46,6 +46,45 @@ __global__ __launch_bounds__(256) void bell_repack_b(const unsigned short *__res
     dst[t] = *reinterpret_cast<const u32x4 *>(p);
 }
 
+// fp32 column-major K x N (any ldb >= K) -> bf16 (round to nearest even) in fragment order, rows k >= K read as
+// zero: the B operand of the dense-tile path of the CSR dispatcher, where the caller's B is fp32 and K need not
+// be a multiple of 32.  One thread per (kb, ntile, kstep, lane).
+__device__ __forceinline__ unsigned f32_to_bf16_bits(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__global__ __launch_bounds__(256) void bell_repack_b_f32(const float *__restrict__ B, int64_t ldb, int K,
+                                                         u32x4 *__restrict__ dst, int kblocks, int ntiles) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)kblocks * ntiles * 128) return;
+    const int l = (int)t & 63, s = (int)(t >> 6) & 1;
+    const int64_t r = t >> 7;
+    const int nt = (int)(r % ntiles);
+    const int64_t kb = r / ntiles;
+    const int64_t k0 = kb * 32 + 16 * s + 8 * (l >> 5);
+    const float *p = B + (int64_t)(nt * 32 + (l & 31)) * ldb + k0;
+    unsigned h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (k0 + e < K) ? f32_to_bf16_bits(p[e]) : 0u;
+    u32x4 w;
+    w.x = h[0] | (h[1] << 16); w.y = h[2] | (h[3] << 16); w.z = h[4] | (h[5] << 16); w.w = h[6] | (h[7] << 16);
+    dst[t] = w;
+}
+
+// C_out rows [row0, M) of every column = (alpha * 0) + (beta * C_in): the rows below the last full 32-row block
+// row, which the MFMA pass of the dense-tile path does not write.
+__global__ __launch_bounds__(256) void scale_tail_rows(const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc, int row0,
+                                                       int M, int N, float alpha, float beta) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int rows = M - row0;
+    if (t >= (int64_t)rows * N) return;
+    const int r = row0 + (int)(t % rows), n = (int)(t / rows);
+    const float t0 = alpha * 0.0f, t1 = beta * Cin[(int64_t)r + n * ldc_in];
+    Cout[(int64_t)r + n * ldc] = t0 + t1;
+}
+
 // One wavefront = one block row x NSUB*32 columns.  Operand fragments of the next block are in flight
 // while the current block's MFMAs issue.
 template <int NSUB>

@@ -88,6 +88,13 @@ struct sextans_engine {
     int win_state = 0;              // 0 = not evaluated, 1 = built, -1 = rejected (skewed rows / K too large)
     int64_t win_built_rows = -1, win_built_cols = -1;
     double plan_build_s = 0.0;      // host seconds spent building packed forms of A for the current matrix
+    // "MFMA only where a tile is actually dense" (options "mfma_dense_tiles" / "dense_tile_fill_x100"): 32x32 tiles of
+    // the main matrix whose fill reaches the threshold, as a blocked-ELL bf16 side matrix; the CSR kernels keep the rest
+    int dense_mb = 0, dense_W = 0;  // full block rows, ELL width (0 = no dense tile / not extracted)
+    int *d_dense_col = nullptr;
+    void *d_dense_Af = nullptr;
+    int64_t dense_tiles = 0, dense_nnz = 0;
+    int64_t dense_built_mfma = -2, dense_built_fill = -2;
     // blocked-ELL bf16 matrix (MFMA path)
     int bell_M = 0, bell_K = 0, bell_W = 0;
     const int *d_bell_col = nullptr;
@@ -130,7 +137,7 @@ struct sextans_engine {
     int64_t opt_kernel = 0, opt_lpr = 4, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;
     int64_t opt_fuse_b = 1;             // panel kernel may stage from column-major B (small matrices: no repack launch)
     int64_t opt_split_rows = -1;        // > 0: rows longer than this are split (re-associated); 0 = never (strict
-                                        // order); -1 = 512
+                                        // order); -1 = max(1024, nnz / 16384)
     int64_t opt_bucket_rows = -1;       // > 0: rows longer than this take the piece path unsplit (still exact); 0 = off;
                                         // -1 = max(32, 2 * mean row length)
     int64_t opt_phase_timing = 0;       // 1: panel kernel accumulates per-phase wave cycles (debug aid)
@@ -139,6 +146,9 @@ struct sextans_engine {
     int64_t opt_win_cols = 65536;       // columns per K window (x 32 B = 2 MiB of the 8-column panel: half an XCD's L2)
     int64_t opt_win_unroll = 8;         // steps in flight per ring (4 or 8)
     int64_t opt_win_auto = 0;           // 1: "kernel" 0 may pick the window kernel from the fabric-byte model
+    int64_t opt_mfma_dense = 0;         // 1: dense 32x32 tiles run on the bf16 MFMA path (the caller opts into bf16 rounding
+                                        // of those tiles and of B for them); 0: they are only counted (get_stat)
+    int64_t opt_dense_fill_x100 = 50;   // a tile is dense when it holds >= this percentage of its 1024 positions
     // profiling
     std::vector<EventPair> ev_kernel, ev_repack;
     const char *last_kernel = "none";
@@ -190,7 +200,16 @@ void free_bell(sextans_engine *h) {
     h->bell_M = h->bell_K = h->bell_W = 0;
 }
 
+void free_dense(sextans_engine *h) {
+    (void)hipFree(h->d_dense_col); (void)hipFree(h->d_dense_Af);
+    h->d_dense_col = nullptr; h->d_dense_Af = nullptr;
+    h->dense_mb = h->dense_W = 0;
+    h->dense_tiles = h->dense_nnz = 0;
+    h->dense_built_mfma = h->dense_built_fill = -2;
+}
+
 void free_split(sextans_engine *h) {
+    free_dense(h);   // the dense tiles are cut out of the main matrix built here
     for (auto *t : {&h->by_len, &h->by_row}) {
         (void)hipFree(t->d_vrp); (void)hipFree(t->d_vend); (void)hipFree(t->d_vfirst); (void)hipFree(t->d_row);
         *t = sextans_engine::PieceTable();
@@ -627,6 +646,8 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "window_cols")) return &h->opt_win_cols;
     if (!strcmp(key, "window_unroll")) return &h->opt_win_unroll;
     if (!strcmp(key, "window_auto")) return &h->opt_win_auto;
+    if (!strcmp(key, "mfma_dense_tiles")) return &h->opt_mfma_dense;
+    if (!strcmp(key, "dense_tile_fill_x100")) return &h->opt_dense_fill_x100;
     return nullptr;
 }
 
@@ -657,21 +678,6 @@ int sextans_phase_timing_read(sextans_handle_t h, int64_t out[8]) {
     SX_HIP(hipSetDevice(h->device));
     SX_HIP(hipDeviceSynchronize());
     SX_HIP(hipMemcpy(out, h->d_dbg, 64, hipMemcpyDeviceToHost));
-    return SEXTANS_OK;
-}
-
-int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
-    if (!h || !key || !value) return SEXTANS_ERR_INVALID;
-    if (!strcmp(key, "plan_build_s")) *value = h->plan_build_s;
-    else if (!strcmp(key, "window_padded_entries")) *value = (double)h->win_padded;
-    else if (!strcmp(key, "window_state")) *value = (double)h->win_state;
-    else if (!strcmp(key, "reassociated_rows")) *value = (double)h->h_split_rows.size();
-    else if (!strcmp(key, "piece_path_rows")) *value = (double)h->nhub;
-    else if (!strcmp(key, "split_threshold")) *value = (double)h->split_T;
-    else if (!strcmp(key, "bucket_threshold")) *value = (double)h->bucket_L0;
-    else if (!strcmp(key, "panel_fraction")) *value = h->plan_panel_frac;
-    else if (!strcmp(key, "panel_blocks")) *value = (double)h->plan_nblk;
-    else return SEXTANS_ERR_INVALID;
     return SEXTANS_OK;
 }
 
@@ -743,10 +749,12 @@ struct Seg { int width, col0, ntiles; };
 //     consecutive rows and lives as long as its longest row, so one 100-entry row among 15-entry rows wastes 85 % of
 //     the workgroup; rows above L0 are processed in a second launch in order of length instead.  Regular matrices
 //     (Poisson, FEM, nasa4704) have no such rows and take none of this path.
-//   T ("split_rows"; -1 = 512; 0 = never): the adds of one row are a serial chain and its B rows arrive at best
-//     ~16 per memory round trip, i.e. ~0.1 us per entry: a 400 000-entry hub row would hold one row group for
-//     40 ms.  Rows above T are cut into pieces of T entries (<= 50 us each) that are summed in parallel and folded
-//     in order (re-associated).
+//   T ("split_rows"; -1 = max(1024, nnz / 16384); 0 = never): the adds of one row are a serial chain and its B
+//     rows arrive at best ~16 per memory round trip, i.e. ~0.05-0.1 us per entry: a 400 000-entry hub row would hold
+//     one row group for tens of milliseconds.  Rows above T are cut into pieces of T entries that are summed in
+//     parallel and folded in order (re-associated).  Measured on a 1M-row power-law matrix (33 M nnz, longest row
+//     399 302): T = 512 / 1024 / 2021 -> 0.81 / 0.74 / 0.77 ms with 4964 / 2190 / 978 rows re-associated (uniform
+//     matrix of the same size: 0.64 ms), so the larger threshold costs nothing and touches fewer rows.
 int ensure_split(sextans_engine *h) {
     if (h->split_built_opt == h->opt_split_rows && h->bucket_built_opt == h->opt_bucket_rows) return SEXTANS_OK;
     free_split(h);
@@ -756,7 +764,7 @@ int ensure_split(sextans_engine *h) {
     h->bucket_built_opt = h->opt_bucket_rows;
     if (h->M == 0 || h->nnz == 0) return SEXTANS_OK;
     int64_t T = h->opt_split_rows, L0 = h->opt_bucket_rows;
-    if (T < 0) T = 512;
+    if (T < 0) T = std::max<int64_t>(1024, h->nnz / 16384);
     if (L0 < 0) L0 = std::max<int64_t>(32, 2 * (h->nnz / h->M));
     if (T == 0) T = INT64_MAX;                 // never split
     if (L0 == 0) L0 = T;                       // no bucketing: only rows that must be split leave
@@ -831,11 +839,132 @@ int ensure_split(sextans_engine *h) {
     return SEXTANS_OK;
 }
 
+// "MFMA only where a tile is actually dense" (north_star).  Counts the 32x32 tiles of the main matrix whose fill
+// reaches the threshold (always: get_stat "dense_tile_fraction" = share of the non-zeros sitting in such tiles) and,
+// when the caller has opted into bf16 for them ("mfma_dense_tiles" = 1), cuts them out of the main matrix into a
+// blocked-ELL bf16 side matrix for spmm_bell_mfma; the CSR kernels keep the remainder in fp32.  Only full 32-row
+// block rows are searched; at most 256 dense tiles per block row (the densest columns first come first served).
+int ensure_dense(sextans_engine *h) {
+    if (h->dense_built_mfma == h->opt_mfma_dense && h->dense_built_fill == h->opt_dense_fill_x100) return SEXTANS_OK;
+    if (h->dense_W > 0) {   // tiles were cut out under other settings: start again from the matrix as set
+        free_split(h);
+        free_plan(h);
+        free_window(h);
+        if (int rc = ensure_split(h)) return rc;
+    }
+    free_dense(h);
+    h->dense_built_mfma = h->opt_mfma_dense;
+    h->dense_built_fill = h->opt_dense_fill_x100;
+    const int mb = h->M / 32;
+    if (mb == 0 || h->m_nnz == 0) return SEXTANS_OK;
+    const int64_t thr = std::max<int64_t>(1, (h->opt_dense_fill_x100 * 1024 + 99) / 100);
+    if (h->m_nnz < thr) return SEXTANS_OK;
+    PlanTimer timer(h);
+    std::vector<int> rp, ci;
+    std::vector<float> va;
+    if (int rc = read_back_row_ptr(h, rp)) return rc;
+    {   // cheap exit: a block row with fewer than `thr` entries cannot hold a dense tile
+        bool any = false;
+        for (int br = 0; br < mb && !any; ++br) any = (int64_t)rp[(size_t)br * 32 + 32] - rp[(size_t)br * 32] >= thr;
+        if (!any) return SEXTANS_OK;
+    }
+    if (int rc = read_back_entries(h, ci, va)) return rc;
+    // pass 1: dense tile columns per block row
+    std::vector<std::vector<int>> dense((size_t)mb);
+    std::vector<int> cols;
+    int W = 0;
+    for (int br = 0; br < mb; ++br) {
+        const int j0 = rp[(size_t)br * 32], j1 = rp[(size_t)br * 32 + 32];
+        if (j1 - j0 < thr) continue;
+        cols.assign(ci.begin() + j0, ci.begin() + j1);
+        for (int &c : cols) c >>= 5;
+        std::sort(cols.begin(), cols.end());
+        for (size_t a = 0; a < cols.size();) {
+            size_t b = a;
+            while (b < cols.size() && cols[b] == cols[a]) ++b;
+            if ((int64_t)(b - a) >= thr && dense[(size_t)br].size() < 256) {
+                dense[(size_t)br].push_back(cols[a]);
+                h->dense_nnz += (int64_t)(b - a);
+            }
+            a = b;
+        }
+        h->dense_tiles += (int64_t)dense[(size_t)br].size();
+        W = std::max(W, (int)dense[(size_t)br].size());
+    }
+    if (W == 0 || !h->opt_mfma_dense) return SEXTANS_OK;   // nothing to route, or report only
+    // pass 2: blocked-ELL values (fp32 sums of duplicates, rounded to bf16 once) + the remainder as the new main matrix
+    std::vector<int> bcol((size_t)mb * W, -1);
+    std::vector<float> blk((size_t)mb * W * 1024, 0.0f);
+    std::vector<int> mrp((size_t)h->M + 1, 0);
+    size_t w = 0;
+    for (int r = 0; r < h->M; ++r) {
+        const int br = r >> 5;
+        const std::vector<int> *d = br < mb ? &dense[(size_t)br] : nullptr;
+        for (int j = rp[(size_t)r]; j < rp[(size_t)r + 1]; ++j) {
+            int slot = -1;
+            if (d && !d->empty()) {
+                const auto it = std::lower_bound(d->begin(), d->end(), ci[(size_t)j] >> 5);
+                if (it != d->end() && *it == (ci[(size_t)j] >> 5)) slot = (int)(it - d->begin());
+            }
+            if (slot >= 0) {
+                blk[(((size_t)br * W + (size_t)slot) * 32 + (size_t)(r & 31)) * 32 + (size_t)(ci[(size_t)j] & 31)] += va[(size_t)j];
+            } else {
+                ci[w] = ci[(size_t)j]; va[w] = va[(size_t)j]; ++w;
+            }
+        }
+        mrp[(size_t)r + 1] = (int)w;
+    }
+    for (int br = 0; br < mb; ++br)
+        for (size_t sl = 0; sl < dense[(size_t)br].size(); ++sl) bcol[(size_t)br * W + sl] = dense[(size_t)br][sl];
+    std::vector<uint16_t> bval(blk.size());
+    for (size_t i = 0; i < blk.size(); ++i) {
+        uint32_t u;
+        memcpy(&u, &blk[i], 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) { bval[i] = (uint16_t)((u >> 16) | 0x40u); continue; }
+        u += 0x7fffu + ((u >> 16) & 1u);
+        bval[i] = (uint16_t)(u >> 16);
+    }
+    std::vector<float>().swap(blk);
+    ci.resize(w ? w : 1); va.resize(w ? w : 1);
+    // the remainder replaces the main matrix (owned copies; the long-row tables address the ORIGINAL arrays and stay)
+    (void)hipFree(h->d_mrp); (void)hipFree(h->d_mci); (void)hipFree(h->d_mv);
+    h->d_mrp = h->d_mci = nullptr; h->d_mv = nullptr;
+    if (int rc = upload(&h->d_mrp, mrp)) return rc;
+    if (int rc = upload(&h->d_mci, ci)) return rc;
+    if (int rc = upload(&h->d_mv, va)) return rc;
+    h->m_rp = h->d_mrp; h->m_ci = h->d_mci; h->m_v = h->d_mv; h->m_nnz = (int64_t)w;
+    free_plan(h);
+    free_window(h);
+    if (int rc = upload(&h->d_dense_col, bcol)) return rc;
+    uint16_t *d_val = nullptr;
+    SX_HIP(hipMalloc((void **)&d_val, bval.size() * 2));
+    SX_HIP(hipMemcpy(d_val, bval.data(), bval.size() * 2, hipMemcpyHostToDevice));
+    const int64_t nslots = (int64_t)mb * W;
+    SX_HIP(hipMalloc(&h->d_dense_Af, (size_t)nslots * 2048));
+    hipLaunchKernelGGL(sx::bell_repack_a, dim3((unsigned)((nslots * 128 + 255) / 256)), dim3(256), 0, nullptr, d_val,
+                       (sx::u32x4 *)h->d_dense_Af, nslots);
+    SX_HIP(hipDeviceSynchronize());
+    (void)hipFree(d_val);
+    h->dense_mb = mb;
+    h->dense_W = W;
+    return SEXTANS_OK;
+}
+
 // Everything that may allocate or run host-side preprocessing for an N-column SpMM: B-panel workspace,
 // N-tile plan, and (for kernel != 1) the packed row-bucketed form of A.  Idempotent; called by
 // sextans_spmm_device2 and, ahead of the timed region, by sextans_spmm_host.
 int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_panel, bool &use_window) {
     if (int rc = ensure_split(h)) return rc;   // first: the packed forms below are built from the main matrix
+    if (int rc = ensure_dense(h)) return rc;   // ... minus the dense tiles, when the caller routes them to MFMA
+    if (h->dense_W > 0 && N % 32 == 0) {
+        const size_t need = (size_t)((h->K + 31) / 32) * 32 * (size_t)N * 2;
+        if (h->bell_Bf_cap < need) {
+            if (h->d_bell_Bf) SX_HIP(hipFree(h->d_bell_Bf));
+            h->d_bell_Bf = nullptr; h->bell_Bf_cap = 0;
+            SX_HIP(hipMalloc(&h->d_bell_Bf, need));
+            h->bell_Bf_cap = need;
+        }
+    }
     if (h->nhub > 0)
         if (int rc = ensure(&h->d_P, &h->P_cap, (size_t)h->split_nv * (size_t)N)) return rc;
     if (h->Bp_cap < (size_t)h->K * (size_t)N || !h->d_Bp) h->bp_layout = 0;   // new workspace: nothing to reuse
@@ -902,6 +1031,17 @@ int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_
 namespace {
 // Hub rows inside [row_begin, row_end): pieces summed as virtual rows by the row-group kernel from B panels of width
 // 4 * LPR at dBp (ntiles panels), then folded in order into the C the main kernel has already written.
+const char *kernel_name(int main, bool hubs, bool dense) {   // static strings for sextans_last_kernel
+    static const char *names[3][2][2] = {
+        {{"spmm_csr_rowgroup", "spmm_csr_rowgroup+dense_tiles_mfma"},
+         {"spmm_csr_rowgroup+hub_pieces", "spmm_csr_rowgroup+hub_pieces+dense_tiles_mfma"}},
+        {{"spmm_csr_panel", "spmm_csr_panel+dense_tiles_mfma"},
+         {"spmm_csr_panel+hub_pieces", "spmm_csr_panel+hub_pieces+dense_tiles_mfma"}},
+        {{"spmm_csr_window", "spmm_csr_window+dense_tiles_mfma"},
+         {"spmm_csr_window+hub_pieces", "spmm_csr_window+hub_pieces+dense_tiles_mfma"}}};
+    return names[main][hubs ? 1 : 0][dense ? 1 : 0];
+}
+
 template <int LPR>
 void launch_hub_pieces(sextans_engine *h, const sextans_engine::PieceTable &t, const float *dBp, int ntiles, int col0,
                        int v0, int v1, hipStream_t s) {
@@ -917,6 +1057,30 @@ void launch_hub_pieces(sextans_engine *h, const sextans_engine::PieceTable &t, c
 }
 }  // namespace
 extern "C" {
+
+int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
+    if (!h || !key || !value) return SEXTANS_ERR_INVALID;
+    if (h->d_rp) {   // figures about the packed forms refer to the current options: bring the cheap ones up to date
+        SX_HIP(hipSetDevice(h->device));
+        if (int rc = ensure_split(h)) return rc;
+        if (int rc = ensure_dense(h)) return rc;
+    }
+    if (!strcmp(key, "plan_build_s")) *value = h->plan_build_s;
+    else if (!strcmp(key, "window_padded_entries")) *value = (double)h->win_padded;
+    else if (!strcmp(key, "window_state")) *value = (double)h->win_state;
+    else if (!strcmp(key, "reassociated_rows")) *value = (double)h->h_split_rows.size();
+    else if (!strcmp(key, "piece_path_rows")) *value = (double)h->nhub;
+    else if (!strcmp(key, "split_threshold")) *value = (double)h->split_T;
+    else if (!strcmp(key, "bucket_threshold")) *value = (double)h->bucket_L0;
+    else if (!strcmp(key, "dense_tiles")) *value = (double)h->dense_tiles;
+    else if (!strcmp(key, "dense_tile_fraction")) *value = h->m_nnz + (h->dense_W > 0 ? h->dense_nnz : 0) > 0
+        ? (double)h->dense_nnz / (double)(h->m_nnz + (h->dense_W > 0 ? h->dense_nnz : 0)) : 0.0;
+    else if (!strcmp(key, "dense_tiles_on_mfma")) *value = h->dense_W > 0 ? 1.0 : 0.0;
+    else if (!strcmp(key, "panel_fraction")) *value = h->plan_panel_frac;
+    else if (!strcmp(key, "panel_blocks")) *value = (double)h->plan_nblk;
+    else return SEXTANS_ERR_INVALID;
+    return SEXTANS_OK;
+}
 
 int sextans_reassociated_rows(sextans_handle_t h, int *rows, int capacity, int *count) {
     if (!h || !count || capacity < 0 || (capacity > 0 && !rows)) return SEXTANS_ERR_INVALID;
@@ -944,6 +1108,36 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     int W = 0;
     bool use_panel = false, use_window = false;
     if (int rc = prepare(h, N, plan, W, use_panel, use_window)) return rc;
+    if (h->dense_W > 0) {
+        // Dense tiles first, on the matrix cores: C_out = alpha * (A_dense * bf16(B)) + beta * C_in for the full block
+        // rows (and alpha * 0 + beta * C_in below them); the CSR kernels then add alpha * (A_rest * B) on top
+        // (their beta becomes 1, their C_in the partial result): one C pass per kernel, no extra combine launch.
+        if (!whole || (N % 32) != 0) {
+            g_last_error = "mfma_dense_tiles = 1 needs whole-matrix calls and N % 32 == 0";
+            return SEXTANS_ERR_INVALID;
+        }
+        const int kblocks = (h->K + 31) / 32, ntiles = N / 32;
+        const int64_t threads = (int64_t)kblocks * ntiles * 128;
+        hipLaunchKernelGGL(sx::bell_repack_b_f32, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_B, ldb, h->K,
+                           (sx::u32x4 *)h->d_bell_Bf, kblocks, ntiles);
+        const auto *Af = (const sx::bf16x8 *)h->d_dense_Af;
+        const auto *Bf = (const sx::bf16x8 *)h->d_bell_Bf;
+#define SX_BELL(NSUB)                                                                                               \
+    {                                                                                                               \
+        const int64_t waves = (int64_t)h->dense_mb * (ntiles / NSUB);                                               \
+        hipLaunchKernelGGL((sx::spmm_bell_mfma<NSUB>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, h->d_dense_col, \
+                           Af, Bf, d_C_in, ldc_in, d_C_out, ldc, h->dense_mb, h->dense_W, ntiles, alpha, beta);            \
+    }
+        if (ntiles % 4 == 0) SX_BELL(4) else if (ntiles % 2 == 0) SX_BELL(2) else SX_BELL(1)
+#undef SX_BELL
+        const int row0 = h->dense_mb * 32;
+        if (row0 < h->M) {
+            const int64_t tot = (int64_t)(h->M - row0) * N;
+            hipLaunchKernelGGL(sx::scale_tail_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, d_C_in, ldc_in,
+                               d_C_out, ldc, row0, h->M, N, alpha, beta);
+        }
+        beta = 1.0f; d_C_in = d_C_out; ldc_in = ldc;
+    }
     // a row range keeps the panel kernel when it starts and ends on row-block boundaries of the plan
     int blk0 = 0, blk1 = h->plan_nblk;
     if (use_panel && !whole) {
@@ -987,7 +1181,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             const int w0 = row_begin / h->win_rw, w1 = (row_end + h->win_rw - 1) / h->win_rw;
             launch_window(h, h->d_Bp, d_C_in, ldc_in, d_C_out, ldc, N / 8, w0, w1, row_begin, alpha, beta, s);
             if (hubs) { launch_hub_pieces<2>(h, pt, h->d_Bp, N / 8, 0, v0, v1, s); fold(); }
-            h->last_kernel = hubs ? "spmm_csr_window+hub_pieces" : "spmm_csr_window";
+            h->last_kernel = kernel_name(2, hubs, h->dense_W > 0);
         }
         SX_HIP(hipGetLastError());
         return SEXTANS_OK;
@@ -1035,8 +1229,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
 #undef SX_SEG
         }
         if (hubs) fold();
-        h->last_kernel = use_panel ? (hubs ? "spmm_csr_panel+hub_pieces" : "spmm_csr_panel")
-                                   : (hubs ? "spmm_csr_rowgroup+hub_pieces" : "spmm_csr_rowgroup");
+        h->last_kernel = kernel_name(use_panel ? 1 : 0, hubs, h->dense_W > 0);
     }
     SX_HIP(hipGetLastError());
     return SEXTANS_OK;

@@ -41,7 +41,7 @@ def test_power_law_default_options(engine, oracle, kernel, N):
     M = K = 20000
     rp, ci, v = api.gen_powerlaw_host(M, K, 3, 120, 15000, 11)
     lens = np.diff(rp)
-    T = 512
+    T = max(1024, int(rp[-1]) // 16384)
     expect = np.nonzero(lens > T)[0]
     assert len(expect) >= 3 and lens.max() > 5000
     rs = np.random.RandomState(N)
