@@ -247,7 +247,8 @@ int sextans_destroy(sextans_handle_t h);
  * nnz >= value/100 * distinct columns; default 400).  Unknown keys -> SEXTANS_ERR_INVALID. */
 /* "mfma_dense_tiles" / "dense_tile_fill_x100": north_star's "MFMA only where a tile is actually dense".  The engine
  * always counts the 32x32 tiles of A whose fill reaches dense_tile_fill_x100 % (default 50) -- sextans_get_stat
- * "dense_tiles", "dense_tile_fraction" (share of the non-zeros in such tiles).  With mfma_dense_tiles = 1 the caller
+ * "dense_tiles", "dense_tile_fraction" (share of the non-zeros in such tiles; estimated from a sample of up to 512
+ * block rows while mfma_dense_tiles = 0, exact once the tiles are extracted).  With mfma_dense_tiles = 1 the caller
  * opts into bf16 for them: those tiles (values rounded to bf16) times bf16(B) run on v_mfma_f32_32x32x16_bf16 with
  * fp32 accumulation, the rest of A stays on the fp32 CSR kernels, whose epilogue adds the two parts; results then
  * meet the blocked-ELL tolerance (tests/test_dense_tiles_gpu.py), not bit identity.  Needs N % 32 == 0 and

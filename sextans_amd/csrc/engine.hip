@@ -868,6 +868,32 @@ int ensure_dense(sextans_engine *h) {
         for (int br = 0; br < mb && !any; ++br) any = (int64_t)rp[(size_t)br * 32 + 32] - rp[(size_t)br * 32] >= thr;
         if (!any) return SEXTANS_OK;
     }
+    if (!h->opt_mfma_dense) {
+        // report only: estimate from a sample of block rows (a few small copies instead of reading the matrix back)
+        const int nsample = std::min(mb, 512);
+        int64_t tot = 0, in_dense = 0, tiles = 0;
+        std::vector<int> cols;
+        for (int sidx = 0; sidx < nsample; ++sidx) {
+            const int br = (int)((int64_t)sidx * mb / nsample);
+            const int j0 = rp[(size_t)br * 32], j1 = rp[(size_t)br * 32 + 32];
+            tot += j1 - j0;
+            if (j1 - j0 < thr) continue;
+            cols.resize((size_t)(j1 - j0));
+            SX_HIP(hipMemcpy(cols.data(), h->m_ci + j0, sizeof(int) * cols.size(), hipMemcpyDeviceToHost));
+            for (int &c : cols) c >>= 5;
+            std::sort(cols.begin(), cols.end());
+            for (size_t a = 0; a < cols.size();) {
+                size_t b = a;
+                while (b < cols.size() && cols[b] == cols[a]) ++b;
+                if ((int64_t)(b - a) >= thr) { in_dense += (int64_t)(b - a); ++tiles; }
+                a = b;
+            }
+        }
+        // scaled to the whole matrix
+        h->dense_nnz = tot ? (int64_t)((double)in_dense / (double)tot * (double)h->m_nnz) : 0;
+        h->dense_tiles = (int64_t)((double)tiles * (double)mb / (double)nsample);
+        return SEXTANS_OK;
+    }
     if (int rc = read_back_entries(h, ci, va)) return rc;
     // pass 1: dense tile columns per block row
     std::vector<std::vector<int>> dense((size_t)mb);
@@ -891,7 +917,7 @@ int ensure_dense(sextans_engine *h) {
         h->dense_tiles += (int64_t)dense[(size_t)br].size();
         W = std::max(W, (int)dense[(size_t)br].size());
     }
-    if (W == 0 || !h->opt_mfma_dense) return SEXTANS_OK;   // nothing to route, or report only
+    if (W == 0) return SEXTANS_OK;   // nothing to route
     // pass 2: blocked-ELL values (fp32 sums of duplicates, rounded to bf16 once) + the remainder as the new main matrix
     std::vector<int> bcol((size_t)mb * W, -1);
     std::vector<float> blk((size_t)mb * W * 1024, 0.0f);
