@@ -415,7 +415,10 @@ int sextans_mtx_read(const char *path, int format, int *M_out, int *K_out, int *
         for (int64_t i = i0; i < i1; ++i) {
             bool keep, mirror;
             classify(i, keep, mirror);
-            if (keep && (fr[(size_t)i] < 1 || fc[(size_t)i] < 1 || fr[(size_t)i] > M || fc[(size_t)i] > K)) {
+            // the mirrored entry (c, r) of a symmetric file must fit too: on a size line with M != K the reference
+            // writes it past the end of its arrays (sparse_helper.h:155-161); here it is an index error
+            if (keep && (fr[(size_t)i] < 1 || fc[(size_t)i] < 1 || fr[(size_t)i] > M || fc[(size_t)i] > K ||
+                         (mirror && (fc[(size_t)i] > M || fr[(size_t)i] > K)))) {
                 rerr[(size_t)t] = {i, SEXTANS_ERR_INDEX};
                 break;
             }

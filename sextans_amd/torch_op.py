@@ -4,14 +4,52 @@
 
 A: torch.sparse_csr_tensor (fp32 values, int32/int64 indices) on a GPU; B: dense (K, N) fp32; returns a
 dense (M, N) tensor (row-major view of the engine's column-major result, no copy).  N is padded up to a
-multiple of 8 internally (the reference's N-tile granularity, sextans-host.cpp:51).  One cached engine
-per (device, matrix identity); not part of the reference, whose only front end is the CLI.
+multiple of 8 internally (the reference's N-tile granularity, sextans-host.cpp:51).  One cached engine per live
+matrix (keyed on tensor identity + version counters, dropped when the tensors die, at most 8 kept); not part of
+the reference, whose only front end is the CLI.
 """
+import collections
+import weakref
+
 import torch
 
 from . import api
 
-_cache = {}
+_MAX_ENGINES = 8
+_cache = collections.OrderedDict()     # key -> (engine, int32/fp32 arrays the engine reads, weakref to A)
+
+
+def _evict(key):
+    ent = _cache.pop(key, None)
+    if ent is not None:
+        ent[0].close()
+
+
+def _engine_for(A, dev):
+    """One engine per live sparse matrix.  The key holds the identity AND the version counters of A's three
+    tensors, so in-place updates of A get a fresh engine (the packed forms snapshot the values); entries die with
+    the matrix (weakref callback: a freed tensor's address can be reused by a different matrix) and the cache
+    is bounded (LRU), because every entry pins an engine with its device workspaces."""
+    crow, col, val = A.crow_indices(), A.col_indices(), A.values()
+    M, K = A.shape
+    key = (dev, crow.data_ptr(), col.data_ptr(), val.data_ptr(), crow._version, col._version, val._version, M, K,
+           val.numel())
+    ent = _cache.get(key)
+    if ent is not None and ent[2]() is not None:
+        _cache.move_to_end(key)
+        return ent[0]
+    _evict(key)
+    crow32, col32 = crow.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
+    val32 = val.to(torch.float32).contiguous()
+    eng = api.Engine(dev)
+    eng.set_matrix_csr_device(M, K, val32.numel(), crow32.data_ptr(), col32.data_ptr(), val32.data_ptr())
+    # crow_indices()/col_indices()/values() hand out fresh alias objects on every call, so the lifetime that matters is
+    # A's own: when A dies its storage may be reused by a different matrix at the same addresses
+    ref = weakref.ref(A, lambda _r, k=key: _evict(k))
+    _cache[key] = (eng, (crow32, col32, val32), ref)       # keep the converted arrays alive: the engine does not copy
+    while len(_cache) > _MAX_ENGINES:
+        _evict(next(iter(_cache)))
+    return eng
 
 
 def spmm(A, B, alpha=1.0, beta=0.0, C=None):
@@ -23,16 +61,7 @@ def spmm(A, B, alpha=1.0, beta=0.0, C=None):
     N = B.shape[1]
     Np = api.round_up_n(N)
     dev = A.device.index or 0
-    crow, col, val = A.crow_indices(), A.col_indices(), A.values()
-    key = (dev, crow.data_ptr(), col.data_ptr(), val.data_ptr(), M, K, val.numel())
-    ent = _cache.get(key)
-    if ent is None:
-        crow32, col32 = crow.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
-        val32 = val.to(torch.float32).contiguous()
-        eng = api.Engine(dev)
-        eng.set_matrix_csr_device(M, K, val32.numel(), crow32.data_ptr(), col32.data_ptr(), val32.data_ptr())
-        ent = _cache[key] = (eng, crow32, col32, val32)      # keep the arrays alive: the engine does not copy
-    eng = ent[0]
+    eng = _engine_for(A, dev)
     # column-major K x Np = the transpose of a row-major (Np, K) tensor
     Bcm = torch.zeros((Np, K), dtype=torch.float32, device=B.device)
     Bcm[:N] = B.to(torch.float32).t()

@@ -136,3 +136,20 @@ def test_cli_usage_and_errors(sx):
     assert "N = 16" in r.stdout and "alpha = 0.85" in r.stdout and "beta = -2.06" in r.stdout
     r = subprocess.run([cli, "/nonexistent.mtx", "13", "3", "1.5", "-0.25"], capture_output=True, text=True)
     assert "N = 16" in r.stdout and "alpha = 1.5" in r.stdout and "beta = -0.25" in r.stdout
+
+
+def test_symmetric_file_with_rectangular_size_line(sx, tmp_path):
+    """a `symmetric` banner over an M != K size line.  The reference mirrors (c, r) into arrays sized for
+    (r, c) (sparse_helper.h:155-161, undefined behaviour); here the mirrored entry is range-checked like any other."""
+    from sextans_amd import api
+    bad = tmp_path / "sym_rect_bad.mtx"
+    bad.write_text("%%MatrixMarket matrix coordinate real symmetric\n2 5 2\n1 1 3.0\n1 5 1.0\n")
+    with pytest.raises(api.SextansError) as e:
+        api.read_suitsparse_matrix(str(bad))
+    assert e.value.code == 6                                       # SEXTANS_ERR_INDEX: (5, 1) does not exist in a 2 x 5 matrix
+    with pytest.raises(api.SextansError):
+        api.read_suitsparse_matrix(str(bad), fmt=api.FMT_CSC)
+    ok = tmp_path / "sym_rect_ok.mtx"                              # every mirrored entry fits: loads, mirrored
+    ok.write_text("%%MatrixMarket matrix coordinate real symmetric\n2 5 2\n1 1 3.0\n2 1 4.0\n")
+    rp, ci, v, M, K, nnz = api.read_suitsparse_matrix(str(ok))
+    assert (M, K, nnz) == (2, 5, 3) and list(rp) == [0, 2, 3] and list(ci) == [0, 1, 0] and list(v) == [3.0, 4.0, 4.0]

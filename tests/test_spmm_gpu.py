@@ -394,3 +394,34 @@ def test_cli_canonical_run(sx):
     r = subprocess.run([sx.api.CLI_PATH, NASA, "100", "5", "1.25", "0.5"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "N = 104" in r.stdout and "Success!" in r.stdout
     assert "num_mismatch = 0" in r.stdout
+
+
+def test_invalid_csr_is_rejected_not_dereferenced(engine, sx):
+    """column indices outside [0, K) and non-monotonic row pointers must come back as error codes --
+    the plan builders index host arrays of size K with them and the kernels gather B rows by them."""
+    import torch
+    from sextans_amd import api
+    rp = np.array([0, 2, 3], np.int32)
+    good_ci, v = np.array([0, 4, 2], np.int32), np.ones(3, np.float32)
+    for bad_ci in (np.array([0, 5, 2], np.int32), np.array([0, -1, 2], np.int32)):
+        with pytest.raises(api.SextansError) as e:
+            engine.set_matrix_csr(2, 5, rp, bad_ci, v)
+        assert e.value.code == 6                                   # SEXTANS_ERR_INDEX
+    with pytest.raises(api.SextansError) as e:
+        engine.set_matrix_csr(3, 5, np.array([0, 2, 1, 3], np.int32), good_ci, v)
+    assert e.value.code == 9                                       # SEXTANS_ERR_INVALID: row_ptr goes backwards
+    # device-resident matrices are looked at when a packed form is built from them
+    d_rp = torch.tensor([0, 2, 3], dtype=torch.int32, device="cuda")
+    d_ci = torch.tensor([0, 700, 2], dtype=torch.int32, device="cuda")
+    d_v = torch.ones(3, device="cuda")
+    for k, val in dict(kernel=2, split_rows=0, bucket_rows=0).items():
+        engine.set_option(k, val)
+    try:
+        engine.set_matrix_csr_device(2, 5, 3, d_rp.data_ptr(), d_ci.data_ptr(), d_v.data_ptr())
+        B = torch.ones(5 * 8, device="cuda"); C = torch.zeros(2 * 8, device="cuda")
+        with pytest.raises(api.SextansError) as e:
+            engine.spmm_device(8, 1.0, B.data_ptr(), 5, 0.0, C.data_ptr(), C.data_ptr(), 2, torch.cuda.current_stream().cuda_stream)
+        assert e.value.code == 6
+    finally:
+        engine.set_option("kernel", 0)
+        engine.set_matrix_csr(2, 5, rp, good_ci, v)

@@ -30,3 +30,43 @@ def test_sparse_csr_op_matches_oracle(sx, oracle):
     ref2 = np.zeros(M * Np, np.float32)
     oracle.spmm(M, Np, K, np.float32(1), rp, ci, v, np.ascontiguousarray(Bp.T).reshape(-1), np.float32(0), ref2)
     assert np.array_equal(np.ascontiguousarray(got2).view(np.uint32), np.ascontiguousarray(ref2.reshape(Np, M).T[:, :N]).view(np.uint32))
+
+
+def test_engine_cache_follows_the_matrix(sx, oracle):
+    """the engine cache must not hand a stale engine to a different matrix that reuses the addresses of
+    a dead one, must notice in-place updates of A's values, and must stay bounded."""
+    import gc
+    import torch
+    from sextans_amd import torch_op
+    rs = np.random.RandomState(9)
+    M, K, N = 300, 200, 8
+
+    def make(seed):
+        r = np.random.RandomState(seed)
+        rp, ci, v = random_csr(r, M, K, 6, empty_frac=0.0)
+        A = torch.sparse_csr_tensor(torch.from_numpy(rp.astype(np.int64)), torch.from_numpy(ci.astype(np.int64)),
+                                    torch.from_numpy(v), size=(M, K)).cuda()
+        return A, rp, ci, v
+
+    def check(A, rp, ci, v, B):
+        want = np.zeros(M * N, np.float32)
+        oracle.spmm(M, N, K, np.float32(1), rp, ci, v, np.ascontiguousarray(B.T).reshape(-1), np.float32(0), want)
+        got = torch_op.spmm(A, torch.from_numpy(B).cuda()).cpu().numpy()
+        assert np.array_equal(np.ascontiguousarray(got).view(np.uint32), np.ascontiguousarray(want.reshape(N, M).T).view(np.uint32))
+
+    B = rs.uniform(-1, 1, (K, N)).astype(np.float32)
+    torch_op._cache.clear()
+    for seed in range(12):                       # same shapes: freed storage is reused, results must follow the data
+        A, rp, ci, v = make(seed)
+        check(A, rp, ci, v, B)
+        del A
+        gc.collect()
+    assert len(torch_op._cache) <= 1             # entries died with their matrices
+    A, rp, ci, v = make(99)
+    check(A, rp, ci, v, B)
+    A.values().mul_(2.0)                         # in-place update: version counter changes, fresh engine
+    check(A, rp, ci, (v * np.float32(2.0)).astype(np.float32), B)
+    keep = [make(100 + i) for i in range(torch_op._MAX_ENGINES + 3)]
+    for a in keep:
+        check(*a, B)
+    assert len(torch_op._cache) <= torch_op._MAX_ENGINES
