@@ -154,4 +154,63 @@ __global__ __launch_bounds__(256) void spmm_bell_mfma(
     }
 }
 
+// Full-width variant for N = 256: one wavefront = one block row x all 8 column tiles, so every A block is
+// requested ONCE (spmm_bell_mfma<4> runs two wavefronts per block row, each fetching the block: the second fetch
+// hits L1/L2 but is still a line request, and line requests are what bounds this kernel).  The 32x256
+// accumulator is 128 registers; operands are pipelined per 16-wide k-step (A fragment + 8 B fragments = 36
+// registers in flight while the previous k-step's 8 MFMAs issue): ~210 registers, 2 wavefronts per SIMD.
+__global__ __launch_bounds__(256, 2) void spmm_bell_mfma_n256(
+    const int *__restrict__ block_col, const bf16x8 *__restrict__ Af, const bf16x8 *__restrict__ Bf,
+    const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc, int mblocks, int ell_width, float alpha, float beta) {
+    constexpr int NT8 = 8;
+    const int lane = threadIdx.x & 63;
+    const int br = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (br >= mblocks) return;
+    f32x16 acc[NT8];
+#pragma unroll
+    for (int t = 0; t < NT8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int *bc_row = block_col + (int64_t)br * ell_width;
+    const bf16x8 *a_row = Af + (int64_t)br * ell_width * 128 + lane;
+    // k-step index q = 2 * slot + ks; fragments of k-step q: A at a_row[slot * 128 + ks * 64], B tile t at
+    // Bf[(bc * 8 + t) * 128 + ks * 64 + lane]
+    bf16x8 a_c, b_c[NT8], a_n, b_n[NT8];
+    const int nq = 2 * ell_width;
+    auto load = [&](int q, bf16x8 &a, bf16x8 (&b)[NT8]) -> int {
+        const int slot = q >> 1, ks = q & 1;
+        const int bc = bc_row[slot];
+        if (bc >= 0) {
+            a = a_row[(int64_t)slot * 128 + ks * 64];
+            const bf16x8 *bp = Bf + ((int64_t)bc * NT8) * 128 + ks * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < NT8; ++t) b[t] = bp[t * 128];
+        }
+        return bc;
+    };
+    int bc_c = nq > 0 ? load(0, a_c, b_c) : -1;
+    for (int q = 0; q < nq; ++q) {
+        const int bc_n = q + 1 < nq ? load(q + 1, a_n, b_n) : -1;
+        if (bc_c >= 0) {
+#pragma unroll
+            for (int t = 0; t < NT8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_c[t], a_c, acc[t], 0, 0, 0);
+        }
+        bc_c = bc_n;
+        a_c = a_n;
+#pragma unroll
+        for (int t = 0; t < NT8; ++t) b_c[t] = b_n[t];
+    }
+    const int64_t m = (int64_t)br * 32 + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < NT8; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float t0 = alpha * acc[t][r];
+            const float t1 = beta * Cin[m + (int64_t)(t * 32 + nl) * ldc_in];
+            Cout[m + (int64_t)(t * 32 + nl) * ldc] = t0 + t1;
+        }
+    }
+}
+
 }  // namespace sx

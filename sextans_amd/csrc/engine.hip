@@ -146,6 +146,7 @@ struct sextans_engine {
     int64_t opt_win_cols = 65536;       // columns per K window (x 32 B = 2 MiB of the 8-column panel: half an XCD's L2)
     int64_t opt_win_unroll = 8;         // steps in flight per ring (4 or 8)
     int64_t opt_win_auto = 0;           // 1: "kernel" 0 may pick the window kernel from the fabric-byte model
+    int64_t opt_bell_wide = 0;          // 1: N = 256 runs one wavefront per block row over all 8 column tiles
     int64_t opt_mfma_dense = 0;         // 1: dense 32x32 tiles run on the bf16 MFMA path (the caller opts into bf16 rounding
                                         // of those tiles and of B for them); 0: they are only counted (get_stat)
     int64_t opt_dense_fill_x100 = 50;   // a tile is dense when it holds >= this percentage of its 1024 positions
@@ -646,6 +647,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "window_cols")) return &h->opt_win_cols;
     if (!strcmp(key, "window_unroll")) return &h->opt_win_unroll;
     if (!strcmp(key, "window_auto")) return &h->opt_win_auto;
+    if (!strcmp(key, "bell_wide")) return &h->opt_bell_wide;
     if (!strcmp(key, "mfma_dense_tiles")) return &h->opt_mfma_dense;
     if (!strcmp(key, "dense_tile_fill_x100")) return &h->opt_dense_fill_x100;
     return nullptr;
@@ -1522,7 +1524,10 @@ int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint1
                            h->d_bell_col, Af, Bf, d_C_in, ldc, d_C_out, ldc, mblocks, h->bell_W, ntiles,    \
                            alpha, beta);                                                                      \
     }
-        if (ntiles % 4 == 0) SX_BELL(4) else if (ntiles % 2 == 0) SX_BELL(2) else SX_BELL(1)
+        if (ntiles == 8 && h->opt_bell_wide) {
+            hipLaunchKernelGGL(sx::spmm_bell_mfma_n256, dim3((unsigned)((mblocks + 3) / 4)), dim3(256), 0, s, h->d_bell_col, Af,
+                               Bf, d_C_in, ldc, d_C_out, ldc, mblocks, h->bell_W, alpha, beta);
+        } else if (ntiles % 4 == 0) SX_BELL(4) else if (ntiles % 2 == 0) SX_BELL(2) else SX_BELL(1)
 #undef SX_BELL
         h->last_kernel = "spmm_bell_mfma";
     }

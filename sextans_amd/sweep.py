@@ -72,9 +72,78 @@ def sweep(paths, n_values, rp_time=20, alpha=0.85, beta=-2.06, check=False, devi
     return records
 
 
+SYNTH_HELP = """synthetic classes (generated in HBM by csrc/synth.hip, seeded, same bits on host and device):
+  synth:uniform:M:mean[:K]          Poisson(mean) non-zeros per row, uniform columns (BASELINE config 4 = synth:uniform:4000000:40)
+  synth:banded:M:mean:bw            the same inside the band |row - col| <= bw (locality)
+  synth:fem3d:nx:ny:nz:dof          27-point node stencil with dof unknowns per node (SuiteSparse FEM class)
+  synth:powerlaw:M:xmin:tail_x100:maxlen   P(len >= x) = (xmin/x)^(tail/100): hub rows over a mass of short rows"""
+
+
+def _synth(spec, device):
+    f = spec.split(":")
+    kind, a = f[1], [int(x) for x in f[2:] if "." not in x]
+    if kind == "uniform":
+        M, K = a[0], (a[2] if len(a) > 2 else a[0])
+        return (M, K) + api.gen_csr_device(device, M, K, float(f[3]), 4)
+    if kind == "banded":
+        M = K = a[0]
+        return (M, K) + api.gen_csr_device(device, M, K, float(f[3]), 4, bandwidth=a[2])
+    if kind == "fem3d":
+        M = K = a[0] * a[1] * a[2] * a[3]
+        return (M, K) + api.gen_fem3d_device(device, a[0], a[1], a[2], a[3], 3)
+    if kind == "powerlaw":
+        M = K = a[0]
+        return (M, K) + api.gen_powerlaw_device(device, M, K, a[1], a[2], a[3], 7)
+    raise ValueError("unknown synthetic class: " + spec)
+
+
+def sweep_synthetic(specs, n_values, steps=20, alpha=0.85, beta=-2.06, device=0, options=None, out=sys.stdout):
+    """The same record per (matrix, N) for matrices generated directly in HBM: device-resident B/C (seeded U(-1,1)),
+    steady-state step time (repack + kernels) over `steps` back-to-back steps."""
+    import torch
+    records = []
+    dev = torch.device("cuda", device)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for spec in specs:
+        M, K, p, i, v, nnz = _synth(spec, device)
+        with api.Engine(device) as eng:
+            for k, val in (options or {}).items():
+                eng.set_option(k, val)
+            eng.set_matrix_csr_device(M, K, nnz, p, i, v)
+            for n in n_values:
+                N = api.round_up_n(n)
+                B = torch.empty(K * N, device=dev); Cin = torch.empty(M * N, device=dev); Cout = torch.empty(M * N, device=dev)
+                api.gen_uniform_device(device, B.data_ptr(), K * N, 41, st)
+                api.gen_uniform_device(device, Cin.data_ptr(), M * N, 42, st)
+                f = lambda: eng.spmm_device(N, alpha, B.data_ptr(), K, beta, Cin.data_ptr(), Cout.data_ptr(), M, st)
+                for _ in range(3):
+                    f()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    f()
+                torch.cuda.synchronize(dev)
+                sec = (time.perf_counter() - t0) / steps
+                by = 8 * nnz + 4 * (M + 1) + 4 * K * N + 8 * M * N
+                rec = {"matrix": spec, "M": M, "K": K, "nnz": nnz, "N": N, "kernel": eng.last_kernel(),
+                       "ms": round(sec * 1e3, 5), "gflops": round(api.gflops(M, N, nnz, sec), 1),
+                       "alg_gbs": round(by / sec / 1e9, 1), "roofline_frac": round(by / sec / 1e9 / HBM_PEAK_GBS, 4),
+                       "piece_path_rows": int(eng.get_stat("piece_path_rows")),
+                       "reassociated_rows": int(eng.get_stat("reassociated_rows")),
+                       "dense_tile_fraction": round(eng.get_stat("dense_tile_fraction"), 4),
+                       "plan_build_s": round(eng.get_stat("plan_build_s"), 3)}
+                records.append(rec)
+                print(json.dumps(rec), file=out, flush=True)
+                del B, Cin, Cout
+        for q in (p, i, v):
+            api.device_free(device, q)
+        torch.cuda.empty_cache()
+    return records
+
+
 def main(argv=None):
-    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("paths", nargs="+", help=".mtx files or globs")
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter, epilog=SYNTH_HELP)
+    ap.add_argument("paths", nargs="+", help=".mtx files or globs, and/or synth:<class>:... specs (see below)")
     ap.add_argument("--n", default="8,16,32,64,128", help="comma-separated N values (rounded up to 8)")
     ap.add_argument("--rp", type=int, default=20, help="rp_time repeats per measurement")
     ap.add_argument("--alpha", type=float, default=0.85)
@@ -85,11 +154,18 @@ def main(argv=None):
                     help="read each matrix through its binary container (<file>.csr.sxbin), writing it on first use")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value")
     a = ap.parse_args(argv)
-    paths = []
+    paths, synth = [], []
     for p in a.paths:
-        paths.extend(sorted(glob.glob(p)) or [p])
+        if p.startswith("synth:"):
+            synth.append(p)
+        else:
+            paths.extend(sorted(glob.glob(p)) or [p])
     opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.opt}
-    sweep(paths, [int(x) for x in a.n.split(",")], a.rp, a.alpha, a.beta, a.check, a.device, opts, cache=a.cache)
+    ns = [int(x) for x in a.n.split(",")]
+    if paths:
+        sweep(paths, ns, a.rp, a.alpha, a.beta, a.check, a.device, opts, cache=a.cache)
+    if synth:
+        sweep_synthetic(synth, ns, max(a.rp, 1), a.alpha, a.beta, a.device, opts)
 
 
 if __name__ == "__main__":
