@@ -231,9 +231,8 @@ int sextans_destroy(sextans_handle_t h);
  * sweep), "window_rows" (rows per wavefront of kernel 3, default 319), "window_cols" (columns per K window,
  * default 65536), "window_unroll" (4 or 8 steps in flight), "window_auto" (1: kernel 0 may choose kernel 3 from
  * its fabric-traffic model; default 0 because the sweep never beat the gather kernel on MI355X),
- * "lanes_per_row"
- * (2/4/8, N-tile = 4*lanes), "stage_a" (0/1 stage the CSR stream through LDS), "xcd_remap"
- * (0/1), "exact" (1 = no FMA, reference rounding; 0 = allow FMA), "profile" (0/1 hipEvent
+ * "lanes_per_row" (2/4/8, N-tile = 4*lanes; 0 = auto, the default: 4 for the panel kernel, 8 for the gather
+ * kernel when N >= 32), "stage_a" (0/1 stage the CSR stream through LDS), "xcd_remap" (0/1), "exact" (1 = no FMA, reference rounding; 0 = allow FMA), "profile" (0/1 hipEvent
  * per-kernel timing), "phase_timing" (0/1, see sextans_phase_timing_read), "bucket_rows" / "split_rows" (long
  * rows, the load-balancing the reference gets from dealing rows to PEs by row % 64: rows longer than L0 =
  * "bucket_rows" leave the main kernel and are processed in a second launch in order of length, still summed in

@@ -134,7 +134,7 @@ struct sextans_engine {
     hipStream_t comm_stream = nullptr;
     std::vector<hipEvent_t> dist_events;
     // options
-    int64_t opt_kernel = 0, opt_lpr = 4, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;
+    int64_t opt_kernel = 0, opt_lpr = 0, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;   // opt_lpr 0 = auto
     int64_t opt_fuse_b = 1;             // panel kernel may stage from column-major B (small matrices: no repack launch)
     int64_t opt_split_rows = -1;        // > 0: rows longer than this are split (re-associated); 0 = never (strict
                                         // order); -1 = max(1024, nnz / 16384)
@@ -657,7 +657,7 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
     if (!h || !key) return SEXTANS_ERR_INVALID;
     int64_t *slot = option_slot(h, key);
     if (!slot) return SEXTANS_ERR_INVALID;
-    if (slot == &h->opt_lpr && value != 2 && value != 4 && value != 8) return SEXTANS_ERR_INVALID;
+    if (slot == &h->opt_lpr && value != 0 && value != 2 && value != 4 && value != 8) return SEXTANS_ERR_INVALID;
     if (slot == &h->opt_win_rows && (value < 1 || value > sx::kWinMaxRowsPerWave)) return SEXTANS_ERR_INVALID;
     if (slot == &h->opt_win_cols && (value < 1 || value > 0x7fffffff)) return SEXTANS_ERR_INVALID;
     if (slot == &h->opt_win_unroll && value != 4 && value != 8) return SEXTANS_ERR_INVALID;
@@ -779,6 +779,16 @@ int ensure_split(sextans_engine *h) {
     for (int r = 0; r < h->M; ++r)
         if ((int64_t)rp[(size_t)r + 1] - rp[(size_t)r] > L0) rows.push_back(r);
     if (rows.empty()) return SEXTANS_OK;
+    {   // bucketing alone (no row that must be split) is only worth three extra launches when the long rows carry
+        // a visible share of the work: a handful of rows just above L0 in a regular matrix stay where they are
+        int64_t long_nnz = 0, longest = 0;
+        for (int r : rows) {
+            const int64_t len = (int64_t)rp[(size_t)r + 1] - rp[(size_t)r];
+            long_nnz += len;
+            longest = std::max(longest, len);
+        }
+        if (longest <= T && h->opt_bucket_rows < 0 && long_nnz * 50 < h->nnz) return SEXTANS_OK;
+    }
     std::vector<int> ci;
     std::vector<float> va;
     if (int rc = read_back_entries(h, ci, va, false)) return rc;
@@ -1000,16 +1010,23 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
     // main tile width: 4*lanes_per_row, but never wider than N itself (N = 8 -> 2 lanes per row); then
     // 16- and 8-wide tiles for the remainder (N is a multiple of 8, the reference's N-tile
     // granularity: sextans.cpp:57-60).
-    int lpr = (int)h->opt_lpr;
-    while (lpr > 2 && 4 * lpr > N) lpr /= 2;
-    W = 4 * lpr;
-    plan.clear();
-    int col = 0;
-    for (int w : {W, 16, 8}) {
-        if (w > W) continue;
-        const int nt = (N - col) / w;
-        if (nt > 0) { plan.push_back({w, col, nt}); col += nt * w; }
-    }
+    // "lanes_per_row" 0 = auto: 4 lanes (16-column tiles) for the panel kernel -- measured best on the FEM class
+    // (config 3, N=128: 23 us with 4 lanes, 31 us with 8) -- and 8 lanes (32-column tiles) for the gather kernel
+    // once N >= 32: a 128-byte B row is one fabric request where two 64-byte tiles are two (uniform 4M matrix,
+    // N = 32/64/128: 3.15/6.9/15.2 ms with 8 lanes against 6.1/12.6/27.7 ms with 4).
+    int lpr = h->opt_lpr ? (int)h->opt_lpr : 4;
+    auto tiles = [&]() {
+        while (lpr > 2 && 4 * lpr > N) lpr /= 2;
+        W = 4 * lpr;
+        plan.clear();
+        int col = 0;
+        for (int w : {W, 16, 8}) {
+            if (w > W) continue;
+            const int nt = (N - col) / w;
+            if (nt > 0) { plan.push_back({w, col, nt}); col += nt * w; }
+        }
+    };
+    tiles();
     // Kernel choice: "kernel" 1 = row-group gather, 2 = LDS panel, 0 = auto (panel when at least half
     // of the non-zeros sit in row blocks whose B rows are reused -- "only where a tile has reuse").
     use_panel = false;
@@ -1017,6 +1034,7 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
         if (int rc = ensure_plan(h, lpr, h->opt_kernel == 2)) return rc;
         use_panel = h->plan_built && ((h->opt_kernel == 2) || h->plan_panel_frac >= 0.5);
     }
+    if (!h->opt_lpr && !use_panel && N >= 32 && lpr != 8) { lpr = 8; tiles(); }
     // "kernel" 3 = K-windowed accumulator-resident kernel; auto picks it for matrices without B-row reuse
     // whose B does not fit the L2s when the traffic model says the sweep moves fewer bytes than the gather.
     use_window = false;

@@ -5,18 +5,17 @@
 A: torch.sparse_csr_tensor (fp32 values, int32/int64 indices) on a GPU; B: dense (K, N) fp32; returns a
 dense (M, N) tensor (row-major view of the engine's column-major result, no copy).  N is padded up to a
 multiple of 8 internally (the reference's N-tile granularity, sextans-host.cpp:51).  One cached engine per live
-matrix (keyed on tensor identity + version counters, dropped when the tensors die, at most 8 kept); not part of
-the reference, whose only front end is the CLI.
+matrix (keyed on tensor addresses + version counters; the entry pins the tensors, at most 8 kept, clear_cache()
+drops them); not part of the reference, whose only front end is the CLI.
 """
 import collections
-import weakref
 
 import torch
 
 from . import api
 
 _MAX_ENGINES = 8
-_cache = collections.OrderedDict()     # key -> (engine, int32/fp32 arrays the engine reads, weakref to A)
+_cache = collections.OrderedDict()     # key -> (engine, arrays the engine reads, A's own index/value tensors)
 
 
 def _evict(key):
@@ -25,28 +24,31 @@ def _evict(key):
         ent[0].close()
 
 
+def clear_cache():
+    """Drop every cached engine (and the references that pin the matrices they were built from)."""
+    for key in list(_cache):
+        _evict(key)
+
+
 def _engine_for(A, dev):
-    """One engine per live sparse matrix.  The key holds the identity AND the version counters of A's three
-    tensors, so in-place updates of A get a fresh engine (the packed forms snapshot the values); entries die with
-    the matrix (weakref callback: a freed tensor's address can be reused by a different matrix) and the cache
-    is bounded (LRU), because every entry pins an engine with its device workspaces."""
+    """One engine per sparse matrix, at most _MAX_ENGINES of them (LRU: every entry pins an engine with its device
+    workspaces).  The key holds the addresses AND the version counters of A's three tensors, so an in-place update
+    of A gets a fresh engine (the packed forms snapshot the values).  The entry also keeps A's own tensors alive:
+    as long as it exists their storage cannot be freed and handed to a different matrix, so equal addresses always
+    mean the same matrix."""
     crow, col, val = A.crow_indices(), A.col_indices(), A.values()
     M, K = A.shape
     key = (dev, crow.data_ptr(), col.data_ptr(), val.data_ptr(), crow._version, col._version, val._version, M, K,
            val.numel())
     ent = _cache.get(key)
-    if ent is not None and ent[2]() is not None:
+    if ent is not None:
         _cache.move_to_end(key)
         return ent[0]
-    _evict(key)
     crow32, col32 = crow.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
     val32 = val.to(torch.float32).contiguous()
     eng = api.Engine(dev)
     eng.set_matrix_csr_device(M, K, val32.numel(), crow32.data_ptr(), col32.data_ptr(), val32.data_ptr())
-    # crow_indices()/col_indices()/values() hand out fresh alias objects on every call, so the lifetime that matters is
-    # A's own: when A dies its storage may be reused by a different matrix at the same addresses
-    ref = weakref.ref(A, lambda _r, k=key: _evict(k))
-    _cache[key] = (eng, (crow32, col32, val32), ref)       # keep the converted arrays alive: the engine does not copy
+    _cache[key] = (eng, (crow32, col32, val32), (crow, col, val))   # the engine does not copy: keep its arrays alive
     while len(_cache) > _MAX_ENGINES:
         _evict(next(iter(_cache)))
     return eng

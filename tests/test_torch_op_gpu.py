@@ -55,13 +55,15 @@ def test_engine_cache_follows_the_matrix(sx, oracle):
         assert np.array_equal(np.ascontiguousarray(got).view(np.uint32), np.ascontiguousarray(want.reshape(N, M).T).view(np.uint32))
 
     B = rs.uniform(-1, 1, (K, N)).astype(np.float32)
-    torch_op._cache.clear()
-    for seed in range(12):                       # same shapes: freed storage is reused, results must follow the data
+    torch_op.clear_cache()
+    for seed in range(12):                       # same shapes, matrices created and dropped: results must follow the data
         A, rp, ci, v = make(seed)
         check(A, rp, ci, v, B)
         del A
         gc.collect()
-    assert len(torch_op._cache) <= 1             # entries died with their matrices
+    assert len(torch_op._cache) <= torch_op._MAX_ENGINES
+    torch_op.clear_cache()
+    assert len(torch_op._cache) == 0
     A, rp, ci, v = make(99)
     check(A, rp, ci, v, B)
     A.values().mul_(2.0)                         # in-place update: version counter changes, fresh engine
