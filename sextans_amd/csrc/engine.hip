@@ -65,21 +65,27 @@ struct sextans_engine {
     float *d_chB = nullptr, *d_chC = nullptr;                    // accelerator channel layouts (sextans_invoke)
     size_t chB_cap = 0, chC_cap = 0;
     // block-dictionary plan for the LDS-panel kernel (built lazily, per lanes_per_row)
-    int plan_lpr = 0;               // 0 = no plan
-    int64_t plan_min_reuse = -1;
-    // d_dict_ptr: entries per block dictionary; d_dict: dictionaries at stride plan_dict_stride;
-    // d_row_off: {first packed entry, entries} per (block, slot)
-    int *d_dict_ptr = nullptr, *d_dict = nullptr, *d_blk_row = nullptr, *d_row_off = nullptr;
-    int *d_pcol32 = nullptr;
-    float *d_pval = nullptr;
-    int plan_nblk = 0;
-    std::vector<int> h_blk_row;     // host copy of the plan's block boundaries (row-range calls, sextans_align_row)
-    unsigned short *d_lidx = nullptr;
-    double plan_panel_frac = 0.0;   // share of non-zeros living in dictionary blocks
-    int plan_max_dict = 0;          // largest block dictionary (entries)
-    int plan_dict_stride = 0;       // ints per block in d_dict (dictionaries padded to a common stride)
-    bool plan_mixed = false;        // some block with non-zeros has no dictionary (global-gather path needed)
-    bool plan_built = false;        // false: only the sampled verdict exists (no packed stream)
+    // One packed form per lanes_per_row value (2 / 4 / 8): the active one below, the others parked in plan_stash, so
+    // callers that alternate between N classes (N = 8 -> 2 lanes, N >= 16 -> 4) do not rebuild on every switch.
+    struct PanelState {
+        int plan_lpr = 0;               // 0 = no plan
+        int64_t plan_min_reuse = -1;
+        // d_dict_ptr: entries per block dictionary; d_dict: dictionaries at stride plan_dict_stride;
+        // d_row_off: {first packed entry, entries} per (block, slot)
+        int *d_dict_ptr = nullptr, *d_dict = nullptr, *d_blk_row = nullptr, *d_row_off = nullptr;
+        int *d_pcol32 = nullptr;
+        float *d_pval = nullptr;
+        int plan_nblk = 0;
+        std::vector<int> h_blk_row;     // host copy of the plan's block boundaries (row-range calls, sextans_align_row)
+        unsigned short *d_lidx = nullptr;
+        double plan_panel_frac = 0.0;   // share of non-zeros living in dictionary blocks
+        int plan_max_dict = 0;          // largest block dictionary (entries)
+        int plan_dict_stride = 0;       // ints per block in d_dict (dictionaries padded to a common stride)
+        bool plan_mixed = false;        // some block with non-zeros has no dictionary (global-gather path needed)
+        bool plan_built = false;        // false: only the sampled verdict exists (no packed stream)
+    };
+    PanelState ps;                      // active
+    PanelState plan_stash[3];           // parked, indexed by lanes_per_row 2 / 4 / 8 -> 0 / 1 / 2
     // K-windowed accumulator-resident plan (spmm_csr_window; built lazily)
     uint2 *d_wstream = nullptr;
     int *d_wstep0 = nullptr;
@@ -173,17 +179,15 @@ int check_device(int device) {
     return SEXTANS_OK;
 }
 
-void free_plan(sextans_engine *h) {
-    (void)hipFree(h->d_dict_ptr); (void)hipFree(h->d_dict); (void)hipFree(h->d_lidx); (void)hipFree(h->d_blk_row);
-    (void)hipFree(h->d_row_off); (void)hipFree(h->d_pcol32); (void)hipFree(h->d_pval);
-    h->d_dict_ptr = h->d_dict = h->d_blk_row = h->d_row_off = h->d_pcol32 = nullptr;
-    h->d_pval = nullptr;
-    h->plan_nblk = 0;
-    h->h_blk_row.clear();
-    h->d_lidx = nullptr;
-    h->plan_lpr = 0;
-    h->plan_panel_frac = 0.0;
-    h->plan_built = false;
+void free_panel_state(sextans_engine::PanelState &p) {
+    (void)hipFree(p.d_dict_ptr); (void)hipFree(p.d_dict); (void)hipFree(p.d_lidx); (void)hipFree(p.d_blk_row);
+    (void)hipFree(p.d_row_off); (void)hipFree(p.d_pcol32); (void)hipFree(p.d_pval);
+    p = sextans_engine::PanelState();
+}
+
+void free_plan(sextans_engine *h) {   // every packed form of the current main matrix
+    free_panel_state(h->ps);
+    for (auto &p : h->plan_stash) free_panel_state(p);
 }
 
 void free_window(sextans_engine *h) {
@@ -374,9 +378,20 @@ int sample_reuse(sextans_engine *h, int RB, int max_unique, double min_reuse, do
 // per matrix ("upload once"), outside any timed region, like the reference's host-side scheduling
 // and packing (generate_edge_list_for_all_PEs + edge_list_64bit, sextans-host.cpp:114-148).
 int ensure_plan(sextans_engine *h, int lpr, bool force) {
-    if (h->plan_lpr == lpr && h->plan_min_reuse == h->opt_min_reuse_x100 && (h->plan_built || !force))
+    if (h->ps.plan_lpr == lpr && h->ps.plan_min_reuse == h->opt_min_reuse_x100 && (h->ps.plan_built || !force))
         return SEXTANS_OK;
-    free_plan(h);
+    if (h->ps.plan_lpr != lpr) {   // park the active form, bring back the one for this lane count (if any)
+        auto idx = [](int l) { return l == 2 ? 0 : l == 4 ? 1 : 2; };
+        if (h->ps.plan_lpr) std::swap(h->ps, h->plan_stash[idx(h->ps.plan_lpr)]);
+        if (h->ps.plan_lpr != lpr) std::swap(h->ps, h->plan_stash[idx(lpr)]);
+        if (h->ps.plan_lpr && h->ps.plan_lpr != lpr) {   // displaced a third form: park it in its own slot
+            std::swap(h->ps, h->plan_stash[idx(h->ps.plan_lpr)]);
+            free_panel_state(h->ps);
+        }
+        if (h->ps.plan_lpr == lpr && h->ps.plan_min_reuse == h->opt_min_reuse_x100 && (h->ps.plan_built || !force))
+            return SEXTANS_OK;
+    }
+    free_panel_state(h->ps);
     PlanTimer timer(h);
     const int RB = sx::kBlock / lpr;
     const double min_reuse = (double)h->opt_min_reuse_x100 / 100.0;
@@ -384,10 +399,10 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
         double frac = 0.0;
         if (int rc = sample_reuse(h, RB, kPanelFloats / (4 * lpr), min_reuse, &frac)) return rc;
         if (frac < 0.5) {   // no reuse worth an LDS panel: remember the verdict, skip the build
-            h->plan_lpr = lpr;
-            h->plan_min_reuse = h->opt_min_reuse_x100;
-            h->plan_panel_frac = frac * 0.999;
-            h->plan_built = false;
+            h->ps.plan_lpr = lpr;
+            h->ps.plan_min_reuse = h->opt_min_reuse_x100;
+            h->ps.plan_panel_frac = frac * 0.999;
+            h->ps.plan_built = false;
             return SEXTANS_OK;
         }
     }
@@ -399,21 +414,21 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
         int64_t padded = 0;
         for (int r = 0; r < h->M; ++r) padded += ((int64_t)(rp[(size_t)r + 1] - rp[(size_t)r]) + 3) / 4 * 4;
         if (padded > 0x7fffffffLL - 4096) {
-            h->plan_lpr = lpr;
-            h->plan_min_reuse = h->opt_min_reuse_x100;
-            h->plan_panel_frac = 0.0;
-            h->plan_built = false;
+            h->ps.plan_lpr = lpr;
+            h->ps.plan_min_reuse = h->opt_min_reuse_x100;
+            h->ps.plan_panel_frac = 0.0;
+            h->ps.plan_built = false;
             return SEXTANS_OK;   // row-group kernel only
         }
     }
     sx::PanelPlan plan;
     sx::build_panel_plan(h->M, h->K, rp.data(), ci.data(), va.data(), RB, kPanelFloats / (4 * lpr),
                          min_reuse, plan);
-    h->plan_nblk = (int)plan.blk_row.size() - 1;
+    h->ps.plan_nblk = (int)plan.blk_row.size() - 1;
     // Block-strided headers for the kernel (addresses depend on the block number only): per slot
     // {first packed entry, entries}; per block its dictionary padded to a common stride with the last
     // column repeated.
-    const int nblk = h->plan_nblk;
+    const int nblk = h->ps.plan_nblk;
     int dstride = ((plan.max_dict + RB - 1) / RB) * RB;
     if (dstride < RB) dstride = RB;
     if (dstride > 9 * RB) return SEXTANS_ERR_STATE;   // kPanelFloats / (4 * lpr) = 9 * RB by construction
@@ -434,13 +449,13 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
         for (int i = 0; i < dstride; ++i)
             bdict[(size_t)b * dstride + i] = nu > 0 ? plan.dict[(size_t)u0 + (size_t)(i < nu ? i : nu - 1)] : 0;
     }
-    h->plan_dict_stride = dstride;
-    h->plan_mixed = mixed;
-    if (int rc = upload(&h->d_blk_row, plan.blk_row)) return rc;
-    h->h_blk_row = plan.blk_row;
-    if (int rc = upload(&h->d_dict_ptr, dcnt)) return rc;
-    if (int rc = upload(&h->d_dict, bdict)) return rc;
-    if (int rc = upload(&h->d_row_off, slot_info)) return rc;
+    h->ps.plan_dict_stride = dstride;
+    h->ps.plan_mixed = mixed;
+    if (int rc = upload(&h->ps.d_blk_row, plan.blk_row)) return rc;
+    h->ps.h_blk_row = plan.blk_row;
+    if (int rc = upload(&h->ps.d_dict_ptr, dcnt)) return rc;
+    if (int rc = upload(&h->ps.d_dict, bdict)) return rc;
+    if (int rc = upload(&h->ps.d_row_off, slot_info)) return rc;
     // the kernel adds the entry straight to its LDS address: store index * (bytes per panel row)
     {
         const unsigned row_bytes = 16u * (unsigned)lpr;
@@ -448,14 +463,14 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
         if (pad_off > 0xffffu) return SEXTANS_ERR_STATE;
         for (auto &x : plan.idx16) x = (uint16_t)(x == sx::kPadIndex ? pad_off : x * row_bytes);
     }
-    if (int rc = upload(&h->d_lidx, plan.idx16)) return rc;
-    if (int rc = upload(&h->d_pcol32, plan.col32)) return rc;
-    if (int rc = upload(&h->d_pval, plan.val)) return rc;
-    h->plan_lpr = lpr;
-    h->plan_min_reuse = h->opt_min_reuse_x100;
-    h->plan_panel_frac = plan.nnz_total ? (double)plan.nnz_in_panel_blocks / (double)plan.nnz_total : 0.0;
-    h->plan_max_dict = plan.max_dict;
-    h->plan_built = true;
+    if (int rc = upload(&h->ps.d_lidx, plan.idx16)) return rc;
+    if (int rc = upload(&h->ps.d_pcol32, plan.col32)) return rc;
+    if (int rc = upload(&h->ps.d_pval, plan.val)) return rc;
+    h->ps.plan_lpr = lpr;
+    h->ps.plan_min_reuse = h->opt_min_reuse_x100;
+    h->ps.plan_panel_frac = plan.nnz_total ? (double)plan.nnz_in_panel_blocks / (double)plan.nnz_total : 0.0;
+    h->ps.plan_max_dict = plan.max_dict;
+    h->ps.plan_built = true;
     return SEXTANS_OK;
 }
 
@@ -473,16 +488,16 @@ void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_
     const int64_t pstride = bcol_ld > 0 ? bcol_ld : (int64_t)h->K * NT;
     const int xcd = (int)h->opt_xcd;
     // LDS = B panel sized for the largest dictionary of this matrix (rounded to 1 KiB) + C tile.
-    const int panel_floats = (h->plan_max_dict + 1) * NT;   // dictionary rows + the +1.0f row the padding entries address
+    const int panel_floats = (h->ps.plan_max_dict + 1) * NT;   // dictionary rows + the +1.0f row the padding entries address
     const int tile_floats = NT * (RB + 1);   // the C tile reuses the panel bytes
     const size_t lds = (size_t)(panel_floats > tile_floats ? panel_floats : tile_floats) * sizeof(int);
     auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(nwg), dim3(sx::kBlock), lds, s, (const int2 *)h->d_row_off, h->d_lidx,
-                           h->d_pcol32, h->d_pval, h->d_blk_row, h->d_dict_ptr, h->d_dict, h->plan_dict_stride, dBp,
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(sx::kBlock), lds, s, (const int2 *)h->ps.d_row_off, h->ps.d_lidx,
+                           h->ps.d_pcol32, h->ps.d_pval, h->ps.d_blk_row, h->ps.d_dict_ptr, h->ps.d_dict, h->ps.plan_dict_stride, dBp,
                            pstride, dCin, ldc_in, dCout, ldc, ntiles, nblk, alpha, beta, xcd, panel_floats,
                            (long long *)h->d_dbg, blk_begin, row_base, (const unsigned char *)h->d_skip);
     };
-    if (h->plan_mixed) {
+    if (h->ps.plan_mixed) {
         if (h->opt_exact) go(sx::spmm_csr_panel<LPR, true, true>);
         else go(sx::spmm_csr_panel<LPR, false, true>);
     } else if (bcol_ld > 0) {
@@ -1032,7 +1047,7 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
     use_panel = false;
     if (h->opt_kernel != 1 && h->m_nnz > 0) {
         if (int rc = ensure_plan(h, lpr, h->opt_kernel == 2)) return rc;
-        use_panel = h->plan_built && ((h->opt_kernel == 2) || h->plan_panel_frac >= 0.5);
+        use_panel = h->ps.plan_built && ((h->opt_kernel == 2) || h->ps.plan_panel_frac >= 0.5);
     }
     if (!h->opt_lpr && !use_panel && N >= 32 && lpr != 8) { lpr = 8; tiles(); }
     // "kernel" 3 = K-windowed accumulator-resident kernel; auto picks it for matrices without B-row reuse
@@ -1060,8 +1075,8 @@ int sextans_align_row(sextans_handle_t h, int N, int row, int *aligned) {
     *aligned = row;
     if (row == h->M) return SEXTANS_OK;
     if (use_window) *aligned = row / h->win_rw * h->win_rw;
-    else if (use_panel && !h->h_blk_row.empty())
-        *aligned = *(std::upper_bound(h->h_blk_row.begin(), h->h_blk_row.end(), row) - 1);
+    else if (use_panel && !h->ps.h_blk_row.empty())
+        *aligned = *(std::upper_bound(h->ps.h_blk_row.begin(), h->ps.h_blk_row.end(), row) - 1);
     return SEXTANS_OK;
 }
 
@@ -1122,8 +1137,8 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "dense_tile_fraction")) *value = h->m_nnz + (h->dense_W > 0 ? h->dense_nnz : 0) > 0
         ? (double)h->dense_nnz / (double)(h->m_nnz + (h->dense_W > 0 ? h->dense_nnz : 0)) : 0.0;
     else if (!strcmp(key, "dense_tiles_on_mfma")) *value = h->dense_W > 0 ? 1.0 : 0.0;
-    else if (!strcmp(key, "panel_fraction")) *value = h->plan_panel_frac;
-    else if (!strcmp(key, "panel_blocks")) *value = (double)h->plan_nblk;
+    else if (!strcmp(key, "panel_fraction")) *value = h->ps.plan_panel_frac;
+    else if (!strcmp(key, "panel_blocks")) *value = (double)h->ps.plan_nblk;
     else return SEXTANS_ERR_INVALID;
     return SEXTANS_OK;
 }
@@ -1185,9 +1200,9 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         beta = 1.0f; d_C_in = d_C_out; ldc_in = ldc;
     }
     // a row range keeps the panel kernel when it starts and ends on row-block boundaries of the plan
-    int blk0 = 0, blk1 = h->plan_nblk;
+    int blk0 = 0, blk1 = h->ps.plan_nblk;
     if (use_panel && !whole) {
-        const auto &br = h->h_blk_row;
+        const auto &br = h->ps.h_blk_row;
         const auto i0 = std::lower_bound(br.begin(), br.end(), row_begin), i1 = std::lower_bound(br.begin(), br.end(), row_end);
         if (i0 == br.end() || *i0 != row_begin || i1 == br.end() || *i1 != row_end) use_panel = false;
         else { blk0 = (int)(i0 - br.begin()); blk1 = (int)(i1 - br.begin()); }
@@ -1234,7 +1249,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     }
     // Small B (fits the L2s), dictionary-only plan, one N segment: the panel kernel stages straight from the
     // caller's column-major B and the repack launch disappears.
-    const bool fuse_b = use_panel && !h->plan_mixed && h->opt_fuse_b && !(flags & kRowsNoFuseB) && plan.size() == 1 &&
+    const bool fuse_b = use_panel && !h->ps.plan_mixed && h->opt_fuse_b && !(flags & kRowsNoFuseB) && plan.size() == 1 &&
                         plan[0].width == W && !hubs &&
                         (size_t)h->K * (size_t)N * sizeof(float) <= ((size_t)16 << 20);
     // (a reuse request is honoured only if the panels in the workspace have this layout: row-range calls of

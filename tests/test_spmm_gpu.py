@@ -425,3 +425,28 @@ def test_invalid_csr_is_rejected_not_dereferenced(engine, sx):
     finally:
         engine.set_option("kernel", 0)
         engine.set_matrix_csr(2, 5, rp, good_ci, v)
+
+
+def test_packed_forms_are_kept_per_lane_count(engine, oracle, sx):
+    """alternating between N classes (N = 8 -> 2 lanes per row, N >= 16 -> 4) must not rebuild the packed
+    row-bucketed form on every switch -- one form per lane count is kept."""
+    from sextans_amd import api
+    rp, ci, v = api.gen_fem3d_host(16, 16, 10, 3, 4)
+    M = K = 16 * 16 * 10 * 3
+    for k, val in dict(lanes_per_row=0, stage_a=1, xcd_remap=1, exact=1, kernel=0, panel_min_reuse_x100=400, fuse_b=1,
+                       split_rows=0, bucket_rows=0).items():
+        engine.set_option(k, val)
+    engine.set_matrix_csr(M, K, rp, ci, v)
+    rs = np.random.RandomState(6)
+    built = []
+    for N in (8, 16, 8, 24, 8, 16):
+        B = rs.uniform(-1, 1, K * N).astype(np.float32)
+        C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+        want = C0.copy()
+        oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+        out = C0.copy()
+        engine.spmm(N, ALPHA, B, BETA, out)
+        assert engine.last_kernel() == "spmm_csr_panel"
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), N
+        built.append(engine.get_stat("plan_build_s"))
+    assert built[1] > built[0] and built[2:] == [built[1]] * 4, built     # two builds (2 and 4 lanes), then none
