@@ -348,8 +348,9 @@ int sextans_invoke(sextans_handle_t h, const int32_t *edge_list_ptr, const uint6
  *                            computed in `nchunks` row chunks into a staging buffer; the all-gather of chunk i
  *                            (ncclAllGather on the engine's communication stream) overlaps the SpMM of chunk
  *                            i+1; a final pass writes every rank's rows into d_C_out.  Enqueued on `stream`,
- *                            returns without synchronising (one short host sync for the row tables).  d_C_out
- *                            holds C = alpha*A*B + beta*C_in for ALL rows on every rank. */
+ *                            returns without synchronising (one short host sync the first time a partition is
+ *                            used, for its row tables).  d_C_out holds C = alpha*A*B + beta*C_in for ALL rows on
+ *                            every rank. */
 int sextans_dist_unique_id(char id[128]);
 int sextans_dist_comm_init(void **comm, int device, int world, int rank, const char id[128]);
 int sextans_dist_comm_destroy(void *comm);

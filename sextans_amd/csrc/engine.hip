@@ -139,6 +139,8 @@ struct sextans_engine {
     size_t stage_cap = 0;
     hipStream_t comm_stream = nullptr;
     std::vector<hipEvent_t> dist_events;
+    std::vector<int> dist_meta;     // {first row, rows} per (chunk, rank) as last uploaded, and where
+    const int *dist_meta_at = nullptr;
     // options
     int64_t opt_kernel = 0, opt_lpr = 0, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;   // opt_lpr 0 = auto
     int64_t opt_fuse_b = 1;             // panel kernel may stage from column-major B (small matrices: no repack launch)
@@ -1684,6 +1686,7 @@ int sextans_dist_spmm(sextans_handle_t h, void *comm, int world, int rank, const
     }
     // staging + per-chunk {row0, len} tables (ints, kept behind the float staging area)
     const size_t meta_floats = (size_t)nchunks * (size_t)world * 2;
+    if (h->stage_cap < (size_t)off[(size_t)nchunks] + meta_floats) h->dist_meta_at = nullptr;   // new buffer: tables gone
     if (int rc = ensure(&h->d_stage, &h->stage_cap, (size_t)off[(size_t)nchunks] + meta_floats)) return rc;
     if (!h->comm_stream) SX_HIP(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
     while (h->dist_events.size() < (size_t)nchunks + 1) {
@@ -1698,8 +1701,12 @@ int sextans_dist_spmm(sextans_handle_t h, void *comm, int world, int rank, const
             meta[((size_t)c * world + g) * 2 + 1] = cut(g, c + 1) - cut(g, c);
         }
     int *d_meta = reinterpret_cast<int *>(h->d_stage + off[(size_t)nchunks]);
-    SX_HIP(hipMemcpyAsync(d_meta, meta.data(), sizeof(int) * meta.size(), hipMemcpyHostToDevice, s));
-    SX_HIP(hipStreamSynchronize(s));   // `meta` is a host temporary
+    if (h->dist_meta != meta || h->dist_meta_at != d_meta) {   // the row tables change only with the partition
+        SX_HIP(hipMemcpyAsync(d_meta, meta.data(), sizeof(int) * meta.size(), hipMemcpyHostToDevice, s));
+        SX_HIP(hipStreamSynchronize(s));   // `meta` is a host temporary; later calls with the same ranges skip this
+        h->dist_meta = meta;
+        h->dist_meta_at = d_meta;
+    }
     bool first = true;
     for (int c = 0; c < nchunks; ++c) {
         float *S = h->d_stage + off[(size_t)c];
