@@ -161,10 +161,11 @@ __global__ __launch_bounds__(256) void spmm_bell_mfma(
 // registers in flight while the previous k-step's 8 MFMAs issue): ~210 registers, 2 wavefronts per SIMD.
 __global__ __launch_bounds__(256, 2) void spmm_bell_mfma_n256(
     const int *__restrict__ block_col, const bf16x8 *__restrict__ Af, const bf16x8 *__restrict__ Bf,
-    const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc, int mblocks, int ell_width, float alpha, float beta) {
+    const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc, int mblocks, int ell_width, float alpha, float beta,
+    int br_begin) {
     constexpr int NT8 = 8;
     const int lane = threadIdx.x & 63;
-    const int br = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int br = __builtin_amdgcn_readfirstlane(br_begin + (int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (br >= mblocks) return;
     f32x16 acc[NT8];
 #pragma unroll
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void spmm_bell_mfma_n256(
         const int slot = q >> 1, ks = q & 1;
         const int bc = bc_row[slot];
         if (bc >= 0) {
-            a = a_row[(int64_t)slot * 128 + ks * 64];
+            a = __builtin_nontemporal_load(a_row + (int64_t)slot * 128 + ks * 64);   // A is read once: keep it out of the caches B lives in
             const bf16x8 *bp = Bf + ((int64_t)bc * NT8) * 128 + ks * 64 + lane;
 #pragma unroll
             for (int t = 0; t < NT8; ++t) b[t] = bp[t * 128];

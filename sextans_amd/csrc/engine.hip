@@ -154,7 +154,9 @@ struct sextans_engine {
     int64_t opt_win_cols = 65536;       // columns per K window (x 32 B = 2 MiB of the 8-column panel: half an XCD's L2)
     int64_t opt_win_unroll = 8;         // steps in flight per ring (4 or 8)
     int64_t opt_win_auto = 0;           // 1: "kernel" 0 may pick the window kernel from the fabric-byte model
-    int64_t opt_bell_wide = 0;          // 1: N = 256 runs one wavefront per block row over all 8 column tiles
+    int64_t opt_bell_gen = 0;           // block rows per launch of the wide kernel (0 = all in one launch)
+    int64_t opt_bell_wide = 1;          // 1 (default): N = 256 runs one wavefront per block row over all 8 column tiles
+                                        // (A requested once, non-temporal); 0: two wavefronts of 4 tiles each
     int64_t opt_mfma_dense = 0;         // 1: dense 32x32 tiles run on the bf16 MFMA path (the caller opts into bf16 rounding
                                         // of those tiles and of B for them); 0: they are only counted (get_stat)
     int64_t opt_dense_fill_x100 = 50;   // a tile is dense when it holds >= this percentage of its 1024 positions
@@ -665,6 +667,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "window_unroll")) return &h->opt_win_unroll;
     if (!strcmp(key, "window_auto")) return &h->opt_win_auto;
     if (!strcmp(key, "bell_wide")) return &h->opt_bell_wide;
+    if (!strcmp(key, "bell_generation")) return &h->opt_bell_gen;
     if (!strcmp(key, "mfma_dense_tiles")) return &h->opt_mfma_dense;
     if (!strcmp(key, "dense_tile_fill_x100")) return &h->opt_dense_fill_x100;
     return nullptr;
@@ -1560,8 +1563,14 @@ int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint1
                            alpha, beta);                                                                      \
     }
         if (ntiles == 8 && h->opt_bell_wide) {
-            hipLaunchKernelGGL(sx::spmm_bell_mfma_n256, dim3((unsigned)((mblocks + 3) / 4)), dim3(256), 0, s, h->d_bell_col, Af,
-                               Bf, d_C_in, ldc, d_C_out, ldc, mblocks, h->bell_W, alpha, beta);
+            // "bell_generation" = G > 0: launches of G block rows, so that the wavefronts of a launch start at block
+            // column 0 together and sweep K side by side (experiment: does the Infinity Cache then serve the B tiles?)
+            const int G = h->opt_bell_gen > 0 ? (int)h->opt_bell_gen : mblocks;
+            for (int b0 = 0; b0 < mblocks; b0 += G) {
+                const int nb = std::min(G, mblocks - b0);
+                hipLaunchKernelGGL(sx::spmm_bell_mfma_n256, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, s, h->d_bell_col, Af,
+                                   Bf, d_C_in, ldc, d_C_out, ldc, std::min(mblocks, b0 + nb), h->bell_W, alpha, beta, b0);
+            }
         } else if (ntiles % 4 == 0) SX_BELL(4) else if (ntiles % 2 == 0) SX_BELL(2) else SX_BELL(1)
 #undef SX_BELL
         h->last_kernel = "spmm_bell_mfma";
