@@ -517,9 +517,9 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
 // Piece kernel: one row group (LPR lanes x 4 columns) per piece [vbeg[v], vend[v]) of a long row, raw sums into
 // the scratch matrix P (no epilogue).  Pieces arrive sorted by length, so the row groups of a workgroup finish
 // together; what matters inside a piece is memory-level parallelism, because the adds of one row are a serial
-// chain anyway: every lane fetches 2 entries per batch (one 8-byte load each for columns and values), the
-// 2 * LPR B-row gathers of batch k + 1 are issued before the multiply-adds of batch k (two register sets, loop
-// unrolled by two), and the entries of batch k + 3 are requested before those of batch k + 1 are used.
+// chain anyway: a batch is 8 entries (8 / LPR per lane), the 8 B-row gathers of batch k + 1 are issued before the
+// multiply-adds of batch k (two register sets), and the entries of batch k + 3 are requested before those of
+// batch k + 1 are used (three entry sets; the loop is unrolled over the six phases of the two rotations).
 // Order inside a piece = CSR order; one lane per output element (exact).
 // ------------------------------------------------------------------------------------------------
 template <int LPR, bool EXACT>
@@ -529,7 +529,8 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_pieces(const int *__restrict_
                                                           int64_t ldp, int v_begin, int v_end, int ntiles) {
     constexpr int NT = 4 * LPR;
     constexpr int RB = kBlock / LPR;
-    constexpr int BATCH = 2 * LPR;
+    constexpr int E = LPR >= 8 ? 1 : 8 / LPR;   // entries per lane and batch: 8 gathers per batch whatever the tile width
+    constexpr int BATCH = E * LPR;
     const int blk = (int)(blockIdx.x / (unsigned)ntiles), tile = (int)(blockIdx.x % (unsigned)ntiles);
     const int tid = threadIdx.x, slot = tid / LPR, q = tid % LPR;
     const int v = v_begin + blk * RB + slot;
@@ -538,61 +539,50 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_pieces(const int *__restrict_
     const float *bq = Bp + (int64_t)tile * panel_stride + 4 * q;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // this lane's two entries of the batch starting at p (clamped inside the piece: never out of bounds; entries
+    struct Ent { int c[E]; float a[E]; };
+    // this lane's E entries of the batch starting at p (clamped inside the piece: never out of bounds; entries
     // past the end are never multiplied)
-    auto fetch = [&](int p, int2 &c, float2 &a) {
-        const int i0 = min(p + 2 * q, jend - 1), i1 = min(p + 2 * q + 1, jend - 1);
-        c = make_int2(col_idx[max(i0, 0)], col_idx[max(i1, 0)]);
-        a = make_float2(val[max(i0, 0)], val[max(i1, 0)]);
+    auto fetch = [&](int p, Ent &x) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = max(min(p + E * q + e, jend - 1), 0);
+            x.c[e] = col_idx[i];
+            x.a[e] = val[i];
+        }
     };
-    auto gather = [&](const int2 &c, float4 (&b)[BATCH]) {
+    auto gather = [&](const Ent &x, float4 (&b)[BATCH]) {
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int cu = __shfl((u & 1) ? c.y : c.x, u >> 1, LPR);
+            const int cu = __shfl(x.c[u % E], u / E, LPR);   // entry u of the batch sits in lane u / E, slot u % E
             b[u] = *reinterpret_cast<const float4 *>(bq + (int64_t)cu * NT);
         }
     };
-    auto macs = [&](const float2 &a, const float4 (&b)[BATCH], int cnt) {
+    auto macs = [&](const Ent &x, const float4 (&b)[BATCH], int cnt) {
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const float au = __shfl((u & 1) ? a.y : a.x, u >> 1, LPR);
+            const float au = __shfl(x.a[u % E], u / E, LPR);
             if (u < cnt) mac4<EXACT>(acc, au, b[u]);
         }
     };
     if (j < jend) {
-        int2 c0, c1, c2;
-        float2 a0, a1, a2;
+        Ent e0, e1, e2, t;
         float4 bA[BATCH], bB[BATCH];
-        fetch(j, c0, a0); fetch(j + BATCH, c1, a1); fetch(j + 2 * BATCH, c2, a2);
-        gather(c0, bA);
+        fetch(j, e0); fetch(j + BATCH, e1); fetch(j + 2 * BATCH, e2);
+        gather(e0, bA);
         int pos = j;
+        // entry sets rotate e0 -> e1 -> e2, row sets bA <-> bB: six phases until both are back where they started
         while (pos < jend) {
-            // batch at pos: rows in bA, values a0; next batch: entries c1/a1
-            gather(c1, bB);
-            { int2 t; float2 ta; fetch(pos + 3 * BATCH, t, ta); macs(a0, bA, jend - pos); c0 = t; a0 = ta; }
-            pos += BATCH;
+            gather(e1, bB); fetch(pos + 3 * BATCH, t); macs(e0, bA, jend - pos); e0 = t; pos += BATCH;
             if (pos >= jend) break;
-            // batch at pos: rows in bB, values a1; next batch: entries c2/a2
-            gather(c2, bA);
-            { int2 t; float2 ta; fetch(pos + 3 * BATCH, t, ta); macs(a1, bB, jend - pos); c1 = t; a1 = ta; }
-            pos += BATCH;
+            gather(e2, bA); fetch(pos + 3 * BATCH, t); macs(e1, bB, jend - pos); e1 = t; pos += BATCH;
             if (pos >= jend) break;
-            // third phase of the entry rotation: rows in bA, values a2; next batch: entries c0/a0
-            gather(c0, bB);
-            { int2 t; float2 ta; fetch(pos + 3 * BATCH, t, ta); macs(a2, bA, jend - pos); c2 = t; a2 = ta; }
-            pos += BATCH;
+            gather(e0, bB); fetch(pos + 3 * BATCH, t); macs(e2, bA, jend - pos); e2 = t; pos += BATCH;
             if (pos >= jend) break;
-            gather(c1, bA);
-            { int2 t; float2 ta; fetch(pos + 3 * BATCH, t, ta); macs(a0, bB, jend - pos); c0 = t; a0 = ta; }
-            pos += BATCH;
+            gather(e1, bA); fetch(pos + 3 * BATCH, t); macs(e0, bB, jend - pos); e0 = t; pos += BATCH;
             if (pos >= jend) break;
-            gather(c2, bB);
-            { int2 t; float2 ta; fetch(pos + 3 * BATCH, t, ta); macs(a1, bA, jend - pos); c1 = t; a1 = ta; }
-            pos += BATCH;
+            gather(e2, bB); fetch(pos + 3 * BATCH, t); macs(e1, bA, jend - pos); e1 = t; pos += BATCH;
             if (pos >= jend) break;
-            gather(c0, bA);
-            { int2 t; float2 ta; fetch(pos + 3 * BATCH, t, ta); macs(a2, bB, jend - pos); c2 = t; a2 = ta; }
-            pos += BATCH;
+            gather(e0, bA); fetch(pos + 3 * BATCH, t); macs(e2, bB, jend - pos); e2 = t; pos += BATCH;
         }
     }
     if (v < v_end) {
