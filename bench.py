@@ -264,7 +264,9 @@ def main():
                          lambda: fem_secondary(api, torch, dev, stream, (35, 19, 7, 3), 128, 300)),
                         ("suitesparse_like_fem_4M_N16",
                          lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 100)),
-                        ("config5_blocked_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream))):
+                        ("config5_blocked_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream)),
+                        ("powerlaw_1M_rows_N16", lambda: powerlaw_secondary(api, torch, dev, stream)),
+                        ("config4_matrix_N32", lambda: uniform_secondary(api, torch, dev, stream, args, 32))):
             try:
                 also[key] = fn()
             except Exception as e:   # secondary measurements only
@@ -432,6 +434,46 @@ def bell_secondary(api, torch, dev, stream, M=1_048_576, W=328, N=256, iters=5):
            "mfma_util_vs_2.5PF": round(flops / (k_ns * 1e-9) / 2.5e15, 4), "dtype": "bf16 in, f32 accumulate"}
     e.close()
     api.device_free(dev.index, dc)
+    return out
+
+
+def powerlaw_secondary(api, torch, dev, stream):
+    """Skewed input of the sweep harness: 1M x 1M, P(len >= x) = (6/x)^1.2, longest row ~400 000,
+    default engine options (long rows bucketed, hub rows split and folded in order), next to a uniform matrix with
+    the same number of non-zeros."""
+    M = K = 1_000_000
+    p, i, v, nnz = api.gen_powerlaw_device(dev.index, M, K, 6, 120, 400_000, 7)
+    e = api.Engine(dev.index)
+    e.set_matrix_csr_device(M, K, nnz, p, i, v)
+    out = _measure(api, torch, e, M, K, 16, nnz, dev, stream, 50)
+    out.update(piece_path_rows=int(e.get_stat("piece_path_rows")), reassociated_rows=int(e.get_stat("reassociated_rows")),
+               matrix="powerlaw xmin 6, tail 1.2, max 400000, seed 7")
+    e.close()
+    for q in (p, i, v):
+        api.device_free(dev.index, q)
+    p, i, v, nnz_u = api.gen_csr_device(dev.index, M, K, nnz / M, 7)
+    e = api.Engine(dev.index)
+    e.set_matrix_csr_device(M, K, nnz_u, p, i, v)
+    u = _measure(api, torch, e, M, K, 16, nnz_u, dev, stream, 50)
+    out["uniform_same_nnz_us_per_step"] = u["us_per_step"]
+    out["ratio_to_uniform"] = round(out["us_per_step"] / u["us_per_step"], 3)
+    e.close()
+    for q in (p, i, v):
+        api.device_free(dev.index, q)
+    return out
+
+
+def uniform_secondary(api, torch, dev, stream, args, N):
+    """The config-4 matrix at N = 32: a B row is a whole 128-byte line, one fabric request per non-zero carries twice
+    the payload of N = 16 (8 lanes per row, chosen automatically)."""
+    M = K = args.rows
+    p, i, v, nnz = api.gen_csr_device(dev.index, M, K, args.mean_nnz, 4)
+    e = api.Engine(dev.index)
+    e.set_matrix_csr_device(M, K, nnz, p, i, v)
+    out = _measure(api, torch, e, M, K, N, nnz, dev, stream, 10)
+    e.close()
+    for q in (p, i, v):
+        api.device_free(dev.index, q)
     return out
 
 
