@@ -243,7 +243,7 @@ int sextans_destroy(sextans_handle_t h);
  * this path),
  * "fuse_b" (1 = the panel kernel may stage B straight from column-major B when B is <= 16 MiB and every row block has a dictionary, saving the
  * repack launch; default 1), "panel_min_reuse_x100" (a row block uses the LDS panel when
- * nnz >= value/100 * distinct columns; default 400).  Unknown keys -> SEXTANS_ERR_INVALID. */
+ * nnz >= value/100 * distinct columns; default 200).  Unknown keys -> SEXTANS_ERR_INVALID. */
 /* "mfma_dense_tiles" / "dense_tile_fill_x100": north_star's "MFMA only where a tile is actually dense".  The engine
  * always counts the 32x32 tiles of A whose fill reaches dense_tile_fill_x100 % (default 50) -- sextans_get_stat
  * "dense_tiles", "dense_tile_fraction" (share of the non-zeros in such tiles; estimated from a sample of up to 512
