@@ -345,11 +345,12 @@ int sextans_invoke(sextans_handle_t h, const int32_t *edge_list_ptr, const uint6
  *                            M_total x K matrix (ranges tile [0, M_total) in rank order, unequal lengths allowed:
  *                            nnz-balanced splits); d_B is the full K x N matrix, d_C_in / d_C_out the full
  *                            column-major M_total x N matrices on this rank's device.  The rank's slab is
- *                            computed in `nchunks` row chunks into a staging buffer; the all-gather of chunk i
+ *                            computed in `nchunks` row chunks (cut at sextans_align_row boundaries, exchanged between
+ *                            the ranks once per partition) into a staging buffer; the all-gather of chunk i
  *                            (ncclAllGather on the engine's communication stream) overlaps the SpMM of chunk
  *                            i+1; a final pass writes every rank's rows into d_C_out.  Enqueued on `stream`,
- *                            returns without synchronising (one short host sync the first time a partition is
- *                            used, for its row tables).  d_C_out holds C = alpha*A*B + beta*C_in for ALL rows on
+ *                            returns without synchronising (host syncs only the first time a partition is used:
+ *                            cut exchange and row tables).  d_C_out holds C = alpha*A*B + beta*C_in for ALL rows on
  *                            every rank. */
 int sextans_dist_unique_id(char id[128]);
 int sextans_dist_comm_init(void **comm, int device, int world, int rank, const char id[128]);

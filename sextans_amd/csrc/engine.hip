@@ -139,6 +139,7 @@ struct sextans_engine {
     size_t stage_cap = 0;
     hipStream_t comm_stream = nullptr;
     std::vector<hipEvent_t> dist_events;
+    std::vector<int> dist_cut_key, dist_cuts;   // (ranges, N, nchunks, rank) the chunk cuts of all ranks were exchanged for
     std::vector<int> dist_meta;     // {first row, rows} per (chunk, rank) as last uploaded, and where
     const int *dist_meta_at = nullptr;
     // options
@@ -249,6 +250,7 @@ void free_matrix(sextans_engine *h) {
     h->d_v = nullptr;
     h->owns_matrix = false;
     h->m_rp = h->m_ci = nullptr; h->m_v = nullptr; h->m_nnz = 0;
+    h->dist_cut_key.clear();   // chunk cuts are aligned to the packed forms of one matrix
 }
 
 int ensure(float **p, size_t *cap, size_t need) {
@@ -1685,10 +1687,44 @@ int sextans_dist_spmm(sextans_handle_t h, void *comm, int world, int rank, const
     hipStream_t s = (hipStream_t)stream;
     if (nchunks < 1) nchunks = 1;
     if (nchunks > 16) nchunks = 16;
-    // Chunk c of rank g = rows [len_g * c / nchunks, len_g * (c+1) / nchunks) of its range -- computable by every
-    // rank for every rank.  This rank's own interior cuts are NOT snapped to kernel-friendly boundaries here
-    // (that would need an exchange); sextans_spmm_device_rows falls back to the gather kernel on unaligned cuts.
-    auto cut = [&](int g, int c) { return (int)((int64_t)(row_ranges[2 * g + 1] - row_ranges[2 * g]) * c / nchunks); };
+    // Chunk c of rank g = local rows [cuts[g][c], cuts[g][c+1]).  Every rank snaps its OWN interior cuts to the
+    // boundaries its kernels want (sextans_align_row: row blocks of the LDS-panel plan, wavefronts of the window kernel,
+    // so every chunk keeps the whole-matrix kernel) and the cut positions are exchanged once per (partition, N, chunk
+    // count) with a small ncclAllGather; they are cached in the engine afterwards.
+    std::vector<int> key(row_ranges, row_ranges + 2 * world);
+    key.push_back(N); key.push_back(nchunks); key.push_back(rank);
+    if (h->dist_cut_key != key) {
+        std::vector<int> mine((size_t)nchunks + 1, 0);
+        mine[(size_t)nchunks] = m_loc;
+        for (int c = 1; c < nchunks; ++c) {
+            int a = (int)((int64_t)m_loc * c / nchunks);
+            if (int rc = sextans_align_row(h, N, a, &a)) return rc;
+            mine[(size_t)c] = std::min(std::max(a, mine[(size_t)c - 1]), m_loc);
+        }
+        int *d_cuts = nullptr;
+        SX_HIP(hipMalloc((void **)&d_cuts, sizeof(int) * (size_t)world * ((size_t)nchunks + 1)));
+        SX_HIP(hipMemcpyAsync(d_cuts + (size_t)rank * (nchunks + 1), mine.data(), sizeof(int) * mine.size(),
+                              hipMemcpyHostToDevice, s));
+        const int rc = rccl_check(r->AllGather(d_cuts + (size_t)rank * (nchunks + 1), d_cuts, (size_t)nchunks + 1, 2 /* ncclInt32 */,
+                                               comm, s), "ncclAllGather(cuts)");
+        std::vector<int> all((size_t)world * ((size_t)nchunks + 1));
+        hipError_t e1 = rc ? hipSuccess : hipMemcpyAsync(all.data(), d_cuts, sizeof(int) * all.size(), hipMemcpyDeviceToHost, s);
+        hipError_t e2 = hipStreamSynchronize(s);
+        (void)hipFree(d_cuts);
+        if (rc) return rc;
+        SX_HIP(e1);
+        SX_HIP(e2);
+        for (int g = 0; g < world; ++g) {   // what arrived must be a monotone cut list of that rank's range
+            const int len = row_ranges[2 * g + 1] - row_ranges[2 * g];
+            const int *cg = all.data() + (size_t)g * (nchunks + 1);
+            if (cg[0] != 0 || cg[nchunks] != len) return SEXTANS_ERR_STATE;
+            for (int c = 0; c < nchunks; ++c)
+                if (cg[c + 1] < cg[c]) return SEXTANS_ERR_STATE;
+        }
+        h->dist_cuts = all;
+        h->dist_cut_key = key;
+    }
+    auto cut = [&](int g, int c) { return h->dist_cuts[(size_t)g * (nchunks + 1) + (size_t)c]; };
     std::vector<int64_t> lmax((size_t)nchunks, 1), off((size_t)nchunks + 1, 0);
     for (int c = 0; c < nchunks; ++c) {
         for (int g = 0; g < world; ++g) lmax[(size_t)c] = std::max<int64_t>(lmax[(size_t)c], cut(g, c + 1) - cut(g, c));

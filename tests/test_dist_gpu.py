@@ -105,6 +105,8 @@ def test_native_dist_spmm_single_rank(engine, oracle, sx):
                                  nchunks=nchunks, stream=st)
                 torch.cuda.synchronize()
                 assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (name, nchunks)
+                if name == "fem":          # chunk cuts are snapped to row-block boundaries: every chunk keeps the panel kernel
+                    assert engine.last_kernel() == "spmm_csr_panel", nchunks
             if name == "fem":
                 # row-range calls cut at sextans_align_row boundaries keep the LDS-panel kernel
                 cuts = [0, engine.align_row(N, M // 3), engine.align_row(N, 2 * M // 3), M]
