@@ -17,7 +17,7 @@ def bf16_round(x):
     return u.astype(np.uint32).view(np.float32)
 
 
-def block_diagonal_plus_noise(rs, M, K, fill_off=0.6):
+def block_diagonal_plus_noise(rs, M, K, fill_off=0.6, hub_row=None):
     """Fully dense 32x32 diagonal blocks, a second band of ~60 %-filled tiles, and 4 random non-zeros per row."""
     rows, cols = [], []
     for br in range(min(M, K) // 32):
@@ -29,6 +29,9 @@ def block_diagonal_plus_noise(rs, M, K, fill_off=0.6):
             rows.append(br * 32 + r[m]); cols.append(bc * 32 + c[m])
     nr = np.repeat(np.arange(M), 4)
     rows.append(nr); cols.append(rs.randint(0, K, len(nr)))
+    if hub_row is not None:                                          # one hub row: the piece path runs next to both kernels
+        hc = rs.choice(K, size=min(K, 1500), replace=False)
+        rows.append(np.full(len(hc), hub_row)); cols.append(hc)
     r = np.concatenate(rows); c = np.concatenate(cols)
     key = np.unique(r.astype(np.int64) * K + c)                      # distinct, sorted by (row, col)
     r, c = (key // K).astype(np.int32), (key % K).astype(np.int32)
@@ -47,7 +50,7 @@ def dense_mask(M, K, rp, ci, thr):
 @pytest.mark.parametrize("M,K,N", [(2048 + 17, 2048 + 40, 64), (1024, 4096, 32), (640, 640, 96)])
 def test_block_diagonal_plus_noise_runs_both_kernels(engine, M, K, N):
     rs = np.random.RandomState(M + N)
-    rp, ci, v = block_diagonal_plus_noise(rs, M, K)
+    rp, ci, v = block_diagonal_plus_noise(rs, M, K, hub_row=M - 3 if M > 2000 else None)
     B = rs.uniform(-1, 1, K * N).astype(np.float32)
     C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
     for k, val in dict(kernel=0, lanes_per_row=4, exact=1, split_rows=-1, bucket_rows=-1, mfma_dense_tiles=0,
@@ -65,6 +68,7 @@ def test_block_diagonal_plus_noise_runs_both_kernels(engine, M, K, N):
     out = C0.copy()
     engine.spmm(N, ALPHA, B, BETA, out, rp_time=2)
     assert engine.last_kernel().endswith("+dense_tiles_mfma") and engine.get_stat("dense_tiles_on_mfma") == 1
+    assert ("+hub_pieces" in engine.last_kernel()) == (M > 2000) and (engine.get_stat("reassociated_rows") == 1) == (M > 2000)
     # the mixed-precision product in float64
     rows = np.repeat(np.arange(M), np.diff(rp))
     Bm = B.reshape(N, K).T.astype(np.float64)
