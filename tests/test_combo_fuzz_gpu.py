@@ -3,6 +3,8 @@ window), lane counts, long-row bucketing and hub splitting thresholds, whole-mat
 with sextans_align_row or deliberately unaligned), in-place C, alpha/beta -- on small matrices of four structures.
 Rows that are not re-associated must be BIT-EXACT against the oracle's cpu_spmm_CSR; re-associated hub rows
 (sextans_reassociated_rows) must meet |d| <= 1e-4 * (|alpha| * sum|a*b| + |beta*c|)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -39,7 +41,7 @@ def make(rs, kind, M, K):
 
 CASES = []
 _rs = np.random.RandomState(77)
-for _i in range(48):
+for _i in range(int(os.environ.get("SEXTANS_COMBO_CASES", "48"))):     # soak: SEXTANS_COMBO_CASES=1000
     CASES.append((_i, ["uniform", "banded", "hubs", "blocky"][_i % 4], int(_rs.choice([700, 1500, 2600])),
                   int(_rs.choice([600, 3000, 9000])), int(_rs.choice([8, 16, 24, 32, 40])), int(_rs.choice([0, 1, 2, 3])),
                   int(_rs.choice([0, 0, 2, 4, 8])), int(_rs.choice([0, -1, 64, 300])), int(_rs.choice([0, -1, 16])),
