@@ -251,6 +251,7 @@ void free_matrix(sextans_engine *h) {
     h->owns_matrix = false;
     h->m_rp = h->m_ci = nullptr; h->m_v = nullptr; h->m_nnz = 0;
     h->dist_cut_key.clear();   // chunk cuts are aligned to the packed forms of one matrix
+    h->bp_layout = 0;          // B panels belong to one (K, B)
 }
 
 int ensure(float **p, size_t *cap, size_t need) {
@@ -1172,7 +1173,12 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     if (ldb < h->K || ldc < nrows || ldc_in < nrows) return SEXTANS_ERR_INVALID;
     SX_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    if (nrows == 0) return SEXTANS_OK;
+    if (nrows == 0) {
+        // an empty range still opens a sequence: without the reuse flag the caller announces a new B, and the next call
+        // (which will carry the flag) must not find the panels of some earlier B
+        if (!(flags & SEXTANS_ROWS_REUSE_B_PANELS)) h->bp_layout = 0;
+        return SEXTANS_OK;
+    }
     std::vector<Seg> plan;
     int W = 0;
     bool use_panel = false, use_window = false;
