@@ -450,3 +450,29 @@ def test_packed_forms_are_kept_per_lane_count(engine, oracle, sx):
         assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), N
         built.append(engine.get_stat("plan_build_s"))
     assert built[1] > built[0] and built[2:] == [built[1]] * 4, built     # two builds (2 and 4 lanes), then none
+
+
+def test_empty_first_range_does_not_leave_stale_b_panels(engine, oracle):
+    """Found by the combination soak: a row-range sequence whose FIRST range is empty (no repack happens in it)
+    followed by calls carrying the reuse flag must not pick up the panels of an earlier B."""
+    import torch
+    rs = np.random.RandomState(3)
+    M, K, N = 400, 300, 16
+    rp, ci, v = random_csr(rs, M, K, 8)
+    for k, val in dict(lanes_per_row=0, stage_a=1, xcd_remap=1, exact=1, kernel=1, split_rows=0, bucket_rows=0).items():
+        engine.set_option(k, val)
+    engine.set_matrix_csr(M, K, rp, ci, v)
+    st = torch.cuda.current_stream().cuda_stream
+    B_old = torch.from_numpy(rs.uniform(-1, 1, K * N).astype(np.float32)).cuda()
+    C = torch.zeros(M * N, device="cuda")
+    engine.spmm_device(N, 1.0, B_old.data_ptr(), K, 0.0, C.data_ptr(), C.data_ptr(), M, st)      # panels of B_old
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    dB = torch.from_numpy(B).cuda(); dC = torch.from_numpy(C0).cuda()
+    for i, (c0, c1) in enumerate([(0, 0), (0, 250), (250, M)]):
+        engine.spmm_device_rows(N, ALPHA, dB.data_ptr(), K, BETA, dC.data_ptr() + 4 * c0, M, dC.data_ptr() + 4 * c0, M,
+                                c0, c1, reuse_b_panels=i > 0, stream=st)
+    torch.cuda.synchronize()
+    assert np.array_equal(dC.cpu().numpy().view(np.uint32), want.view(np.uint32))
