@@ -40,7 +40,7 @@ def make_matrix(rs, kind, M, K, mean):
 
 CASES = []
 _rs = np.random.RandomState(2024)
-for _i in range(36):
+for _i in range(int(__import__("os").environ.get("SEXTANS_FUZZ_CASES", "36"))):     # soak: SEXTANS_FUZZ_CASES=1000
     CASES.append((_i, ["banded", "blocky", "uniform", "tails"][_i % 4], int(_rs.choice([1, 7, 63, 64, 65, 200, 777, 2500])),
                   int(_rs.choice([1, 5, 40, 300, 5000])), float(_rs.choice([0.7, 3, 11, 30])),
                   int(_rs.choice([8, 16, 24, 40])), int(_rs.choice([2, 4, 8])), int(_rs.choice([0, 0, 400, 100000]))))
