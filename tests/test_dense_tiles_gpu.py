@@ -115,3 +115,59 @@ def test_no_dense_tiles_nothing_changes(engine, oracle):
         assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
     finally:
         engine.set_option("mfma_dense_tiles", 0)
+
+
+_CASES = int(__import__("os").environ.get("SEXTANS_DENSE_CASES", "6"))     # soak: SEXTANS_DENSE_CASES=300
+
+
+@pytest.mark.parametrize("seed", range(_CASES))
+def test_random_shapes_thresholds_kernels(engine, seed):
+    """Random sizes (incl. M, K not multiples of 32), fill thresholds, main kernels and an optional hub row."""
+    rs = np.random.RandomState(500 + seed)
+    M, K = int(rs.choice([96, 333, 1000, 1700])), int(rs.choice([64, 257, 1024, 3000]))
+    N = int(rs.choice([32, 64, 96]))
+    hub = int(rs.randint(0, M)) if rs.rand() < 0.5 and K >= 1024 else None
+    rp, ci, v = block_diagonal_plus_noise(rs, M, K, fill_off=float(rs.choice([0.3, 0.6, 0.9])), hub_row=hub)
+    fill = int(rs.choice([25, 50, 75]))
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    for k, val in dict(kernel=int(rs.choice([0, 1, 2, 3])), lanes_per_row=int(rs.choice([0, 4, 8])), exact=1, split_rows=-1,
+                       bucket_rows=int(rs.choice([-1, 0])), mfma_dense_tiles=1, dense_tile_fill_x100=fill).items():
+        engine.set_option(k, val)
+    try:
+        engine.set_matrix_csr(M, K, rp, ci, v)
+        out = C0.copy()
+        engine.spmm(N, ALPHA, B, BETA, out)
+        thr = (fill * 1024 + 99) // 100
+        dm = dense_mask(M, K, rp, ci, thr)
+        if hub is not None:                                  # the hub row left the main matrix before the tile search
+            rows_all = np.repeat(np.arange(M), np.diff(rp))
+            lens = np.diff(rp)
+            T = max(1024, int(rp[-1]) // 16384)
+            L0 = max(32, 2 * (int(rp[-1]) // M))
+            off = lens > (L0 if engine.get_option("bucket_rows") == -1 else T)
+            # recompute the mask on the matrix without the rows that took the piece path (if any did)
+            if engine.get_stat("piece_path_rows") > 0:
+                keep = ~off[rows_all]
+                cnt_rows = rows_all[keep]
+                tile = (cnt_rows // 32).astype(np.int64) * ((K + 31) // 32) + ci[keep] // 32
+                cnt = np.bincount(tile, minlength=((M + 31) // 32) * ((K + 31) // 32))
+                dm = np.zeros(len(ci), bool)
+                dm[keep] = (cnt[tile] >= thr) & (cnt_rows < (M // 32) * 32)
+        assert (engine.get_stat("dense_tiles_on_mfma") == 1) == bool(dm.any())
+        rows = np.repeat(np.arange(M), np.diff(rp))
+        Bm = B.reshape(N, K).T.astype(np.float64)
+        Bb = bf16_round(B).reshape(N, K).T.astype(np.float64)
+        a_used = np.where(dm, bf16_round(v), v).astype(np.float64)
+        want = np.zeros((M, N)); asum = np.zeros((M, N))
+        for sel, Bx in ((dm, Bb), (~dm, Bm)):
+            np.add.at(want, rows[sel], a_used[sel, None] * Bx[ci[sel]])
+            np.add.at(asum, rows[sel], np.abs(a_used[sel, None] * Bx[ci[sel]]))
+        Cm = C0.reshape(N, M).T.astype(np.float64)
+        want = float(ALPHA) * want + float(BETA) * Cm
+        got = out.reshape(N, M).T.astype(np.float64)
+        tol = 4e-6 * asum * abs(float(ALPHA)) + 2e-6 * np.abs(float(BETA) * Cm) + 1e-30
+        assert np.all(np.abs(got - want) <= tol), (float(np.max(np.abs(got - want) / tol)), engine.last_kernel())
+    finally:
+        for k, val in dict(kernel=0, lanes_per_row=0, mfma_dense_tiles=0, dense_tile_fill_x100=50, bucket_rows=-1).items():
+            engine.set_option(k, val)
