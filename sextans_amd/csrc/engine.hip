@@ -115,6 +115,13 @@ struct sextans_engine {
     //     for one long row among 63 short ones;
     //   hub rows (longer than the split threshold T, option "split_rows"): pieces of T entries summed in parallel
     //     and folded in order = re-associated (stated tolerance), reported by sextans_reassociated_rows.
+    // Chain of matrices: the matrix as set (d_rp / d_ci / d_v) -> [dense 32x32 tiles cut out, when routed to MFMA] ->
+    // "source" (s_*) -> [long rows emptied] -> "main" (m_*).  Without dense tiles / long rows the stages alias.
+    const int *s_rp = nullptr, *s_ci = nullptr;
+    const float *s_v = nullptr;
+    int64_t s_nnz = 0;
+    int *d_srp = nullptr, *d_sci = nullptr;   // owned copy of the source (exists only when tiles were cut out)
+    float *d_sv = nullptr;
     const int *m_rp = nullptr, *m_ci = nullptr;
     const float *m_v = nullptr;
     int64_t m_nnz = 0;
@@ -211,16 +218,7 @@ void free_bell(sextans_engine *h) {
     h->bell_M = h->bell_K = h->bell_W = 0;
 }
 
-void free_dense(sextans_engine *h) {
-    (void)hipFree(h->d_dense_col); (void)hipFree(h->d_dense_Af);
-    h->d_dense_col = nullptr; h->d_dense_Af = nullptr;
-    h->dense_mb = h->dense_W = 0;
-    h->dense_tiles = h->dense_nnz = 0;
-    h->dense_built_mfma = h->dense_built_fill = -2;
-}
-
-void free_split(sextans_engine *h) {
-    free_dense(h);   // the dense tiles are cut out of the main matrix built here
+void free_split(sextans_engine *h) {   // long-row state: main matrix, skip flags, piece tables (built from the source)
     for (auto *t : {&h->by_len, &h->by_row}) {
         (void)hipFree(t->d_vrp); (void)hipFree(t->d_vend); (void)hipFree(t->d_vfirst); (void)hipFree(t->d_row);
         *t = sextans_engine::PieceTable();
@@ -233,12 +231,25 @@ void free_split(sextans_engine *h) {
     h->nhub = h->split_nv = 0;
     h->split_T = h->bucket_L0 = 0;
     h->split_built_opt = h->bucket_built_opt = -2;
-    h->m_rp = h->d_rp; h->m_ci = h->d_ci; h->m_v = h->d_v; h->m_nnz = h->nnz;
+    h->m_rp = h->s_rp; h->m_ci = h->s_ci; h->m_v = h->s_v; h->m_nnz = h->s_nnz;
+}
+
+void free_dense(sextans_engine *h) {   // dense-tile state and everything downstream of the source matrix
+    (void)hipFree(h->d_dense_col); (void)hipFree(h->d_dense_Af);
+    h->d_dense_col = nullptr; h->d_dense_Af = nullptr;
+    h->dense_mb = h->dense_W = 0;
+    h->dense_tiles = h->dense_nnz = 0;
+    h->dense_built_mfma = h->dense_built_fill = -2;
+    (void)hipFree(h->d_srp); (void)hipFree(h->d_sci); (void)hipFree(h->d_sv);
+    h->d_srp = h->d_sci = nullptr;
+    h->d_sv = nullptr;
+    h->s_rp = h->d_rp; h->s_ci = h->d_ci; h->s_v = h->d_v; h->s_nnz = h->nnz;
+    free_split(h);
 }
 
 void free_matrix(sextans_engine *h) {
     free_plan(h);
-    free_split(h);
+    free_dense(h);
     free_window(h);
     h->plan_build_s = 0.0;
     if (h->owns_matrix) {
@@ -249,7 +260,7 @@ void free_matrix(sextans_engine *h) {
     h->d_rp = h->d_ci = nullptr;
     h->d_v = nullptr;
     h->owns_matrix = false;
-    h->m_rp = h->m_ci = nullptr; h->m_v = nullptr; h->m_nnz = 0;
+    h->m_rp = h->m_ci = h->s_rp = h->s_ci = nullptr; h->m_v = h->s_v = nullptr; h->m_nnz = h->s_nnz = 0;
     h->dist_cut_key.clear();   // chunk cuts are aligned to the packed forms of one matrix
     h->bp_layout = 0;          // B panels belong to one (K, B)
 }
@@ -326,22 +337,23 @@ struct PlanTimer {   // accumulates host seconds spent packing A (reported by se
 // Device copy of the CSR arrays -> host, validated: the host-side plan builders index arrays of size K with
 // the column indices and trust row_ptr to be monotonic (a matrix handed over with
 // sextans_set_matrix_csr_device has not been looked at by anybody yet).
-// (main = true: the arrays the kernels work on, hub rows emptied; false: the matrix as the caller set it)
-int read_back_row_ptr(sextans_engine *h, std::vector<int> &rp, bool main = true) {
+// (level 2: the main matrix the kernels work on; 1: the source of the long-row split; 0: the matrix as the caller set it)
+int read_back_row_ptr(sextans_engine *h, std::vector<int> &rp, int level = 2) {
     rp.resize((size_t)h->M + 1);
-    SX_HIP(hipMemcpy(rp.data(), main ? h->m_rp : h->d_rp, sizeof(int) * ((size_t)h->M + 1), hipMemcpyDeviceToHost));
-    if (rp[0] != 0 || (int64_t)rp[(size_t)h->M] != (main ? h->m_nnz : h->nnz)) return SEXTANS_ERR_INVALID;
+    const int *src = level == 2 ? h->m_rp : level == 1 ? h->s_rp : h->d_rp;
+    SX_HIP(hipMemcpy(rp.data(), src, sizeof(int) * ((size_t)h->M + 1), hipMemcpyDeviceToHost));
+    if (rp[0] != 0 || (int64_t)rp[(size_t)h->M] != (level == 2 ? h->m_nnz : level == 1 ? h->s_nnz : h->nnz)) return SEXTANS_ERR_INVALID;
     for (int r = 0; r < h->M; ++r)
         if (rp[(size_t)r + 1] < rp[(size_t)r]) return SEXTANS_ERR_INVALID;
     return SEXTANS_OK;
 }
-int read_back_entries(sextans_engine *h, std::vector<int> &ci, std::vector<float> &va, bool main = true) {
-    const int64_t nnz = main ? h->m_nnz : h->nnz;
+int read_back_entries(sextans_engine *h, std::vector<int> &ci, std::vector<float> &va, int level = 2) {
+    const int64_t nnz = level == 2 ? h->m_nnz : level == 1 ? h->s_nnz : h->nnz;
     const size_t n1 = (size_t)(nnz ? nnz : 1);
     ci.assign(n1, 0); va.assign(n1, 0.f);
     if (nnz) {
-        SX_HIP(hipMemcpy(ci.data(), main ? h->m_ci : h->d_ci, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost));
-        SX_HIP(hipMemcpy(va.data(), main ? h->m_v : h->d_v, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost));
+        SX_HIP(hipMemcpy(ci.data(), level == 2 ? h->m_ci : level == 1 ? h->s_ci : h->d_ci, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost));
+        SX_HIP(hipMemcpy(va.data(), level == 2 ? h->m_v : level == 1 ? h->s_v : h->d_v, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost));
     }
     const unsigned K = (unsigned)h->K;
     unsigned bad = 0;
@@ -744,7 +756,7 @@ int sextans_set_matrix_csr(sextans_handle_t h, int M, int K, int64_t nnz, const 
     h->d_rp = rp; h->d_ci = ci; h->d_v = v;
     h->owns_matrix = true;
     h->M = M; h->K = K; h->nnz = nnz;
-    free_split(h);   // main matrix = the matrix itself until the hub test has run
+    free_dense(h);   // source = main = the matrix itself until the dense-tile and long-row tests have run
     return SEXTANS_OK;
 }
 
@@ -757,7 +769,7 @@ int sextans_set_matrix_csr_device(sextans_handle_t h, int M, int K, int64_t nnz,
     h->d_rp = d_row_ptr; h->d_ci = d_col_idx; h->d_v = d_val;
     h->owns_matrix = false;
     h->M = M; h->K = K; h->nnz = nnz;
-    free_split(h);
+    free_dense(h);
     return SEXTANS_OK;
 }
 
@@ -788,17 +800,17 @@ int ensure_split(sextans_engine *h) {
     free_window(h);
     h->split_built_opt = h->opt_split_rows;
     h->bucket_built_opt = h->opt_bucket_rows;
-    if (h->M == 0 || h->nnz == 0) return SEXTANS_OK;
+    if (h->M == 0 || h->s_nnz == 0) return SEXTANS_OK;
     int64_t T = h->opt_split_rows, L0 = h->opt_bucket_rows;
-    if (T < 0) T = std::max<int64_t>(1024, h->nnz / 16384);
-    if (L0 < 0) L0 = std::max<int64_t>(32, 2 * (h->nnz / h->M));
+    if (T < 0) T = std::max<int64_t>(1024, h->s_nnz / 16384);
+    if (L0 < 0) L0 = std::max<int64_t>(32, 2 * (h->s_nnz / h->M));
     if (T == 0) T = INT64_MAX;                 // never split
     if (L0 == 0) L0 = T;                       // no bucketing: only rows that must be split leave
     if (L0 > T) L0 = T;
     if (L0 == INT64_MAX) return SEXTANS_OK;
     PlanTimer timer(h);
     std::vector<int> rp;
-    if (int rc = read_back_row_ptr(h, rp, false)) return rc;
+    if (int rc = read_back_row_ptr(h, rp, 1)) return rc;
     std::vector<int> rows;                     // ascending
     for (int r = 0; r < h->M; ++r)
         if ((int64_t)rp[(size_t)r + 1] - rp[(size_t)r] > L0) rows.push_back(r);
@@ -811,11 +823,11 @@ int ensure_split(sextans_engine *h) {
             long_nnz += len;
             longest = std::max(longest, len);
         }
-        if (longest <= T && h->opt_bucket_rows < 0 && long_nnz * 50 < h->nnz) return SEXTANS_OK;
+        if (longest <= T && h->opt_bucket_rows < 0 && long_nnz * 50 < h->s_nnz) return SEXTANS_OK;
     }
     std::vector<int> ci;
     std::vector<float> va;
-    if (int rc = read_back_entries(h, ci, va, false)) return rc;
+    if (int rc = read_back_entries(h, ci, va, 1)) return rc;
     // piece tables in two row orders
     auto build = [&](const std::vector<int> &order, sextans_engine::PieceTable &t) -> int {
         std::vector<int> vrp, vend, vfirst;
@@ -882,23 +894,23 @@ int ensure_split(sextans_engine *h) {
 // block rows are searched; at most 256 dense tiles per block row (the densest columns first come first served).
 int ensure_dense(sextans_engine *h) {
     if (h->dense_built_mfma == h->opt_mfma_dense && h->dense_built_fill == h->opt_dense_fill_x100) return SEXTANS_OK;
-    if (h->dense_W > 0) {   // tiles were cut out under other settings: start again from the matrix as set
-        free_split(h);
+    if (h->dense_W > 0 || h->opt_mfma_dense) {   // the source matrix may change: everything downstream starts again
         free_plan(h);
         free_window(h);
-        if (int rc = ensure_split(h)) return rc;
     }
-    free_dense(h);
+    const bool had_tiles = h->dense_W > 0;
+    if (had_tiles || h->opt_mfma_dense) free_dense(h);
+    else { h->dense_tiles = h->dense_nnz = 0; }
     h->dense_built_mfma = h->opt_mfma_dense;
     h->dense_built_fill = h->opt_dense_fill_x100;
     const int mb = h->M / 32;
-    if (mb == 0 || h->m_nnz == 0) return SEXTANS_OK;
+    if (mb == 0 || h->nnz == 0) return SEXTANS_OK;
     const int64_t thr = std::max<int64_t>(1, (h->opt_dense_fill_x100 * 1024 + 99) / 100);
-    if (h->m_nnz < thr) return SEXTANS_OK;
+    if (h->nnz < thr) return SEXTANS_OK;
     PlanTimer timer(h);
     std::vector<int> rp, ci;
     std::vector<float> va;
-    if (int rc = read_back_row_ptr(h, rp)) return rc;
+    if (int rc = read_back_row_ptr(h, rp, 0)) return rc;
     {   // cheap exit: a block row with fewer than `thr` entries cannot hold a dense tile
         bool any = false;
         for (int br = 0; br < mb && !any; ++br) any = (int64_t)rp[(size_t)br * 32 + 32] - rp[(size_t)br * 32] >= thr;
@@ -915,8 +927,11 @@ int ensure_dense(sextans_engine *h) {
             tot += j1 - j0;
             if (j1 - j0 < thr) continue;
             cols.resize((size_t)(j1 - j0));
-            SX_HIP(hipMemcpy(cols.data(), h->m_ci + j0, sizeof(int) * cols.size(), hipMemcpyDeviceToHost));
-            for (int &c : cols) c >>= 5;
+            SX_HIP(hipMemcpy(cols.data(), h->d_ci + j0, sizeof(int) * cols.size(), hipMemcpyDeviceToHost));
+            for (int &c : cols) {
+                if ((unsigned)c >= (unsigned)h->K) return SEXTANS_ERR_INDEX;
+                c >>= 5;
+            }
             std::sort(cols.begin(), cols.end());
             for (size_t a = 0; a < cols.size();) {
                 size_t b = a;
@@ -926,11 +941,11 @@ int ensure_dense(sextans_engine *h) {
             }
         }
         // scaled to the whole matrix
-        h->dense_nnz = tot ? (int64_t)((double)in_dense / (double)tot * (double)h->m_nnz) : 0;
+        h->dense_nnz = tot ? (int64_t)((double)in_dense / (double)tot * (double)h->nnz) : 0;
         h->dense_tiles = (int64_t)((double)tiles * (double)mb / (double)nsample);
         return SEXTANS_OK;
     }
-    if (int rc = read_back_entries(h, ci, va)) return rc;
+    if (int rc = read_back_entries(h, ci, va, 0)) return rc;
     // pass 1: dense tile columns per block row
     std::vector<std::vector<int>> dense((size_t)mb);
     std::vector<int> cols;
@@ -988,15 +1003,12 @@ int ensure_dense(sextans_engine *h) {
     }
     std::vector<float>().swap(blk);
     ci.resize(w ? w : 1); va.resize(w ? w : 1);
-    // the remainder replaces the main matrix (owned copies; the long-row tables address the ORIGINAL arrays and stay)
-    (void)hipFree(h->d_mrp); (void)hipFree(h->d_mci); (void)hipFree(h->d_mv);
-    h->d_mrp = h->d_mci = nullptr; h->d_mv = nullptr;
-    if (int rc = upload(&h->d_mrp, mrp)) return rc;
-    if (int rc = upload(&h->d_mci, ci)) return rc;
-    if (int rc = upload(&h->d_mv, va)) return rc;
-    h->m_rp = h->d_mrp; h->m_ci = h->d_mci; h->m_v = h->d_mv; h->m_nnz = (int64_t)w;
-    free_plan(h);
-    free_window(h);
+    // the remainder becomes the source matrix of the long-row split (which has not run yet for this source)
+    if (int rc = upload(&h->d_srp, mrp)) return rc;
+    if (int rc = upload(&h->d_sci, ci)) return rc;
+    if (int rc = upload(&h->d_sv, va)) return rc;
+    h->s_rp = h->d_srp; h->s_ci = h->d_sci; h->s_v = h->d_sv; h->s_nnz = (int64_t)w;
+    h->m_rp = h->s_rp; h->m_ci = h->s_ci; h->m_v = h->s_v; h->m_nnz = h->s_nnz;
     if (int rc = upload(&h->d_dense_col, bcol)) return rc;
     uint16_t *d_val = nullptr;
     SX_HIP(hipMalloc((void **)&d_val, bval.size() * 2));
@@ -1016,8 +1028,8 @@ int ensure_dense(sextans_engine *h) {
 // N-tile plan, and (for kernel != 1) the packed row-bucketed form of A.  Idempotent; called by
 // sextans_spmm_device2 and, ahead of the timed region, by sextans_spmm_host.
 int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_panel, bool &use_window) {
-    if (int rc = ensure_split(h)) return rc;   // first: the packed forms below are built from the main matrix
-    if (int rc = ensure_dense(h)) return rc;   // ... minus the dense tiles, when the caller routes them to MFMA
+    if (int rc = ensure_dense(h)) return rc;   // first the dense tiles leave (when the caller routes them to MFMA) ...
+    if (int rc = ensure_split(h)) return rc;   // ... then the long rows; the packed forms below are built from what remains
     if (h->dense_W > 0 && N % 32 == 0) {
         const size_t need = (size_t)((h->K + 31) / 32) * 32 * (size_t)N * 2;
         if (h->bell_Bf_cap < need) {
@@ -1120,8 +1132,8 @@ void launch_hub_pieces(sextans_engine *h, const sextans_engine::PieceTable &t, c
     if (nblk <= 0) return;
     float *P = h->d_P + (int64_t)col0 * h->split_nv;
     auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ntiles), dim3(sx::kBlock), 0, s, t.d_vrp, t.d_vend, h->d_ci,
-                           h->d_v, dBp, (int64_t)h->K * 4 * LPR, P, (int64_t)h->split_nv, v0, v1, ntiles);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ntiles), dim3(sx::kBlock), 0, s, t.d_vrp, t.d_vend, h->s_ci,
+                           h->s_v, dBp, (int64_t)h->K * 4 * LPR, P, (int64_t)h->split_nv, v0, v1, ntiles);
     };
     if (h->opt_exact) go(sx::spmm_csr_pieces<LPR, true>); else go(sx::spmm_csr_pieces<LPR, false>);
 }
@@ -1132,8 +1144,8 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     if (!h || !key || !value) return SEXTANS_ERR_INVALID;
     if (h->d_rp) {   // figures about the packed forms refer to the current options: bring the cheap ones up to date
         SX_HIP(hipSetDevice(h->device));
-        if (int rc = ensure_split(h)) return rc;
         if (int rc = ensure_dense(h)) return rc;
+        if (int rc = ensure_split(h)) return rc;
     }
     if (!strcmp(key, "plan_build_s")) *value = h->plan_build_s;
     else if (!strcmp(key, "window_padded_entries")) *value = (double)h->win_padded;
@@ -1143,8 +1155,7 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "split_threshold")) *value = (double)h->split_T;
     else if (!strcmp(key, "bucket_threshold")) *value = (double)h->bucket_L0;
     else if (!strcmp(key, "dense_tiles")) *value = (double)h->dense_tiles;
-    else if (!strcmp(key, "dense_tile_fraction")) *value = h->m_nnz + (h->dense_W > 0 ? h->dense_nnz : 0) > 0
-        ? (double)h->dense_nnz / (double)(h->m_nnz + (h->dense_W > 0 ? h->dense_nnz : 0)) : 0.0;
+    else if (!strcmp(key, "dense_tile_fraction")) *value = h->nnz > 0 ? (double)h->dense_nnz / (double)h->nnz : 0.0;
     else if (!strcmp(key, "dense_tiles_on_mfma")) *value = h->dense_W > 0 ? 1.0 : 0.0;
     else if (!strcmp(key, "panel_fraction")) *value = h->ps.plan_panel_frac;
     else if (!strcmp(key, "panel_blocks")) *value = (double)h->ps.plan_nblk;
@@ -1156,6 +1167,7 @@ int sextans_reassociated_rows(sextans_handle_t h, int *rows, int capacity, int *
     if (!h || !count || capacity < 0 || (capacity > 0 && !rows)) return SEXTANS_ERR_INVALID;
     if (!h->d_rp) return SEXTANS_ERR_STATE;
     SX_HIP(hipSetDevice(h->device));
+    if (int rc = ensure_dense(h)) return rc;
     if (int rc = ensure_split(h)) return rc;
     *count = (int)h->h_split_rows.size();
     for (int i = 0; i < *count && i < capacity; ++i) rows[i] = h->h_split_rows[(size_t)i];

@@ -140,20 +140,7 @@ def test_random_shapes_thresholds_kernels(engine, seed):
         engine.spmm(N, ALPHA, B, BETA, out)
         thr = (fill * 1024 + 99) // 100
         dm = dense_mask(M, K, rp, ci, thr)
-        if hub is not None:                                  # the hub row left the main matrix before the tile search
-            rows_all = np.repeat(np.arange(M), np.diff(rp))
-            lens = np.diff(rp)
-            T = max(1024, int(rp[-1]) // 16384)
-            L0 = max(32, 2 * (int(rp[-1]) // M))
-            off = lens > (L0 if engine.get_option("bucket_rows") == -1 else T)
-            # recompute the mask on the matrix without the rows that took the piece path (if any did)
-            if engine.get_stat("piece_path_rows") > 0:
-                keep = ~off[rows_all]
-                cnt_rows = rows_all[keep]
-                tile = (cnt_rows // 32).astype(np.int64) * ((K + 31) // 32) + ci[keep] // 32
-                cnt = np.bincount(tile, minlength=((M + 31) // 32) * ((K + 31) // 32))
-                dm = np.zeros(len(ci), bool)
-                dm[keep] = (cnt[tile] >= thr) & (cnt_rows < (M // 32) * 32)
+        # (the tiles are cut out of the matrix as set, BEFORE long rows are bucketed or split)
         assert (engine.get_stat("dense_tiles_on_mfma") == 1) == bool(dm.any())
         rows = np.repeat(np.arange(M), np.diff(rp))
         Bm = B.reshape(N, K).T.astype(np.float64)
