@@ -160,3 +160,22 @@ def test_power_law_1m_rows_within_1p5x_of_uniform(engine, sx):
     assert hubs > 100 and k_pl.endswith("+hub_pieces")
     assert abs(un[3] - pl[3]) < 0.02 * pl[3]
     assert t_pl <= 1.5 * t_un, (t_pl, t_un)
+
+
+def test_cli_on_a_power_law_file(sx, tmp_path):
+    """The reference's program flow (`sextans A.mtx N`) on a skewed matrix: hub rows are re-associated by default and
+    must still pass the reference's own verification (sextans-host.cpp:262-289: 0 mismatches at 1e-4)."""
+    import subprocess
+    from sextans_amd import api
+    M = K = 6000
+    rp, ci, v = api.gen_powerlaw_host(M, K, 3, 120, 5000, 3)
+    assert np.diff(rp).max() > 2000
+    path = tmp_path / "powerlaw.mtx"
+    rows = np.repeat(np.arange(M), np.diff(rp))
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (M, K, len(ci)))
+        for r, c, x in zip(rows, ci, v):
+            f.write("%d %d %.9g\n" % (r + 1, c + 1, x))
+    r = subprocess.run([sx.api.CLI_PATH, str(path), "16", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Success!" in r.stdout and "num_mismatch = 0" in r.stdout, r.stdout[-600:]
