@@ -173,7 +173,8 @@ def test_cli_on_a_power_law_file(sx, tmp_path):
     path = tmp_path / "powerlaw.mtx"
     rows = np.repeat(np.arange(M), np.diff(rp))
     with open(path, "w") as f:
-        f.write("%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (M, K, len(ci)))
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write("%d %d %d\n" % (M, K, len(ci)))
         for r, c, x in zip(rows, ci, v):
             f.write("%d %d %.9g\n" % (r + 1, c + 1, x))
     r = subprocess.run([sx.api.CLI_PATH, str(path), "16", "3"], capture_output=True, text=True, timeout=300)
