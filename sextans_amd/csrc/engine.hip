@@ -1,9 +1,14 @@
 // engine.hip -- the SpMM engine behind the C ABI (include/sextans_amd.h): replaces the
 // tapa::invoke(Sextans, ...) boundary of the reference (sextans-host.cpp:237-251, sextans.h:20-26).
 //
-// One engine = one HIP device.  The CSR arrays are uploaded once (sextans_set_matrix_csr); every
-// spmm call then enqueues: (1) B repack column-major -> N-tile panels, (2) the CSR row-group
-// kernel(s), all on the caller's stream, no host synchronisation in the device-resident form.
+// One engine = one HIP device.  The CSR arrays are uploaded once (sextans_set_matrix_csr).  The first SpMM on a
+// matrix (or sextans_align_row / sextans_get_stat) prepares it on the host, outside every timed region like the
+// reference's scheduling and packing (sextans-host.cpp:114-148): matrix as set -> [dense 32x32 tiles to bf16 MFMA,
+// opt-in] -> source -> [long rows to the piece path] -> main matrix -> packed row-bucketed form (LDS-panel kernel)
+// where row blocks reuse B rows.  Every spmm call then enqueues on the caller's stream, without host
+// synchronisation in the device-resident form: (1) B repack column-major -> N-tile panels, (2) the main kernel
+// (row-group gather / LDS panel / K-window sweep) [+ MFMA pass over the dense tiles, + piece kernel and in-order
+// fold for long rows], (3) for the multi-GPU entry the RCCL all-gather of the C slabs, chunk-pipelined.
 // There is NO CPU fallback anywhere in this file: no device => SEXTANS_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
