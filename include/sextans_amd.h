@@ -352,6 +352,9 @@ int sextans_invoke(sextans_handle_t h, const int32_t *edge_list_ptr, const uint6
  *                            returns without synchronising (host syncs only the first time a partition is used:
  *                            cut exchange and row tables).  d_C_out holds C = alpha*A*B + beta*C_in for ALL rows on
  *                            every rank. */
+/* Contiguous row ranges with (nearly) equal non-zero counts for `world` ranks: ranges[2g], ranges[2g+1] = rows of rank g
+ * (split points by binary search in row_ptr; host function, no device needed). */
+int sextans_partition_rows_by_nnz(int M, const int *row_ptr, int world, int *ranges);
 int sextans_dist_unique_id(char id[128]);
 int sextans_dist_comm_init(void **comm, int device, int world, int rank, const char id[128]);
 int sextans_dist_comm_destroy(void *comm);

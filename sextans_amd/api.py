@@ -110,6 +110,7 @@ def lib():
     L.sextans_get_stat.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
     L.sextans_align_row.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.sextans_reassociated_rows.argtypes = [C.c_void_p, _i32p, C.c_int, C.POINTER(C.c_int)]
+    L.sextans_partition_rows_by_nnz.argtypes = [C.c_int, _i32p, C.c_int, _i32p]
     L.sextans_dist_unique_id.argtypes = [C.c_char_p]
     L.sextans_dist_comm_init.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.sextans_dist_comm_destroy.argtypes = [C.c_void_p]
@@ -719,6 +720,14 @@ def gen_uniform_host(n, seed):
 
 def gen_uniform_device(device, d_ptr, n, seed, stream=None):
     _check(lib().sextans_gen_uniform_device(device, d_ptr, n, seed, stream), "gen_uniform_device")
+
+
+def partition_rows_by_nnz(row_ptr, world):
+    """C-ABI twin of sextans_amd.dist.partition_rows_by_nnz: [(r0, r1)] * world."""
+    rp = _buf(row_ptr, np.int32)
+    out = np.zeros(2 * world, np.int32)
+    _check(lib().sextans_partition_rows_by_nnz(len(rp) - 1, rp, world, out), "partition_rows_by_nnz")
+    return [(int(out[2 * g]), int(out[2 * g + 1])) for g in range(world)]
 
 
 def dist_unique_id():

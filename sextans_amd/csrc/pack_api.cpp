@@ -110,4 +110,26 @@ void sextans_window_packed_free(sextans_window_packed *p) {
     memset(p, 0, sizeof *p);
 }
 
+int sextans_partition_rows_by_nnz(int M, const int *row_ptr, int world, int *ranges) {
+    if (M < 0 || !row_ptr || world < 1 || !ranges) return SEXTANS_ERR_INVALID;
+    const int64_t nnz = row_ptr[M];
+    int prev = 0;
+    for (int g = 0; g < world; ++g) {
+        int cut = M;
+        if (g + 1 < world) {
+            const int64_t target = nnz * (g + 1) / world;
+            int lo = prev, hi = M;                      // first row r with row_ptr[r] >= target
+            while (lo < hi) {
+                const int mid = lo + (hi - lo) / 2;
+                if ((int64_t)row_ptr[mid] < target) lo = mid + 1; else hi = mid;
+            }
+            cut = lo;
+        }
+        ranges[2 * g] = prev;
+        ranges[2 * g + 1] = cut;
+        prev = cut;
+    }
+    return SEXTANS_OK;
+}
+
 }  // extern "C"

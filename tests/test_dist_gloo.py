@@ -109,6 +109,11 @@ def test_partition_properties():
         assert max(loads) - min(loads) <= 2 * int(np.diff(rp).max())
         ev = sxd.partition_rows_even(1000, world)
         assert ev[0][0] == 0 and ev[-1][1] == 1000 and len({b - a for a, b in ev}) == 1
+    # the C-ABI twin gives the same cuts
+    from sextans_amd import api
+    for world in (1, 2, 3, 8):
+        assert api.partition_rows_by_nnz(rp, world) == [(int(a), int(b)) for a, b in sxd.partition_rows_by_nnz(rp, world)]
+    assert api.partition_rows_by_nnz(np.array([0, 5, 5], np.int32), 4) == sxd.partition_rows_by_nnz(np.array([0, 5, 5]), 4)
     # degenerate: more ranks than rows, empty matrix
     assert sxd.partition_rows_by_nnz(np.array([0, 5, 5]), 4)[-1][1] == 2
     assert sxd.partition_rows_by_nnz(np.zeros(4, np.int32), 2)[-1][1] == 3
