@@ -2,6 +2,7 @@
 
   sextans_amd/lib/libsextans_amd.so   C-ABI shared library (include/sextans_amd.h)
   sextans_amd/bin/sextans             CLI with the reference's call surface
+  sextans_amd/bin/dist_spmm           examples/dist_spmm.cpp: multi-GPU SpMM through the C ABI alone (one thread per GPU)
 
 hipcc cross-compiles without a GPU.  Artefacts are git-ignored but travel to the GPU box.
 """
@@ -74,6 +75,13 @@ def build(force=False, verbose=False):
     if force or _stale(CLI, [cli_src, LIB]):
         cmd = [hipcc()] + FLAGS + ["-o", CLI, cli_src, "-L", LIBDIR, "-lsextans_amd",
                                    "-Wl,-rpath,$ORIGIN/../lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    ex_src = os.path.join(ROOT, "examples", "dist_spmm.cpp")
+    ex_bin = os.path.join(BINDIR, "dist_spmm")
+    if os.path.exists(ex_src) and (force or _stale(ex_bin, [ex_src, LIB])):
+        cmd = [hipcc()] + FLAGS + ["-o", ex_bin, ex_src, "-L", LIBDIR, "-lsextans_amd", "-Wl,-rpath,$ORIGIN/../lib"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
