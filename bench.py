@@ -107,6 +107,8 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
+    if multi:   # hub-split threshold (only used with --opt split_rows=-1) from the whole matrix, as on one GPU
+        eng.set_option("global_nnz", sxd.global_nnz(nnz_loc, dev))
     eng.set_matrix_csr_device(m_loc, K, nnz_loc, d_rp, d_ci, d_v)
     cin_ptr = Cin.data_ptr() + 4 * r0
     cout_ptr = Cout.data_ptr() + 4 * r0
@@ -248,6 +250,11 @@ def main():
                             "collectives": "sextans_dist_spmm (RCCL from the C ABI)" if comm is not None
                             else "torch.distributed all_gather_into_tensor"}
 
+    if rank == 0 and world > 1 and not args.no_cpu_baseline:
+        # N > 1: the same CPU leg on a smaller bounded sample (the other ranks wait at the final barrier meanwhile);
+        # C_out is complete on every rank after the all-gather, so rank 0 also checks the first rows bit for bit
+        args.cpu_seconds = min(args.cpu_seconds, 5.0)
+        out["cpu_baseline"] = cpu_baseline(api, M, K, N, args, Cout, flops_per_row=None, all_cores=False)
     if rank == 0 and world == 1:
         if multi:   # forced single-rank distributed run: check the gathered C against the plain path
             ref = torch.empty_like(Cout)
@@ -295,7 +302,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(api, M, K, N, args, Cout, flops_per_row):
+def cpu_baseline(api, M, K, N, args, Cout, flops_per_row, all_cores=True):
     """Single-thread CPU baseline on the first R rows of the same matrix (same B, same C_in):
     the reference's own cpu_spmm_CSR when oracle/_ref is present, else our C restatement.
     Also cross-checks the GPU result on those rows bit-for-bit."""
@@ -333,6 +340,8 @@ def cpu_baseline(api, M, K, N, args, Cout, flops_per_row):
            "sample": f"rows [0,{R}) of the same matrix ({nnz_s} nnz), same B and C_in, "
                      f"{sec:.2f} s single thread; host has {os.cpu_count()} logical cores",
            "gpu_matches_cpu_bitwise_on_sample": match}
+    if not all_cores:
+        return out
     # Same loop nest, row-parallel on ALL host cores (SURVEY.md 8d baseline 2): OpenMP loop in oracle/, same sample.
     try:
         rp, ci, v = csr
@@ -439,14 +448,16 @@ def bell_secondary(api, torch, dev, stream, M=1_048_576, W=328, N=256, iters=5):
 
 def powerlaw_secondary(api, torch, dev, stream):
     """Skewed input of the sweep harness: 1M x 1M, P(len >= x) = (6/x)^1.2, longest row ~400 000,
-    default engine options (long rows bucketed, hub rows split and folded in order), next to a uniform matrix with
-    the same number of non-zeros."""
+    long rows bucketed (default) and hub rows split and folded in order (split_rows = -1, opt-in), next to a uniform
+    matrix with the same number of non-zeros."""
     M = K = 1_000_000
     p, i, v, nnz = api.gen_powerlaw_device(dev.index, M, K, 6, 120, 400_000, 7)
     e = api.Engine(dev.index)
+    e.set_option("split_rows", -1)   # opt in: hub rows are cut at T = max(1024, nnz/16384) and re-associated (engine default
+                                     # since round 3 is strict order for every row)
     e.set_matrix_csr_device(M, K, nnz, p, i, v)
     out = _measure(api, torch, e, M, K, 16, nnz, dev, stream, 50)
-    out.update(piece_path_rows=int(e.get_stat("piece_path_rows")), reassociated_rows=int(e.get_stat("reassociated_rows")),
+    out.update(options="split_rows=-1 (opt-in re-association of hub rows)", piece_path_rows=int(e.get_stat("piece_path_rows")), reassociated_rows=int(e.get_stat("reassociated_rows")),
                matrix="powerlaw xmin 6, tail 1.2, max 400000, seed 7")
     e.close()
     for q in (p, i, v):

@@ -238,9 +238,14 @@ int sextans_destroy(sextans_handle_t h);
  * "bucket_rows" leave the main kernel and are processed in a second launch in order of length, still summed in
  * CSR order = bit-identical; rows longer than T = "split_rows" are cut into pieces of T entries that are summed in
  * parallel and folded in order -- THOSE rows are re-associated and meet the stated 1e-4 tolerance instead of bit
- * identity; sextans_reassociated_rows lists them.  Values: > 0 explicit, 0 off, -1 (default) chosen from the
- * matrix: L0 = max(32, 2 * mean row length), T = max(1024, nnz / 16384); matrices without long rows take none of
- * this path),
+ * identity; sextans_reassociated_rows lists them.  Values: > 0 explicit, 0 off, -1 chosen from the matrix:
+ * L0 = max(32, 2 * mean row length), T = max(1024, nnz / 16384).  Defaults: "bucket_rows" = -1 (exact, so it costs
+ * nothing in parity), "split_rows" = 0 -- EVERY row is summed in strict CSR order and the result is bit-identical to
+ * cpu_spmm_CSR unless the caller opts into re-association with "split_rows" = -1 or > 0 (power-law inputs with rows of
+ * 10^5 entries want that: a serial row holds one row group for milliseconds).  Matrices without long rows take none
+ * of this path.  "global_nnz": non-zeros of the WHOLE matrix when this engine holds a row range of it (multi-GPU);
+ * the automatic T is derived from it so that every rank cuts hub rows exactly as one GPU would; sextans_dist_spmm sets
+ * it from an exchanged sum; 0 = this engine's matrix is the whole matrix),
  * "fuse_b" (1 = the panel kernel may stage B straight from column-major B when B is <= 16 MiB and every row block has a dictionary, saving the
  * repack launch; default 1), "panel_min_reuse_x100" (a row block uses the LDS panel when
  * nnz >= value/100 * distinct columns; default 200).  Unknown keys -> SEXTANS_ERR_INVALID. */

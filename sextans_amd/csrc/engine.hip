@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -142,7 +143,7 @@ struct sextans_engine {
     int nhub = 0;                             // long rows (bucketed + split)
     int split_nv = 0;                         // pieces of all long rows
     int64_t split_T = 0, bucket_L0 = 0;       // thresholds in effect (0 = none)
-    int64_t split_built_opt = -2, bucket_built_opt = -2;   // option values the state above was built for
+    int64_t split_built_opt = -2, bucket_built_opt = -2, split_built_gnnz = -2;   // option values the state above was built for
     float *d_P = nullptr;
     size_t P_cap = 0;
     long long *d_dbg = nullptr;     // 8 counters for phase timing (option "phase_timing")
@@ -157,8 +158,11 @@ struct sextans_engine {
     // options
     int64_t opt_kernel = 0, opt_lpr = 0, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;   // opt_lpr 0 = auto
     int64_t opt_fuse_b = 1;             // panel kernel may stage from column-major B (small matrices: no repack launch)
-    int64_t opt_split_rows = -1;        // > 0: rows longer than this are split (re-associated); 0 = never (strict
-                                        // order); -1 = max(1024, nnz / 16384)
+    int64_t opt_split_rows = 0;         // 0 (default) = never: every row is summed in strict CSR order, bit-identical to
+                                        // cpu_spmm_CSR; > 0: rows longer than this are split (re-associated, opt-in);
+                                        // -1 = opt in with the automatic threshold max(1024, global nnz / 16384)
+    int64_t opt_global_nnz = 0;         // multi-GPU: non-zeros of the WHOLE matrix (0 = this engine's matrix is the whole
+                                        // matrix), so every rank derives the same split threshold as a single GPU would
     int64_t opt_bucket_rows = -1;       // > 0: rows longer than this take the piece path unsplit (still exact); 0 = off;
                                         // -1 = max(32, 2 * mean row length)
     int64_t opt_phase_timing = 0;       // 1: panel kernel accumulates per-phase wave cycles (debug aid)
@@ -235,7 +239,7 @@ void free_split(sextans_engine *h) {   // long-row state: main matrix, skip flag
     h->h_split_rows.clear();
     h->nhub = h->split_nv = 0;
     h->split_T = h->bucket_L0 = 0;
-    h->split_built_opt = h->bucket_built_opt = -2;
+    h->split_built_opt = h->bucket_built_opt = h->split_built_gnnz = -2;
     h->m_rp = h->s_rp; h->m_ci = h->s_ci; h->m_v = h->s_v; h->m_nnz = h->s_nnz;
 }
 
@@ -682,6 +686,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "phase_timing")) return &h->opt_phase_timing;
     if (!strcmp(key, "split_rows")) return &h->opt_split_rows;
     if (!strcmp(key, "bucket_rows")) return &h->opt_bucket_rows;
+    if (!strcmp(key, "global_nnz")) return &h->opt_global_nnz;
     if (!strcmp(key, "fuse_b")) return &h->opt_fuse_b;
     if (!strcmp(key, "window_rows")) return &h->opt_win_rows;
     if (!strcmp(key, "window_cols")) return &h->opt_win_cols;
@@ -706,6 +711,9 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
         (void)hipSetDevice(h->device);
         free_window(h);   // the stream is built for one (rows per wavefront, window) pair
     }
+    if (*slot != value) h->dist_cut_key.clear();   // chunk cuts are aligned to the packed forms the options select (all
+                                                   // ranks of a partition must change options together: the cut
+                                                   // exchange is a collective)
     *slot = value;
     if (slot == &h->opt_phase_timing) {
         (void)hipSetDevice(h->device);
@@ -799,15 +807,20 @@ struct Seg { int width, col0, ntiles; };
 //     399 302): T = 512 / 1024 / 2021 -> 0.81 / 0.74 / 0.77 ms with 4964 / 2190 / 978 rows re-associated (uniform
 //     matrix of the same size: 0.64 ms), so the larger threshold costs nothing and touches fewer rows.
 int ensure_split(sextans_engine *h) {
-    if (h->split_built_opt == h->opt_split_rows && h->bucket_built_opt == h->opt_bucket_rows) return SEXTANS_OK;
+    if (h->split_built_opt == h->opt_split_rows && h->bucket_built_opt == h->opt_bucket_rows &&
+        h->split_built_gnnz == h->opt_global_nnz)
+        return SEXTANS_OK;
     free_split(h);
     free_plan(h);      // the packed forms are built from the main matrix
     free_window(h);
     h->split_built_opt = h->opt_split_rows;
     h->bucket_built_opt = h->opt_bucket_rows;
+    h->split_built_gnnz = h->opt_global_nnz;
     if (h->M == 0 || h->s_nnz == 0) return SEXTANS_OK;
     int64_t T = h->opt_split_rows, L0 = h->opt_bucket_rows;
-    if (T < 0) T = std::max<int64_t>(1024, h->s_nnz / 16384);
+    // the automatic threshold follows the non-zeros of the whole matrix: a rank of a row-partitioned SpMM ("global_nnz")
+    // then cuts a hub row into the same pieces as a single GPU holding all rows => bitwise equal results
+    if (T < 0) T = std::max<int64_t>(1024, std::max<int64_t>(h->opt_global_nnz, h->s_nnz) / 16384);
     if (L0 < 0) L0 = std::max<int64_t>(32, 2 * (h->s_nnz / h->M));
     if (T == 0) T = INT64_MAX;                 // never split
     if (L0 == 0) L0 = T;                       // no bucketing: only rows that must be split leave
@@ -974,9 +987,18 @@ int ensure_dense(sextans_engine *h) {
         W = std::max(W, (int)dense[(size_t)br].size());
     }
     if (W == 0) return SEXTANS_OK;   // nothing to route
-    // pass 2: blocked-ELL values (fp32 sums of duplicates, rounded to bf16 once) + the remainder as the new main matrix
+    // The device form is blocked-ELL (mb x W slots of 2 KiB): one crowded block row sets W for all of them, so bound
+    // the padded size; a matrix that would need more keeps its dense tiles on the fp32 kernels (reported, not routed).
+    if ((int64_t)mb * W * 2048 > ((int64_t)8 << 30)) {
+        g_last_error = "mfma_dense_tiles: blocked-ELL form of the dense tiles would exceed 8 GiB; tiles stay on the fp32 kernels";
+        return SEXTANS_OK;
+    }
+    // pass 2: tile values, stored COMPACTLY on the host (one 32x32 fp32 tile per dense tile, not per ELL slot: fp32 sums
+    // of duplicates, rounded to bf16 once) + the remainder as the new main matrix
+    std::vector<int64_t> tile0((size_t)mb + 1, 0);   // first compact tile of every block row
+    for (int br = 0; br < mb; ++br) tile0[(size_t)br + 1] = tile0[(size_t)br] + (int64_t)dense[(size_t)br].size();
     std::vector<int> bcol((size_t)mb * W, -1);
-    std::vector<float> blk((size_t)mb * W * 1024, 0.0f);
+    std::vector<float> blk((size_t)tile0[(size_t)mb] * 1024, 0.0f);
     std::vector<int> mrp((size_t)h->M + 1, 0);
     size_t w = 0;
     for (int r = 0; r < h->M; ++r) {
@@ -989,7 +1011,7 @@ int ensure_dense(sextans_engine *h) {
                 if (it != d->end() && *it == (ci[(size_t)j] >> 5)) slot = (int)(it - d->begin());
             }
             if (slot >= 0) {
-                blk[(((size_t)br * W + (size_t)slot) * 32 + (size_t)(r & 31)) * 32 + (size_t)(ci[(size_t)j] & 31)] += va[(size_t)j];
+                blk[(((size_t)tile0[(size_t)br] + (size_t)slot) * 32 + (size_t)(r & 31)) * 32 + (size_t)(ci[(size_t)j] & 31)] += va[(size_t)j];
             } else {
                 ci[w] = ci[(size_t)j]; va[w] = va[(size_t)j]; ++w;
             }
@@ -998,14 +1020,19 @@ int ensure_dense(sextans_engine *h) {
     }
     for (int br = 0; br < mb; ++br)
         for (size_t sl = 0; sl < dense[(size_t)br].size(); ++sl) bcol[(size_t)br * W + sl] = dense[(size_t)br][sl];
-    std::vector<uint16_t> bval(blk.size());
-    for (size_t i = 0; i < blk.size(); ++i) {
-        uint32_t u;
-        memcpy(&u, &blk[i], 4);
-        if ((u & 0x7fffffffu) > 0x7f800000u) { bval[i] = (uint16_t)((u >> 16) | 0x40u); continue; }
-        u += 0x7fffu + ((u >> 16) & 1u);
-        bval[i] = (uint16_t)(u >> 16);
-    }
+    std::vector<uint16_t> bval((size_t)mb * W * 1024, 0);   // ELL slots without a tile stay +0.0
+    for (int br = 0; br < mb; ++br)
+        for (size_t sl = 0; sl < dense[(size_t)br].size(); ++sl) {
+            const float *src = blk.data() + ((size_t)tile0[(size_t)br] + sl) * 1024;
+            uint16_t *dst = bval.data() + ((size_t)br * W + sl) * 1024;
+            for (int i = 0; i < 1024; ++i) {
+                uint32_t u;
+                memcpy(&u, &src[i], 4);
+                if ((u & 0x7fffffffu) > 0x7f800000u) { dst[i] = (uint16_t)((u >> 16) | 0x40u); continue; }
+                u += 0x7fffu + ((u >> 16) & 1u);
+                dst[i] = (uint16_t)(u >> 16);
+            }
+        }
     std::vector<float>().swap(blk);
     ci.resize(w ? w : 1); va.resize(w ? w : 1);
     // the remainder becomes the source matrix of the long-row split (which has not run yet for this source)
@@ -1196,6 +1223,10 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         if (!(flags & SEXTANS_ROWS_REUSE_B_PANELS)) h->bp_layout = 0;
         return SEXTANS_OK;
     }
+    // A call without the reuse flag announces a new B: whatever panels the workspace holds are stale from here on,
+    // also when THIS call does not repack (column-major staging, fuse_b) -- a later chunk of the same pipelined SpMM
+    // that does need panels must not find those of an earlier B.
+    if (!(flags & SEXTANS_ROWS_REUSE_B_PANELS)) h->bp_layout = 0;
     std::vector<Seg> plan;
     int W = 0;
     bool use_panel = false, use_window = false;
@@ -1622,28 +1653,34 @@ struct Rccl {
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
-Rccl *rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r.lib ? &r : nullptr;
-    tried = true;
+std::string g_rccl_error;   // written once, inside the call_once below
+void rccl_bind(Rccl &r) {
     const char *env = getenv("SEXTANS_RCCL_PATH");
     for (const char *name : {env, "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
         if (!name || !*name) continue;
         r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (r.lib) break;
     }
-    if (!r.lib) { g_last_error = std::string("RCCL not found: ") + dlerror(); return nullptr; }
+    if (!r.lib) {
+        const char *why = dlerror();
+        g_rccl_error = std::string("RCCL not found: ") + (why ? why : "dlopen failed");
+        return;
+    }
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
     r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) {
-        g_last_error = "RCCL library lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllGather";
+        g_rccl_error = "RCCL library lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllGather";
         dlclose(r.lib); r.lib = nullptr;
-        return nullptr;
     }
+}
+Rccl *rccl() {   // one thread per GPU is the documented model: the binding happens exactly once whoever comes first
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_bind(r); });
+    if (!r.lib) { g_last_error = g_rccl_error; return nullptr; }
     return &r;
 }
 int rccl_check(int rc, const char *what) {
@@ -1717,6 +1754,25 @@ int sextans_dist_spmm(sextans_handle_t h, void *comm, int world, int rank, const
     std::vector<int> key(row_ranges, row_ranges + 2 * world);
     key.push_back(N); key.push_back(nchunks); key.push_back(rank);
     if (h->dist_cut_key != key) {
+        {   // Non-zeros of the whole matrix = sum over ranks: the automatic hub-split threshold ("split_rows" = -1) is
+            // derived from it, so a rank cuts a hub row into the same pieces as one GPU holding every row would and the
+            // N-GPU result equals the 1-GPU result bit for bit (a row lives on exactly one rank).
+            int *d_nz = nullptr;
+            SX_HIP(hipMalloc((void **)&d_nz, sizeof(int) * 2 * (size_t)world));
+            const int mine_nz[2] = {(int)(h->nnz & 0x7fffffff), (int)(h->nnz >> 31)};
+            SX_HIP(hipMemcpyAsync(d_nz + 2 * (size_t)rank, mine_nz, sizeof mine_nz, hipMemcpyHostToDevice, s));
+            const int rc = rccl_check(r->AllGather(d_nz + 2 * (size_t)rank, d_nz, 2, 2 /* ncclInt32 */, comm, s), "ncclAllGather(nnz)");
+            std::vector<int> all_nz(2 * (size_t)world);
+            hipError_t e1 = rc ? hipSuccess : hipMemcpyAsync(all_nz.data(), d_nz, sizeof(int) * all_nz.size(), hipMemcpyDeviceToHost, s);
+            hipError_t e2 = hipStreamSynchronize(s);
+            (void)hipFree(d_nz);
+            if (rc) return rc;
+            SX_HIP(e1);
+            SX_HIP(e2);
+            int64_t total = 0;
+            for (int g = 0; g < world; ++g) total += (int64_t)all_nz[2 * (size_t)g] + ((int64_t)all_nz[2 * (size_t)g + 1] << 31);
+            h->opt_global_nnz = total;
+        }
         std::vector<int> mine((size_t)nchunks + 1, 0);
         mine[(size_t)nchunks] = m_loc;
         for (int c = 1; c < nchunks; ++c) {
@@ -1787,21 +1843,20 @@ int sextans_dist_spmm(sextans_handle_t h, void *comm, int world, int rank, const
                 return rc;
             first = false;
         }
-        // the all-gather of chunk c runs on the communication stream while the SpMM of chunk c+1 runs on `stream`
+        // the all-gather of chunk c runs on the communication stream while the SpMM of chunk c+1 runs on `stream`; its
+        // slabs are unpacked into column-major C right behind it on the same stream, i.e. under all-gather c+1 / SpMM c+2,
+        // so only the last chunk's unpack is exposed
         SX_HIP(hipEventRecord(h->dist_events[(size_t)c], s));
         SX_HIP(hipStreamWaitEvent(h->comm_stream, h->dist_events[(size_t)c], 0));
         if (int rc = rccl_check(r->AllGather(mine, S, (size_t)N * (size_t)lmax[(size_t)c], 7 /* ncclFloat */, comm,
                                              h->comm_stream), "ncclAllGather"))
             return rc;
+        const unsigned gx = (unsigned)((lmax[(size_t)c] + 255) / 256);
+        hipLaunchKernelGGL(dist_unpack_slabs, dim3(gx, (unsigned)N, (unsigned)world), dim3(256), 0, h->comm_stream, S,
+                           lmax[(size_t)c], N, reinterpret_cast<const int2 *>(d_meta) + (size_t)c * world, d_C_out, ldc);
     }
     SX_HIP(hipEventRecord(h->dist_events[(size_t)nchunks], h->comm_stream));
     SX_HIP(hipStreamWaitEvent(s, h->dist_events[(size_t)nchunks], 0));
-    for (int c = 0; c < nchunks; ++c) {
-        const unsigned gx = (unsigned)((lmax[(size_t)c] + 255) / 256);
-        hipLaunchKernelGGL(dist_unpack_slabs, dim3(gx, (unsigned)N, (unsigned)world), dim3(256), 0, s,
-                           h->d_stage + off[(size_t)c], lmax[(size_t)c], N, reinterpret_cast<const int2 *>(d_meta) + (size_t)c * world,
-                           d_C_out, ldc);
-    }
     SX_HIP(hipGetLastError());
     return SEXTANS_OK;
 }

@@ -40,6 +40,18 @@ def partition_rows_even(M, world):
     return out
 
 
+def global_nnz(local_nnz, device="cpu", group=None):
+    """Non-zeros of the whole matrix = sum of the ranks' local counts.  Handed to every rank's engine as option
+    "global_nnz", it makes the automatic hub-split threshold ("split_rows" = -1) the one a single GPU holding all rows
+    would choose, so the row-partitioned result equals the single-GPU result bit for bit also on power-law inputs."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(local_nnz)], dtype=torch.int64, device=device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, group=group)
+    return int(t.item())
+
+
 def slice_csr(row_ptr, col_idx, val, r0, r1):
     """Local CSR of rows [r0, r1): row_ptr rebased to 0, column indices unchanged (B is replicated)."""
     row_ptr = np.asarray(row_ptr)
@@ -207,18 +219,22 @@ class PipelinedSlabGather:
                                                               group=group, async_op=True))
 
     def finish(self, C_full):
-        for w in self.works:
-            w.wait()
+        """Chunk c is unpacked as soon as ITS all-gather has landed (Work.wait() only orders the current stream behind
+        that collective), so the copies of chunks 0..n-2 run under the all-gathers still in flight and only the last
+        chunk's copy is exposed."""
+        works = self.works if self.works else [None] * len(self.S)
         self.works = []
-        if self.even:
-            cols = C_full.view(self.N, self.world, self.L)
-            for (c0, c1), S in zip(self.chunks, self.S):
-                if c1 > c0:
-                    cols[:, :, c0:c1].copy_(S.permute(1, 0, 2))
-            return
+        cols_even = C_full.view(self.N, self.world, self.L) if self.even else None
         cols = C_full.view(self.N, self.M)
-        for g, (a, _) in enumerate(self.ranges):
-            for c, S in enumerate(self.S):
+        for c, (S, w) in enumerate(zip(self.S, works)):
+            if w is not None:
+                w.wait()
+            if self.even:
+                c0, c1 = self.chunks[c]
+                if c1 > c0:
+                    cols_even[:, :, c0:c1].copy_(S.permute(1, 0, 2))
+                continue
+            for g, (a, _) in enumerate(self.ranges):
                 c0, c1 = self.cuts[g][c], self.cuts[g][c + 1]
                 if c1 > c0:
                     cols[:, a + c0:a + c1] = S[g, :, :c1 - c0]

@@ -38,8 +38,12 @@ def _engine_for(A, dev):
     mean the same matrix."""
     crow, col, val = A.crow_indices(), A.col_indices(), A.values()
     M, K = A.shape
-    key = (dev, crow.data_ptr(), col.data_ptr(), val.data_ptr(), crow._version, col._version, val._version, M, K,
-           val.numel())
+    def ver(t):   # inference-mode tensors have no version counter: address-only key (the entry pins the tensors)
+        try:
+            return t._version
+        except RuntimeError:
+            return -1
+    key = (dev, crow.data_ptr(), col.data_ptr(), val.data_ptr(), ver(crow), ver(col), ver(val), M, K, val.numel())
     ent = _cache.get(key)
     if ent is not None:
         _cache.move_to_end(key)

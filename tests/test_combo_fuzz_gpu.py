@@ -94,6 +94,6 @@ def test_combination(engine, oracle, seed, kind, M, K, N, kernel, lpr, split, bu
             bound = np.bincount(rows, weights=np.abs(v).astype(np.float64) * np.abs(B[n * K + ci]), minlength=M)
             bound = 1e-4 * (abs(float(alpha)) * bound + np.abs(float(beta) * C0[n * M:(n + 1) * M]))
             assert np.all(np.abs(o2[n].astype(np.float64) - w2[n]) <= bound + 1e-30)
-    for k, val in dict(kernel=0, lanes_per_row=0, split_rows=-1, bucket_rows=-1, window_rows=319, window_cols=65536,
+    for k, val in dict(kernel=0, lanes_per_row=0, split_rows=0, bucket_rows=-1, window_rows=319, window_cols=65536,
                        window_unroll=8).items():
         engine.set_option(k, val)

@@ -77,6 +77,8 @@ def _worker(rank, world, port, mode, q):
         pg.finish(t3)
         ok = ok and keep[0] is True and not any(keep[1:]) and np.array_equal(t3.numpy().view(np.uint32), want.view(np.uint32))
         assert pg.even == (mode == "even")
+        # every rank derives the hub-split threshold from the non-zeros of the WHOLE matrix (engine option "global_nnz")
+        ok = ok and sxd.global_nnz(int(lrp[-1])) == int(rp[-1])
         q.put((rank, ok, ranges))
     finally:
         dist.destroy_process_group()

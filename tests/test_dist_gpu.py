@@ -234,3 +234,106 @@ def test_cpp_example_multi_gpu_through_the_c_abi(sx):
     for n in ("16", "40"):
         r = subprocess.run([exe, nasa, n], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "all ranks match the single-GPU result" in r.stdout, r.stdout + r.stderr
+
+
+def test_new_b_after_a_fused_chunk_repacks_for_later_chunks(engine, oracle):
+    """Round-2 ADVICE: a row-range call that stages straight from column-major B (no repack) left the panel
+    workspace marked as valid; the next pipelined SpMM with ANOTHER B then reused the first B's panels in a later chunk
+    that needs them (here: the chunk holding a long row, which goes through the piece kernel and its panels)."""
+    import torch
+    from sextans_amd import api
+    rp, ci, v = api.gen_fem3d_host(12, 11, 10, 3, 7)
+    M = K = 12 * 11 * 10 * 3
+    N = 16
+    rs = np.random.RandomState(11)
+    # one long row in the last third: replace row `hub` by 400 random distinct columns
+    hub = M - 500
+    cols = np.sort(rs.choice(K, 400, replace=False)).astype(np.int32)
+    a, b = int(rp[hub]), int(rp[hub + 1])
+    ci = np.concatenate([ci[:a], cols, ci[b:]]).astype(np.int32)
+    v = np.concatenate([v[:a], rs.uniform(-1, 1, 400).astype(np.float32), v[b:]]).astype(np.float32)
+    rp = rp.copy(); rp[hub + 1:] += 400 - (b - a)
+    for k, val in dict(kernel=0, lanes_per_row=4, exact=1, split_rows=0, bucket_rows=200, fuse_b=1).items():
+        engine.set_option(k, val)
+    try:
+        engine.set_matrix_csr(M, K, rp, ci, v)
+        assert engine.get_stat("piece_path_rows") == 1
+        cut = engine.align_row(N, M // 2)
+        assert 0 < cut < hub
+        st = torch.cuda.current_stream().cuda_stream
+        C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+        dCin = torch.from_numpy(C0).cuda()
+        for trial in range(3):                      # a different B every time, same engine, same workspace
+            B = rs.uniform(-1, 1, K * N).astype(np.float32)
+            want = C0.copy()
+            oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+            dB = torch.from_numpy(B).cuda()
+            out = torch.full((M * N,), float("nan"), device="cuda")
+            kernels = []
+            for i, (c0, c1) in enumerate(((0, cut), (cut, M))):
+                engine.spmm_device_rows(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr() + 4 * c0, M,
+                                        out.data_ptr() + 4 * c0, M, c0, c1, reuse_b_panels=i > 0, stream=st)
+                kernels.append(engine.last_kernel())
+            torch.cuda.synchronize()
+            assert kernels == ["spmm_csr_panel", "spmm_csr_panel+hub_pieces"], kernels
+            assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), trial
+    finally:
+        for k, val in dict(bucket_rows=-1, split_rows=0).items():
+            engine.set_option(k, val)
+
+
+def test_hub_split_threshold_follows_the_global_nnz(engine, sx):
+    """VERDICT r02 task 6c: with "split_rows" = -1 the threshold T = max(1024, nnz / 16384) used the rank-LOCAL nnz, so a
+    row-partitioned SpMM could cut a hub row differently from a single GPU.  With option "global_nnz" (set by
+    sextans_dist_spmm from an exchanged sum, by bench.py from dist.global_nnz) both halves of a power-law matrix on two
+    engines give the single-engine result bit for bit and the same list of re-associated rows."""
+    import torch
+    from sextans_amd import api, dist as sxd
+    M = K = 600_000
+    N = 8
+    rp, ci, v = api.gen_powerlaw_host(M, K, 6, 120, 400_000, 7)
+    nnz = int(rp[-1])
+    T = nnz // 16384
+    assert T > 1100, nnz                       # the global threshold is above the floor of 1024 ...
+    lens = np.diff(rp)
+    half = sxd.partition_rows_by_nnz(rp, 2)
+    between = np.nonzero((lens > 1024) & (lens <= T))[0]
+    assert len(between) > 0                    # ... and some rows sit between the local and the global one
+    st = torch.cuda.current_stream().cuda_stream
+    rs = np.random.RandomState(5)
+    dB = torch.from_numpy(rs.uniform(-1, 1, K * N).astype(np.float32)).cuda()
+    dCin = torch.from_numpy(rs.uniform(-1, 1, M * N).astype(np.float32)).cuda()
+    opts = dict(kernel=0, lanes_per_row=0, exact=1, split_rows=-1, bucket_rows=-1, global_nnz=0)
+    try:
+        for k, val in opts.items():
+            engine.set_option(k, val)
+        engine.set_matrix_csr(M, K, rp, ci, v)
+        whole = torch.empty(M * N, device="cuda")
+        engine.spmm_device(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr(), whole.data_ptr(), M, st)
+        torch.cuda.synchronize()
+        hubs = engine.reassociated_rows()
+        assert engine.get_stat("split_threshold") == T and np.array_equal(hubs, np.nonzero(lens > T)[0])
+        for use_global in (True, False):
+            parts = torch.full((M * N,), float("nan"), device="cuda")
+            got_hubs = []
+            for r0, r1 in half:
+                lrp, lci, lv = sxd.slice_csr(rp, ci, v, r0, r1)
+                with sx.Engine(0) as e2:
+                    for k, val in opts.items():
+                        e2.set_option(k, val)
+                    if use_global:
+                        e2.set_option("global_nnz", nnz)
+                    e2.set_matrix_csr(r1 - r0, K, lrp, lci, lv)
+                    e2.spmm_device2(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr() + 4 * r0, M,
+                                    parts.data_ptr() + 4 * r0, M, st)
+                    torch.cuda.synchronize()
+                    got_hubs.append(e2.reassociated_rows() + r0)
+            same = bool(torch.equal(parts, whole))
+            if use_global:
+                assert same and np.array_equal(np.concatenate(got_hubs), hubs)
+            else:   # the defect being fixed: local thresholds (1024 here) re-associate more rows than one GPU does
+                assert len(np.concatenate(got_hubs)) > len(hubs)
+    finally:
+        engine.set_matrix_csr(1, 1, np.array([0, 0], np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
+        for k, val in dict(split_rows=0, bucket_rows=-1, global_nnz=0).items():
+            engine.set_option(k, val)

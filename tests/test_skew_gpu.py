@@ -1,7 +1,8 @@
 """Automatic handling of skewed (power-law) matrices, SURVEY.md 8f row 1.  The reference balances by construction
 (rows dealt to PEs by row % 64 + bubble padding, sparse_helper.h:345-403); here rows longer than a threshold chosen
-from the matrix are summed in parallel pieces and folded in order.  Default engine options throughout
-(split_rows = -1): rows that are NOT hubs must stay bit-identical to cpu_spmm_CSR under every kernel; hub rows
+from the matrix are summed in parallel pieces and folded in order.  Engine defaults plus the opt-in to re-association
+(split_rows = -1, automatic threshold; the engine's own default is 0 = strict order for every row since round 3):
+rows that are NOT hubs must stay bit-identical to cpu_spmm_CSR under every kernel; hub rows
 (reported by sextans_reassociated_rows) must meet |d| <= 1e-4 * (|alpha| * sum|a*b| + |beta*c|)."""
 import time
 
@@ -19,6 +20,12 @@ def _defaults(engine, **opts):
     d.update(opts)
     for k, v in d.items():
         engine.set_option(k, v)
+
+
+@pytest.fixture(autouse=True)
+def _strict_order_afterwards(engine):
+    yield
+    engine.set_option("split_rows", 0)   # the shared engine goes back to the library default
 
 
 def _check(out, want, M, N, rp, ci, v, B, C0, hubs, alpha, beta):
