@@ -20,7 +20,7 @@ CLI = os.path.join(BINDIR, "sextans")
 
 LIB_SOURCES = ["engine.hip", "synth.hip", "host_mtx.cpp", "panel_plan.cpp", "window_plan.cpp", "pack_api.cpp",
                "edge_stream.cpp"]
-HEADERS = ["spmm_csr_kernels.h", "spmm_window_kernel.h", "bell_kernels.h", "chan_kernels.h", "panel_plan.h",
+HEADERS = ["spmm_csr_kernels.h", "spmm_panel_v2.h", "spmm_window_kernel.h", "bell_kernels.h", "chan_kernels.h", "panel_plan.h",
            "window_plan.h", os.path.join("..", "..", "include", "sextans_amd.h")]
 OBJDIR = os.path.join(LIBDIR, "obj")
 

@@ -28,6 +28,7 @@
 #include "panel_plan.h"
 #include "sextans_amd.h"
 #include "spmm_csr_kernels.h"
+#include "spmm_panel_v2.h"
 #include "spmm_window_kernel.h"
 #include "window_plan.h"
 
@@ -157,6 +158,15 @@ struct sextans_engine {
     const int *dist_meta_at = nullptr;
     // options
     int64_t opt_kernel = 0, opt_lpr = 0, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;   // opt_lpr 0 = auto
+    int64_t opt_cols_per_lane = 0;      // LDS-panel kernel: output columns per lane.  4 (= 0, the default) = 16-column tiles;
+                                        // 8 = register-blocked 32-column super tiles (spmm_csr_panel_v2<2>: 2 workgroups per
+                                        // CU -- measured slower than 4 columns per lane at 4 workgroups per CU)
+    int64_t opt_panel_v2 = -1;          // 16-column tiles on the register-resident form (spmm_csr_panel_v2<1>: row entries
+                                        // loaded once per block, panels by LDS-DMA, tile loop inside the workgroup, C stored
+                                        // straight from the accumulators): 1 = yes, 0 = no (spmm_csr_panel), -1 = auto: yes
+                                        // unless the column-major staging of small matrices applies ("fuse_b")
+    int64_t opt_tiles_per_wg = 0;       // wide kernel: super tiles one workgroup walks (A stream from HBM once per that many
+                                        // columns); 0 = auto: all of N while the launch still fills the chip several times
     int64_t opt_fuse_b = 1;             // panel kernel may stage from column-major B (small matrices: no repack launch)
     int64_t opt_split_rows = 0;         // 0 (default) = never: every row is summed in strict CSR order, bit-identical to
                                         // cpu_spmm_CSR; > 0: rows longer than this are split (re-associated, opt-in);
@@ -538,6 +548,49 @@ void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_
     }
 }
 
+// Wide-N form of the panel kernel (spmm_panel_v2.h): `nsuper` super tiles of 32 columns starting at the pointers
+// given; dictionary-only plans built for 4 lanes per row.
+template <int H>
+int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc,
+                      int nsuper, float alpha, float beta, hipStream_t s, int64_t bcol_ld, int blk_begin, int blk_end,
+                      int row_base) {
+    const int nblk = blk_end - blk_begin;
+    if (nblk <= 0 || nsuper <= 0) return SEXTANS_OK;
+    int tpw = (int)h->opt_tiles_per_wg;
+    if (tpw <= 0) {   // all of N in one workgroup while that still leaves >= 4 rounds of workgroups (2 per CU)
+        const int64_t rounds = (int64_t)nblk * nsuper / ((int64_t)8 * h->num_cus);
+        tpw = (int)std::max<int64_t>(1, std::min<int64_t>(nsuper, rounds));
+    }
+    tpw = std::min(tpw, nsuper);
+    const int ngrp = (nsuper + tpw - 1) / tpw;
+    const int64_t pstride = bcol_ld > 0 ? bcol_ld : (int64_t)h->K * 16;
+    const size_t lds = (size_t)H * sx::kWideHalfBytes;
+    auto go = [&](auto kern) -> int {
+        static bool attr_set = false;   // one flag per instantiation (the lambda body is instantiated per kernel type)
+        if (!attr_set) {
+            SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)h->ps.d_row_off,
+                           h->ps.d_lidx, h->ps.d_pval, h->ps.d_blk_row, h->ps.d_dict_ptr, h->ps.d_dict, h->ps.plan_dict_stride,
+                           dBp, pstride, dCin, ldc_in, dCout, ldc, nsuper, tpw, nblk, alpha, beta, (int)h->opt_xcd,
+                           h->ps.plan_max_dict, blk_begin, row_base, (const unsigned char *)h->d_skip);
+        return SEXTANS_OK;
+    };
+    // register-resident batches (16 entries each) per row: from the mean row length of the main matrix, so that matrices
+    // with short rows (1-dof stencils: 27 entries) do not fetch six batches per row
+    const int64_t mean_len = h->M > 0 ? h->m_nnz / h->M : 0;
+    const int nb = mean_len + 8 <= 32 ? 2 : mean_len + 8 <= 64 ? 4 : 6;
+    if constexpr (H > 1) {
+        if (bcol_ld > 0) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, true>) : go(sx::spmm_csr_panel_v2<H, 6, false, true>);
+        return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, false>) : go(sx::spmm_csr_panel_v2<H, 6, false, false>);
+    } else {
+        if (nb == 2) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false>) : go(sx::spmm_csr_panel_v2<H, 2, false, false>);
+        if (nb == 4) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 4, true, false>) : go(sx::spmm_csr_panel_v2<H, 4, false, false>);
+        return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, false>) : go(sx::spmm_csr_panel_v2<H, 6, false, false>);
+    }
+}
+
 // Traffic model behind the automatic choice between the gather kernel and the window kernel for matrices
 // without B-row reuse (bytes crossing the L2 <-> memory fabric per SpMM):
 //   gather: every non-zero pulls max(128, 4 * tile width) bytes of B (a 64-byte B row still costs a
@@ -688,6 +741,9 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "bucket_rows")) return &h->opt_bucket_rows;
     if (!strcmp(key, "global_nnz")) return &h->opt_global_nnz;
     if (!strcmp(key, "fuse_b")) return &h->opt_fuse_b;
+    if (!strcmp(key, "cols_per_lane")) return &h->opt_cols_per_lane;
+    if (!strcmp(key, "tiles_per_wg")) return &h->opt_tiles_per_wg;
+    if (!strcmp(key, "panel_v2")) return &h->opt_panel_v2;
     if (!strcmp(key, "window_rows")) return &h->opt_win_rows;
     if (!strcmp(key, "window_cols")) return &h->opt_win_cols;
     if (!strcmp(key, "window_unroll")) return &h->opt_win_unroll;
@@ -707,6 +763,8 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
     if (slot == &h->opt_win_rows && (value < 1 || value > sx::kWinMaxRowsPerWave)) return SEXTANS_ERR_INVALID;
     if (slot == &h->opt_win_cols && (value < 1 || value > 0x7fffffff)) return SEXTANS_ERR_INVALID;
     if (slot == &h->opt_win_unroll && value != 4 && value != 8) return SEXTANS_ERR_INVALID;
+    if (slot == &h->opt_cols_per_lane && value != 0 && value != 4 && value != 8) return SEXTANS_ERR_INVALID;
+    if (slot == &h->opt_tiles_per_wg && (value < 0 || value > 1024)) return SEXTANS_ERR_INVALID;
     if ((slot == &h->opt_win_rows || slot == &h->opt_win_cols) && *slot != value) {
         (void)hipSetDevice(h->device);
         free_window(h);   // the stream is built for one (rows per wavefront, window) pair
@@ -1146,13 +1204,15 @@ namespace {
 // Hub rows inside [row_begin, row_end): pieces summed as virtual rows by the row-group kernel from B panels of width
 // 4 * LPR at dBp (ntiles panels), then folded in order into the C the main kernel has already written.
 const char *kernel_name(int main, bool hubs, bool dense) {   // static strings for sextans_last_kernel
-    static const char *names[3][2][2] = {
+    static const char *names[4][2][2] = {
         {{"spmm_csr_rowgroup", "spmm_csr_rowgroup+dense_tiles_mfma"},
          {"spmm_csr_rowgroup+hub_pieces", "spmm_csr_rowgroup+hub_pieces+dense_tiles_mfma"}},
         {{"spmm_csr_panel", "spmm_csr_panel+dense_tiles_mfma"},
          {"spmm_csr_panel+hub_pieces", "spmm_csr_panel+hub_pieces+dense_tiles_mfma"}},
         {{"spmm_csr_window", "spmm_csr_window+dense_tiles_mfma"},
-         {"spmm_csr_window+hub_pieces", "spmm_csr_window+hub_pieces+dense_tiles_mfma"}}};
+         {"spmm_csr_window+hub_pieces", "spmm_csr_window+hub_pieces+dense_tiles_mfma"}},
+        {{"spmm_csr_panel_v2", "spmm_csr_panel_v2+dense_tiles_mfma"},
+         {"spmm_csr_panel_v2+hub_pieces", "spmm_csr_panel_v2+hub_pieces+dense_tiles_mfma"}}};
     return names[main][hubs ? 1 : 0][dense ? 1 : 0];
 }
 
@@ -1332,6 +1392,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     }
     {
         Prof p(h, &h->ev_kernel, s);
+        bool v2_used = false;
         for (const Seg &g : plan) {
             const float *bp = h->d_Bp + (size_t)h->K * (size_t)g.col0;
             const float *cin = d_C_in + (int64_t)g.col0 * ldc_in;
@@ -1339,6 +1400,31 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             const bool panel_here = use_panel && g.width == W;   // the plan is built for width W
             const float *bsrc = fuse_b ? d_B + (int64_t)g.col0 * ldb : bp;
             const int64_t bld = fuse_b ? ldb : 0;
+            // N >= 32 on a dictionary-only plan at 4 lanes per row: register-blocked 32-column super tiles with the
+            // tile loop inside the workgroup; an odd 16-column tile at the end goes to the plain panel kernel
+            // (32-bit byte offsets inside the wide kernels: panels, C columns)
+            const bool wide_ok = h->ps.plan_max_dict <= sx::kWideMaxDict && (int64_t)h->K * 64 < ((int64_t)1 << 32) &&
+                                 std::max(ldc, ldc_in) * 64 < ((int64_t)1 << 32) && (!fuse_b || ldb * 64 < ((int64_t)1 << 32));
+            if (panel_here && g.width == 16 && !h->ps.plan_mixed && h->opt_cols_per_lane == 8 && g.ntiles >= 2 && wide_ok) {
+                const int nsuper = g.ntiles / 2;
+                if (int rc = launch_panel_v2<2>(h, bsrc, cin, ldc_in, cout, ldc, nsuper, alpha, beta, s, bld, blk0, blk1, row_begin))
+                    return rc;
+                if (g.ntiles & 1) {
+                    const int64_t c0 = (int64_t)nsuper * 32;
+                    launch_panel<4>(h, fuse_b ? bsrc + c0 * ldb : bsrc + c0 * (int64_t)h->K, cin + c0 * ldc_in, ldc_in, cout + c0 * ldc,
+                                    ldc, 1, alpha, beta, s, bld, blk0, blk1, row_begin);
+                }
+                v2_used = true;
+                if (hubs) launch_hub_pieces<4>(h, pt, bp, g.ntiles, g.col0, v0, v1, s);
+                continue;
+            }
+            if (panel_here && g.width == 16 && !h->ps.plan_mixed && h->opt_panel_v2 != 0 && !fuse_b && wide_ok) {
+                if (int rc = launch_panel_v2<1>(h, bsrc, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, bld, blk0, blk1, row_begin))
+                    return rc;
+                v2_used = true;
+                if (hubs) launch_hub_pieces<4>(h, pt, bp, g.ntiles, g.col0, v0, v1, s);
+                continue;
+            }
 #define SX_SEG(L)                                                                                                       \
     if (panel_here) launch_panel<L>(h, bsrc, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, bld, blk0, blk1, row_begin);  \
     else launch_rowgroup<L>(h, h->m_rp, h->m_rp + 1, h->m_ci, h->m_v, false, h->d_skip, bp, cin, ldc_in, cout, ldc, row_begin, row_end, \
@@ -1352,7 +1438,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
 #undef SX_SEG
         }
         if (hubs) fold();
-        h->last_kernel = kernel_name(use_panel ? 1 : 0, hubs, h->dense_W > 0);
+        h->last_kernel = kernel_name(v2_used ? 3 : use_panel ? 1 : 0, hubs, h->dense_W > 0);
     }
     SX_HIP(hipGetLastError());
     return SEXTANS_OK;

@@ -1,0 +1,340 @@
+// spmm_panel_v2.h -- the LDS-panel kernel with the N dimension register-blocked: the wide-N form of
+// spmm_csr_panel (spmm_csr_kernels.h) for N >= 32.
+//
+// The reference re-streams its packed non-zero list once per 8-column N tile (read_A, sextans.cpp:57-60,84-87)
+// while the B window stays on chip (PEG_Bmtx local_B, sextans.cpp:337,353-381).  The N = 16 kernel inherited that
+// shape: one workgroup per (row block, 16-column tile), so at N = 128 every block's meta data, dictionary, A stream
+// and per-entry index/broadcast work was done 8 times.  Here
+//   * every lane owns 4*H output columns (H "half panels" of 16 columns, H = 2 -> 8 columns per lane): one index
+//     unpack, one DPP broadcast pair and one LDS address serve 2x the multiply-adds; the H B rows of an entry are
+//     read with H ds_read_b128 at a compile-time offset from the same address register;
+//   * a workgroup walks `tpw` such 16*H-column super tiles (tile loop inside the workgroup): block meta, row
+//     extents and dictionary indices are fetched once, the A stream comes from HBM once and from L2 afterwards.
+// Same packed plan as spmm_csr_panel (panel_plan.h; dictionary-only plans), same 16-bit byte-offset stream, same
+// exact-safe padding, same per-row order: bit-identical to cpu_spmm_CSR (sparse_helper.h:262-290).
+// LDS: H half panels at a fixed stride (kWideHalfBytes, so the half offset folds into the ds_read immediate) =
+// 73.9 KB for H = 2 -> 2 workgroups per CU, up to 256 VGPRs per lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "spmm_csr_kernels.h"
+
+namespace sx {
+
+constexpr int kWideMaxDict = 576;                                // dictionary capacity of the plan at 4 lanes per row (9 * 64)
+constexpr int kWideHalfBytes = (kWideMaxDict + 1) * 64;          // one half panel: 576 B rows of 64 bytes + the +1.0f row
+
+template <int G>
+__device__ __forceinline__ int quad_bcast(int x) {               // value of lane G of the 4-lane row group
+    return __builtin_amdgcn_update_dpp(0, x, G * 0x55, 0xF, 0xF, true);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void mac4v(f32x4 &acc, float a, const f32x4 &b) {
+    acc.x = mac<EXACT>(acc.x, a, b.x);
+    acc.y = mac<EXACT>(acc.y, a, b.y);
+    acc.z = mac<EXACT>(acc.z, a, b.z);
+    acc.w = mac<EXACT>(acc.w, a, b.w);
+}
+
+// Entries 4G .. 4G+3 of the current 16-entry batch (held by lane G of the row group): broadcast, 4*H LDS reads in
+// flight, then the multiply-adds in entry order.
+template <int G, int H, bool EXACT>
+__device__ __forceinline__ void wide_quad(const int (&ix)[4], const float (&vx)[4], const char *pq, f32x4 (&acc)[H]) {
+    int i[4];
+    float a[4];
+    f32x4 b[4][H];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        i[e] = quad_bcast<G>(ix[e]);
+        a[e] = __int_as_float(quad_bcast<G>(__float_as_int(vx[e])));
+#pragma unroll
+        for (int h = 0; h < H; ++h) b[e][h] = *reinterpret_cast<const f32x4 *>(pq + i[e] + h * kWideHalfBytes);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int h = 0; h < H; ++h) mac4v<EXACT>(acc[h], a[e], b[e][h]);
+}
+
+// Pins the accumulators at this point of the program: the multiply-adds before it cannot sink below it and (being a
+// volatile asm with a memory clobber) the LDS reads after it cannot be hoisted above it.  Without it the compiler
+// gathers the reads of a whole batch (128 registers at H = 2) in front of the arithmetic and spills.
+template <int H>
+__device__ __forceinline__ void pin(f32x4 (&acc)[H]) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) asm volatile("" : "+v"(acc[h]) : : "memory");
+}
+
+template <int H, bool EXACT>
+__device__ __forceinline__ void wide_batch(const int (&ix)[4], const float (&vx)[4], const char *pq, f32x4 (&acc)[H]) {
+    wide_quad<0, H, EXACT>(ix, vx, pq, acc); pin<H>(acc);
+    wide_quad<1, H, EXACT>(ix, vx, pq, acc); pin<H>(acc);
+    wide_quad<2, H, EXACT>(ix, vx, pq, acc); pin<H>(acc);
+    wide_quad<3, H, EXACT>(ix, vx, pq, acc); pin<H>(acc);
+}
+
+// Async global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): the LDS destination is the wave-uniform
+// `lds_dst` + 16 * lane, the global source is per lane.  No staging registers, no ds_write pass.
+__device__ __forceinline__ void glds16(const float *gsrc, char *lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+}
+
+// Vector-memory operations the COMPILER DOES NOT SEE (inline asm: saddr + 32-bit voffset form).  Everything that is in
+// flight while a super tile's rows are multiplied -- C_in of the tile, the B rows of the next panel, the C stores of
+// the previous tile -- goes through these, and is waited for by ONE explicit `s_waitcnt vmcnt(0)` after the row loop.
+// With compiler-visible loads/stores the wait-count insertion pass (which must assume the worst over loop back-edges
+// and protects registers it recycles as address temporaries) put full-drain waits -- including waits for the previous
+// tile's STORES to be acknowledged -- at the top of every super tile: 12 k of 16 k cycles per tile were spent waiting.
+// Rules (cdna_hip_programming.md, inline-asm section): a destination counts as written at the asm statement, so
+// nothing may read it before the matching drain(); drain() names every such register as an in/out operand.
+__device__ __forceinline__ void aload4(f32x4 &dst, const float *sbase, unsigned voff_bytes) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void aload1(float &dst, const float *sbase, unsigned voff_bytes) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void astore1(float *sbase, unsigned voff_bytes, float val) {
+    asm volatile("global_store_dword %0, %1, %2" : : "v"(voff_bytes), "v"(val), "s"(sbase) : "memory");
+}
+
+// BCOL: Bp is the caller's column-major B (panel_stride = its leading dimension), staged with 4-byte loads; else Bp
+// holds row-major K x 16 panels at stride panel_stride floats.
+// Super tile st covers columns [16*H*st, 16*H*(st+1)) of this launch; workgroup (blk, grp) walks super tiles
+// [grp*tpw, min(nsuper, (grp+1)*tpw)).
+// Phases of one super tile, software-pipelined ACROSS super tiles so that only the first panel of a workgroup is
+// waited for: [B rows of super tile st+1 requested into registers] -> row stream of st out of the LDS panel -> C of st
+// stored straight from the accumulators (a lane owns 4 consecutive columns of one row: a wavefront's store covers 16
+// consecutive rows x 4 columns = 64-byte runs, merged to full lines in L2) -> barrier -> registers -> panel -> barrier.
+template <int H, int NB, bool EXACT, bool BCOL>
+__global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
+    const int2 *__restrict__ slot_info, const unsigned short *__restrict__ p_idx16, const float *__restrict__ p_val,
+    const int *__restrict__ blk_row, const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
+    const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc,
+    int nsuper, int tpw, int nblk, float alpha, float beta, int use_xcd_remap, int pad_row, int blk_begin, int row_base,
+    const unsigned char *__restrict__ skip) {
+    constexpr int LPR = 4;
+    constexpr int RB = kBlock / LPR;          // 64 rows per workgroup
+    constexpr int NTT = 16 * H;               // columns per super tile
+    constexpr int BATCH = 16;
+    constexpr int MAXD = 9;                   // dictionary capacity = MAXD * RB
+    constexpr int PFT = 3;                    // batches of the row in flight beyond the current one
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    char *lds = reinterpret_cast<char *>(smem);
+
+    const int ngrp = (nsuper + tpw - 1) / tpw;
+    const unsigned nwg = (unsigned)nblk * (unsigned)ngrp;
+    unsigned wg = blockIdx.x;
+    if (use_xcd_remap) wg = xcd_remap(wg, nwg);
+    const int blk = blk_begin + (int)(wg / (unsigned)ngrp);
+    const int grp = (int)(wg % (unsigned)ngrp);
+    const int st_begin = grp * tpw, st_end = min(nsuper, st_begin + tpw);
+
+    const int tid = threadIdx.x;
+    const int slot = tid / LPR;
+    const int q = tid % LPR;
+    // first round trip: everything at addresses that depend on the block number only
+    const int row0 = blk_row[blk];
+    const int row1 = blk_row[blk + 1];
+    const int nu = dict_cnt[blk];
+    const int2 si = slot_info[(int64_t)blk * RB + slot];
+    unsigned boff[MAXD];                      // float offset of "my" dictionary rows inside a K x 16 panel (+ my 4 columns)
+    {
+        const int *bd = blk_dict + (int64_t)blk * dict_stride + slot;
+#pragma unroll
+        for (int u = 0; u < MAXD; ++u) {
+            const int col = bd[min(u * RB, dict_stride - RB)];
+            boff[u] = BCOL ? (unsigned)col : (unsigned)col * 16u + 4u * (unsigned)q;
+        }
+    }
+    const int len = si.y;
+    // Row stream: wave-uniform base (first entry of the wave's first row) + a 32-bit lane offset, so every fetch is one
+    // `global_load saddr + voffset + immediate` without 64-bit vector address arithmetic.  Slots past the block's last
+    // row ({0, 0}) fetch from the base (never consumed).  The stream is padded: over-reads stay in bounds.
+    const int wbase = __builtin_amdgcn_readfirstlane(si.x);
+    const float *pv = p_val + wbase;
+    const unsigned short *pi = p_idx16 + wbase;
+    const unsigned loff = (len > 0 ? (unsigned)(si.x - wbase) : 0u) + 4u * (unsigned)q;
+    // C: this lane's row (clamped for the loads) and whether it is written
+    const int myrow = min(row0 + slot, row1 - 1);
+    const unsigned coff = (unsigned)(myrow - row_base);
+    const bool cwrite = row0 + slot < row1 && !(skip && skip[myrow]);
+    const char *pq = lds + 16 * q;
+
+    // B rows of a panel travel through registers: bv (16-byte loads from the repacked panels) or bs (column-major B:
+    // four 4-byte loads per row and lane).  `first`: plain loads the compiler tracks (preheader); otherwise the asm
+    // forms above, drained explicitly after the row loop.
+    f32x4 bv[BCOL ? 1 : MAXD][H];
+    float bs[BCOL ? MAXD : 1][H][4];
+    unsigned bvoff[MAXD];                     // byte offset of "my" 16 bytes of dictionary row u from the panel / column base
+#pragma unroll
+    for (int u = 0; u < MAXD; ++u)
+        bvoff[u] = BCOL ? (boff[u] + 4u * (unsigned)q * (unsigned)panel_stride) * 4u : boff[u] * 4u;
+    auto load_panel = [&](int st, bool first) {
+#pragma unroll
+        for (int u = 0; u < MAXD; ++u)
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                if constexpr (BCOL) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float *sb = Bp + ((int64_t)(st * H + h) * 16 + j) * panel_stride;   // uniform
+                        if (first) bs[u][h][j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sb) + bvoff[u]);
+                        else aload1(bs[u][h][j], sb, bvoff[u]);
+                    }
+                } else {
+                    const float *sb = Bp + (int64_t)(st * H + h) * panel_stride;                   // uniform
+                    if (first) bv[u][h] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(sb) + bvoff[u]);
+                    else aload4(bv[u][h], sb, bvoff[u]);
+                }
+            }
+    };
+    // H = 1 (16-column tiles, 4 workgroups per CU, 128 registers): no room for a panel in registers -- every panel goes
+    // straight from global memory into LDS (LDS-DMA: chunk u = dictionary entries 64u .. 64u+63, entry (64u + slot) is
+    // copied by the 4 lanes of `slot`, a wave's 64 lanes write 1 KiB of consecutive LDS; rows past the dictionary stay
+    // unwritten and are never read).
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto dma_panel = [&](int st) {
+#pragma unroll
+        for (int u = 0; u < MAXD; ++u)
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+                if (u * RB + slot < nu)
+                    glds16(Bp + (int64_t)(st * H + h) * panel_stride + boff[u], lds + h * kWideHalfBytes + (u * RB + wave * 16) * 64);
+        if (tid < 16 * H) {
+            const int h = tid / 16;
+            *reinterpret_cast<float *>(lds + h * kWideHalfBytes + pad_row * 64 + 4 * (tid % 16)) = 1.0f;
+        }
+    };
+    constexpr bool DMA = (H == 1);            // (not with BCOL: the dispatcher keeps column-major staging on the plain kernel)
+    static_assert(!(DMA && BCOL), "LDS-DMA staging reads the repacked panels");
+    auto store_panel = [&]() {                // registers -> LDS panel (+ the +1.0f row the padding entries point at)
+#pragma unroll
+        for (int u = 0; u < MAXD; ++u)
+#pragma unroll
+            for (int h = 0; h < H; ++h)   // entries past the dictionary rewrite its last row
+                *reinterpret_cast<f32x4 *>(lds + h * kWideHalfBytes + max(min(slot + min(u * RB, dict_stride - RB), nu - 1), 0) * 64 +
+                                           16 * q) = BCOL ? f32x4{bs[u][h][0], bs[u][h][1], bs[u][h][2], bs[u][h][3]} : bv[u][h];
+        if (tid < 16 * H) {
+            const int h = tid / 16;
+            *reinterpret_cast<float *>(lds + h * kWideHalfBytes + pad_row * 64 + 4 * (tid % 16)) = 1.0f;
+        }
+    };
+
+    // ---- the row's entries: the first NB batches (96 entries) are loaded ONCE per block and stay in registers for every
+    // super tile (indices already unpacked): the row loop below then contains no memory waits at all, and the loads
+    // that ARE in flight during it (C_in, next panel) are only waited for after it.  Longer rows continue from the
+    // stream (L2) with plain loads.
+    static_assert(NB >= 1 && NB <= 6, "register-resident batches");
+    f32x4 av[NB];
+    int ai[NB][4];
+    {
+        uint2 aw[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            // (unconditional, immediate offsets: all 2 * NB loads are in flight together; lanes whose row ends earlier
+            // over-read inside the padded stream and never multiply what they read.  NB is chosen per matrix from its
+            // mean row length so that short-row matrices do not multiply their A traffic.)
+            av[b] = *reinterpret_cast<const f32x4 *>(pv + loff + b * BATCH);
+            aw[b] = *reinterpret_cast<const uint2 *>(pi + loff + b * BATCH);
+        }
+        if constexpr (DMA) dma_panel(st_begin); else load_panel(st_begin, true);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            ai[b][0] = (int)(aw[b].x & 0xffffu); ai[b][1] = (int)(aw[b].x >> 16);
+            ai[b][2] = (int)(aw[b].y & 0xffffu); ai[b][3] = (int)(aw[b].y >> 16);
+        }
+    }
+    if constexpr (!DMA) store_panel();
+    // (a use of the row registers HERE makes the compiler wait for their loads before the loop; otherwise its wait
+    // bookkeeping carries them into the loop as "possibly pending" and every batch waits for younger loads)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(av[b]));
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing the compiler tracks is outstanding from here on
+    // C: column (col0 + 16h + 4q + j) of this lane = uniform column base (col0 + 16h + j) + a per-lane byte offset
+    const unsigned cvoff_in = (4u * (unsigned)q * (unsigned)ldc_in + coff) * 4u;
+    const unsigned cvoff_out = (4u * (unsigned)q * (unsigned)ldc + coff) * 4u;
+    for (int st = st_begin; st < st_end; ++st) {
+        const int64_t col0 = (int64_t)st * NTT;
+        // ---- requests that fly under this super tile's row loop: its C_in, the next panel
+        float cin[H][4];
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) aload1(cin[h][j], Cin + (col0 + h * 16 + j) * ldc_in, cvoff_in);
+        if constexpr (DMA) {
+            if (st != st_begin) {
+                __syncthreads();               // every wave is done reading the previous panel
+                dma_panel(st);
+                __syncthreads();               // (the compiler drains the DMA, and with it C_in, before the barrier)
+            }
+        } else if (st + 1 < st_end) {
+            load_panel(st + 1, false);
+        }
+        f32x4 acc[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // a batch whose 16 entries are live for every lane of the wavefront runs without predicates
+#define SX_RBATCH(b)                                                                                  \
+        if constexpr ((b) < NB) {                                                                      \
+        if (__builtin_amdgcn_ballot_w64(len >= ((b) + 1) * BATCH) == __builtin_amdgcn_ballot_w64(true)) { \
+            float vb[4] = {av[b].x, av[b].y, av[b].z, av[b].w};                                        \
+            wide_batch<H, EXACT>(ai[b], vb, pq, acc);                                                  \
+        } else if (len > (b) * BATCH) {                                                               \
+            float vb[4] = {av[b].x, av[b].y, av[b].z, av[b].w};                                        \
+            const int cnt = len - (b) * BATCH;                                                         \
+            wide_quad<0, H, EXACT>(ai[b], vb, pq, acc); pin<H>(acc);                                   \
+            if (cnt > 4) { wide_quad<1, H, EXACT>(ai[b], vb, pq, acc); pin<H>(acc); }                  \
+            if (cnt > 8) { wide_quad<2, H, EXACT>(ai[b], vb, pq, acc); pin<H>(acc); }                  \
+            if (cnt > 12) { wide_quad<3, H, EXACT>(ai[b], vb, pq, acc); pin<H>(acc); }                 \
+        }                                                                                              \
+        }
+        SX_RBATCH(0) SX_RBATCH(1) SX_RBATCH(2) SX_RBATCH(3) SX_RBATCH(4) SX_RBATCH(5)
+#undef SX_RBATCH
+        for (int pos = NB * BATCH; pos < len; pos += BATCH) {   // rows longer than NB batches: the rest from the stream
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(pv + loff + pos);
+            const uint2 w = *reinterpret_cast<const uint2 *>(pi + loff + pos);
+            int ix[4] = {(int)(w.x & 0xffffu), (int)(w.x >> 16), (int)(w.y & 0xffffu), (int)(w.y >> 16)};
+            float vx[4] = {v.x, v.y, v.z, v.w};
+            const int cnt = len - pos;
+            wide_quad<0, H, EXACT>(ix, vx, pq, acc); pin<H>(acc);
+            if (cnt > 4) { wide_quad<1, H, EXACT>(ix, vx, pq, acc); pin<H>(acc); }
+            if (cnt > 8) { wide_quad<2, H, EXACT>(ix, vx, pq, acc); pin<H>(acc); }
+            if (cnt > 12) { wide_quad<3, H, EXACT>(ix, vx, pq, acc); pin<H>(acc); }
+        }
+
+        // ---- drain: C_in and the next panel have landed (and the previous super tile's stores are acknowledged)
+        if constexpr (H == 2) {
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(cin[0][0]), "+v"(cin[0][1]), "+v"(cin[0][2]), "+v"(cin[0][3]), "+v"(cin[1][0]), "+v"(cin[1][1]),
+                           "+v"(cin[1][2]), "+v"(cin[1][3])
+                         :
+                         : "memory");
+        } else {
+            static_assert(H == 1 || H == 2, "the drain names the C_in registers explicitly");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cin[0][0]), "+v"(cin[0][1]), "+v"(cin[0][2]), "+v"(cin[0][3]) : : "memory");
+        }
+        // ---- C straight from the accumulators
+        if (cwrite) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const float a4[4] = {acc[h].x, acc[h].y, acc[h].z, acc[h].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    astore1(Cout + (col0 + h * 16 + j) * ldc, cvoff_out, epilogue<EXACT>(alpha, a4[j], beta, cin[h][j]));
+            }
+        }
+        if constexpr (!DMA) {
+            if (st + 1 < st_end) {
+                __syncthreads();               // every wave is done reading this super tile's panel
+                store_panel();
+                __syncthreads();
+            }
+        }
+    }
+}
+
+}  // namespace sx

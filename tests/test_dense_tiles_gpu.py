@@ -53,8 +53,8 @@ def test_block_diagonal_plus_noise_runs_both_kernels(engine, M, K, N):
     rp, ci, v = block_diagonal_plus_noise(rs, M, K, hub_row=M - 3 if M > 2000 else None)
     B = rs.uniform(-1, 1, K * N).astype(np.float32)
     C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
-    for k, val in dict(kernel=0, lanes_per_row=4, exact=1, split_rows=0, bucket_rows=-1, mfma_dense_tiles=0,
-                       dense_tile_fill_x100=50).items():
+    for k, val in dict(kernel=0, lanes_per_row=4, exact=1, split_rows=-1, bucket_rows=-1, mfma_dense_tiles=0,
+                       dense_tile_fill_x100=50).items():      # split_rows = -1: the hub row is re-associated (opt-in)
         engine.set_option(k, val)
     engine.set_matrix_csr(M, K, rp, ci, v)
     dm = dense_mask(M, K, rp, ci, 512)

@@ -106,7 +106,7 @@ def test_native_dist_spmm_single_rank(engine, oracle, sx):
                 torch.cuda.synchronize()
                 assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (name, nchunks)
                 if name == "fem":          # chunk cuts are snapped to row-block boundaries: every chunk keeps the panel kernel
-                    assert engine.last_kernel() == "spmm_csr_panel", nchunks
+                    assert engine.last_kernel() in ("spmm_csr_panel", "spmm_csr_panel_v2"), nchunks
             if name == "fem":
                 # row-range calls cut at sextans_align_row boundaries keep the LDS-panel kernel
                 cuts = [0, engine.align_row(N, M // 3), engine.align_row(N, 2 * M // 3), M]
@@ -117,7 +117,7 @@ def test_native_dist_spmm_single_rank(engine, oracle, sx):
                     slab = torch.full(((c1 - c0) * N,), float("nan"), device="cuda")
                     engine.spmm_device_rows(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr() + 4 * c0, M, slab.data_ptr(),
                                             c1 - c0, c0, c1, reuse_b_panels=i > 0, stream=st)
-                    assert engine.last_kernel() == "spmm_csr_panel"
+                    assert engine.last_kernel() in ("spmm_csr_panel", "spmm_csr_panel_v2")
                     out.view(N, M)[:, c0:c1] = slab.view(N, c1 - c0)
                 torch.cuda.synchronize()
                 assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
@@ -275,7 +275,8 @@ def test_new_b_after_a_fused_chunk_repacks_for_later_chunks(engine, oracle):
                                         out.data_ptr() + 4 * c0, M, c0, c1, reuse_b_panels=i > 0, stream=st)
                 kernels.append(engine.last_kernel())
             torch.cuda.synchronize()
-            assert kernels == ["spmm_csr_panel", "spmm_csr_panel+hub_pieces"], kernels
+            # chunk 1: column-major staging (no repack); chunk 2: long row => repacked panels (register-resident form + piece kernel)
+            assert kernels == ["spmm_csr_panel", "spmm_csr_panel_v2+hub_pieces"], kernels
             assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), trial
     finally:
         for k, val in dict(bucket_rows=-1, split_rows=0).items():

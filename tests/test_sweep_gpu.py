@@ -46,10 +46,11 @@ def test_sweep_synthetic_classes(sx):
     from sextans_amd import sweep
     buf = io.StringIO()
     recs = sweep.sweep_synthetic(["synth:uniform:20000:20", "synth:banded:20000:20:300", "synth:fem3d:12:12:12:3",
-                                  "synth:powerlaw:30000:4:120:20000"], [8, 32], steps=3, out=buf)
+                                  "synth:powerlaw:30000:4:120:20000"], [8, 32], steps=3, out=buf,
+                                 options={"split_rows": -1})   # opt in to re-associated hub rows (default: strict order)
     assert len(recs) == 8 and len(buf.getvalue().splitlines()) == 8
     by = {(r["matrix"].split(":")[1], r["N"]): r for r in recs}
-    assert by[("fem3d", 32)]["kernel"] == "spmm_csr_panel" and by[("uniform", 8)]["kernel"] == "spmm_csr_rowgroup"
+    assert by[("fem3d", 32)]["kernel"].startswith("spmm_csr_panel") and by[("uniform", 8)]["kernel"] == "spmm_csr_rowgroup"
     assert by[("powerlaw", 8)]["kernel"].endswith("+hub_pieces") and by[("powerlaw", 8)]["reassociated_rows"] > 0
     assert by[("uniform", 8)]["piece_path_rows"] == 0
     assert all(r["ms"] > 0 and 0 < r["roofline_frac"] < 1 for r in recs)

@@ -27,6 +27,8 @@ def workload(name):
         return dict(M=13965, K=13965, N=128, fem=(35, 19, 7, 3, 2))
     if name == "fem":
         return dict(M=110 * 110 * 110 * 3, K=110 * 110 * 110 * 3, N=16, fem=(110, 110, 110, 3, 3))
+    if name.startswith("femN"):   # the FEM class at another N: femN32, femN128
+        return dict(M=110 * 110 * 110 * 3, K=110 * 110 * 110 * 3, N=int(name[4:]), fem=(110, 110, 110, 3, 3))
     if name == "fem1":
         return dict(M=160 ** 3, K=160 ** 3, N=16, fem=(160, 160, 160, 1, 3))
     if name == "powerlaw":
