@@ -263,6 +263,12 @@ int sextans_get_option(sextans_handle_t h, const char *key, int64_t *value);
  * writes at most `capacity` of them, *count = how many there are.  sextans_get_stat: "reassociated_rows",
  * "split_threshold". */
 int sextans_reassociated_rows(sextans_handle_t h, int *rows, int capacity, int *count);
+/* The packed row-bucketed form the ENGINE built for the current matrix at `lanes_per_row` (on the device since round 3:
+ * the CSR arrays never leave HBM, csrc/plan_device.hip), read back in the public layout of sextans_pack_csr -- the host
+ * builder of the same format; the two are byte-identical (tests/test_plan_device_gpu.py).  Free with
+ * sextans_packed_free.  Analogue being replaced: generate_edge_list_for_all_PEs + edge_list_64bit on the host,
+ * sparse_helper.h:345-473, sextans-host.cpp:114-148. */
+int sextans_export_plan(sextans_handle_t h, int lanes_per_row, struct sextans_packed *out);
 /* Read-only figures about the matrix currently set.  key: "plan_build_s" (host seconds spent so far
  * building packed forms of A -- read back from the device, pack on all cores, upload; outside every timed
  * region like the reference's scheduling/packing, sextans-host.cpp:114-148), "window_padded_entries",

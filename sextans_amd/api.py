@@ -110,6 +110,7 @@ def lib():
     L.sextans_get_stat.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
     L.sextans_align_row.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.sextans_reassociated_rows.argtypes = [C.c_void_p, _i32p, C.c_int, C.POINTER(C.c_int)]
+    L.sextans_export_plan.argtypes = [C.c_void_p, C.c_int, C.POINTER(Packed)]
     L.sextans_partition_rows_by_nnz.argtypes = [C.c_int, _i32p, C.c_int, _i32p]
     L.sextans_dist_unique_id.argtypes = [C.c_char_p]
     L.sextans_dist_comm_init.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_char_p]
@@ -486,6 +487,23 @@ class Engine:
         rr = np.ascontiguousarray(np.asarray(ranges, np.int32).reshape(-1))
         _check(lib().sextans_dist_spmm(self._h, comm, world, rank, rr, N, alpha, d_B, ldb, beta, d_C_in, ldc_in,
                                        d_C_out, ldc, nchunks, stream), "dist_spmm")
+
+    def export_plan(self, lanes_per_row=4):
+        """The packed row-bucketed form the engine built ON THE DEVICE for the current matrix, read back in the layout of
+        pack_csr (the host builder of the same format): dict of numpy arrays + scalars."""
+        P = Packed()
+        _check(lib().sextans_export_plan(self._h, lanes_per_row, C.byref(P)), "export_plan")
+        try:
+            nb, sl, M = P.nblk, P.stream_len, P.M
+            out = dict(M=P.M, K=P.K, nnz=P.nnz, lanes_per_row=P.lanes_per_row, nblk=nb, stream_len=sl,
+                       max_dict=P.max_dict, nnz_in_panel_blocks=P.nnz_in_panel_blocks,
+                       blk_row=_take(P.blk_row, nb + 1, np.int32), dict_ptr=_take(P.dict_ptr, nb + 1, np.int32),
+                       row_off=_take(P.row_off, M + 1, np.int32), idx16=_take(P.idx16, sl, np.uint16),
+                       col32=_take(P.col32, sl, np.int32), val=_take(P.val, sl, np.float32))
+            out["dict"] = _take(P.dict, int(out["dict_ptr"][-1]), np.int32)
+            return out
+        finally:
+            lib().sextans_packed_free(C.byref(P))
 
     def reassociated_rows(self):
         """Hub rows whose sums are formed in pieces under the current "split_rows" setting (ascending)."""

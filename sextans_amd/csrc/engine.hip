@@ -26,6 +26,7 @@
 #include "bell_kernels.h"
 #include "chan_kernels.h"
 #include "panel_plan.h"
+#include "plan_device.h"
 #include "sextans_amd.h"
 #include "spmm_csr_kernels.h"
 #include "spmm_panel_v2.h"
@@ -62,6 +63,7 @@ struct sextans_engine {
     const int *d_rp = nullptr, *d_ci = nullptr;
     const float *d_v = nullptr;
     bool owns_matrix = false;
+    bool device_matrix_checked = false;   // a caller-provided device matrix has been validated (row_ptr monotone, columns < K)
     // workspaces
     float *d_Bp = nullptr;
     size_t Bp_cap = 0;              // floats
@@ -87,6 +89,8 @@ struct sextans_engine {
         unsigned short *d_lidx = nullptr;
         double plan_panel_frac = 0.0;   // share of non-zeros living in dictionary blocks
         int plan_max_dict = 0;          // largest block dictionary (entries)
+        int64_t plan_stream_len = 0, plan_nnz_panel = 0;
+        int plan_pad_row = 0;           // panel row holding +1.0f for the padding entries = panel capacity in rows
         int plan_dict_stride = 0;       // ints per block in d_dict (dictionaries padded to a common stride)
         bool plan_mixed = false;        // some block with non-zeros has no dictionary (global-gather path needed)
         bool plan_built = false;        // false: only the sampled verdict exists (no packed stream)
@@ -279,6 +283,7 @@ void free_matrix(sextans_engine *h) {
     h->d_rp = h->d_ci = nullptr;
     h->d_v = nullptr;
     h->owns_matrix = false;
+    h->device_matrix_checked = false;
     h->m_rp = h->m_ci = h->s_rp = h->s_ci = nullptr; h->m_v = h->s_v = nullptr; h->m_nnz = h->s_nnz = 0;
     h->dist_cut_key.clear();   // chunk cuts are aligned to the packed forms of one matrix
     h->bp_layout = 0;          // B panels belong to one (K, B)
@@ -432,6 +437,15 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
     }
     free_panel_state(h->ps);
     PlanTimer timer(h);
+    // A matrix handed over with sextans_set_matrix_csr_device has not been looked at by anybody yet: the kernels gather B
+    // rows by column index and the builders trust row_ptr to be monotone, so it is validated once, on the device.
+    if (!h->owns_matrix && !h->device_matrix_checked) {
+        int bad = 0;
+        std::string verr;
+        if (sx::validate_csr_device(h->M, h->K, h->nnz, h->d_rp, h->d_ci, &bad, verr)) { g_last_error = verr; return SEXTANS_ERR_HIP; }
+        if (bad) return (bad & 1) ? SEXTANS_ERR_INVALID : SEXTANS_ERR_INDEX;
+        h->device_matrix_checked = true;
+    }
     const int RB = sx::kBlock / lpr;
     const double min_reuse = (double)h->opt_min_reuse_x100 / 100.0;
     if (!force) {
@@ -445,70 +459,31 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
             return SEXTANS_OK;
         }
     }
-    std::vector<int> rp, ci;
-    std::vector<float> va;
-    if (int rc = read_back_row_ptr(h, rp)) return rc;
-    if (int rc = read_back_entries(h, ci, va)) return rc;
-    {   // the packed stream is addressed with 32-bit entry offsets: rows padded to 4 entries must fit
-        int64_t padded = 0;
-        for (int r = 0; r < h->M; ++r) padded += ((int64_t)(rp[(size_t)r + 1] - rp[(size_t)r]) + 3) / 4 * 4;
-        if (padded > 0x7fffffffLL - 4096) {
-            h->ps.plan_lpr = lpr;
-            h->ps.plan_min_reuse = h->opt_min_reuse_x100;
-            h->ps.plan_panel_frac = 0.0;
-            h->ps.plan_built = false;
-            return SEXTANS_OK;   // row-group kernel only
-        }
-    }
-    sx::PanelPlan plan;
-    sx::build_panel_plan(h->M, h->K, rp.data(), ci.data(), va.data(), RB, kPanelFloats / (4 * lpr),
-                         min_reuse, plan);
-    h->ps.plan_nblk = (int)plan.blk_row.size() - 1;
-    // Block-strided headers for the kernel (addresses depend on the block number only): per slot
-    // {first packed entry, entries}; per block its dictionary padded to a common stride with the last
-    // column repeated.
-    const int nblk = h->ps.plan_nblk;
-    int dstride = ((plan.max_dict + RB - 1) / RB) * RB;
-    if (dstride < RB) dstride = RB;
-    if (dstride > 9 * RB) return SEXTANS_ERR_STATE;   // kPanelFloats / (4 * lpr) = 9 * RB by construction
-    bool mixed = false;
-    std::vector<int> slot_info((size_t)nblk * RB * 2, 0), bdict((size_t)nblk * dstride, 0), dcnt((size_t)nblk);
-    for (int b = 0; b < nblk; ++b) {
-        const int r0 = plan.blk_row[b], r1 = plan.blk_row[b + 1];
-        const int u0 = plan.dict_ptr[b], nu = plan.dict_ptr[b + 1] - u0;
-        for (int r = r0; r < r1; ++r) {
-            // dictionary rows are consumed in whole groups of 4 entries (exact-safe padding, panel_plan.cpp);
-            // direct rows keep their true length (their padding is never multiplied)
-            const int len = rp[(size_t)r + 1] - rp[(size_t)r];
-            slot_info[((size_t)b * RB + (size_t)(r - r0)) * 2] = plan.row_off[r];
-            slot_info[((size_t)b * RB + (size_t)(r - r0)) * 2 + 1] = nu > 0 ? (len + 3) / 4 * 4 : len;
-        }
-        dcnt[(size_t)b] = nu;
-        if (nu == 0 && rp[(size_t)r1] > rp[(size_t)r0]) mixed = true;
-        for (int i = 0; i < dstride; ++i)
-            bdict[(size_t)b * dstride + i] = nu > 0 ? plan.dict[(size_t)u0 + (size_t)(i < nu ? i : nu - 1)] : 0;
-    }
-    h->ps.plan_dict_stride = dstride;
-    h->ps.plan_mixed = mixed;
-    if (int rc = upload(&h->ps.d_blk_row, plan.blk_row)) return rc;
-    h->ps.h_blk_row = plan.blk_row;
-    if (int rc = upload(&h->ps.d_dict_ptr, dcnt)) return rc;
-    if (int rc = upload(&h->ps.d_dict, bdict)) return rc;
-    if (int rc = upload(&h->ps.d_row_off, slot_info)) return rc;
-    // the kernel adds the entry straight to its LDS address: store index * (bytes per panel row)
-    {
-        const unsigned row_bytes = 16u * (unsigned)lpr;
-        const unsigned pad_off = (unsigned)plan.max_dict * row_bytes;   // the +1.0f row sits right after the largest dictionary
-        if (pad_off > 0xffffu) return SEXTANS_ERR_STATE;
-        for (auto &x : plan.idx16) x = (uint16_t)(x == sx::kPadIndex ? pad_off : x * row_bytes);
-    }
-    if (int rc = upload(&h->ps.d_lidx, plan.idx16)) return rc;
-    if (int rc = upload(&h->ps.d_pcol32, plan.col32)) return rc;
-    if (int rc = upload(&h->ps.d_pval, plan.val)) return rc;
+    // The packed form is built on the device (plan_device.hip): the CSR arrays never leave HBM.
+    sx::DevicePlan dp;
+    std::string err;
+    const int cap = kPanelFloats / (4 * lpr);
+    const int brc = sx::build_panel_plan_device(h->M, h->K, h->m_rp, h->m_ci, h->m_v, lpr, cap, min_reuse, dp, err);
+    if (brc == 2) { g_last_error = err; sx::free_device_plan(dp); return SEXTANS_ERR_HIP; }
     h->ps.plan_lpr = lpr;
     h->ps.plan_min_reuse = h->opt_min_reuse_x100;
-    h->ps.plan_panel_frac = plan.nnz_total ? (double)plan.nnz_in_panel_blocks / (double)plan.nnz_total : 0.0;
-    h->ps.plan_max_dict = plan.max_dict;
+    if (brc == 1) {   // rows padded to 4 entries exceed 32-bit entry offsets: row-group kernel only
+        h->ps.plan_panel_frac = 0.0;
+        h->ps.plan_built = false;
+        return SEXTANS_OK;
+    }
+    if (dp.dict_stride > 9 * RB) { sx::free_device_plan(dp); return SEXTANS_ERR_STATE; }   // capacity = 9 * RB by construction
+    h->ps.plan_nblk = dp.nblk;
+    h->ps.plan_dict_stride = dp.dict_stride;
+    h->ps.plan_mixed = dp.mixed;
+    h->ps.d_blk_row = dp.d_blk_row; h->ps.d_dict_ptr = dp.d_dict_cnt; h->ps.d_dict = dp.d_dict; h->ps.d_row_off = dp.d_slot_info;
+    h->ps.d_lidx = dp.d_idx16; h->ps.d_pcol32 = dp.d_col32; h->ps.d_pval = dp.d_val;
+    h->ps.h_blk_row.swap(dp.h_blk_row);
+    h->ps.plan_stream_len = dp.stream_len;
+    h->ps.plan_panel_frac = h->m_nnz ? (double)dp.nnz_in_panel_blocks / (double)h->m_nnz : 0.0;
+    h->ps.plan_nnz_panel = dp.nnz_in_panel_blocks;
+    h->ps.plan_max_dict = dp.max_dict;
+    h->ps.plan_pad_row = cap;
     h->ps.plan_built = true;
     return SEXTANS_OK;
 }
@@ -527,7 +502,7 @@ void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_
     const int64_t pstride = bcol_ld > 0 ? bcol_ld : (int64_t)h->K * NT;
     const int xcd = (int)h->opt_xcd;
     // LDS = B panel sized for the largest dictionary of this matrix (rounded to 1 KiB) + C tile.
-    const int panel_floats = (h->ps.plan_max_dict + 1) * NT;   // dictionary rows + the +1.0f row the padding entries address
+    const int panel_floats = (h->ps.plan_pad_row + 1) * NT;   // dictionary capacity + the +1.0f row the padding entries address
     const int tile_floats = NT * (RB + 1);   // the C tile reuses the panel bytes
     const size_t lds = (size_t)(panel_floats > tile_floats ? panel_floats : tile_floats) * sizeof(int);
     auto go = [&](auto kern) {
@@ -574,7 +549,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)h->ps.d_row_off,
                            h->ps.d_lidx, h->ps.d_pval, h->ps.d_blk_row, h->ps.d_dict_ptr, h->ps.d_dict, h->ps.plan_dict_stride,
                            dBp, pstride, dCin, ldc_in, dCout, ldc, nsuper, tpw, nblk, alpha, beta, (int)h->opt_xcd,
-                           h->ps.plan_max_dict, blk_begin, row_base, (const unsigned char *)h->d_skip);
+                           h->ps.plan_pad_row, blk_begin, row_base, (const unsigned char *)h->d_skip);
         return SEXTANS_OK;
     };
     // register-resident batches (16 entries each) per row: from the mean row length of the main matrix, so that matrices
@@ -1252,6 +1227,58 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "panel_fraction")) *value = h->ps.plan_panel_frac;
     else if (!strcmp(key, "panel_blocks")) *value = (double)h->ps.plan_nblk;
     else return SEXTANS_ERR_INVALID;
+    return SEXTANS_OK;
+}
+
+int sextans_export_plan(sextans_handle_t h, int lanes_per_row, sextans_packed *out) {
+    if (!h || !out || (lanes_per_row != 2 && lanes_per_row != 4 && lanes_per_row != 8)) return SEXTANS_ERR_INVALID;
+    if (!h->d_rp) return SEXTANS_ERR_STATE;
+    SX_HIP(hipSetDevice(h->device));
+    if (int rc = ensure_dense(h)) return rc;
+    if (int rc = ensure_split(h)) return rc;
+    if (int rc = ensure_plan(h, lanes_per_row, true)) return rc;
+    if (!h->ps.plan_built) return SEXTANS_ERR_STATE;
+    const auto &ps = h->ps;
+    const int M = h->M, nblk = ps.plan_nblk, RB = sx::kBlock / lanes_per_row;
+    const size_t L = (size_t)ps.plan_stream_len;
+    memset(out, 0, sizeof *out);
+    out->M = M; out->K = h->K; out->nnz = h->m_nnz; out->lanes_per_row = lanes_per_row; out->nblk = nblk;
+    out->stream_len = (int64_t)L; out->max_dict = ps.plan_max_dict; out->nnz_in_panel_blocks = ps.plan_nnz_panel;
+    std::vector<int> rp((size_t)M + 1), cnt((size_t)nblk), bd((size_t)nblk * ps.plan_dict_stride);
+    SX_HIP(hipMemcpy(rp.data(), h->m_rp, sizeof(int) * rp.size(), hipMemcpyDeviceToHost));
+    if (nblk) {
+        SX_HIP(hipMemcpy(cnt.data(), ps.d_dict_ptr, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost));
+        SX_HIP(hipMemcpy(bd.data(), ps.d_dict, sizeof(int) * bd.size(), hipMemcpyDeviceToHost));
+    }
+    auto alloc = [](size_t bytes) { return calloc(bytes ? bytes : 1, 1); };
+    out->blk_row = (int *)alloc(sizeof(int) * ((size_t)nblk + 1));
+    out->dict_ptr = (int *)alloc(sizeof(int) * ((size_t)nblk + 1));
+    out->row_off = (int *)alloc(sizeof(int) * ((size_t)M + 1));
+    out->idx16 = (uint16_t *)alloc(sizeof(uint16_t) * L);
+    out->col32 = (int *)alloc(sizeof(int) * L);
+    out->val = (float *)alloc(sizeof(float) * L);
+    size_t ndict = 0;
+    for (int b = 0; b < nblk; ++b) ndict += (size_t)cnt[(size_t)b];
+    out->dict = (int *)alloc(sizeof(int) * ndict);
+    if (!out->blk_row || !out->dict_ptr || !out->row_off || !out->idx16 || !out->col32 || !out->val || !out->dict) {
+        sextans_packed_free(out);
+        return SEXTANS_ERR_ALLOC;
+    }
+    memcpy(out->blk_row, ps.h_blk_row.data(), sizeof(int) * ((size_t)nblk + 1));
+    size_t w = 0;
+    for (int b = 0; b < nblk; ++b) {
+        out->dict_ptr[b] = (int)w;
+        for (int i = 0; i < cnt[(size_t)b]; ++i) out->dict[w++] = bd[(size_t)b * ps.plan_dict_stride + (size_t)i];
+    }
+    out->dict_ptr[nblk] = (int)w;
+    for (int r = 0; r < M; ++r) out->row_off[r + 1] = out->row_off[r] + ((rp[(size_t)r + 1] - rp[(size_t)r] + 3) & ~3);
+    SX_HIP(hipMemcpy(out->idx16, ps.d_lidx, sizeof(uint16_t) * L, hipMemcpyDeviceToHost));
+    SX_HIP(hipMemcpy(out->val, ps.d_pval, sizeof(float) * L, hipMemcpyDeviceToHost));
+    if (ps.plan_mixed) SX_HIP(hipMemcpy(out->col32, ps.d_pcol32, sizeof(int) * L, hipMemcpyDeviceToHost));
+    // device stream: byte offset of the B row in the panel; public form: dictionary index, 0xFFFF in the padding
+    const unsigned row_bytes = 16u * (unsigned)lanes_per_row, pad_off = (unsigned)ps.plan_pad_row * row_bytes;
+    for (size_t i = 0; i < L; ++i) out->idx16[i] = out->idx16[i] == pad_off ? (uint16_t)0xFFFF : (uint16_t)(out->idx16[i] / row_bytes);
+    (void)RB;
     return SEXTANS_OK;
 }
 

@@ -2,14 +2,17 @@
 #include "panel_plan.h"
 
 #include <algorithm>
+#include <atomic>
 #include <thread>
+
+#include "plan_device.h"
 
 namespace sx {
 
 namespace {
 
 constexpr int kPad = 4;       // entries; every row of the packed stream starts on this boundary
-constexpr int kTailPad = 256; // extra zero entries at the end (the kernel keeps up to 4 batches of 32 ahead in flight)
+constexpr int kTailPad = kPlanTailPad;   // extra zero entries at the end (the kernels fetch whole batches ahead)
 
 struct Part {
     std::vector<int> blk_row;   // first rows of the blocks of this part (without the final end)
@@ -20,11 +23,13 @@ struct Part {
 };
 
 // Rows [r0, r1) -> blocks, dictionaries and packed entries.
-void build_part(int K, const int *rp, const int *ci, const float *va, int RB, int r0, int r1,
+void build_part(const int *rp, const int *ci, const float *va, int RB, int r0, int r1,
                 int max_unique, double min_reuse, const int *row_off, uint16_t *idx16, int *col32,
-                float *pval, Part &out) {
-    std::vector<int> stamp((size_t)K, -1), local((size_t)K, 0), uniq;
-    int blk_id = 0;
+                float *pval, Part &out, std::vector<int> &stamp, std::vector<int> &local) {
+    // stamp / local: K-sized scratch of the calling thread, reused from part to part (block ids are global row numbers,
+    // so a stale stamp of an earlier part never equals a current one)
+    std::vector<int> uniq;
+    int blk_id = r0;
     for (int r = r0; r < r1;) {
         // grow the block row by row while its distinct columns fit the panel
         uniq.clear();
@@ -51,7 +56,10 @@ void build_part(int K, const int *rp, const int *ci, const float *va, int RB, in
         }
         if (e == r) e = r + 1;              // the oversized row forms a (direct) block of its own
         const int64_t n = (int64_t)rp[e] - rp[r];
-        const bool use_dict = fits && !uniq.empty() && (double)n >= min_reuse * (double)uniq.size();
+        // (a block cut short by the end of its part is judged by fit alone: a one-row remnant has no reuse of its own,
+        // and a single direct block would push the whole matrix onto the slower mixed kernel instantiation)
+        const bool remnant = e == r1 && e - r < RB;
+        const bool use_dict = fits && !uniq.empty() && ((double)n >= min_reuse * (double)uniq.size() || remnant);
         out.blk_row.push_back(r);
         if (use_dict) {
             std::sort(uniq.begin(), uniq.end());
@@ -77,7 +85,7 @@ void build_part(int K, const int *rp, const int *ci, const float *va, int RB, in
             if (use_dict)
                 for (; o < row_off[row + 1]; ++o) { pval[o] = -0.0f; idx16[o] = kPadIndex; }
         }
-        ++blk_id;
+        blk_id = e;
         r = e;
     }
 }
@@ -105,29 +113,26 @@ void build_panel_plan(int M, int K, const int *row_ptr, const int *col_idx, cons
     out.dict_ptr.assign(1, 0);
     if (M == 0) { out.blk_row.push_back(0); return; }
 
+    // Rows are cut into PARTS of kPlanPartBlocks * RB rows; every part starts a new block.  The parts are a property of
+    // the format, not of the machine: the device builder (plan_device.hip) walks the same parts, one workgroup each, so
+    // host and device produce the same block list (tests/test_plan_device_gpu.py compares the arrays byte for byte).
+    const int PR = kPlanPartBlocks * RB;
+    const int nparts = (M + PR - 1) / PR;
     unsigned hw = std::thread::hardware_concurrency();
     int nthreads = (int)std::min<unsigned>(hw ? hw : 1, 16);
     if (out.nnz_total < (1 << 20)) nthreads = 1;   // two K-sized scratch arrays per thread
-    nthreads = std::max(1, std::min(nthreads, M / (4 * RB) + 1));
-    // split rows at multiples of RB so every part has about the same number of non-zeros; parts
-    // start new blocks, so the cut positions only influence block boundaries, never results
-    std::vector<int> cut((size_t)nthreads + 1, 0);
-    cut[(size_t)nthreads] = M;
-    for (int t = 1; t < nthreads; ++t) {
-        const int64_t target = out.nnz_total * t / nthreads;
-        const int row = (int)(std::lower_bound(row_ptr, row_ptr + M + 1, (int)target) - row_ptr);
-        cut[(size_t)t] = std::min(M, std::max(cut[(size_t)t - 1], row / RB * RB));
-    }
-    std::vector<Part> parts((size_t)nthreads);
+    nthreads = std::max(1, std::min(nthreads, nparts));
+    std::vector<Part> parts((size_t)nparts);
+    std::atomic<int> next(0);
     std::vector<std::thread> pool;
-    for (int t = 0; t < nthreads; ++t) {
-        auto fn = [&, t]() {
-            build_part(K, row_ptr, col_idx, val, RB, cut[(size_t)t], cut[(size_t)t + 1], max_unique,
-                       min_reuse, out.row_off.data(), out.idx16.data(), out.col32.data(),
-                       out.val.data(), parts[(size_t)t]);
-        };
-        if (nthreads == 1) fn(); else pool.emplace_back(fn);
-    }
+    auto fn = [&]() {
+        std::vector<int> stamp((size_t)K, -1), local((size_t)K, 0);
+        for (int t = next.fetch_add(1); t < nparts; t = next.fetch_add(1))
+            build_part(row_ptr, col_idx, val, RB, t * PR, std::min(M, (t + 1) * PR), max_unique, min_reuse,
+                       out.row_off.data(), out.idx16.data(), out.col32.data(), out.val.data(), parts[(size_t)t], stamp, local);
+    };
+    if (nthreads == 1) fn();
+    else for (int t = 0; t < nthreads; ++t) pool.emplace_back(fn);
     for (auto &th : pool) th.join();
     for (auto &p : parts) {
         out.blk_row.insert(out.blk_row.end(), p.blk_row.begin(), p.blk_row.end());

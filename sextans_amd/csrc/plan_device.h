@@ -1,0 +1,37 @@
+// plan_device.h -- device-side builder of the packed row-bucketed form of A (see plan_device.hip, panel_plan.h).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace sx {
+
+constexpr int kPlanPartBlocks = 64;   // rows are cut into parts of kPlanPartBlocks * rows_per_block rows; every part starts a
+                                      // new block (host and device builders alike, so their block lists are identical)
+constexpr int kPlanTailPad = 256;     // zero entries behind the last row (the kernels fetch up to 6 batches of 16 ahead)
+
+struct DevicePlan {                   // device arrays in exactly the form the LDS-panel kernels read
+    int lpr = 0, rows_per_block = 0;
+    int nblk = 0;
+    int *d_blk_row = nullptr;         // nblk + 1
+    int *d_dict_cnt = nullptr;        // nblk: dictionary entries (0 = direct block)
+    int *d_dict = nullptr;            // nblk x dict_stride, last column repeated
+    int dict_stride = 0;
+    int *d_slot_info = nullptr;       // nblk x rows_per_block x {first packed entry, entries}
+    unsigned short *d_idx16 = nullptr;   // BYTE offset of the entry's B row in the panel (index * 16 * lpr); padding -> pad row
+    int *d_col32 = nullptr;           // stream_len when `mixed`, else 1 element
+    float *d_val = nullptr;
+    int64_t stream_len = 0;
+    int max_dict = 0;
+    bool mixed = false;
+    int64_t nnz_in_panel_blocks = 0;
+    std::vector<int> h_blk_row;
+};
+
+// *bad: bit 0 = row_ptr not a monotone 0 .. nnz sequence, bit 1 = a column index outside [0, K).  Returns non-zero on a HIP error.
+int validate_csr_device(int M, int K, int64_t nnz, const int *d_rp, const int *d_ci, int *bad, std::string &err);
+void free_device_plan(DevicePlan &d);
+int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, const float *d_v, int lpr, int max_unique,
+                            double min_reuse, DevicePlan &out, std::string &err);
+
+}  // namespace sx

@@ -1,0 +1,395 @@
+// plan_device.hip -- the packed row-bucketed form of A (panel_plan.h) built ON THE DEVICE.
+//
+// The reference schedules and packs its non-zero stream on the host before the accelerator runs
+// (generate_edge_list_for_all_PEs + edge_list_64bit, sparse_helper.h:345-473, sextans-host.cpp:114-148); round 1/2 of
+// this engine did the same: copy the matrix to the host, pack on all cores, upload -- 2.3 s for a 318 M non-zero
+// matrix against a 0.7 ms SpMM.  Here the CSR arrays never leave HBM:
+//   pass A  padded row lengths -> stream offset of every row (two-level scan);
+//   pass B  block formation: one workgroup per PART of kPlanPartBlocks * RB rows walks its rows in order and grows a
+//           block while the distinct columns (LDS hash set) fit the panel -- the same greedy rule as
+//           build_panel_plan, whose parts are the same fixed row ranges, so the block list is identical;
+//   pass C  one workgroup per BLOCK: hash the block's columns, sort them (bitonic, LDS) into its dictionary, write the
+//           strided dictionary / per-slot row extents / 16-bit byte-offset stream the kernels read.
+// Result: byte-identical to the host builder (tests/test_plan_device_gpu.py), in milliseconds.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <vector>
+
+#include "plan_device.h"
+
+namespace sx {
+namespace {
+
+constexpr int kHT = 4096;   // hash slots: >= largest panel capacity (1152 at 2 lanes per row) + one 256-entry chunk, load < 0.35
+constexpr int kEmpty = -1;
+
+__device__ __forceinline__ unsigned hash_col(int c) { return ((unsigned)c * 2654435761u) >> 20; }   // 12 bits
+
+// returns true when `col` was not in the set yet
+__device__ __forceinline__ bool hs_insert(int *keys, int *stamp, int col, int st) {
+    unsigned h = hash_col(col) & (kHT - 1);
+    while (true) {
+        const int prev = atomicCAS(&keys[h], kEmpty, col);
+        if (prev == kEmpty) { stamp[h] = st; return true; }
+        if (prev == col) return false;
+        h = (h + 1) & (kHT - 1);
+    }
+}
+
+__device__ __forceinline__ int hs_find(const int *keys, int col) {
+    unsigned h = hash_col(col) & (kHT - 1);
+    while (keys[h] != col) h = (h + 1) & (kHT - 1);
+    return (int)h;
+}
+
+// ---- pass A: padded lengths.  part_sum[p] = padded entries of rows [p*PR, (p+1)*PR)
+__global__ __launch_bounds__(256) void plan_part_sums(const int *__restrict__ rp, int M, int PR, long long *part_sum) {
+    __shared__ long long s[256];
+    const int p = blockIdx.x, r0 = p * PR, r1 = min(M, r0 + PR);
+    long long acc = 0;
+    for (int r = r0 + threadIdx.x; r < r1; r += 256) acc += (long long)((rp[r + 1] - rp[r] + 3) & ~3);
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part_sum[p] = s[0];
+}
+
+// row_off[r] for the rows of part p (exclusive scan inside the part on top of part_base[p]); row_off[M] by the last part
+__global__ __launch_bounds__(256) void plan_row_off(const int *__restrict__ rp, int M, int PR, const int *__restrict__ part_base,
+                                                    int *__restrict__ row_off) {
+    __shared__ int s[256];
+    const int p = blockIdx.x, r0 = p * PR, r1 = min(M, r0 + PR);
+    const int per = (PR + 255) / 256;
+    const int a = min(r1, r0 + (int)threadIdx.x * per), b = min(r1, a + per);
+    int acc = 0;
+    for (int r = a; r < b; ++r) acc += (rp[r + 1] - rp[r] + 3) & ~3;
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {   // inclusive scan (Hillis-Steele)
+        const int v = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0;
+        __syncthreads();
+        s[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int off = part_base[p] + s[threadIdx.x] - acc;
+    for (int r = a; r < b; ++r) { row_off[r] = off; off += (rp[r + 1] - rp[r] + 3) & ~3; }
+    if (r1 == M && threadIdx.x == 255) row_off[M] = part_base[p] + s[255];
+}
+
+// ---- pass B: block formation, one workgroup per part
+__global__ __launch_bounds__(256) void plan_blocks(const int *__restrict__ rp, const int *__restrict__ ci, int M, int PR, int RB,
+                                                   int cap, double min_reuse, int *__restrict__ pb_row, int *__restrict__ pb_cnt,
+                                                   int *__restrict__ part_nblk) {
+    __shared__ int keys[kHT], stamp[kHT];
+    __shared__ int s_count;
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x, part_begin = p * PR, part_end = min(M, part_begin + PR);
+    int nb = 0;
+    for (int r = part_begin; r < part_end;) {
+        for (int i = tid; i < kHT; i += 256) keys[i] = kEmpty;
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+        int e = r, uniq = 0;
+        bool fits = true;
+        while (e < part_end && e - r < RB) {
+            const int before = uniq;
+            bool over = false;
+            const int j1 = rp[e + 1];
+            for (int j0 = rp[e]; j0 < j1 && !over; j0 += 256) {   // (a chunk at a time: the set never holds more than cap + 256 keys)
+                const int j = j0 + tid;
+                if (j < j1 && hs_insert(keys, stamp, ci[j], e - r)) atomicAdd(&s_count, 1);
+                __syncthreads();
+                uniq = s_count;
+                __syncthreads();                                  // everybody has read the count before it moves again
+                over = uniq > cap;
+            }
+            if (over) {                                           // row e does not fit: its keys (stamp == e - r) are not part
+                uniq = before;                                    // of the block; the set is rebuilt for the next block anyway
+                if (e == r) fits = false;                         // a single row already exceeds the panel
+                break;
+            }
+            ++e;
+        }
+        if (e == r) e = r + 1;                                    // the oversized row forms a (direct) block of its own
+        const long long n = (long long)rp[e] - rp[r];
+        // (a block cut short by the end of its part is judged by fit alone: a one-row remnant has no reuse of its own,
+        // and a single direct block would push the whole matrix onto the slower mixed kernel instantiation)
+        const bool remnant = e == part_end && e - r < RB;
+        const bool use_dict = fits && uniq > 0 && ((double)n >= min_reuse * (double)uniq || remnant);
+        if (tid == 0) { pb_row[(long long)p * PR + nb] = r; pb_cnt[(long long)p * PR + nb] = use_dict ? uniq : 0; }
+        ++nb;
+        r = e;
+        __syncthreads();
+    }
+    if (tid == 0) part_nblk[p] = nb;
+}
+
+// blocks of all parts -> contiguous arrays + plan statistics
+__global__ __launch_bounds__(256) void plan_compact(const int *__restrict__ rp, int M, int PR, const int *__restrict__ pb_row,
+                                                    const int *__restrict__ pb_cnt, const int *__restrict__ part_nblk,
+                                                    const int *__restrict__ part_blk_base, int nblk, int *__restrict__ blk_row,
+                                                    int *__restrict__ dict_cnt, int *stats /* max_dict, mixed */,
+                                                    unsigned long long *nnz_panel) {
+    const int p = blockIdx.x;
+    const int nb = part_nblk[p], base = part_blk_base[p];
+    int mx = 0, mixed = 0;
+    unsigned long long covered = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        const int r0 = pb_row[(long long)p * PR + i];
+        const int r1 = i + 1 < nb ? pb_row[(long long)p * PR + i + 1] : min(M, (p + 1) * PR);
+        const int c = pb_cnt[(long long)p * PR + i];
+        blk_row[base + i] = r0;
+        dict_cnt[base + i] = c;
+        const long long n = (long long)rp[r1] - rp[r0];
+        mx = max(mx, c);
+        if (c > 0) covered += (unsigned long long)n;
+        else if (n > 0) mixed = 1;
+    }
+    if (p == 0 && threadIdx.x == 0) blk_row[nblk] = M;
+    if (mx) atomicMax(&stats[0], mx);
+    if (mixed) atomicOr(&stats[1], 1);
+    if (covered) atomicAdd(nnz_panel, covered);
+}
+
+// ---- pass C: one workgroup per block
+template <int P>   // P = power of two >= panel capacity (sort width)
+__global__ __launch_bounds__(256) void plan_emit(const int *__restrict__ rp, const int *__restrict__ ci, const float *__restrict__ va,
+                                                 const int *__restrict__ row_off, const int *__restrict__ blk_row,
+                                                 const int *__restrict__ dict_cnt, int RB, int dstride, unsigned row_bytes,
+                                                 unsigned pad_off, int *__restrict__ bdict, int *__restrict__ slot_info,
+                                                 unsigned short *__restrict__ idx16, int *__restrict__ col32, float *__restrict__ pval) {
+    __shared__ int keys[kHT], rankv[kHT];
+    __shared__ int sorted[P];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int r0 = blk_row[b], r1 = blk_row[b + 1], nu = dict_cnt[b];
+    const int lpr = 256 / RB, slot = tid / lpr, q = tid % lpr;
+    // per-slot row extents {first packed entry, entries}: dictionary rows are consumed in whole groups of 4 entries
+    // (exact-safe padding), direct rows keep their true length; slots past the block's last row stay {0, 0}
+    if (q == 0) {
+        int2 si = make_int2(0, 0);
+        if (r0 + slot < r1) {
+            const int len = rp[r0 + slot + 1] - rp[r0 + slot];
+            si = make_int2(row_off[r0 + slot], nu > 0 ? (len + 3) & ~3 : len);
+        }
+        reinterpret_cast<int2 *>(slot_info)[(long long)b * RB + slot] = si;
+    }
+    if (nu == 0) {   // direct block: 32-bit columns, B rows gathered from global memory by the kernel
+        for (int i = tid; i < dstride; i += 256) bdict[(long long)b * dstride + i] = 0;
+        if (r0 + slot < r1) {
+            const int row = r0 + slot, j0 = rp[row], len = rp[row + 1] - j0, o0 = row_off[row];
+            for (int e = q; e < len; e += lpr) { pval[o0 + e] = va[j0 + e]; col32[o0 + e] = ci[j0 + e]; }
+        }
+        return;
+    }
+    for (int i = tid; i < kHT; i += 256) keys[i] = kEmpty;
+    for (int i = tid; i < P; i += 256) sorted[i] = INT_MAX;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int jb = rp[r0], je = rp[r1];
+    for (int j = jb + tid; j < je; j += 256) {
+        const int c = ci[j];
+        if (hs_insert(keys, rankv, c, 0)) sorted[atomicAdd(&s_n, 1)] = c;   // (s_n ends at nu: pass B counted the same set)
+    }
+    __syncthreads();
+    // bitonic sort, ascending, P elements
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int a = sorted[i], c = sorted[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { sorted[i] = c; sorted[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // dictionary at a fixed stride per block, last column repeated; rank of every column for the re-encoding
+    for (int i = tid; i < dstride; i += 256) bdict[(long long)b * dstride + i] = sorted[min(i, nu - 1)];
+    for (int i = tid; i < nu; i += 256) rankv[hs_find(keys, sorted[i])] = i;
+    __syncthreads();
+    if (r0 + slot < r1) {
+        const int row = r0 + slot, j0 = rp[row], len = rp[row + 1] - j0, o0 = row_off[row], plen = (len + 3) & ~3;
+        for (int e = q; e < plen; e += lpr) {
+            if (e < len) {
+                pval[o0 + e] = va[j0 + e];
+                idx16[o0 + e] = (unsigned short)((unsigned)rankv[hs_find(keys, ci[j0 + e])] * row_bytes);
+            } else {   // padding consumed by the kernel: -0.0f against the +1.0f panel row
+                pval[o0 + e] = -0.0f;
+                idx16[o0 + e] = (unsigned short)pad_off;
+            }
+        }
+    }
+}
+
+#define PD_HIP(call)                                                                                           \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            char buf_[256];                                                                                    \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (plan_device.hip:%d)", #call, hipGetErrorString(e_), __LINE__); \
+            err = buf_;                                                                                        \
+            return 2;                                                                                          \
+        }                                                                                                      \
+    } while (0)
+
+struct Scratch {   // freed on every exit path
+    std::vector<void *> p;
+    ~Scratch() { for (void *q : p) (void)hipFree(q); }
+    template <class T> hipError_t alloc(T **out, size_t n) {
+        hipError_t e = hipMalloc((void **)out, sizeof(T) * (n ? n : 1));
+        if (e == hipSuccess) p.push_back(*out);
+        return e;
+    }
+};
+
+}  // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void csr_validate(const int *__restrict__ rp, const int *__restrict__ ci, int M, int K, long long nnz,
+                                                    int *bad) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+    int b = 0;
+    if (t == 0 && (rp[0] != 0 || (long long)rp[M] != nnz)) b |= 1;
+    for (long long r = t; r < M; r += stride)
+        if (rp[r + 1] < rp[r]) b |= 1;
+    for (long long j = t; j < nnz; j += stride)
+        if ((unsigned)ci[j] >= (unsigned)K) b |= 2;
+    if (b) atomicOr(bad, b);
+}
+}  // namespace
+
+int validate_csr_device(int M, int K, int64_t nnz, const int *d_rp, const int *d_ci, int *bad, std::string &err) {
+    *bad = 0;
+    int *d_bad = nullptr;
+    PD_HIP(hipMalloc((void **)&d_bad, sizeof(int)));
+    hipError_t e1 = hipMemset(d_bad, 0, sizeof(int));
+    hipLaunchKernelGGL(csr_validate, dim3(2048), dim3(256), 0, nullptr, d_rp, d_ci, M, K, (long long)nnz, d_bad);
+    hipError_t e2 = hipMemcpy(bad, d_bad, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    PD_HIP(e1);
+    PD_HIP(e2);
+    return 0;
+}
+
+void free_device_plan(DevicePlan &d) {
+    (void)hipFree(d.d_blk_row); (void)hipFree(d.d_dict_cnt); (void)hipFree(d.d_dict); (void)hipFree(d.d_slot_info);
+    (void)hipFree(d.d_idx16); (void)hipFree(d.d_col32); (void)hipFree(d.d_val);
+    d = DevicePlan();
+}
+
+// 0 = built; 1 = not representable (padded stream exceeds 32-bit entry offsets): caller keeps the row-group kernel;
+// 2 = HIP error (err set)
+int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, const float *d_v, int lpr, int max_unique,
+                            double min_reuse, DevicePlan &out, std::string &err) {
+    (void)K;
+    free_device_plan(out);
+    const int RB = 256 / lpr;
+    const int PR = kPlanPartBlocks * RB;
+    const int nparts = M > 0 ? (M + PR - 1) / PR : 0;
+    out.rows_per_block = RB;
+    out.lpr = lpr;
+    const unsigned row_bytes = 16u * (unsigned)lpr;
+    const unsigned pad_off = (unsigned)max_unique * row_bytes;   // the +1.0f row sits right behind a full dictionary
+    if (pad_off > 0xffffu) { err = "panel capacity does not fit 16-bit byte offsets"; return 2; }
+    Scratch tmp;
+    if (M == 0) {
+        PD_HIP(hipMalloc((void **)&out.d_blk_row, sizeof(int)));
+        PD_HIP(hipMemset(out.d_blk_row, 0, sizeof(int)));
+        PD_HIP(hipMalloc((void **)&out.d_dict_cnt, sizeof(int)));
+        PD_HIP(hipMalloc((void **)&out.d_dict, sizeof(int)));
+        PD_HIP(hipMalloc((void **)&out.d_slot_info, sizeof(int)));
+        PD_HIP(hipMalloc((void **)&out.d_idx16, sizeof(unsigned short) * kPlanTailPad));
+        PD_HIP(hipMalloc((void **)&out.d_col32, sizeof(int)));
+        PD_HIP(hipMalloc((void **)&out.d_val, sizeof(float) * kPlanTailPad));
+        PD_HIP(hipMemset(out.d_idx16, 0, sizeof(unsigned short) * kPlanTailPad));
+        PD_HIP(hipMemset(out.d_val, 0, sizeof(float) * kPlanTailPad));
+        out.h_blk_row.assign(1, 0);
+        out.dict_stride = RB;
+        out.stream_len = kPlanTailPad;
+        return 0;
+    }
+    // ---- pass A
+    long long *d_part_sum = nullptr;
+    int *d_part_base = nullptr, *d_row_off = nullptr;
+    PD_HIP(tmp.alloc(&d_part_sum, (size_t)nparts));
+    PD_HIP(tmp.alloc(&d_part_base, (size_t)nparts));
+    PD_HIP(tmp.alloc(&d_row_off, (size_t)M + 1));
+    hipLaunchKernelGGL(plan_part_sums, dim3((unsigned)nparts), dim3(256), 0, nullptr, d_rp, M, PR, d_part_sum);
+    std::vector<long long> h_sum((size_t)nparts);
+    PD_HIP(hipMemcpy(h_sum.data(), d_part_sum, sizeof(long long) * (size_t)nparts, hipMemcpyDeviceToHost));
+    std::vector<int> h_base((size_t)nparts);
+    long long total = 0;
+    for (int p = 0; p < nparts; ++p) { h_base[(size_t)p] = (int)total; total += h_sum[(size_t)p]; }
+    if (total > 0x7fffffffLL - 4096) return 1;
+    PD_HIP(hipMemcpy(d_part_base, h_base.data(), sizeof(int) * (size_t)nparts, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(plan_row_off, dim3((unsigned)nparts), dim3(256), 0, nullptr, d_rp, M, PR, d_part_base, d_row_off);
+    // ---- pass B
+    int *d_pb_row = nullptr, *d_pb_cnt = nullptr, *d_part_nblk = nullptr, *d_part_blk_base = nullptr;
+    PD_HIP(tmp.alloc(&d_pb_row, (size_t)nparts * (size_t)PR));
+    PD_HIP(tmp.alloc(&d_pb_cnt, (size_t)nparts * (size_t)PR));
+    PD_HIP(tmp.alloc(&d_part_nblk, (size_t)nparts));
+    PD_HIP(tmp.alloc(&d_part_blk_base, (size_t)nparts));
+    hipLaunchKernelGGL(plan_blocks, dim3((unsigned)nparts), dim3(256), 0, nullptr, d_rp, d_ci, M, PR, RB, max_unique, min_reuse,
+                       d_pb_row, d_pb_cnt, d_part_nblk);
+    std::vector<int> h_nblk((size_t)nparts), h_bbase((size_t)nparts);
+    PD_HIP(hipMemcpy(h_nblk.data(), d_part_nblk, sizeof(int) * (size_t)nparts, hipMemcpyDeviceToHost));
+    long long nblk = 0;
+    for (int p = 0; p < nparts; ++p) { h_bbase[(size_t)p] = (int)nblk; nblk += h_nblk[(size_t)p]; }
+    PD_HIP(hipMemcpy(d_part_blk_base, h_bbase.data(), sizeof(int) * (size_t)nparts, hipMemcpyHostToDevice));
+    out.nblk = (int)nblk;
+    int *d_stats = nullptr;
+    unsigned long long *d_cov = nullptr;
+    PD_HIP(tmp.alloc(&d_stats, 2));
+    PD_HIP(tmp.alloc(&d_cov, 1));
+    PD_HIP(hipMemset(d_stats, 0, 2 * sizeof(int)));
+    PD_HIP(hipMemset(d_cov, 0, sizeof(unsigned long long)));
+    PD_HIP(hipMalloc((void **)&out.d_blk_row, sizeof(int) * ((size_t)nblk + 1)));
+    PD_HIP(hipMalloc((void **)&out.d_dict_cnt, sizeof(int) * (size_t)nblk));
+    hipLaunchKernelGGL(plan_compact, dim3((unsigned)nparts), dim3(256), 0, nullptr, d_rp, M, PR, d_pb_row, d_pb_cnt, d_part_nblk,
+                       d_part_blk_base, (int)nblk, out.d_blk_row, out.d_dict_cnt, d_stats, d_cov);
+    int h_stats[2] = {0, 0};
+    unsigned long long h_cov = 0;
+    PD_HIP(hipMemcpy(h_stats, d_stats, sizeof h_stats, hipMemcpyDeviceToHost));
+    PD_HIP(hipMemcpy(&h_cov, d_cov, sizeof h_cov, hipMemcpyDeviceToHost));
+    out.max_dict = h_stats[0];
+    out.mixed = h_stats[1] != 0;
+    out.nnz_in_panel_blocks = (int64_t)h_cov;
+    out.h_blk_row.resize((size_t)nblk + 1);
+    PD_HIP(hipMemcpy(out.h_blk_row.data(), out.d_blk_row, sizeof(int) * ((size_t)nblk + 1), hipMemcpyDeviceToHost));
+    // ---- pass C
+    int dstride = ((out.max_dict + RB - 1) / RB) * RB;
+    if (dstride < RB) dstride = RB;
+    out.dict_stride = dstride;
+    const size_t stream = (size_t)total + kPlanTailPad;
+    out.stream_len = (int64_t)stream;
+    PD_HIP(hipMalloc((void **)&out.d_dict, sizeof(int) * (size_t)nblk * (size_t)dstride));
+    PD_HIP(hipMalloc((void **)&out.d_slot_info, sizeof(int) * (size_t)nblk * (size_t)RB * 2));
+    PD_HIP(hipMalloc((void **)&out.d_idx16, sizeof(unsigned short) * stream));
+    PD_HIP(hipMalloc((void **)&out.d_val, sizeof(float) * stream));
+    PD_HIP(hipMalloc((void **)&out.d_col32, sizeof(int) * (out.mixed ? stream : 1)));   // only direct blocks read it
+    PD_HIP(hipMemsetAsync(out.d_idx16, 0, sizeof(unsigned short) * stream, nullptr));
+    PD_HIP(hipMemsetAsync(out.d_val, 0, sizeof(float) * stream, nullptr));
+    if (out.mixed) PD_HIP(hipMemsetAsync(out.d_col32, 0, sizeof(int) * stream, nullptr));
+    auto emit = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, nullptr, d_rp, d_ci, d_v, d_row_off, out.d_blk_row,
+                           out.d_dict_cnt, RB, dstride, row_bytes, pad_off, out.d_dict, out.d_slot_info, out.d_idx16,
+                           out.d_col32, out.d_val);
+    };
+    if (max_unique <= 512) emit(plan_emit<512>);
+    else if (max_unique <= 1024) emit(plan_emit<1024>);
+    else emit(plan_emit<2048>);
+    PD_HIP(hipGetLastError());
+    PD_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
+}  // namespace sx
