@@ -271,7 +271,12 @@ def main():
                          lambda: fem_secondary(api, torch, dev, stream, (35, 19, 7, 3), 128, 300)),
                         ("suitesparse_like_fem_4M_N16",
                          lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 100)),
+                        ("suitesparse_like_fem_4M_N32",
+                         lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 32, 30)),
+                        ("suitesparse_like_fem_4M_N128",
+                         lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 128, 10)),
                         ("config5_blocked_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream)),
+                        ("blockbanded_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream, banded_half_width=127)),
                         ("powerlaw_1M_rows_N16", lambda: powerlaw_secondary(api, torch, dev, stream)),
                         ("config4_matrix_N32", lambda: uniform_secondary(api, torch, dev, stream, args, 32))):
             try:
@@ -408,11 +413,17 @@ def nasa_secondary(api, torch, dev, stream):
     return out
 
 
-def bell_secondary(api, torch, dev, stream, M=1_048_576, W=328, N=256, iters=5):
+def bell_secondary(api, torch, dev, stream, M=1_048_576, W=328, N=256, iters=5, banded_half_width=None):
     """BASELINE config 5: blocked-ELL 32x32 bf16 blocks, 1% block fill, N=256, bf16 MFMA path.
-    F = 2*N*(1024*nblocks + M); bytes = 2048*nb + 4*nb + 2*K*N + 8*M*N."""
+    F = 2*N*(1024*nblocks + M); bytes = 2048*nb + 4*nb + 2*K*N + 8*M*N.
+    banded_half_width: the block-banded variant instead (2*hw + 1 consecutive block columns per block row: block rows
+    share block columns, the input class where a B tile staged once per workgroup is reused -- spmm_bell_mfma_shared)."""
     K = M
-    dc, dv = api.gen_bell_device(dev.index, M, K, W, 5)
+    if banded_half_width is not None:
+        W = 2 * banded_half_width + 1
+        dc, dv = api.gen_bell_banded_device(dev.index, M, K, banded_half_width, 5)
+    else:
+        dc, dv = api.gen_bell_device(dev.index, M, K, W, 5)
     e = api.Engine(dev.index)
     e.set_matrix_bell_device(M, K, W, dc, dv)
     api.device_free(dev.index, dv)                      # the engine keeps its own fragment-order copy
@@ -441,6 +452,9 @@ def bell_secondary(api, torch, dev, stream, M=1_048_576, W=328, N=256, iters=5):
            "repack_b_us": round(rp_ns / 1e3, 1), "alg_gbs_kernel": round(by / (k_ns * 1e-9) / 1e9, 1),
            "roofline_frac_kernel": round(by / (k_ns * 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
            "mfma_util_vs_2.5PF": round(flops / (k_ns * 1e-9) / 2.5e15, 4), "dtype": "bf16 in, f32 accumulate"}
+    if banded_half_width is not None:
+        out["matrix"] = f"block-banded, {W} consecutive block columns per block row"
+        out["blocks_per_distinct_column_in_a_workgroup"] = round(e.get_stat("bell_share"), 2)
     e.close()
     api.device_free(dev.index, dc)
     return out

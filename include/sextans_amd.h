@@ -439,6 +439,11 @@ int sextans_gen_powerlaw_device(int device, int M, int K, int xmin, int tail_x10
 int sextans_gen_bell_host(int M, int K, int ell_width, uint64_t seed, int **block_col, uint16_t **block_val);
 int sextans_gen_bell_device(int device, int M, int K, int ell_width, uint64_t seed, int **d_block_col,
                             uint16_t **d_block_val);
+/* Block-banded blocked-ELL (ell_width = 2 * half_width + 1 consecutive block columns around the diagonal block, window
+ * shifted inwards at the edges): block rows share block columns, the case spmm_bell_mfma_shared is built for. */
+int sextans_gen_bell_banded_host(int M, int K, int half_width, uint64_t seed, int **block_col, uint16_t **block_val);
+int sextans_gen_bell_banded_device(int device, int M, int K, int half_width, uint64_t seed, int **d_block_col,
+                                   uint16_t **d_block_val);
 /* bf16(U(-1,1)) fill (same bits on host and device). */
 int sextans_gen_uniform_bf16_host(uint16_t *dst, int64_t n, uint64_t seed);
 int sextans_gen_uniform_bf16_device(int device, uint16_t *d_dst, int64_t n, uint64_t seed, void *stream);

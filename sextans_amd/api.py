@@ -186,6 +186,9 @@ def lib():
     L.sextans_set_matrix_bell_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.sextans_spmm_bell_device.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
                                            C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.sextans_gen_bell_banded_host.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, pi, C.POINTER(C.POINTER(C.c_uint16))]
+    L.sextans_gen_bell_banded_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_void_p),
+                                                 C.POINTER(C.c_void_p)]
     L.sextans_gen_bell_host.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, pi,
                                         C.POINTER(C.POINTER(C.c_uint16))]
     L.sextans_gen_bell_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
@@ -717,6 +720,23 @@ def gen_bell_host(M, K, ell_width, seed):
 def gen_bell_device(device, M, K, ell_width, seed):
     c, v = C.c_void_p(), C.c_void_p()
     _check(lib().sextans_gen_bell_device(device, M, K, ell_width, seed, C.byref(c), C.byref(v)), "gen_bell_device")
+    return c.value, v.value
+
+
+def gen_bell_banded_host(M, K, half_width, seed):
+    """Block-banded blocked-ELL (2 * half_width + 1 consecutive block columns per block row): block rows share columns."""
+    L = lib()
+    c, v = C.POINTER(C.c_int)(), C.POINTER(C.c_uint16)()
+    _check(L.sextans_gen_bell_banded_host(M, K, half_width, seed, c, v), "gen_bell_banded_host")
+    n = (M // 32) * (2 * half_width + 1)
+    out = (_take(c, n, np.int32), np.ctypeslib.as_array(v, shape=(n * 1024,)).astype(np.uint16, copy=True))
+    L.sextans_host_free(c); L.sextans_host_free(v)
+    return out
+
+
+def gen_bell_banded_device(device, M, K, half_width, seed):
+    c, v = C.c_void_p(), C.c_void_p()
+    _check(lib().sextans_gen_bell_banded_device(device, M, K, half_width, seed, C.byref(c), C.byref(v)), "gen_bell_banded_device")
     return c.value, v.value
 
 

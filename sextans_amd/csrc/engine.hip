@@ -114,6 +114,8 @@ struct sextans_engine {
     int64_t dense_built_mfma = -2, dense_built_fill = -2;
     // blocked-ELL bf16 matrix (MFMA path)
     int bell_M = 0, bell_K = 0, bell_W = 0;
+    int bell_max_union = 0;         // largest number of distinct block columns inside a group of 8 block rows
+    double bell_share = 0.0;        // blocks per distinct block column inside groups of 8 block rows (1 = no sharing, 8 = identical rows)
     const int *d_bell_col = nullptr;
     int *d_bell_col_owned = nullptr;
     void *d_bell_Af = nullptr;      // A blocks in MFMA fragment order (owned)
@@ -186,6 +188,10 @@ struct sextans_engine {
     int64_t opt_win_cols = 65536;       // columns per K window (x 32 B = 2 MiB of the 8-column panel: half an XCD's L2)
     int64_t opt_win_unroll = 8;         // steps in flight per ring (4 or 8)
     int64_t opt_win_auto = 0;           // 1: "kernel" 0 may pick the window kernel from the fabric-byte model
+    int64_t opt_bell_shared = -1;       // N = 256: workgroups of 8 block rows share each B tile through an LDS ring
+                                        // (spmm_bell_mfma_shared).  1 = always, 0 = never, -1 = when the 8 block rows of a
+                                        // workgroup share block columns (blocks per distinct column >= 1.5)
+    int64_t opt_bell_debug = 0;         // measurements only (wrong results): ablation bits of spmm_bell_mfma_shared
     int64_t opt_bell_gen = 0;           // block rows per launch of the wide kernel (0 = all in one launch)
     int64_t opt_bell_wide = 1;          // 1 (default): N = 256 runs one wavefront per block row over all 8 column tiles
                                         // (A requested once, non-temporal); 0: two wavefronts of 4 tiles each
@@ -725,6 +731,8 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "window_auto")) return &h->opt_win_auto;
     if (!strcmp(key, "bell_wide")) return &h->opt_bell_wide;
     if (!strcmp(key, "bell_generation")) return &h->opt_bell_gen;
+    if (!strcmp(key, "bell_shared")) return &h->opt_bell_shared;
+    if (!strcmp(key, "bell_debug")) return &h->opt_bell_debug;
     if (!strcmp(key, "mfma_dense_tiles")) return &h->opt_mfma_dense;
     if (!strcmp(key, "dense_tile_fill_x100")) return &h->opt_dense_fill_x100;
     return nullptr;
@@ -1224,6 +1232,7 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "dense_tiles")) *value = (double)h->dense_tiles;
     else if (!strcmp(key, "dense_tile_fraction")) *value = h->nnz > 0 ? (double)h->dense_nnz / (double)h->nnz : 0.0;
     else if (!strcmp(key, "dense_tiles_on_mfma")) *value = h->dense_W > 0 ? 1.0 : 0.0;
+    else if (!strcmp(key, "bell_share")) *value = h->bell_share;
     else if (!strcmp(key, "panel_fraction")) *value = h->ps.plan_panel_frac;
     else if (!strcmp(key, "panel_blocks")) *value = (double)h->ps.plan_nblk;
     else return SEXTANS_ERR_INVALID;
@@ -1678,6 +1687,20 @@ int sextans_set_matrix_bell_device(sextans_handle_t h, int M, int K, int ell_wid
     SX_HIP(hipDeviceSynchronize());
     h->d_bell_col = d_block_col;
     h->bell_M = M; h->bell_K = K; h->bell_W = ell_width;
+    {   // do the block rows of a workgroup share block columns?  (decides between the per-wavefront kernels and the
+        // LDS-shared one, "MFMA only where a tile is actually dense" + reuse)
+        unsigned long long *d_cnt = nullptr, h_cnt[3] = {0, 0, 0};
+        SX_HIP(hipMalloc((void **)&d_cnt, 3 * sizeof(unsigned long long)));
+        SX_HIP(hipMemset(d_cnt, 0, 3 * sizeof(unsigned long long)));
+        const int groups = (M / 32 + sx::kShRows - 1) / sx::kShRows;
+        hipLaunchKernelGGL(sx::bell_union_count, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, nullptr, d_block_col, M / 32,
+                           ell_width, d_cnt, d_cnt + 1, d_cnt + 2);
+        const hipError_t e = hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost);
+        (void)hipFree(d_cnt);
+        SX_HIP(e);
+        h->bell_share = h_cnt[0] ? (double)h_cnt[1] / (double)h_cnt[0] : 0.0;
+        h->bell_max_union = (int)h_cnt[2];
+    }
     return SEXTANS_OK;
 }
 
@@ -1732,7 +1755,24 @@ int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint1
                            h->d_bell_col, Af, Bf, d_C_in, ldc, d_C_out, ldc, mblocks, h->bell_W, ntiles,    \
                            alpha, beta);                                                                      \
     }
-        if (ntiles == 8 && h->opt_bell_wide) {
+        const bool shared = ntiles == 8 && h->opt_bell_shared != 0 && sx::kShRows * h->bell_W <= sx::kShMaxRowCols &&
+                            h->bell_max_union <= sx::kShMaxUnion &&
+                            (h->opt_bell_shared == 1 || h->bell_share >= 1.5);
+        if (shared) {
+            constexpr size_t lds = (size_t)sx::kShRing * sx::kShTileBytes + (size_t)(sx::kShMaxUnion + 8) * (sizeof(int) + sx::kShRows * sizeof(short)) +
+                                  (size_t)sx::kShMaxRowCols * sizeof(int);
+            static bool attr_set = false;
+            if (!attr_set) {
+                SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sx::spmm_bell_mfma_shared),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(sx::spmm_bell_mfma_shared, dim3((unsigned)((mblocks + sx::kShRows - 1) / sx::kShRows)), dim3(sx::kShThreads), lds,
+                               s, h->d_bell_col, Af, Bf, d_C_in, ldc, d_C_out, ldc, mblocks, h->bell_W, alpha, beta, (int)h->opt_bell_debug);
+            h->last_kernel = "spmm_bell_mfma_shared";
+            SX_HIP(hipGetLastError());
+            return SEXTANS_OK;
+        } else if (ntiles == 8 && h->opt_bell_wide) {
             // "bell_generation" = G > 0: launches of G block rows, so that the wavefronts of a launch start at block
             // column 0 together and sweep K side by side (experiment: does the Infinity Cache then serve the B tiles?)
             const int G = h->opt_bell_gen > 0 ? (int)h->opt_bell_gen : mblocks;

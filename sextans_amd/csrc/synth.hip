@@ -428,6 +428,60 @@ int sextans_gen_bell_device(int device, int M, int K, int ell_width, uint64_t se
     return SEXTANS_OK;
 }
 
+// Block-banded blocked-ELL: block row br holds the 2*half_width + 1 consecutive block columns centred on its diagonal
+// block (window shifted inwards at the matrix edges, so every row is full): neighbouring block rows share all but one of
+// their block columns -- the structure (banded / FEM-like at block level) where a B tile staged once per workgroup is
+// reused by several block rows.  Values as in the uniform generator (slot-indexed, seeded).
+SX_HD int bell_band_start(int br, int mb, int kb, int W) {
+    const int64_t centre = (int64_t)br * kb / mb;
+    int64_t s0 = centre - W / 2;
+    if (s0 < 0) s0 = 0;
+    if (s0 > kb - W) s0 = kb - W;
+    return (int)s0;
+}
+__global__ void k_bell_band_cols(int mb, int kb, int W, int *block_col) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)mb * W) return;
+    const int br = (int)(t / W), i = (int)(t % W);
+    block_col[t] = bell_band_start(br, mb, kb, W) + i;
+}
+
+int sextans_gen_bell_banded_host(int M, int K, int half_width, uint64_t seed, int **block_col, uint16_t **block_val) {
+    const int W = 2 * half_width + 1;
+    if (M <= 0 || K <= 0 || M % 32 || K % 32 || half_width < 0 || W > K / 32 || !block_col || !block_val) return SEXTANS_ERR_INVALID;
+    const int mb = M / 32, kb = K / 32;
+    const int64_t nslots = (int64_t)mb * W;
+    int *c = (int *)malloc(sizeof(int) * (size_t)nslots);
+    uint16_t *v = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)nslots * 1024);
+    if (!c || !v) { free(c); free(v); return SEXTANS_ERR_ALLOC; }
+    for (int br = 0; br < mb; ++br)
+        for (int i = 0; i < W; ++i) c[(int64_t)br * W + i] = bell_band_start(br, mb, kb, W) + i;
+    for (int64_t sl = 0; sl < nslots; ++sl)
+        for (int e = 0; e < 1024; ++e) v[sl * 1024 + e] = bell_value(seed, sl, e);
+    *block_col = c; *block_val = v;
+    return SEXTANS_OK;
+}
+
+int sextans_gen_bell_banded_device(int device, int M, int K, int half_width, uint64_t seed, int **d_block_col,
+                                   uint16_t **d_block_val) {
+    const int W = 2 * half_width + 1;
+    if (M <= 0 || K <= 0 || M % 32 || K % 32 || half_width < 0 || W > K / 32 || !d_block_col || !d_block_val) return SEXTANS_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SEXTANS_ERR_NO_DEVICE;
+    SY_HIP(hipSetDevice(device));
+    const int mb = M / 32, kb = K / 32;
+    const int64_t nslots = (int64_t)mb * W;
+    int *c = nullptr;
+    uint16_t *v = nullptr;
+    SY_HIP(hipMalloc((void **)&c, sizeof(int) * (size_t)nslots));
+    SY_HIP(hipMalloc((void **)&v, sizeof(uint16_t) * (size_t)nslots * 1024));
+    hipLaunchKernelGGL(k_bell_band_cols, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, 0, mb, kb, W, c);
+    hipLaunchKernelGGL(k_bell_vals, dim3(65536), dim3(256), 0, 0, seed, nslots, v);
+    SY_HIP(hipDeviceSynchronize());
+    *d_block_col = c; *d_block_val = v;
+    return SEXTANS_OK;
+}
+
 int sextans_gen_uniform_bf16_host(uint16_t *dst, int64_t n, uint64_t seed) {
     if (!dst || n < 0) return SEXTANS_ERR_INVALID;
     for (int64_t i = 0; i < n; ++i) dst[i] = f32_to_bf16_rne(u01m1(rnd(seed, (uint64_t)i, 0x51)));

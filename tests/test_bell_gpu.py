@@ -66,7 +66,7 @@ def test_bell_mfma_vs_cpu_restatement(engine, oracle, sx, M, K, N, W):
     engine.spmm_bell_device(N, alpha, dB.data_ptr(), K, beta, dCin.data_ptr(), dC.data_ptr(), M,
                             torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    assert engine.last_kernel() == "spmm_bell_mfma"
+    assert engine.last_kernel() in ("spmm_bell_mfma", "spmm_bell_mfma_shared")
     got = dC.cpu().numpy().astype(np.float64)
     tol = 4e-6 * asum + 1e-6 * np.abs(float(beta) * C0) + 1e-30
     assert np.all(np.abs(got - want64) <= tol), float(np.max(np.abs(got - want64) / tol))
@@ -102,3 +102,83 @@ def test_bell_device_generator_matches_host(engine, sx):
     api.gen_uniform_bf16_device(0, t.data_ptr(), 10000, 6, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(t.cpu().numpy().view(np.uint16), api.gen_uniform_bf16_host(10000, 6))
+
+
+def _run_bell(engine, M, K, N, W, bcol, bval, B16, alpha, beta, C0):
+    import torch
+    engine.set_matrix_bell(M, K, W, bcol, bval)
+    dB = torch.from_numpy(B16.view(np.int16)).cuda()
+    dCin = torch.from_numpy(C0).cuda()
+    dC = torch.zeros(M * N, device="cuda")
+    engine.spmm_bell_device(N, alpha, dB.data_ptr(), K, beta, dCin.data_ptr(), dC.data_ptr(), M, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return dC.cpu().numpy().astype(np.float64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,hw,holes", [(1024, 1024, 2, False), (32 * 6, 32 * 40, 5, True), (32 * 13, 32 * 13, 6, True),
+                                          (2048, 4096, 0, False), (32 * 9, 32 * 64, 12, True)])
+def test_bell_shared_tile_kernel_on_block_banded_matrices(engine, sx, M, K, hw, holes):
+    """spmm_bell_mfma_shared (N = 256): workgroups of 8 block rows walk the union of their block columns, each B tile
+    staged once in an LDS ring.  Block-banded inputs (rows share columns), with empty slots, block-row counts that are not
+    a multiple of 8, one-block bands; the per-wavefront kernel on the same input must give the same numbers within the
+    stated bound, and both sit inside it."""
+    from sextans_amd import api
+    N, W = 256, 2 * hw + 1
+    rs = np.random.RandomState(M + hw)
+    bcol, bval = api.gen_bell_banded_host(M, K, hw, 9)
+    bc2 = bcol.reshape(M // 32, W)
+    assert np.all(np.diff(bc2, axis=1) == 1) and bc2.min() >= 0 and bc2.max() < K // 32
+    if M == K:
+        assert np.all(bc2[W:-W, hw] == np.arange(M // 32)[W:-W])           # centred on the diagonal block away from the edges
+    if holes:
+        bc2 = bc2.copy()
+        bc2[::3, 0] = -1; bc2[1::4, W // 2] = -1; bc2[2, :] = -1                # empty slots, one completely empty block row
+        bcol = bc2.reshape(-1)
+    B16 = api.gen_uniform_bf16_host(K * N, 6)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    alpha, beta = np.float32(0.85), np.float32(-2.06)
+    want64, asum = f64_reference(M, K, N, W, bcol, bval, B16, float(alpha), float(beta), C0)
+    tol = 4e-6 * asum + 1e-6 * np.abs(float(beta) * C0) + 1e-30
+    try:
+        engine.set_option("bell_shared", 1)
+        got = _run_bell(engine, M, K, N, W, bcol, bval, B16, alpha, beta, C0)
+        assert engine.last_kernel() == "spmm_bell_mfma_shared"
+        assert np.all(np.abs(got - want64) <= tol), float(np.max(np.abs(got - want64) / tol))
+        engine.set_option("bell_shared", 0)
+        plain = _run_bell(engine, M, K, N, W, bcol, bval, B16, alpha, beta, C0)
+        assert engine.last_kernel() == "spmm_bell_mfma"
+        assert np.all(np.abs(plain - want64) <= tol)
+        engine.set_option("bell_shared", -1)                                    # auto: banded rows share columns
+        _run_bell(engine, M, K, N, W, bcol, bval, B16, alpha, beta, C0)
+        share = engine.get_stat("bell_share")
+        assert engine.last_kernel() == ("spmm_bell_mfma_shared" if share >= 1.5 else "spmm_bell_mfma"), share
+        if hw >= 2 and not holes:
+            assert share > 2.0
+    finally:
+        engine.set_option("bell_shared", -1)
+
+
+@pytest.mark.gpu
+def test_bell_shared_tile_kernel_without_sharing_and_auto_dispatch(engine, sx):
+    """Uniformly random block columns (the config-5 generator): no sharing -- forced through the shared-tile kernel the
+    result is still right (every tile used by one wavefront), and the automatic choice stays on the per-wavefront kernel."""
+    from sextans_amd import api
+    M, K, N, W = 32 * 10, 32 * 200, 256, 17
+    rs = np.random.RandomState(3)
+    bcol, bval = api.gen_bell_host(M, K, W, 5)
+    B16 = api.gen_uniform_bf16_host(K * N, 6)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    alpha, beta = np.float32(1.25), np.float32(0.5)
+    want64, asum = f64_reference(M, K, N, W, bcol, bval, B16, float(alpha), float(beta), C0)
+    tol = 4e-6 * asum + 1e-6 * np.abs(float(beta) * C0) + 1e-30
+    try:
+        engine.set_option("bell_shared", 1)
+        got = _run_bell(engine, M, K, N, W, bcol, bval, B16, alpha, beta, C0)
+        assert engine.last_kernel() == "spmm_bell_mfma_shared" and np.all(np.abs(got - want64) <= tol)
+        engine.set_option("bell_shared", -1)
+        got = _run_bell(engine, M, K, N, W, bcol, bval, B16, alpha, beta, C0)
+        assert engine.last_kernel() == "spmm_bell_mfma" and engine.get_stat("bell_share") < 1.5
+        assert np.all(np.abs(got - want64) <= tol)
+    finally:
+        engine.set_option("bell_shared", -1)

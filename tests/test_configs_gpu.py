@@ -176,3 +176,64 @@ def test_config5_full_size(engine, oracle):
         finally:
             api.device_free(0, dc)
             torch.cuda.empty_cache()
+
+
+def test_block_banded_bell_full_size(engine, oracle):
+    """The blocked-ELL workload WITH block-column reuse (north_star: "feeds MFMA only where a tile is actually dense ...
+    MFMA utilisation against the roofline"): 1 048 576^2, 32x32 bf16 blocks, 255 consecutive block columns per block row
+    (8.4 M blocks), N = 256, through spmm_bell_mfma_shared (8 block rows per workgroup share each B tile through an LDS
+    ring).  Sampled block rows -- first, last, around the edges where the band window is shifted, random interior --
+    against the oracle's blocked-ELL restatement with the stated condition-aware bound."""
+    import torch
+    from sextans_amd import api
+    M = K = 1_048_576
+    hw, N = 127, 256
+    W = 2 * hw + 1
+    st = torch.cuda.current_stream().cuda_stream
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    dc, dv = api.gen_bell_banded_device(0, M, K, hw, 5)
+    try:
+        rs = np.random.RandomState(6)
+        mb = M // 32
+        brs = np.unique(np.concatenate([[0, 1, 7, 8, hw - 1, hw, hw + 1, mb - hw - 1, mb - 9, mb - 8, mb - 1], rs.randint(0, mb, 6)]))
+        cols, vals = [], []
+        for br in brs:
+            tc = torch.empty(W, dtype=torch.int32, device="cuda")
+            tv = torch.empty(W * 1024, dtype=torch.int16, device="cuda")
+            assert hip.hipMemcpy(tc.data_ptr(), dc + int(br) * W * 4, W * 4, 3) == 0
+            assert hip.hipMemcpy(tv.data_ptr(), dv + int(br) * W * 2048, W * 2048, 3) == 0
+            cols.append(tc.cpu().numpy()); vals.append(tv.cpu().numpy().view(np.uint16))
+        engine.set_option("bell_shared", -1)
+        engine.set_matrix_bell_device(M, K, W, dc, dv)
+        api.device_free(0, dv); dv = None
+        assert engine.get_stat("bell_share") > 7.0            # 8 block rows share all but 7 of their 262 block columns
+        B = torch.empty(K * N, dtype=torch.int16, device="cuda")
+        Cin = torch.empty(M * N, device="cuda")
+        Cout = torch.empty(M * N, device="cuda")
+        api.gen_uniform_bf16_device(0, B.data_ptr(), K * N, 51, st)
+        api.gen_uniform_device(0, Cin.data_ptr(), M * N, 52, st)
+        engine.spmm_bell_device(N, float(ALPHA), B.data_ptr(), K, float(BETA), Cin.data_ptr(), Cout.data_ptr(), M, st)
+        torch.cuda.synchronize()
+        assert engine.last_kernel() == "spmm_bell_mfma_shared"
+        Bh = B.cpu().numpy().view(np.uint16)
+        worst = 0.0
+        for br, bc, bv in zip(brs, cols, vals):
+            assert np.all(np.diff(bc) == 1) and bc.min() >= 0 and bc.max() < K // 32
+            c0 = Cin.view(N, M)[:, br * 32:(br + 1) * 32].cpu().numpy().reshape(-1).copy()
+            want = c0.copy()
+            asum = oracle.bell_spmm(32, K, N, W, bc, bv, Bh, ALPHA, BETA, want)
+            got = Cout.view(N, M)[:, br * 32:(br + 1) * 32].cpu().numpy().reshape(-1).astype(np.float64)
+            tol = 4e-6 * asum + 1e-6 * np.abs(float(BETA) * c0) + 1e-30
+            worst = max(worst, float(np.max(np.abs(got - want) / tol)))
+        print(f"block-banded blocked-ELL full size: worst |gpu - fp32 oracle| / bound = {worst:.3f} over {len(brs)} block rows")
+        assert worst <= 1.0
+    finally:
+        if dv is not None:
+            api.device_free(0, dv)
+        try:
+            bc1, bv1 = api.gen_bell_host(32, 32, 1, 1)
+            engine.set_matrix_bell(32, 32, 1, bc1, bv1)
+        finally:
+            api.device_free(0, dc)
+            torch.cuda.empty_cache()

@@ -11,5 +11,5 @@ for C in "${SETS[@]}"; do
   i=$((i+1))
   (cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$$_$i -o p -- "$@" > $OUT/pass$i.log 2>&1)
   F=$(find /tmp/pmc_$$_$i -name "*counter_collection.csv" | head -1)
-  if [ -n "$F" ]; then python $REPO/tools/pmc_summary.py $F | grep -E "spmm_csr|repack|counter" >> $OUT/summary.txt; else echo "pass $i ($C): no output" >> $OUT/summary.txt; tail -3 $OUT/pass$i.log >> $OUT/summary.txt; fi
+  if [ -n "$F" ]; then python $REPO/tools/pmc_summary.py $F | grep -E "spmm_|repack|counter" >> $OUT/summary.txt; else echo "pass $i ($C): no output" >> $OUT/summary.txt; tail -3 $OUT/pass$i.log >> $OUT/summary.txt; fi
 done
