@@ -108,6 +108,8 @@ struct sextans_engine {
     // "MFMA only where a tile is actually dense" (options "mfma_dense_tiles" / "dense_tile_fill_x100"): 32x32 tiles of
     // the main matrix whose fill reaches the threshold, as a blocked-ELL bf16 side matrix; the CSR kernels keep the rest
     int dense_mb = 0, dense_W = 0;  // full block rows, ELL width (0 = no dense tile / not extracted)
+    double dense_share = 0.0;       // blocks per distinct block column in groups of 8 block rows of the dense-tile matrix
+    int dense_max_union = 0;
     int *d_dense_col = nullptr;
     void *d_dense_Af = nullptr;
     int64_t dense_tiles = 0, dense_nnz = 0;
@@ -1094,6 +1096,20 @@ int ensure_dense(sextans_engine *h) {
     (void)hipFree(d_val);
     h->dense_mb = mb;
     h->dense_W = W;
+    {   // do neighbouring block rows share tile columns (block-diagonal / banded dense structure)?  Then N = 256 runs the
+        // LDS-shared MFMA kernel
+        unsigned long long *d_cnt = nullptr, h_cnt[3] = {0, 0, 0};
+        SX_HIP(hipMalloc((void **)&d_cnt, 3 * sizeof(unsigned long long)));
+        SX_HIP(hipMemset(d_cnt, 0, 3 * sizeof(unsigned long long)));
+        const int groups = (mb + sx::kShRows - 1) / sx::kShRows;
+        hipLaunchKernelGGL(sx::bell_union_count, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, nullptr, h->d_dense_col, mb, W,
+                           d_cnt, d_cnt + 1, d_cnt + 2);
+        const hipError_t e = hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost);
+        (void)hipFree(d_cnt);
+        SX_HIP(e);
+        h->dense_share = h_cnt[0] ? (double)h_cnt[1] / (double)h_cnt[0] : 0.0;
+        h->dense_max_union = (int)h_cnt[2];
+    }
     return SEXTANS_OK;
 }
 
@@ -1347,7 +1363,21 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         hipLaunchKernelGGL((sx::spmm_bell_mfma<NSUB>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, h->d_dense_col, \
                            Af, Bf, d_C_in, ldc_in, d_C_out, ldc, h->dense_mb, h->dense_W, ntiles, alpha, beta);            \
     }
-        if (ntiles % 4 == 0) SX_BELL(4) else if (ntiles % 2 == 0) SX_BELL(2) else SX_BELL(1)
+        const bool shared = ntiles == 8 && h->opt_bell_shared != 0 && sx::kShRows * h->dense_W <= sx::kShMaxRowCols &&
+                            h->dense_max_union <= sx::kShMaxUnion && (h->opt_bell_shared == 1 || h->dense_share >= 1.5);
+        if (shared) {
+            constexpr size_t lds = (size_t)sx::kShRing * sx::kShTileBytes + (size_t)(sx::kShMaxUnion + 8) * (sizeof(int) + sx::kShRows * sizeof(short)) +
+                                   (size_t)sx::kShMaxRowCols * sizeof(int);
+            static bool attr_set = false;
+            if (!attr_set) {
+                SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sx::spmm_bell_mfma_shared),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(sx::spmm_bell_mfma_shared, dim3((unsigned)((h->dense_mb + sx::kShRows - 1) / sx::kShRows)),
+                               dim3(sx::kShThreads), lds, s, h->d_dense_col, Af, Bf, d_C_in, ldc_in, d_C_out, ldc, h->dense_mb, h->dense_W,
+                               alpha, beta, 0);
+        } else if (ntiles % 4 == 0) SX_BELL(4) else if (ntiles % 2 == 0) SX_BELL(2) else SX_BELL(1)
 #undef SX_BELL
         const int row0 = h->dense_mb * 32;
         if (row0 < h->M) {

@@ -47,7 +47,7 @@ def dense_mask(M, K, rp, ci, thr):
     return (cnt[tile] >= thr) & (rows < (M // 32) * 32)
 
 
-@pytest.mark.parametrize("M,K,N", [(2048 + 17, 2048 + 40, 64), (1024, 4096, 32), (640, 640, 96)])
+@pytest.mark.parametrize("M,K,N", [(2048 + 17, 2048 + 40, 64), (1024, 4096, 32), (640, 640, 96), (1024 + 5, 1024, 256)])
 def test_block_diagonal_plus_noise_runs_both_kernels(engine, M, K, N):
     rs = np.random.RandomState(M + N)
     rp, ci, v = block_diagonal_plus_noise(rs, M, K, hub_row=M - 3 if M > 2000 else None)
