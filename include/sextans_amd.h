@@ -430,6 +430,16 @@ int sextans_gen_fem3d_device(int device, int nx, int ny, int nz, int dof, uint64
  * P(len >= x) = (xmin / x)^(tail_x100 / 100) on [xmin, min(max_len, K)] -- a few hub rows hundreds of thousands
  * of entries long next to a mass of short rows -- columns one uniform draw per equal stratum of [0, K) (distinct,
  * ascending), values U(-1,1).  Same bits on host and device. */
+/* 2-D stencil (points = 5 or 9) on an nx x ny grid with dof unknowns per node; KKT / arrow block structure
+ * [[H, A^T, U], [A, 0, U], [V, V, D]] with n variables (pentadiagonal H), n/2 constraints of 3 variables each and `arrow`
+ * border rows/columns (border rows hold every 16th column: a few very long rows).  Same bits on host and device. */
+int sextans_gen_stencil2d_host(int nx, int ny, int points, int dof, uint64_t seed, int r0, int r1, int **row_ptr, int **col_idx,
+                               float **val, int64_t *nnz);
+int sextans_gen_stencil2d_device(int device, int nx, int ny, int points, int dof, uint64_t seed, int r0, int r1, int **d_row_ptr,
+                                 int **d_col_idx, float **d_val, int64_t *nnz);
+int sextans_gen_kkt_host(int n, int arrow, uint64_t seed, int r0, int r1, int **row_ptr, int **col_idx, float **val, int64_t *nnz);
+int sextans_gen_kkt_device(int device, int n, int arrow, uint64_t seed, int r0, int r1, int **d_row_ptr, int **d_col_idx,
+                           float **d_val, int64_t *nnz);
 int sextans_gen_powerlaw_host(int M, int K, int xmin, int tail_x100, int max_len, uint64_t seed, int r0, int r1,
                               int **row_ptr, int **col_idx, float **val, int64_t *nnz);
 int sextans_gen_powerlaw_device(int device, int M, int K, int xmin, int tail_x100, int max_len, uint64_t seed, int r0,

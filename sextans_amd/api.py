@@ -170,6 +170,14 @@ def lib():
                                          C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_int64)]
+    L.sextans_gen_stencil2d_host.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, pi, pi, pf,
+                                             C.POINTER(C.c_int64)]
+    L.sextans_gen_stencil2d_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                                               C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_int64)]
+    L.sextans_gen_kkt_host.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, pi, pi, pf, C.POINTER(C.c_int64)]
+    L.sextans_gen_kkt_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.sextans_gen_fem3d_host.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
                                          pi, pi, pf, C.POINTER(C.c_int64)]
     L.sextans_gen_fem3d_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64,
@@ -682,6 +690,50 @@ def gen_fem3d_device(device, nx, ny, nz, dof, seed, r0=0, r1=None):
     _check(lib().sextans_gen_fem3d_device(device, nx, ny, nz, dof, seed, r0, r1, C.byref(p), C.byref(i),
                                           C.byref(v), C.byref(nnz)), "gen_fem3d_device")
     return p.value, i.value, v.value, nnz.value
+
+
+def _gen_host(fn, args, nrows):
+    L = lib()
+    p, i, v = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()
+    nnz = C.c_int64()
+    _check(fn(*args, p, i, v, C.byref(nnz)), fn.__name__)
+    out = (_take(p, nrows + 1, np.int32), _take(i, nnz.value, np.int32), _take(v, nnz.value, np.float32))
+    for q in (p, i, v):
+        L.sextans_host_free(q)
+    return out
+
+
+def _gen_device(fn, args):
+    p, i, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    nnz = C.c_int64()
+    _check(fn(*args, C.byref(p), C.byref(i), C.byref(v), C.byref(nnz)), fn.__name__)
+    return p.value, i.value, v.value, nnz.value
+
+
+def gen_stencil2d_host(nx, ny, points, dof, seed, r0=0, r1=None):
+    """2-D stencil (5 or 9 points) on an nx x ny grid, dof unknowns per node -> (row_ptr, col_idx, val)."""
+    r1 = nx * ny * dof if r1 is None else r1
+    return _gen_host(lib().sextans_gen_stencil2d_host, (nx, ny, points, dof, seed, r0, r1), r1 - r0)
+
+
+def gen_stencil2d_device(device, nx, ny, points, dof, seed, r0=0, r1=None):
+    r1 = nx * ny * dof if r1 is None else r1
+    return _gen_device(lib().sextans_gen_stencil2d_device, (device, nx, ny, points, dof, seed, r0, r1))
+
+
+def kkt_rows(n, arrow):
+    return n + n // 2 + arrow
+
+
+def gen_kkt_host(n, arrow, seed, r0=0, r1=None):
+    """KKT / arrow block structure (n variables, n/2 constraints, `arrow` border rows/columns) -> (row_ptr, col_idx, val)."""
+    r1 = kkt_rows(n, arrow) if r1 is None else r1
+    return _gen_host(lib().sextans_gen_kkt_host, (n, arrow, seed, r0, r1), r1 - r0)
+
+
+def gen_kkt_device(device, n, arrow, seed, r0=0, r1=None):
+    r1 = kkt_rows(n, arrow) if r1 is None else r1
+    return _gen_device(lib().sextans_gen_kkt_device, (device, n, arrow, seed, r0, r1))
 
 
 def gen_powerlaw_host(M, K, xmin, tail_x100, max_len, seed, r0=0, r1=None):

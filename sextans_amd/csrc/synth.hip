@@ -87,8 +87,47 @@ SX_HD int fem_neighbors(const Spec &sp, int node, int *nb) {
     return n;
 }
 
+// kind 3: 2-D stencil on an nx * ny grid, `bw` = 5 (von Neumann) or 9 (Moore) points, dof unknowns per node: the structure
+// of 2-D PDE discretisations in SuiteSparse (ecology, G2_circuit-like grids, Poisson problems).
+SX_HD int stencil2d_neighbors(const Spec &sp, int node, int *nb) {
+    const int x = node % sp.nx, y = node / sp.nx;
+    int n = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            if (sp.bw == 5 && dx != 0 && dy != 0) continue;
+            const int xx = x + dx, yy = y + dy;
+            if (xx < 0 || xx >= sp.nx || yy < 0 || yy >= sp.ny) continue;
+            if (nb) nb[n] = xx + sp.nx * yy;
+            ++n;
+        }
+    return n;
+}
+// kind 4: KKT / arrow block structure  [[H, A^T, U], [A, 0, U], [V, V, D]]  of constrained optimisation and bordered
+// systems: n = sp.nx variables with a pentadiagonal H, m = n / 2 constraints each tying variables 2j, 2j+1, 2j+2, and
+// a = sp.ny border ("arrow") rows/columns: every row carries the a border columns, every border row holds every 16th
+// column of the rest plus the border block.  Short rows without locality between blocks + a few very long rows.
+SX_HD int kkt_row(const Spec &sp, int row, int *c) {
+    const int n = sp.nx, m = n / 2, a = sp.ny;
+    int k = 0;
+    if (row < n) {
+        for (int d = -2; d <= 2; ++d) { const int cc = row + d; if (cc >= 0 && cc < n) { if (c) c[k] = cc; ++k; } }
+        const int j1 = row / 2;
+        if ((row & 1) == 0 && row >= 2 && j1 - 1 < m) { if (c) c[k] = n + j1 - 1; ++k; }
+        if (j1 < m) { if (c) c[k] = n + j1; ++k; }
+    } else if (row < n + m) {
+        const int j = row - n;
+        for (int d = 0; d < 3; ++d) { const int cc = 2 * j + d; if (cc < n) { if (c) c[k] = cc; ++k; } }
+    } else {
+        for (int cc = (row - n - m) % 16; cc < n + m; cc += 16) { if (c) c[k] = cc; ++k; }
+    }
+    for (int e = 0; e < a; ++e) { if (c) c[k] = n + m + e; ++k; }
+    return k;
+}
+
 SX_HD int row_len(const Spec &sp, const uint64_t *table, int row) {
     if (sp.kind == 1) return fem_neighbors(sp, row / sp.dof, nullptr) * sp.dof;
+    if (sp.kind == 3) return stencil2d_neighbors(sp, row / sp.dof, nullptr) * sp.dof;
+    if (sp.kind == 4) return kkt_row(sp, row, nullptr);
     if (sp.kind == 2) {
         // table[0 .. nb) = thresholds (CDF at the upper edge of bucket b, 64-bit fixed point), table[kTable/2 + b] =
         // lower edge of bucket b (edges[nb] = max_len + 1); nb = sp.bw
@@ -118,6 +157,14 @@ SX_HD void fill_row(const Spec &sp, int row, int len, int *c, float *v) {
         int i = 0;
         for (int a = 0; a < n; ++a)
             for (int e = 0; e < sp.dof; ++e) c[i++] = nb[a] * sp.dof + e;
+    } else if (sp.kind == 3) {
+        int nb[9];
+        const int n = stencil2d_neighbors(sp, row / sp.dof, nb);   // ascending node order by construction
+        int i = 0;
+        for (int a = 0; a < n; ++a)
+            for (int e = 0; e < sp.dof; ++e) c[i++] = nb[a] * sp.dof + e;
+    } else if (sp.kind == 4) {
+        kkt_row(sp, row, c);
     } else if (sp.kind == 2) {
         for (int i = 0; i < len; ++i) {
             const int64_t lo = (int64_t)i * sp.K / len, hi = (int64_t)(i + 1) * sp.K / len;   // len <= K: hi > lo
@@ -374,6 +421,47 @@ int sextans_gen_fem3d_device(int device, int nx, int ny, int nz, int dof, uint64
     const int M = nx * ny * nz * dof;
     if (r0 < 0 || r1 < r0 || r1 > M) return SEXTANS_ERR_INVALID;
     const Spec sp{1, M, 0, nx, ny, nz, dof, seed};
+    return gen_device(device, sp, 1.0, r0, r1, d_row_ptr, d_col_idx, d_val, nnz);
+}
+
+int sextans_gen_stencil2d_host(int nx, int ny, int points, int dof, uint64_t seed, int r0, int r1, int **row_ptr, int **col_idx,
+                               float **val, int64_t *nnz) {
+    if (nx <= 0 || ny <= 0 || dof <= 0 || dof > 8 || (points != 5 && points != 9) || (int64_t)nx * ny * dof > 0x7fffffffLL ||
+        !row_ptr || !col_idx || !val || !nnz)
+        return SEXTANS_ERR_INVALID;
+    const int M = nx * ny * dof;
+    if (r0 < 0 || r1 < r0 || r1 > M) return SEXTANS_ERR_INVALID;
+    const Spec sp{3, M, points, nx, ny, 1, dof, seed};
+    return gen_host(sp, 1.0, r0, r1, row_ptr, col_idx, val, nnz);
+}
+
+int sextans_gen_stencil2d_device(int device, int nx, int ny, int points, int dof, uint64_t seed, int r0, int r1, int **d_row_ptr,
+                                 int **d_col_idx, float **d_val, int64_t *nnz) {
+    if (nx <= 0 || ny <= 0 || dof <= 0 || dof > 8 || (points != 5 && points != 9) || (int64_t)nx * ny * dof > 0x7fffffffLL ||
+        !d_row_ptr || !d_col_idx || !d_val || !nnz)
+        return SEXTANS_ERR_INVALID;
+    const int M = nx * ny * dof;
+    if (r0 < 0 || r1 < r0 || r1 > M) return SEXTANS_ERR_INVALID;
+    const Spec sp{3, M, points, nx, ny, 1, dof, seed};
+    return gen_device(device, sp, 1.0, r0, r1, d_row_ptr, d_col_idx, d_val, nnz);
+}
+
+static bool kkt_ok(int n, int arrow) { return n >= 4 && arrow >= 0 && arrow <= 64 && (int64_t)n + n / 2 + arrow <= 0x7fffffffLL; }
+
+int sextans_gen_kkt_host(int n, int arrow, uint64_t seed, int r0, int r1, int **row_ptr, int **col_idx, float **val, int64_t *nnz) {
+    if (!kkt_ok(n, arrow) || !row_ptr || !col_idx || !val || !nnz) return SEXTANS_ERR_INVALID;
+    const int M = n + n / 2 + arrow;
+    if (r0 < 0 || r1 < r0 || r1 > M) return SEXTANS_ERR_INVALID;
+    const Spec sp{4, M, 0, n, arrow, 1, 1, seed};
+    return gen_host(sp, 1.0, r0, r1, row_ptr, col_idx, val, nnz);
+}
+
+int sextans_gen_kkt_device(int device, int n, int arrow, uint64_t seed, int r0, int r1, int **d_row_ptr, int **d_col_idx,
+                           float **d_val, int64_t *nnz) {
+    if (!kkt_ok(n, arrow) || !d_row_ptr || !d_col_idx || !d_val || !nnz) return SEXTANS_ERR_INVALID;
+    const int M = n + n / 2 + arrow;
+    if (r0 < 0 || r1 < r0 || r1 > M) return SEXTANS_ERR_INVALID;
+    const Spec sp{4, M, 0, n, arrow, 1, 1, seed};
     return gen_device(device, sp, 1.0, r0, r1, d_row_ptr, d_col_idx, d_val, nnz);
 }
 

@@ -76,7 +76,9 @@ SYNTH_HELP = """synthetic classes (generated in HBM by csrc/synth.hip, seeded, s
   synth:uniform:M:mean[:K]          Poisson(mean) non-zeros per row, uniform columns (BASELINE config 4 = synth:uniform:4000000:40)
   synth:banded:M:mean:bw            the same inside the band |row - col| <= bw (locality)
   synth:fem3d:nx:ny:nz:dof          27-point node stencil with dof unknowns per node (SuiteSparse FEM class)
-  synth:powerlaw:M:xmin:tail_x100:maxlen   P(len >= x) = (xmin/x)^(tail/100): hub rows over a mass of short rows"""
+  synth:powerlaw:M:xmin:tail_x100:maxlen   P(len >= x) = (xmin/x)^(tail/100): hub rows over a mass of short rows
+  synth:stencil2d:nx:ny:points:dof  5- or 9-point 2-D grid stencil, dof unknowns per node
+  synth:kkt:n:arrow                 KKT / arrow blocks: n variables (pentadiagonal H), n/2 constraints, `arrow` dense borders"""
 
 
 def _synth(spec, device):
@@ -94,6 +96,12 @@ def _synth(spec, device):
     if kind == "powerlaw":
         M = K = a[0]
         return (M, K) + api.gen_powerlaw_device(device, M, K, a[1], a[2], a[3], 7)
+    if kind == "stencil2d":
+        M = K = a[0] * a[1] * a[3]
+        return (M, K) + api.gen_stencil2d_device(device, a[0], a[1], a[2], a[3], 3)
+    if kind == "kkt":
+        M = K = api.kkt_rows(a[0], a[1])
+        return (M, K) + api.gen_kkt_device(device, a[0], a[1], 3)
     raise ValueError("unknown synthetic class: " + spec)
 
 

@@ -123,3 +123,86 @@ def test_powerlaw_device_generator_bit_identical_to_host(sx, engine):
     finally:
         for q in (p, i, v):
             api.device_free(0, q)
+
+
+def test_stencil2d_and_kkt_host_generators(sx):
+    """Round 3: two more SuiteSparse-like classes for the sweep -- 2-D 5/9-point grid stencils and the KKT / arrow block
+    structure (short rows without locality between blocks + a few very long border rows)."""
+    import scipy.sparse as sp
+    from sextans_amd import api
+    nx, ny = 17, 11
+    for points, dof in ((5, 1), (9, 1), (9, 2), (5, 3)):
+        rp, ci, v = api.gen_stencil2d_host(nx, ny, points, dof, 3)
+        M = nx * ny * dof
+        assert len(rp) == M + 1 and rp[-1] == len(ci) == len(v) and np.diff(rp).max() == points * dof
+        A = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(M, M))
+        assert (A != A.T).nnz == 0                                          # structurally symmetric
+        assert all(np.all(np.diff(ci[rp[r]:rp[r + 1]]) > 0) for r in range(M))
+        interior = (nx - 2) * (ny - 2)
+        assert (np.diff(rp) == points * dof).sum() == interior * dof
+        rp2, ci2, v2 = api.gen_stencil2d_host(nx, ny, points, dof, 3, 40, 97)   # any row range, same rows
+        assert np.array_equal(ci2, ci[rp[40]:rp[97]]) and np.array_equal(v2.view(np.uint32), v[rp[40]:rp[97]].view(np.uint32))
+    n, arrow = 1000, 4
+    rp, ci, v = api.gen_kkt_host(n, arrow, 3)
+    M = api.kkt_rows(n, arrow)
+    m = n // 2
+    assert M == n + m + arrow and len(rp) == M + 1
+    A = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(M, M)).toarray()
+    assert np.array_equal(A[:n, n:n + m], A[n:n + m, :n].T)                # [[H, A^T], [A, 0]]
+    assert not A[n:n + m, n:n + m].any()
+    assert A[:, n + m:].all()                                              # every row carries the border columns
+    assert np.array_equal(np.diff(rp)[n + m:], [len(range(k % 16, n + m, 16)) + arrow for k in range(arrow)])   # long border rows
+    assert all(np.all(np.diff(ci[rp[r]:rp[r + 1]]) > 0) for r in range(M))
+    assert np.abs(np.nonzero(A[:n, :n])[0] - np.nonzero(A[:n, :n])[1]).max() == 2                    # pentadiagonal H
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec", ["stencil2d5", "stencil2d9x2", "kkt"])
+def test_new_classes_device_generators_and_spmm(sx, engine, oracle, spec):
+    """Device generator == host generator bit for bit; SpMM (default options: strict order, long rows bucketed) is
+    bit-identical to the oracle -- the KKT class has border rows of thousands of entries next to 7-entry rows."""
+    import ctypes as C
+    import torch
+    from sextans_amd import api
+    from util import ALPHA, BETA
+    if spec == "kkt":
+        n, arrow = 40000, 3
+        M = K = api.kkt_rows(n, arrow)
+        host = api.gen_kkt_host(n, arrow, 3)
+        dev = api.gen_kkt_device(0, n, arrow, 3)
+    else:
+        nx, ny, points, dof = (150, 120, 5, 1) if spec == "stencil2d5" else (90, 70, 9, 2)
+        M = K = nx * ny * dof
+        host = api.gen_stencil2d_host(nx, ny, points, dof, 3)
+        dev = api.gen_stencil2d_device(0, nx, ny, points, dof, 3)
+    hp, hi, hv = host
+    p, i, v, nnz = dev
+    try:
+        hip = C.CDLL("libamdhip64.so.7")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        def pull(ptr, n_, dt):
+            t = torch.empty(n_, dtype=dt, device="cuda")
+            assert hip.hipMemcpy(t.data_ptr(), ptr, n_ * 4, 3) == 0
+            return t.cpu().numpy()
+        assert nnz == len(hi) and np.array_equal(pull(p, M + 1, torch.int32), hp) and np.array_equal(pull(i, nnz, torch.int32), hi)
+        assert np.array_equal(pull(v, nnz, torch.float32).view(np.uint32), hv.view(np.uint32))
+        for k, val in dict(kernel=0, lanes_per_row=0, exact=1, split_rows=0, bucket_rows=-1, panel_v2=-1, cols_per_lane=0).items():
+            engine.set_option(k, val)
+        engine.set_matrix_csr_device(M, K, nnz, p, i, v)
+        rs = np.random.RandomState(7)
+        for N in (16, 64):
+            B = rs.uniform(-1, 1, K * N).astype(np.float32)
+            C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+            want = C0.copy()
+            oracle.spmm(M, N, K, ALPHA, hp, hi, hv, B, BETA, want)
+            out = C0.copy()
+            dB = torch.from_numpy(B).cuda(); dC = torch.from_numpy(out).cuda()
+            engine.spmm_device(N, ALPHA, dB.data_ptr(), K, BETA, dC.data_ptr(), dC.data_ptr(), M, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(dC.cpu().numpy().view(np.uint32), want.view(np.uint32)), (spec, N, engine.last_kernel())
+            if spec == "kkt":
+                assert engine.last_kernel().endswith("+hub_pieces") and engine.get_stat("reassociated_rows") == 0
+    finally:
+        engine.set_matrix_csr(1, 1, np.array([0, 0], np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
+        for q in (p, i, v):
+            api.device_free(0, q)
