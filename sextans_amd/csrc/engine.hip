@@ -148,6 +148,19 @@ struct sextans_engine {
         std::vector<int> h_row, h_vfirst;
     };
     PieceTable by_len, by_row;                // sorted by length (whole-matrix calls: balanced workgroups) / by row (row ranges)
+    // exact chains (strict order, "exact_chain" = 1): rows longer than the automatic threshold leave the piece tables too
+    // and are summed by chain_products + chain_sum -- still one serial chain of rounded adds, bit-identical
+    int nchain = 0;
+    int *d_chain_row = nullptr, *d_chain_beg = nullptr;
+    long long *d_chain_off = nullptr, *d_chain_offc = nullptr;   // prefix of the lengths / of the lengths padded to 64-entry chunks
+    std::vector<int> h_chain_row;
+    std::vector<long long> h_chain_off, h_chain_offc;
+    float *d_Pc = nullptr;
+    size_t Pc_cap = 0;
+    int64_t chain_T = 0;
+    int64_t chain_built_opt = -2;
+    hipStream_t aux_stream = nullptr;         // the chain kernels need one or two wavefronts for ~1 ms: they run beside the main kernel
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<int> h_split_rows;            // ascending: rows cut into more than one piece
     int nhub = 0;                             // long rows (bucketed + split)
     int split_nv = 0;                         // pieces of all long rows
@@ -181,6 +194,9 @@ struct sextans_engine {
                                         // -1 = opt in with the automatic threshold max(1024, global nnz / 16384)
     int64_t opt_global_nnz = 0;         // multi-GPU: non-zeros of the WHOLE matrix (0 = this engine's matrix is the whole
                                         // matrix), so every rank derives the same split threshold as a single GPU would
+    int64_t opt_exact_chain = 1;        // strict order ("split_rows" = 0): rows longer than max(1024, nnz / 16384) are summed as
+                                        // exact chains (all products in parallel, one lane per column adds them in order);
+                                        // 0 = such rows stay on the piece path (one row group, ~80 ns per entry)
     int64_t opt_bucket_rows = -1;       // > 0: rows longer than this take the piece path unsplit (still exact); 0 = off;
                                         // -1 = max(32, 2 * mean row length)
     int64_t opt_phase_timing = 0;       // 1: panel kernel accumulates per-phase wave cycles (debug aid)
@@ -254,6 +270,9 @@ void free_split(sextans_engine *h) {   // long-row state: main matrix, skip flag
         (void)hipFree(t->d_vrp); (void)hipFree(t->d_vend); (void)hipFree(t->d_vfirst); (void)hipFree(t->d_row);
         *t = sextans_engine::PieceTable();
     }
+    (void)hipFree(h->d_chain_row); (void)hipFree(h->d_chain_beg); (void)hipFree(h->d_chain_off); (void)hipFree(h->d_chain_offc);
+    h->d_chain_row = h->d_chain_beg = nullptr; h->d_chain_off = h->d_chain_offc = nullptr;
+    h->nchain = 0; h->h_chain_row.clear(); h->h_chain_off.clear(); h->h_chain_offc.clear(); h->chain_T = 0; h->chain_built_opt = -2;
     (void)hipFree(h->d_mrp); (void)hipFree(h->d_mci); (void)hipFree(h->d_mv); (void)hipFree(h->d_skip);
     h->d_mrp = h->d_mci = nullptr;
     h->d_mv = nullptr;
@@ -701,6 +720,10 @@ int sextans_destroy(sextans_handle_t h) {
     (void)hipFree(h->d_Bp); (void)hipFree(h->d_B); (void)hipFree(h->d_Cin); (void)hipFree(h->d_Cout);
     sextans_profile_reset(h);
     (void)hipFree(h->d_P);
+    (void)hipFree(h->d_Pc);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     (void)hipFree(h->d_dbg);
     (void)hipFree(h->d_chB); (void)hipFree(h->d_chC);
     (void)hipFree(h->d_stage);
@@ -723,6 +746,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "split_rows")) return &h->opt_split_rows;
     if (!strcmp(key, "bucket_rows")) return &h->opt_bucket_rows;
     if (!strcmp(key, "global_nnz")) return &h->opt_global_nnz;
+    if (!strcmp(key, "exact_chain")) return &h->opt_exact_chain;
     if (!strcmp(key, "fuse_b")) return &h->opt_fuse_b;
     if (!strcmp(key, "cols_per_lane")) return &h->opt_cols_per_lane;
     if (!strcmp(key, "tiles_per_wg")) return &h->opt_tiles_per_wg;
@@ -849,9 +873,16 @@ struct Seg { int width, col0, ntiles; };
 //     parallel and folded in order (re-associated).  Measured on a 1M-row power-law matrix (33 M nnz, longest row
 //     399 302): T = 512 / 1024 / 2021 -> 0.81 / 0.74 / 0.77 ms with 4964 / 2190 / 978 rows re-associated (uniform
 //     matrix of the same size: 0.64 ms), so the larger threshold costs nothing and touches fewer rows.
+// Scratch rows (entries) one group of chain rows may hold: at least the longest chain row, at most 2 GiB of products.
+int64_t chain_group_cap(const sextans_engine *h, int N) {
+    int64_t longest = 0;
+    for (int k = 0; k < h->nchain; ++k) longest = std::max<int64_t>(longest, h->h_chain_offc[(size_t)k + 1] - h->h_chain_offc[(size_t)k]);
+    return std::max<int64_t>(longest, ((int64_t)1 << 29) / N);
+}
+
 int ensure_split(sextans_engine *h) {
     if (h->split_built_opt == h->opt_split_rows && h->bucket_built_opt == h->opt_bucket_rows &&
-        h->split_built_gnnz == h->opt_global_nnz)
+        h->split_built_gnnz == h->opt_global_nnz && h->chain_built_opt == h->opt_exact_chain)
         return SEXTANS_OK;
     free_split(h);
     free_plan(h);      // the packed forms are built from the main matrix
@@ -859,15 +890,19 @@ int ensure_split(sextans_engine *h) {
     h->split_built_opt = h->opt_split_rows;
     h->bucket_built_opt = h->opt_bucket_rows;
     h->split_built_gnnz = h->opt_global_nnz;
+    h->chain_built_opt = h->opt_exact_chain;
     if (h->M == 0 || h->s_nnz == 0) return SEXTANS_OK;
     int64_t T = h->opt_split_rows, L0 = h->opt_bucket_rows;
+    // strict order: rows above the automatic threshold become exact chains instead of one-piece rows
+    const int64_t Tc = (h->opt_split_rows == 0 && h->opt_exact_chain)
+                           ? std::max<int64_t>(1024, std::max<int64_t>(h->opt_global_nnz, h->s_nnz) / 16384) : INT64_MAX;
     // the automatic threshold follows the non-zeros of the whole matrix: a rank of a row-partitioned SpMM ("global_nnz")
     // then cuts a hub row into the same pieces as a single GPU holding all rows => bitwise equal results
     if (T < 0) T = std::max<int64_t>(1024, std::max<int64_t>(h->opt_global_nnz, h->s_nnz) / 16384);
     if (L0 < 0) L0 = std::max<int64_t>(32, 2 * (h->s_nnz / h->M));
     if (T == 0) T = INT64_MAX;                 // never split
-    if (L0 == 0) L0 = T;                       // no bucketing: only rows that must be split leave
-    if (L0 > T) L0 = T;
+    if (L0 == 0) L0 = std::min(T, Tc);         // no bucketing: only rows that must be split / chained leave
+    if (L0 > std::min(T, Tc)) L0 = std::min(T, Tc);
     if (L0 == INT64_MAX) return SEXTANS_OK;
     PlanTimer timer(h);
     std::vector<int> rp;
@@ -884,7 +919,29 @@ int ensure_split(sextans_engine *h) {
             long_nnz += len;
             longest = std::max(longest, len);
         }
-        if (longest <= T && h->opt_bucket_rows < 0 && long_nnz * 50 < h->s_nnz) return SEXTANS_OK;
+        if (longest <= std::min(T, Tc) && h->opt_bucket_rows < 0 && long_nnz * 50 < h->s_nnz) return SEXTANS_OK;
+    }
+    // chain rows leave the piece tables
+    std::vector<int> chain_rows, piece_rows;
+    for (int r : rows) ((int64_t)rp[(size_t)r + 1] - rp[(size_t)r] > Tc ? chain_rows : piece_rows).push_back(r);
+    if (!chain_rows.empty()) {
+        std::vector<int> beg;
+        std::vector<long long> off(1, 0), offc(1, 0);
+        for (int r : chain_rows) {
+            const long long len = rp[(size_t)r + 1] - rp[(size_t)r];
+            beg.push_back(rp[(size_t)r]);
+            off.push_back(off.back() + len);
+            offc.push_back(offc.back() + (len + sx::kChainCE - 1) / sx::kChainCE * sx::kChainCE);
+        }
+        if (int rc = upload(&h->d_chain_row, chain_rows)) return rc;
+        if (int rc = upload(&h->d_chain_beg, beg)) return rc;
+        if (int rc = upload(&h->d_chain_off, off)) return rc;
+        if (int rc = upload(&h->d_chain_offc, offc)) return rc;
+        h->h_chain_row = chain_rows;
+        h->h_chain_off = off;
+        h->h_chain_offc = offc;
+        h->nchain = (int)chain_rows.size();
+        h->chain_T = Tc;
     }
     std::vector<int> ci;
     std::vector<float> va;
@@ -907,12 +964,12 @@ int ensure_split(sextans_engine *h) {
         t.h_vfirst = vfirst;
         return SEXTANS_OK;
     };
-    std::vector<int> by_len = rows;
+    std::vector<int> by_len = piece_rows;
     std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b) {
         return rp[(size_t)a + 1] - rp[(size_t)a] > rp[(size_t)b + 1] - rp[(size_t)b];
     });
     if (int rc = build(by_len, h->by_len)) return rc;
-    if (int rc = build(rows, h->by_row)) return rc;
+    if (int rc = build(piece_rows, h->by_row)) return rc;
     // main matrix: long rows emptied; skip flags
     std::vector<int> mrp((size_t)h->M + 1, 0);
     std::vector<unsigned char> skip((size_t)h->M, 0);
@@ -941,7 +998,7 @@ int ensure_split(sextans_engine *h) {
     if (int rc = upload(&h->d_mv, va)) return rc;
     if (int rc = upload(&h->d_skip, skip)) return rc;
     h->m_rp = h->d_mrp; h->m_ci = h->d_mci; h->m_v = h->d_mv;
-    h->nhub = (int)rows.size();
+    h->nhub = (int)piece_rows.size();
     h->split_nv = h->by_len.h_vfirst.back();
     h->split_T = T == INT64_MAX ? 0 : T;
     h->bucket_L0 = L0;
@@ -1130,6 +1187,15 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
     }
     if (h->nhub > 0)
         if (int rc = ensure(&h->d_P, &h->P_cap, (size_t)h->split_nv * (size_t)N)) return rc;
+    if (h->nchain > 0) {
+        const int64_t rows = std::min<int64_t>(h->h_chain_offc.back(), chain_group_cap(h, N));
+        if (int rc = ensure(&h->d_Pc, &h->Pc_cap, (size_t)rows * (size_t)N)) return rc;
+        if (!h->aux_stream) {
+            SX_HIP(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+            SX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            SX_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
+    }
     if (h->Bp_cap < (size_t)h->K * (size_t)N || !h->d_Bp) h->bp_layout = 0;   // new workspace: nothing to reuse
     if (int rc = ensure(&h->d_Bp, &h->Bp_cap, (size_t)h->K * (size_t)N)) return rc;
     // main tile width: 4*lanes_per_row, but never wider than N itself (N = 8 -> 2 lanes per row); then
@@ -1215,6 +1281,46 @@ const char *kernel_name(int main, bool hubs, bool dense) {   // static strings f
     return names[main][hubs ? 1 : 0][dense ? 1 : 0];
 }
 
+// Exact chains of the chain rows [c0, c1) (see chain_products / chain_sum): products of a group of rows into the scratch
+// matrix from the repacked B panels (segment by segment, like the piece kernel), then one lane per (row, column) sums
+// them in order and applies the epilogue.
+void launch_chains(sextans_engine *h, const std::vector<Seg> &plan, const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc,
+                   int N, int c0, int c1, int row_base, float alpha, float beta, hipStream_t s) {
+    const int64_t G = chain_group_cap(h, N);
+    for (int k = c0; k < c1;) {
+        int ke = k + 1;
+        while (ke < c1 && h->h_chain_offc[(size_t)ke + 1] - h->h_chain_offc[(size_t)k] <= G) ++ke;
+        const int64_t entries = h->h_chain_off[(size_t)ke] - h->h_chain_off[(size_t)k];
+        for (const Seg &g : plan) {
+            const float *bp = h->d_Bp + (size_t)h->K * (size_t)g.col0;
+#define SX_CHAIN(L)                                                                                                    \
+    hipLaunchKernelGGL((sx::chain_products<L>), dim3((unsigned)((entries + 256 / L - 1) / (256 / L)) * (unsigned)g.ntiles),   \
+                       dim3(sx::kBlock), 0, s, h->d_chain_beg, h->d_chain_off, h->d_chain_offc, h->s_ci, h->s_v, bp,             \
+                       (int64_t)h->K * 4 * L, h->d_Pc, N, g.col0, g.ntiles, k, ke)
+            switch (g.width) {
+                case 32: SX_CHAIN(8); break;
+                case 16: SX_CHAIN(4); break;
+                default: SX_CHAIN(2); break;
+            }
+#undef SX_CHAIN
+        }
+        // one workgroup per (chain row, block of NB columns); NB = the largest of 32 / 16 / 8 dividing N
+        const int NB = N % 32 == 0 ? 32 : N % 16 == 0 ? 16 : 8;
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)(ke - k) * (unsigned)(N / NB)), dim3(sx::kBlock), 0, s, h->d_chain_row, h->d_chain_off,
+                               h->d_chain_offc, h->d_Pc, N, dCin, ldc_in, dCout, ldc, k, row_base, alpha, beta);
+        };
+#define SX_SUM(NBV) if (h->opt_exact) go(sx::chain_sum<NBV, true>); else go(sx::chain_sum<NBV, false>)
+        switch (NB) {
+            case 32: SX_SUM(32); break;
+            case 16: SX_SUM(16); break;
+            default: SX_SUM(8); break;
+        }
+#undef SX_SUM
+        k = ke;
+    }
+}
+
 template <int LPR>
 void launch_hub_pieces(sextans_engine *h, const sextans_engine::PieceTable &t, const float *dBp, int ntiles, int col0,
                        int v0, int v1, hipStream_t s) {
@@ -1242,7 +1348,9 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "window_padded_entries")) *value = (double)h->win_padded;
     else if (!strcmp(key, "window_state")) *value = (double)h->win_state;
     else if (!strcmp(key, "reassociated_rows")) *value = (double)h->h_split_rows.size();
-    else if (!strcmp(key, "piece_path_rows")) *value = (double)h->nhub;
+    else if (!strcmp(key, "piece_path_rows")) *value = (double)(h->nhub + h->nchain);
+    else if (!strcmp(key, "exact_chain_rows")) *value = (double)h->nchain;
+    else if (!strcmp(key, "chain_threshold")) *value = (double)h->chain_T;
     else if (!strcmp(key, "split_threshold")) *value = (double)h->split_T;
     else if (!strcmp(key, "bucket_threshold")) *value = (double)h->bucket_L0;
     else if (!strcmp(key, "dense_tiles")) *value = (double)h->dense_tiles;
@@ -1410,6 +1518,12 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         v0 = pt.h_vfirst[(size_t)hub0]; v1 = pt.h_vfirst[(size_t)hub1];
     }
     const bool hubs = hub1 > hub0;
+    int ch0 = 0, ch1 = h->nchain;              // chain rows of this range
+    if (h->nchain > 0 && !whole) {
+        ch0 = (int)(std::lower_bound(h->h_chain_row.begin(), h->h_chain_row.end(), row_begin) - h->h_chain_row.begin());
+        ch1 = (int)(std::lower_bound(h->h_chain_row.begin(), h->h_chain_row.end(), row_end) - h->h_chain_row.begin());
+    }
+    const bool chains = ch1 > ch0;
     auto fold = [&]() {
         const int64_t tot = (int64_t)(hub1 - hub0) * N;
         auto go = [&](auto kern) {
@@ -1430,7 +1544,11 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             const int w0 = row_begin / h->win_rw, w1 = (row_end + h->win_rw - 1) / h->win_rw;
             launch_window(h, h->d_Bp, d_C_in, ldc_in, d_C_out, ldc, N / 8, w0, w1, row_begin, alpha, beta, s);
             if (hubs) { launch_hub_pieces<2>(h, pt, h->d_Bp, N / 8, 0, v0, v1, s); fold(); }
-            h->last_kernel = kernel_name(2, hubs, h->dense_W > 0);
+            if (chains) {
+                const std::vector<Seg> p8{{8, 0, N / 8}};
+                launch_chains(h, p8, d_C_in, ldc_in, d_C_out, ldc, N, ch0, ch1, row_begin, alpha, beta, s);
+            }
+            h->last_kernel = kernel_name(2, hubs || chains, h->dense_W > 0);
         }
         SX_HIP(hipGetLastError());
         return SEXTANS_OK;
@@ -1438,7 +1556,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     // Small B (fits the L2s), dictionary-only plan, one N segment: the panel kernel stages straight from the
     // caller's column-major B and the repack launch disappears.
     const bool fuse_b = use_panel && !h->ps.plan_mixed && h->opt_fuse_b && !(flags & kRowsNoFuseB) && plan.size() == 1 &&
-                        plan[0].width == W && !hubs &&
+                        plan[0].width == W && !hubs && !chains &&
                         (size_t)h->K * (size_t)N * sizeof(float) <= ((size_t)16 << 20);
     // (a reuse request is honoured only if the panels in the workspace have this layout: row-range calls of
     // one pipelined SpMM may alternate between the window kernel's 8-column panels and these)
@@ -1459,6 +1577,14 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     {
         Prof p(h, &h->ev_kernel, s);
         bool v2_used = false;
+        if (chains) {
+            // the chains need one or two wavefronts for about a millisecond: on their own stream, beside the main kernel
+            // (fork after the B panels are in place, join before the call's work on `s` is considered complete)
+            SX_HIP(hipEventRecord(h->ev_fork, s));
+            SX_HIP(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+            launch_chains(h, plan, d_C_in, ldc_in, d_C_out, ldc, N, ch0, ch1, row_begin, alpha, beta, h->aux_stream);
+            SX_HIP(hipEventRecord(h->ev_join, h->aux_stream));
+        }
         for (const Seg &g : plan) {
             const float *bp = h->d_Bp + (size_t)h->K * (size_t)g.col0;
             const float *cin = d_C_in + (int64_t)g.col0 * ldc_in;
@@ -1504,7 +1630,8 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
 #undef SX_SEG
         }
         if (hubs) fold();
-        h->last_kernel = kernel_name(v2_used ? 3 : use_panel ? 1 : 0, hubs, h->dense_W > 0);
+        if (chains) SX_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+        h->last_kernel = kernel_name(v2_used ? 3 : use_panel ? 1 : 0, hubs || chains, h->dense_W > 0);
     }
     SX_HIP(hipGetLastError());
     return SEXTANS_OK;

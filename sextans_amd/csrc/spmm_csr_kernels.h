@@ -615,6 +615,149 @@ __global__ __launch_bounds__(kBlock) void fold_hub_pieces(const int *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Exact chains for VERY long rows (hub rows of power-law matrices, border rows of arrow / KKT systems) in strict-order mode.
+// The reference's sum of a row is one serial chain of rounded adds (cpu_spmm_CSR, sparse_helper.h:279-289; the PEs
+// accumulate one entry at a time too, sextans.cpp:425-446): bit-identical results allow no re-association, so a 400 000-entry
+// row cannot be summed in parallel pieces.  What CAN be parallel is everything except the adds: chain_products forms all
+// rounded products a_j * B[col_j][n] of the row at full memory-level parallelism (every entry independent) into a scratch
+// matrix P; chain_sum then walks that matrix with one lane per output column: a dependent add every few cycles, the
+// products streamed through an LDS ring several chunks ahead (a first version with plain strided loads, 16 in flight per
+// lane, was bound by memory latency: 30 ns per entry).  400 000 entries x a few ns instead of ~32 ms through the piece
+// kernel, whose serial chain also contains the B-row gathers (~80 ns per entry).
+// ------------------------------------------------------------------------------------------------
+// Scratch layout: chain row k owns ceil(len_k / 64) CHUNKS of 64 entries (coffc = prefix of the padded lengths); a chunk
+// is stored column-major, [N][64] floats, so that (1) the 64 x NB block a summing workgroup needs is one contiguous
+// NB * 256-byte run that LDS-DMA copies without touching registers, and (2) the lane that owns column n reads four
+// consecutive entries of its chain with one ds_read_b128.
+constexpr int kChainCE = 64;
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void chain_products(const int *__restrict__ cbeg, const long long *__restrict__ coff,
+                                                         const long long *__restrict__ coffc, const int *__restrict__ col_idx,
+                                                         const float *__restrict__ val, const float *__restrict__ Bp,
+                                                         int64_t panel_stride, float *__restrict__ P, int N, int col0, int ntiles,
+                                                         int k0, int k1) {
+    // chain rows [k0, k1): entries cbeg[k] .. of the CSR arrays; flat entry index e over all of them
+    constexpr int NT = 4 * LPR;
+    constexpr int EB = kBlock / LPR;                       // entries per workgroup
+    const int tile = (int)(blockIdx.x % (unsigned)ntiles);
+    const long long e = (long long)(blockIdx.x / (unsigned)ntiles) * EB + threadIdx.x / LPR;
+    const int q = threadIdx.x % LPR;
+    const long long base = coff[k0], total = coff[k1] - base;
+    // chain row holding the workgroup's FIRST entry: one binary search per workgroup (a search per thread -- ten
+    // dependent loads each -- was most of this kernel's time); the other entries walk forward from there
+    __shared__ int s_row0;
+    if (threadIdx.x == 0) {
+        const long long e0 = (long long)(blockIdx.x / (unsigned)ntiles) * EB;
+        int lo0 = k0, hi0 = k1 - 1;
+        while (lo0 < hi0) { const int mid = (lo0 + hi0 + 1) >> 1; if (coff[mid] - base <= e0) lo0 = mid; else hi0 = mid - 1; }
+        s_row0 = lo0;
+    }
+    __syncthreads();
+    if (e >= total) return;
+    int lo = s_row0;
+    while (lo + 1 < k1 && coff[lo + 1] - base <= e) ++lo;
+    const long long er = e - (coff[lo] - base);            // entry inside the row
+    const int j = cbeg[lo] + (int)er;
+    const float a = val[j];
+    const float4 b = *reinterpret_cast<const float4 *>(Bp + (int64_t)tile * panel_stride + (int64_t)col_idx[j] * NT + 4 * q);
+    // chunk-major, column-major inside the chunk
+    float *dst = P + ((coffc[lo] - coffc[k0]) + (er / kChainCE) * kChainCE) * N + (int64_t)(col0 + tile * NT + 4 * q) * kChainCE +
+                 (er % kChainCE);
+    dst[0] = a * b.x;                                      // rounded products (-ffp-contract=off)
+    dst[kChainCE] = a * b.y;
+    dst[2 * kChainCE] = a * b.z;
+    dst[3 * kChainCE] = a * b.w;
+}
+
+// One workgroup = one chain row x NB output columns (NB = 32, 16 or 8).  All four wavefronts stream the row's chunks into
+// an LDS ring with LDS-DMA, requested kChainDepth chunks ahead (hand-counted vmcnt: inline-asm requests, one per
+// wavefront and chunk); the first NB lanes add the products of their column in order: ds_read_b128 = 4 entries, 4 adds.
+template <int NB, bool EXACT>
+__global__ __launch_bounds__(kBlock) void chain_sum(const int *__restrict__ crow, const long long *__restrict__ coff,
+                                                    const long long *__restrict__ coffc, const float *__restrict__ P, int N,
+                                                    const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc, int k0,
+                                                    int row_base, float alpha, float beta) {
+    constexpr int CHB = NB * kChainCE * 4;                 // bytes of one chunk slice
+    constexpr int kChainRing = 61440 / CHB;                // ring slots: 60 KiB of LDS, i.e. ~52 KiB of products in flight per
+    constexpr int kChainDepth = kChainRing - 2;            // workgroup (6 chunks of 4 KiB in flight were memory-latency bound)
+    constexpr int PIECES = CHB / 1024;                     // 1 KiB LDS-DMA pieces per chunk: NB / 4
+    static_assert(PIECES >= 1 && PIECES <= 8, "NB in 8 .. 32");
+    constexpr int PW = (PIECES + 3) / 4;                   // pieces per wavefront and chunk (the vmcnt unit)
+    __shared__ __attribute__((aligned(16))) char ring[kChainRing * CHB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = N / NB;
+    const int k = k0 + (int)(blockIdx.x / (unsigned)nblk), cb = (int)(blockIdx.x % (unsigned)nblk) * NB;
+    const long long len = coff[k + 1] - coff[k];
+    const int nch = (int)((len + kChainCE - 1) / kChainCE);
+    const char *src0 = reinterpret_cast<const char *>(P + (coffc[k] - coffc[k0]) * N + (int64_t)cb * kChainCE) + lane * 16;
+    const unsigned ring0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)ring);
+    auto request = [&](int c, int slot) {                  // chunk c (clamped: counts stay constant) -> ring slot
+        const char *src = src0 + (int64_t)min(c, nch - 1) * kChainCE * N * 4;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int piece = min(wave * PW + i, PIECES - 1);   // (wavefronts beyond the chunk re-request its last piece)
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src + piece * 1024), "s"(ring0 + slot * CHB + piece * 1024) : "memory");
+        }
+    };
+    float acc = 0.f;
+    if (nch > 0) {
+#pragma unroll
+        for (int d = 0; d < kChainDepth; ++d) request(d, d);
+        const int nfull = (int)(len / kChainCE);               // chunks with all 64 entries
+        const char *mycol = ring + tid * (kChainCE * 4);
+        f32x4 x[kChainCE / 4], xn[kChainCE / 4];
+        // chunk 0 into registers
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PW * (kChainDepth - 1)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tid < NB) {
+#pragma unroll
+            for (int u = 0; u < kChainCE / 4; ++u) x[u] = reinterpret_cast<const f32x4 *>(mycol)[u];
+        }
+        // chunk c + 1 has landed (mine; after the barrier everybody's): its LDS reads are issued BEFORE the 64 dependent adds
+        // of chunk c, so neither the LDS round trip nor memory latency sits in the chain; ring slot (c - 2) is free for the
+        // request of chunk c + depth.  Two chunks per loop trip: the register sets swap roles without copies.
+#define SX_CHAIN_STEP(cc, cur, nxt)                                                                              \
+        {                                                                                                        \
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PW * (kChainDepth - 2)) : "memory");                       \
+            __builtin_amdgcn_s_barrier();                                                                        \
+            asm volatile("" ::: "memory");                                                                       \
+            request((cc) + kChainDepth, ((cc) + kChainDepth) % kChainRing);                                       \
+            if (tid < NB) {                                                                                      \
+                const f32x4 *np_ = reinterpret_cast<const f32x4 *>(mycol + (((cc) + 1) % kChainRing) * CHB);     \
+                _Pragma("unroll") for (int u = 0; u < kChainCE / 4; ++u) nxt[u] = np_[u];                        \
+                _Pragma("unroll") for (int u = 0; u < kChainCE / 4; ++u) {                                       \
+                    acc = acc + cur[u].x; acc = acc + cur[u].y; acc = acc + cur[u].z; acc = acc + cur[u].w;      \
+                }                                                                                                \
+            }                                                                                                    \
+        }
+        int c = 0;
+        for (; c + 2 <= nfull; c += 2) {
+            SX_CHAIN_STEP(c, x, xn)
+            SX_CHAIN_STEP(c + 1, xn, x)
+        }
+        if (c < nfull) SX_CHAIN_STEP(c, x, xn)
+#undef SX_CHAIN_STEP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the over-requested chunks; the partial last chunk (if any)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tid < NB && nfull < nch) {
+            const float *cf = reinterpret_cast<const float *>(mycol + (nfull % kChainRing) * CHB);
+            const int cnt = (int)(len - (long long)nfull * kChainCE);
+            for (int u = 0; u < cnt; ++u) acc = acc + cf[u];
+        }
+    }
+    if (tid < NB) {
+        const int64_t r = (int64_t)(crow[k] - row_base);
+        Cout[r + (int64_t)(cb + tid) * ldc] = epilogue<EXACT>(alpha, acc, beta, Cin[r + (int64_t)(cb + tid) * ldc_in]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // B repack: column-major K x N (leading dimension ldb) -> row-major panels of width W.
 // Panel t (columns col_base + t*W ...) is written at Bp + t*K*W as K rows of W floats.  The
 // reference does the equivalent re-layout for its HBM channels on the host

@@ -55,7 +55,7 @@ def _cases():
 @pytest.mark.parametrize("min_reuse", [0, 200, 400])
 def test_device_plan_is_byte_identical_to_the_host_builder(engine, sx, lanes, min_reuse):
     from sextans_amd import api
-    for k, v in dict(kernel=2, split_rows=0, bucket_rows=0, mfma_dense_tiles=0).items():
+    for k, v in dict(kernel=2, split_rows=0, bucket_rows=0, exact_chain=0, mfma_dense_tiles=0).items():   # no row leaves the main matrix
         engine.set_option(k, v)
     try:
         for what, (rp, ci, v, K) in _cases():
@@ -69,7 +69,7 @@ def test_device_plan_is_byte_identical_to_the_host_builder(engine, sx, lanes, mi
         engine.set_matrix_csr(M, K, rp, ci, v)
         _same(engine.export_plan(lanes), api.pack_csr(M, K, rp, ci, v, lanes, min_reuse), ("nasa4704", lanes, min_reuse))
     finally:
-        for k, v in dict(kernel=0, bucket_rows=-1, panel_min_reuse_x100=200).items():
+        for k, v in dict(kernel=0, bucket_rows=-1, exact_chain=1, panel_min_reuse_x100=200).items():
             engine.set_option(k, v)
 
 

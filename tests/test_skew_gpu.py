@@ -76,10 +76,12 @@ def test_power_law_default_options(engine, oracle, kernel, N):
     assert len(engine.reassociated_rows()) == 0 and engine.last_kernel().endswith("+hub_pieces")
     assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
     _defaults(engine, kernel=kernel, split_rows=0, bucket_rows=0)          # ... or nothing leaves the main kernel
+    engine.set_option("exact_chain", 0)                                    # (not even as exact chains)
     out = C0.copy()
     engine.spmm(N, ALPHA, B, BETA, out)
     assert "+hub" not in engine.last_kernel() and engine.get_stat("piece_path_rows") == 0
     assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    engine.set_option("exact_chain", 1)
     _defaults(engine)
 
 
@@ -188,3 +190,88 @@ def test_cli_on_a_power_law_file(sx, tmp_path):
     r = subprocess.run([sx.api.CLI_PATH, str(path), "16", "3"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Success!" in r.stdout and "num_mismatch = 0" in r.stdout, r.stdout[-600:]
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
+@pytest.mark.parametrize("N", [8, 16, 40, 96])
+def test_exact_chains_keep_strict_order_bit_identical(engine, oracle, kernel, N):
+    """Round 3: the engine's DEFAULT is strict CSR order for every row (split_rows = 0).  Rows longer than
+    max(1024, nnz / 16384) are then summed as exact chains (chain_products: all rounded products in parallel;
+    chain_sum: one lane per output column adds them in order) -- bit-identical to cpu_spmm_CSR like everything else,
+    at ~3 ns per entry instead of ~80 ns through the piece kernel.  exact_chain = 0 keeps those rows on the piece path:
+    same bits."""
+    import torch
+    from sextans_amd import api
+    M = K = 20000
+    rp, ci, v = api.gen_powerlaw_host(M, K, 3, 120, 15000, 11)
+    lens = np.diff(rp)
+    Tc = max(1024, int(rp[-1]) // 16384)
+    assert (lens > Tc).sum() >= 3
+    rs = np.random.RandomState(N)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    for chain in (1, 0):
+        _defaults(engine, kernel=kernel, split_rows=0)
+        engine.set_option("exact_chain", chain)
+        engine.set_matrix_csr(M, K, rp, ci, v)
+        assert engine.get_stat("exact_chain_rows") == ((lens > Tc).sum() if chain else 0)
+        assert engine.get_stat("piece_path_rows") == (lens > max(32, 2 * (int(rp[-1]) // M))).sum()
+        out = C0.copy()
+        engine.spmm(N, ALPHA, B, BETA, out, rp_time=2)          # (hipGraph replay: the fork/join onto the side stream is captured)
+        assert len(engine.reassociated_rows()) == 0 and engine.last_kernel().endswith("+hub_pieces")
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (kernel, N, chain)
+    # row ranges (multi-GPU chunks): each call sums the chain rows of its range
+    engine.set_option("exact_chain", 1)
+    st = torch.cuda.current_stream().cuda_stream
+    dB = torch.from_numpy(B).cuda(); dCin = torch.from_numpy(C0).cuda()
+    got = torch.full((M * N,), float("nan"), device="cuda")
+    cuts = [0, 3000, 3001, 12000, M]
+    for i in range(4):
+        c0, c1 = cuts[i], cuts[i + 1]
+        slab = torch.full(((c1 - c0) * N,), float("nan"), device="cuda")
+        engine.spmm_device_rows(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr() + 4 * c0, M, slab.data_ptr(), c1 - c0, c0, c1,
+                                reuse_b_panels=i > 0, stream=st)
+        got.view(N, M)[:, c0:c1] = slab.view(N, c1 - c0)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    engine.set_option("exact_chain", 1)
+
+
+def test_power_law_1m_rows_strict_order_default(engine, sx):
+    """The same 1M-row power-law matrix with NO option set: every row in strict order, the 399 302-entry row included.
+    Round 2 needed 31.6 ms for that (one row group walking the row); the exact chains bring it to a small multiple of
+    the uniform matrix, bit-identical (sampled hub rows against the oracle in test_exact_chains...)."""
+    import torch
+    from sextans_amd import api
+    M = K = 1_000_000
+    N = 16
+    st = torch.cuda.current_stream().cuda_stream
+    B = torch.empty(K * N, device="cuda"); Cin = torch.empty(M * N, device="cuda"); Cout = torch.empty(M * N, device="cuda")
+    api.gen_uniform_device(0, B.data_ptr(), K * N, 41, st)
+    api.gen_uniform_device(0, Cin.data_ptr(), M * N, 42, st)
+    pl = api.gen_powerlaw_device(0, M, K, 6, 120, 400_000, 7)
+    try:
+        with api.Engine(0) as e:                       # a fresh engine: every option at its default
+            e.set_matrix_csr_device(M, K, pl[3], *pl[:3])
+            f = lambda: e.spmm_device(N, 0.85, B.data_ptr(), K, -2.06, Cin.data_ptr(), Cout.data_ptr(), M, st)
+            for _ in range(3):
+                f()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                f()
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / 10
+            chains, reass = int(e.get_stat("exact_chain_rows")), int(e.get_stat("reassociated_rows"))
+            strict = Cout.clone()
+            e.set_option("exact_chain", 0)             # the same rows through the piece kernel: same bits, ~30 ms
+            f(); torch.cuda.synchronize()
+            same = bool(torch.equal(strict, Cout))
+        print(f"power-law {pl[3]} nnz, strict order: {t * 1e3:.3f} ms ({chains} exact chains, {reass} re-associated rows)")
+        assert chains > 100 and reass == 0 and same
+        assert t < 4e-3, t
+    finally:
+        for q in pl[:3]:
+            api.device_free(0, q)
