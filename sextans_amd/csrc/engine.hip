@@ -587,6 +587,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
         if (bcol_ld > 0) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, true>) : go(sx::spmm_csr_panel_v2<H, 6, false, true>);
         return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, false>) : go(sx::spmm_csr_panel_v2<H, 6, false, false>);
     } else {
+        if (bcol_ld > 0) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, true>) : go(sx::spmm_csr_panel_v2<H, 2, false, true>);
         if (nb == 2) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false>) : go(sx::spmm_csr_panel_v2<H, 2, false, false>);
         if (nb == 4) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 4, true, false>) : go(sx::spmm_csr_panel_v2<H, 4, false, false>);
         return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, false>) : go(sx::spmm_csr_panel_v2<H, 6, false, false>);
@@ -1610,7 +1611,10 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
                 if (hubs) launch_hub_pieces<4>(h, pt, bp, g.ntiles, g.col0, v0, v1, s);
                 continue;
             }
-            if (panel_here && g.width == 16 && !h->ps.plan_mixed && h->opt_panel_v2 != 0 && !fuse_b && wide_ok) {
+            // (column-major staging keeps the round-1 kernel unless the rows are short: then the register-resident form fits
+            // 128 registers together with a panel in registers)
+            const bool short_rows = h->M > 0 && h->m_nnz / h->M + 8 <= 32;
+            if (panel_here && g.width == 16 && !h->ps.plan_mixed && h->opt_panel_v2 != 0 && (!fuse_b || short_rows) && wide_ok) {
                 if (int rc = launch_panel_v2<1>(h, bsrc, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, bld, blk0, blk1, row_begin))
                     return rc;
                 v2_used = true;

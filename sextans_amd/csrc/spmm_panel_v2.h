@@ -208,8 +208,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
             *reinterpret_cast<float *>(lds + h * kWideHalfBytes + pad_row * 64 + 4 * (tid % 16)) = 1.0f;
         }
     };
-    constexpr bool DMA = (H == 1);            // (not with BCOL: the dispatcher keeps column-major staging on the plain kernel)
-    static_assert(!(DMA && BCOL), "LDS-DMA staging reads the repacked panels");
+    constexpr bool DMA = (H == 1) && !BCOL;   // (column-major staging, BCOL, goes through registers: small matrices with short rows)
     auto store_panel = [&]() {                // registers -> LDS panel (+ the +1.0f row the padding entries point at)
 #pragma unroll
         for (int u = 0; u < MAXD; ++u)
@@ -247,6 +246,16 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
             ai[b][2] = (int)(aw[b].y & 0xffffu); ai[b][3] = (int)(aw[b].y >> 16);
         }
     }
+    // C: column (col0 + 16h + 4q + j) of this lane = uniform column base (col0 + 16h + j) + a per-lane byte offset
+    const unsigned cvoff_in = (4u * (unsigned)q * (unsigned)ldc_in + coff) * 4u;
+    const unsigned cvoff_out = (4u * (unsigned)q * (unsigned)ldc + coff) * 4u;
+    // C_in of the FIRST super tile is requested here, in the same round trip as the panel and the row entries (for a
+    // matrix of a few thousand rows the whole kernel is three round trips: one more is 15 % of its time)
+    float cin[H][4];
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aload1(cin[h][j], Cin + ((int64_t)st_begin * NTT + h * 16 + j) * ldc_in, cvoff_in);
     if constexpr (!DMA) store_panel();
     // (a use of the row registers HERE makes the compiler wait for their loads before the loop; otherwise its wait
     // bookkeeping carries them into the loop as "possibly pending" and every batch waits for younger loads)
@@ -254,17 +263,15 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
     for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(av[b]));
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing the compiler tracks is outstanding from here on
-    // C: column (col0 + 16h + 4q + j) of this lane = uniform column base (col0 + 16h + j) + a per-lane byte offset
-    const unsigned cvoff_in = (4u * (unsigned)q * (unsigned)ldc_in + coff) * 4u;
-    const unsigned cvoff_out = (4u * (unsigned)q * (unsigned)ldc + coff) * 4u;
     for (int st = st_begin; st < st_end; ++st) {
         const int64_t col0 = (int64_t)st * NTT;
         // ---- requests that fly under this super tile's row loop: its C_in, the next panel
-        float cin[H][4];
+        if (st != st_begin) {
 #pragma unroll
-        for (int h = 0; h < H; ++h)
+            for (int h = 0; h < H; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) aload1(cin[h][j], Cin + (col0 + h * 16 + j) * ldc_in, cvoff_in);
+                for (int j = 0; j < 4; ++j) aload1(cin[h][j], Cin + (col0 + h * 16 + j) * ldc_in, cvoff_in);
+        }
         if constexpr (DMA) {
             if (st != st_begin) {
                 __syncthreads();               // every wave is done reading the previous panel
