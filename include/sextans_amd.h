@@ -242,13 +242,20 @@ int sextans_destroy(sextans_handle_t h);
  * L0 = max(32, 2 * mean row length), T = max(1024, nnz / 16384).  Defaults: "bucket_rows" = -1 (exact, so it costs
  * nothing in parity), "split_rows" = 0 -- EVERY row is summed in strict CSR order and the result is bit-identical to
  * cpu_spmm_CSR unless the caller opts into re-association with "split_rows" = -1 or > 0 (power-law inputs with rows of
- * 10^5 entries want that: a serial row holds one row group for milliseconds).  Matrices without long rows take none
- * of this path.  "global_nnz": non-zeros of the WHOLE matrix when this engine holds a row range of it (multi-GPU);
+ * 10^5 entries may want that).  "exact_chain" (default 1): in strict-order mode a row longer than max(1024, nnz/16384)
+ * is summed by the exact-chain kernels -- all rounded products formed in parallel, then ONE serial chain of rounded adds
+ * per output column, bit-identical to cpu_spmm_CSR; 0 = such rows stay on the piece kernel (the same bits,
+ * ~40x slower for a 400 000-entry row).  Matrices without long rows take none of this path.  "global_nnz": non-zeros of the WHOLE matrix when this engine holds a row range of it (multi-GPU);
  * the automatic T is derived from it so that every rank cuts hub rows exactly as one GPU would; sextans_dist_spmm sets
  * it from an exchanged sum; 0 = this engine's matrix is the whole matrix),
  * "fuse_b" (1 = the panel kernel may stage B straight from column-major B when B is <= 16 MiB and every row block has a dictionary, saving the
  * repack launch; default 1), "panel_min_reuse_x100" (a row block uses the LDS panel when
- * nnz >= value/100 * distinct columns; default 200).  Unknown keys -> SEXTANS_ERR_INVALID. */
+ * nnz >= value/100 * distinct columns; default 200), "panel_v2" (-1 auto / 0 / 1: the register-resident form of the panel
+ * kernel, spmm_csr_panel_v2), "tiles_per_wg" (N tiles one workgroup of that kernel walks; 0 = auto),
+ * "cols_per_lane" (0/4 = 16-column tiles at 4 workgroups per CU, the default; 8 = 32-column super tiles at 2 per CU),
+ * "bell_shared" (blocked-ELL, N = 256: -1 = use the union-walk kernel spmm_bell_mfma_shared when 8 consecutive block rows
+ * share block columns, stat "bell_share" >= 1.5; 0 never; 1 whenever the unions fit), "bell_debug" (measurements only:
+ * ablation bits of that kernel, results are wrong when non-zero).  Unknown keys -> SEXTANS_ERR_INVALID. */
 /* "mfma_dense_tiles" / "dense_tile_fill_x100": north_star's "MFMA only where a tile is actually dense".  The engine
  * always counts the 32x32 tiles of A whose fill reaches dense_tile_fill_x100 % (default 50) -- sextans_get_stat
  * "dense_tiles", "dense_tile_fraction" (share of the non-zeros in such tiles; estimated from a sample of up to 512
@@ -269,8 +276,8 @@ int sextans_reassociated_rows(sextans_handle_t h, int *rows, int capacity, int *
  * sextans_packed_free.  Analogue being replaced: generate_edge_list_for_all_PEs + edge_list_64bit on the host,
  * sparse_helper.h:345-473, sextans-host.cpp:114-148. */
 int sextans_export_plan(sextans_handle_t h, int lanes_per_row, struct sextans_packed *out);
-/* Read-only figures about the matrix currently set.  key: "plan_build_s" (host seconds spent so far
- * building packed forms of A -- read back from the device, pack on all cores, upload; outside every timed
+/* Read-only figures about the matrix currently set.  key: "plan_build_s" (seconds spent so far
+ * building packed forms of A -- on the device for the panel plan, on the host for the window stream; outside every timed
  * region like the reference's scheduling/packing, sextans-host.cpp:114-148), "window_padded_entries",
  * "window_state" (0 not evaluated, 1 built, -1 rejected), "panel_fraction", "panel_blocks", "piece_path_rows",
  * "reassociated_rows", "bucket_threshold", "split_threshold", "dense_tiles", "dense_tile_fraction",

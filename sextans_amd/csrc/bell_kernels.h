@@ -221,14 +221,14 @@ __global__ __launch_bounds__(256, 2) void spmm_bell_mfma_n256(
 // structure): the case north_star's "MFMA only where a tile is actually dense ... MFMA utilisation against the roofline"
 // is about.  The kernels above fetch every operand of every block from global memory per wavefront: with uniformly
 // random block columns (BASELINE config 5) nothing else is possible, every 32x32 block needs its own 32x256 B tile and
-// the launch is bound by line requests.  Here a workgroup owns 4 consecutive block rows (one wavefront
+// the launch is bound by line requests.  Here a workgroup owns kShRows (8) consecutive block rows (one wavefront
 // each, 32 x 256 accumulators = 128 registers) and walks the UNION of their block columns: the 16 KiB B tile of a block
 // column is copied ONCE per workgroup from global memory into an LDS ring (LDS-DMA, global_load_lds_dwordx4: no
-// staging registers) and multiplied by up to 4 A blocks, whose fragments come straight from HBM (read once,
-// non-temporal).  Software pipeline, hand-counted: at step s the tile and the A fragments of step s + 2 are requested;
+// staging registers) and multiplied by up to kShRows A blocks, whose fragments come straight from HBM (read once,
+// non-temporal).  Software pipeline, hand-counted: at step s the tile and the A fragments of step s + kShDepth are requested;
 // every step issues exactly kShVmemPerStep vector-memory instructions per wavefront (dummy A loads when the wavefront's
-// row has no block at that column), so `s_waitcnt vmcnt(kShVmemPerStep)` at the top of a step means "everything of
-// step s has landed, step s + 1 may still be in flight" -- the compiler cannot count these (inline asm), which is the
+// row has no block at that column), so `s_waitcnt vmcnt((kShDepth - 1) * kShVmemPerStep)` at the top of a step means "everything of
+// step s has landed, the later steps may still be in flight" -- the compiler cannot count these (inline asm), which is the
 // point: its own bookkeeping would drain the prefetches at every barrier (cdna_hip_programming.md, LDS-DMA section).
 // ------------------------------------------------------------------------------------------------
 constexpr int kShRows = 8;                 // block rows per workgroup = wavefronts (512 threads, one workgroup per CU)
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kShThreads, 2) void spmm_bell_mfma_shared(
     const int *__restrict__ block_col, const bf16x8 *__restrict__ Af, const bf16x8 *__restrict__ Bf, const float *Cin,
     int64_t ldc_in, float *Cout, int64_t ldc, int mblocks, int ell_width, float alpha, float beta, int dbg) {
     // dbg (engine option "bell_debug", measurements only -- results are wrong): 1 = no global-memory requests in the
-    // main loop, 2 = no LDS reads / MFMAs, 4 = no per-step barrier, 8 = no main loop, 16 = no epilogue
+    // main loop, 2 = no MFMAs (the LDS reads stay), 4 = no per-step barrier, 8 = no main loop, 16 = no epilogue
     constexpr int NT8 = 8;
     constexpr int T = kShThreads;
     extern __shared__ __attribute__((aligned(16))) char sh_lds[];   // [ring: kShRing tiles][union list][ELL rows]
