@@ -89,6 +89,7 @@ struct sextans_engine {
         unsigned short *d_lidx = nullptr;
         double plan_panel_frac = 0.0;   // share of non-zeros living in dictionary blocks
         int plan_max_dict = 0;          // largest block dictionary (entries)
+        int plan_max_row = 0;           // longest row of the planned matrix
         int64_t plan_stream_len = 0, plan_nnz_panel = 0;
         int plan_pad_row = 0;           // panel row holding +1.0f for the padding entries = panel capacity in rows
         int plan_dict_stride = 0;       // ints per block in d_dict (dictionaries padded to a common stride)
@@ -182,6 +183,7 @@ struct sextans_engine {
     int64_t opt_cols_per_lane = 0;      // LDS-panel kernel: output columns per lane.  4 (= 0, the default) = 16-column tiles;
                                         // 8 = register-blocked 32-column super tiles (spmm_csr_panel_v2<2>: 2 workgroups per
                                         // CU -- measured slower than 4 columns per lane at 4 workgroups per CU)
+    int64_t opt_small_v2 = 1;           // measurement switch: 0 = small matrices keep the full-capacity, 4-deep form of spmm_csr_panel_v2
     int64_t opt_panel_v2 = -1;          // 16-column tiles on the register-resident form (spmm_csr_panel_v2<1>: row entries
                                         // loaded once per block, panels by LDS-DMA, tile loop inside the workgroup, C stored
                                         // straight from the accumulators): 1 = yes, 0 = no (spmm_csr_panel), -1 = auto: yes
@@ -510,6 +512,7 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
     h->ps.plan_panel_frac = h->m_nnz ? (double)dp.nnz_in_panel_blocks / (double)h->m_nnz : 0.0;
     h->ps.plan_nnz_panel = dp.nnz_in_panel_blocks;
     h->ps.plan_max_dict = dp.max_dict;
+    h->ps.plan_max_row = dp.max_row_len;
     h->ps.plan_pad_row = cap;
     h->ps.plan_built = true;
     return SEXTANS_OK;
@@ -576,18 +579,37 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)h->ps.d_row_off,
                            h->ps.d_lidx, h->ps.d_pval, h->ps.d_blk_row, h->ps.d_dict_ptr, h->ps.d_dict, h->ps.plan_dict_stride,
                            dBp, pstride, dCin, ldc_in, dCout, ldc, nsuper, tpw, nblk, alpha, beta, (int)h->opt_xcd,
-                           h->ps.plan_pad_row, blk_begin, row_base, (const unsigned char *)h->d_skip);
+                           h->ps.plan_pad_row, blk_begin, row_base, (const unsigned char *)h->d_skip, (long long *)h->d_dbg);
         return SEXTANS_OK;
     };
     // register-resident batches (16 entries each) per row: from the mean row length of the main matrix, so that matrices
     // with short rows (1-dof stencils: 27 entries) do not fetch six batches per row
     const int64_t mean_len = h->M > 0 ? h->m_nnz / h->M : 0;
-    const int nb = mean_len + 8 <= 32 ? 2 : mean_len + 8 <= 64 ? 4 : 6;
+    int nb = mean_len + 8 <= 32 ? 2 : mean_len + 8 <= 64 ? 4 : 6;
+    {   // ... corrected by the longest row: no more batches than any row has, and one more when that makes EVERY row
+        // register-resident (nasa4704: mean 22, longest 42 -- a quarter of the wavefronts otherwise finish a row from the
+        // stream, one L2 round trip per 16 entries, and their workgroup waits for them)
+        const int nb_max = std::max(1, (h->ps.plan_max_row + 15) / 16);
+        if (nb_max <= nb) nb = nb_max <= 2 ? 2 : nb_max <= 3 ? 3 : nb_max <= 4 ? 4 : 6;
+        else if (nb == 2 && nb_max == 3) nb = 3;
+    }
     if constexpr (H > 1) {
         if (bcol_ld > 0) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, true>) : go(sx::spmm_csr_panel_v2<H, 6, false, true>);
         return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, false>) : go(sx::spmm_csr_panel_v2<H, 6, false, false>);
     } else {
+        // small matrices staged from column-major B: dictionary capacity from the plan (5 x 64 covers nasa4704's 300)
+        const bool small_dict = bcol_ld > 0 && h->ps.plan_max_dict <= 5 * 64;
+        if (h->opt_phase_timing && h->d_dbg && h->opt_exact) {   // diagnostic instantiations: the forms the dispatcher uses most
+            if (small_dict && nb == 3 && h->opt_small_v2 != 0) return go(sx::spmm_csr_panel_v2<H, 3, true, true, true, 5>);
+            if (bcol_ld > 0) return go(sx::spmm_csr_panel_v2<H, 2, true, true, true>);
+            if (nb == 6) return go(sx::spmm_csr_panel_v2<H, 6, true, false, true>);
+        }
+        if (small_dict && h->opt_small_v2 != 0) {
+            if (nb == 3) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 3, true, true, false, 5>) : go(sx::spmm_csr_panel_v2<H, 3, false, true, false, 5>);
+            return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, true, false, 5>) : go(sx::spmm_csr_panel_v2<H, 2, false, true, false, 5>);
+        }
         if (bcol_ld > 0) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, true>) : go(sx::spmm_csr_panel_v2<H, 2, false, true>);
+        if (nb == 3) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 3, true, false>) : go(sx::spmm_csr_panel_v2<H, 3, false, false>);
         if (nb == 2) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false>) : go(sx::spmm_csr_panel_v2<H, 2, false, false>);
         if (nb == 4) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 4, true, false>) : go(sx::spmm_csr_panel_v2<H, 4, false, false>);
         return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, false>) : go(sx::spmm_csr_panel_v2<H, 6, false, false>);
@@ -752,6 +774,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "cols_per_lane")) return &h->opt_cols_per_lane;
     if (!strcmp(key, "tiles_per_wg")) return &h->opt_tiles_per_wg;
     if (!strcmp(key, "panel_v2")) return &h->opt_panel_v2;
+    if (!strcmp(key, "small_v2")) return &h->opt_small_v2;
     if (!strcmp(key, "window_rows")) return &h->opt_win_rows;
     if (!strcmp(key, "window_cols")) return &h->opt_win_cols;
     if (!strcmp(key, "window_unroll")) return &h->opt_win_unroll;

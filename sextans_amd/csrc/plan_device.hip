@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void plan_blocks(const int *__restrict__ rp, c
 __global__ __launch_bounds__(256) void plan_compact(const int *__restrict__ rp, int M, int PR, const int *__restrict__ pb_row,
                                                     const int *__restrict__ pb_cnt, const int *__restrict__ part_nblk,
                                                     const int *__restrict__ part_blk_base, int nblk, int *__restrict__ blk_row,
-                                                    int *__restrict__ dict_cnt, int *stats /* max_dict, mixed */,
+                                                    int *__restrict__ dict_cnt, int *stats /* max_dict, mixed, longest row */,
                                                     unsigned long long *nnz_panel) {
     const int p = blockIdx.x;
     const int nb = part_nblk[p], base = part_blk_base[p];
@@ -152,6 +152,9 @@ __global__ __launch_bounds__(256) void plan_compact(const int *__restrict__ rp, 
         else if (n > 0) mixed = 1;
     }
     if (p == 0 && threadIdx.x == 0) blk_row[nblk] = M;
+    int mlen = 0;                                   // longest row of the part (the kernels size their register-resident batches by it)
+    for (int r = p * PR + threadIdx.x; r < min(M, (p + 1) * PR); r += 256) mlen = max(mlen, rp[r + 1] - rp[r]);
+    if (mlen) atomicMax(&stats[2], mlen);
     if (mx) atomicMax(&stats[0], mx);
     if (mixed) atomicOr(&stats[1], 1);
     if (covered) atomicAdd(nnz_panel, covered);
@@ -348,20 +351,21 @@ int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, cons
     out.nblk = (int)nblk;
     int *d_stats = nullptr;
     unsigned long long *d_cov = nullptr;
-    PD_HIP(tmp.alloc(&d_stats, 2));
+    PD_HIP(tmp.alloc(&d_stats, 3));
     PD_HIP(tmp.alloc(&d_cov, 1));
-    PD_HIP(hipMemset(d_stats, 0, 2 * sizeof(int)));
+    PD_HIP(hipMemset(d_stats, 0, 3 * sizeof(int)));
     PD_HIP(hipMemset(d_cov, 0, sizeof(unsigned long long)));
     PD_HIP(hipMalloc((void **)&out.d_blk_row, sizeof(int) * ((size_t)nblk + 1)));
     PD_HIP(hipMalloc((void **)&out.d_dict_cnt, sizeof(int) * (size_t)nblk));
     hipLaunchKernelGGL(plan_compact, dim3((unsigned)nparts), dim3(256), 0, nullptr, d_rp, M, PR, d_pb_row, d_pb_cnt, d_part_nblk,
                        d_part_blk_base, (int)nblk, out.d_blk_row, out.d_dict_cnt, d_stats, d_cov);
-    int h_stats[2] = {0, 0};
+    int h_stats[3] = {0, 0, 0};
     unsigned long long h_cov = 0;
     PD_HIP(hipMemcpy(h_stats, d_stats, sizeof h_stats, hipMemcpyDeviceToHost));
     PD_HIP(hipMemcpy(&h_cov, d_cov, sizeof h_cov, hipMemcpyDeviceToHost));
     out.max_dict = h_stats[0];
     out.mixed = h_stats[1] != 0;
+    out.max_row_len = h_stats[2];
     out.nnz_in_panel_blocks = (int64_t)h_cov;
     out.h_blk_row.resize((size_t)nblk + 1);
     PD_HIP(hipMemcpy(out.h_blk_row.data(), out.d_blk_row, sizeof(int) * ((size_t)nblk + 1), hipMemcpyDeviceToHost));

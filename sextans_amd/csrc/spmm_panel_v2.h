@@ -108,18 +108,26 @@ __device__ __forceinline__ void astore1(float *sbase, unsigned voff_bytes, float
 // waited for: [B rows of super tile st+1 requested into registers] -> row stream of st out of the LDS panel -> C of st
 // stored straight from the accumulators (a lane owns 4 consecutive columns of one row: a wavefront's store covers 16
 // consecutive rows x 4 columns = 64-byte runs, merged to full lines in L2) -> barrier -> registers -> panel -> barrier.
-template <int H, int NB, bool EXACT, bool BCOL>
+// TIMED (engine option "phase_timing"; diagnostic instantiations only): one workgroup in 16 adds its wavefront-0 cycle counts
+// per phase to dbg[0..3], a launch counter to dbg[4] and the same span in 100 MHz ticks to dbg[5].
+// DCAP: dictionary capacity of the launch in units of 64 rows (9 = the plan's maximum; the small-matrix instantiation uses the
+// plan's actual maximum, so that a block with 235 dictionary rows does not issue the loads and LDS writes of 576).
+// (8 instead of 4 B rows in flight per lane for launches that cannot fill the chip -- one wavefront per SIMD -- was measured on
+// nasa4704: row loop 2833 vs 2829 cycles, not kept.)
+template <int H, int NB, bool EXACT, bool BCOL, bool TIMED = false, int DCAP = 9>
 __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
     const int2 *__restrict__ slot_info, const unsigned short *__restrict__ p_idx16, const float *__restrict__ p_val,
     const int *__restrict__ blk_row, const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
     const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc,
     int nsuper, int tpw, int nblk, float alpha, float beta, int use_xcd_remap, int pad_row, int blk_begin, int row_base,
-    const unsigned char *__restrict__ skip) {
+    const unsigned char *__restrict__ skip, long long *dbg) {
+    long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, w0 = 0;
+    if constexpr (TIMED) { t0 = clock64(); w0 = wall_clock64(); }
     constexpr int LPR = 4;
     constexpr int RB = kBlock / LPR;          // 64 rows per workgroup
     constexpr int NTT = 16 * H;               // columns per super tile
     constexpr int BATCH = 16;
-    constexpr int MAXD = 9;                   // dictionary capacity = MAXD * RB
+    constexpr int MAXD = DCAP;                // dictionary capacity of this launch = MAXD * RB (<= 9 * RB, the plan's limit)
     constexpr int PFT = 3;                    // batches of the row in flight beyond the current one
     extern __shared__ __attribute__((aligned(16))) int smem[];
     char *lds = reinterpret_cast<char *>(smem);
@@ -150,6 +158,10 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
         }
     }
     const int len = si.y;
+    if constexpr (TIMED) {   // first round trip done: block meta, row extents, dictionary indices
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(boff[0]), "+v"(boff[MAXD - 1]) : : "memory");
+        t1 = clock64();
+    }
     // Row stream: wave-uniform base (first entry of the wave's first row) + a 32-bit lane offset, so every fetch is one
     // `global_load saddr + voffset + immediate` without 64-bit vector address arithmetic.  Slots past the block's last
     // row ({0, 0}) fetch from the base (never consumed).  The stream is padded: over-reads stay in bounds.
@@ -263,6 +275,8 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
     for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(av[b]));
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing the compiler tracks is outstanding from here on
+    if constexpr (TIMED) t2 = clock64();                // second round trip done: row entries, first panel (and C_in)
+    long long t_rows = 0;
     for (int st = st_begin; st < st_end; ++st) {
         const int64_t col0 = (int64_t)st * NTT;
         // ---- requests that fly under this super tile's row loop: its C_in, the next panel
@@ -313,6 +327,10 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
             if (cnt > 12) { wide_quad<3, H, EXACT>(ix, vx, pq, acc); pin<H>(acc); }
         }
 
+        if constexpr (TIMED) {
+            asm volatile("" : "+v"(acc[0]) : : "memory");
+            t_rows += clock64() - (st == st_begin ? t2 : t3);
+        }
         // ---- drain: C_in and the next panel have landed (and the previous super tile's stores are acknowledged)
         if constexpr (H == 2) {
             asm volatile("s_waitcnt vmcnt(0)"
@@ -340,6 +358,19 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
                 store_panel();
                 __syncthreads();
             }
+        }
+        if constexpr (TIMED) t3 = clock64();
+    }
+    if constexpr (TIMED) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last tile's C stores are acknowledged
+        const long long t4 = clock64();
+        if (dbg && tid == 0 && (blockIdx.x & 15) == 5) {
+            atomicAdd((unsigned long long *)&dbg[0], (unsigned long long)(t1 - t0));            // kernel arguments + block meta, extents, dictionary
+            atomicAdd((unsigned long long *)&dbg[1], (unsigned long long)(t2 - t1));            // row entries + first panel + barrier
+            atomicAdd((unsigned long long *)&dbg[2], (unsigned long long)t_rows);               // row loops of all tiles
+            atomicAdd((unsigned long long *)&dbg[3], (unsigned long long)(t4 - t2 - t_rows));   // drains, C stores, panel turnover
+            atomicAdd((unsigned long long *)&dbg[4], 1ull);
+            atomicAdd((unsigned long long *)&dbg[5], (unsigned long long)(wall_clock64() - w0));
         }
     }
 }

@@ -180,3 +180,45 @@ def test_panel_v2_sixteen_column_tiles(engine, oracle, fem, N):
                 assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (N, cpl, tpw)
     finally:
         _set(engine)
+
+
+def _short_row_matrix(rs, M, max_len, spread):
+    """Rows of 1 .. max_len entries with columns within +-spread of the diagonal (heavy B-row reuse inside a 64-row block)."""
+    rp = np.zeros(M + 1, dtype=np.int32)
+    cols = []
+    for r in range(M):
+        n = int(rs.randint(1, max_len + 1))
+        lo, hi = max(0, r - spread), min(M, r + spread + 1)
+        cols.append(np.sort(rs.choice(np.arange(lo, hi), size=min(n, hi - lo), replace=False)).astype(np.int32))
+        rp[r + 1] = rp[r] + len(cols[-1])
+    ci = np.concatenate(cols)
+    return rp, ci, rs.uniform(-1, 1, len(ci)).astype(np.float32)
+
+
+@pytest.mark.parametrize("max_len,spread", [(20, 60), (42, 60), (48, 40), (60, 200), (100, 100)])
+def test_small_matrix_forms_of_panel_v2(engine, oracle, max_len, spread):
+    """Small matrices with short rows staged from column-major B (fuse_b): the register-resident batches follow the LONGEST row
+    (2, 3, 4 or 6 batches: every row register-resident when that costs at most one more batch), and the dictionary capacity of
+    the launch follows the plan (5 x 64 rows when no block needs more; the full 9 x 64 otherwise).  small_v2 = 0 keeps the
+    full-capacity form; both, and the rp_time loop (panels repacked once, LDS-DMA form), give the oracle's bits."""
+    M = K = 1500
+    rs = np.random.RandomState(max_len * 7 + spread)
+    rp, ci, v = _short_row_matrix(rs, M, max_len, spread)
+    for N in (16, 32):
+        B = rs.uniform(-1, 1, K * N).astype(np.float32)
+        C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+        want = C0.copy()
+        oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+        try:
+            for small in (1, 0):
+                _set(engine, fuse_b=1, panel_v2=-1)
+                engine.set_option("small_v2", small)
+                engine.set_matrix_csr(M, K, rp, ci, v)
+                for rp_time in (1, 5):
+                    out = C0.copy()
+                    engine.spmm(N, ALPHA, B, BETA, out, rp_time=rp_time)
+                    assert engine.last_kernel().startswith("spmm_csr_panel"), engine.last_kernel()
+                    assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (N, small, rp_time, engine.last_kernel())
+        finally:
+            engine.set_option("small_v2", 1)
+            _set(engine)

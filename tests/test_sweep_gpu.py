@@ -38,7 +38,7 @@ def test_sweep_all_fixtures(sx, oracle):
         if r["matrix"] != "number_formats":        # that fixture holds inf: NaN compare as mismatches
             assert r["passed"] and r["mismatch"] == 0 and r["bit_identical"], r
     nasa = [r for r in recs if r["matrix"] == "nasa4704" and r["N"] == 16][0]
-    assert nasa["nnz"] == 104756 and nasa["kernel"] == "spmm_csr_panel"
+    assert nasa["nnz"] == 104756 and nasa["kernel"].startswith("spmm_csr_panel")
 
 
 def test_sweep_synthetic_classes(sx):

@@ -142,7 +142,7 @@ def test_auto_dispatch_rules(engine, sx):
     engine.set_matrix_csr(M, K, rp, ci, v)
     C = sx.init_dense_C(M, 16)
     engine.spmm(16, ALPHA, sx.init_dense_B(K, 16), BETA, C)
-    assert engine.last_kernel() == "spmm_csr_panel"
+    assert engine.last_kernel().startswith("spmm_csr_panel")
     rs = np.random.RandomState(5)
     rp, ci, v = random_csr(rs, 3000, 2000, 10)
     engine.set_matrix_csr(3000, 2000, rp, ci, v)
