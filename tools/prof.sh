@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -o stats -
 find /tmp/rp_stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum"; do
   N=$(echo $C | tr ' ' '_')
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/rp_$N -o pmc -- $CMD > $OUT/pmc_$N.log 2>&1
+  timeout -k 10 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/rp_$N -o pmc -- $CMD > $OUT/pmc_$N.log 2>&1
   F=$(find /tmp/rp_$N -name "*counter_collection.csv" | head -1)
   if [ -n "$F" ]; then python $REPO/tools/pmc_summary.py $F > $OUT/pmc_$N.txt 2>&1; fi
 done
