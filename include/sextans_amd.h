@@ -250,7 +250,9 @@ int sextans_destroy(sextans_handle_t h);
  * it from an exchanged sum; 0 = this engine's matrix is the whole matrix),
  * "fuse_b" (1 = the panel kernel may stage B straight from column-major B when B is <= 16 MiB and every row block has a dictionary, saving the
  * repack launch; default 1), "panel_min_reuse_x100" (a row block uses the LDS panel when
- * nnz >= value/100 * distinct columns; default 200), "panel_v2" (-1 auto / 0 / 1: the register-resident form of the panel
+ * nnz >= value/100 * distinct columns; default 200; decides for N <= 16) and "panel_min_reuse_wide_x100" (the same for
+ * N >= 32, default 150: with more columns per B row the panel pays earlier; the packed plan is built once, for the lower
+ * of the two), "panel_v2" (-1 auto / 0 / 1: the register-resident form of the panel
  * kernel, spmm_csr_panel_v2), "tiles_per_wg" (N tiles one workgroup of that kernel walks; 0 = auto),
  * "cols_per_lane" (0/4 = 16-column tiles at 4 workgroups per CU, the default; 8 = 32-column super tiles at 2 per CU),
  * "bell_shared" (blocked-ELL, N = 256: -1 = use the union-walk kernel spmm_bell_mfma_shared when 8 consecutive block rows

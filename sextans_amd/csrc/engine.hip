@@ -88,6 +88,7 @@ struct sextans_engine {
         std::vector<int> h_blk_row;     // host copy of the plan's block boundaries (row-range calls, sextans_align_row)
         unsigned short *d_lidx = nullptr;
         double plan_panel_frac = 0.0;   // share of non-zeros living in dictionary blocks
+        double plan_narrow_frac = 0.0;  // sampled share of non-zeros in row blocks that meet the N <= 16 threshold ("panel_min_reuse_x100")
         int plan_max_dict = 0;          // largest block dictionary (entries)
         int plan_max_row = 0;           // longest row of the planned matrix
         int64_t plan_stream_len = 0, plan_nnz_panel = 0;
@@ -204,6 +205,9 @@ struct sextans_engine {
     int64_t opt_phase_timing = 0;       // 1: panel kernel accumulates per-phase wave cycles (debug aid)
     int64_t opt_min_reuse_x100 = 200;   // a block uses the LDS panel if nnz >= 2 * distinct columns (measured: a 1-dof 3-D
                                         // stencil, reuse 2.9, runs 18 % faster on the panel kernel; FEM/banded classes unchanged)
+    int64_t opt_min_reuse_wide_x100 = 150;   // the same threshold for N >= 32: with more columns per B row read the panel pays
+                                        // earlier (2-D 5-point stencil, reuse 1.65: N = 128 2.28 ms vs 2.60 ms on the gather kernel,
+                                        // N = 16 0.370 vs 0.350 ms)
     int64_t opt_win_rows = 319;         // rows per wavefront of the window kernel (+1 dummy row: 4 x 320 x 32 B = 40 KiB)
     int64_t opt_win_cols = 65536;       // columns per K window (x 32 B = 2 MiB of the 8-column panel: half an XCD's L2)
     int64_t opt_win_unroll = 8;         // steps in flight per ring (4 or 8)
@@ -421,12 +425,14 @@ int read_back_entries(sextans_engine *h, std::vector<int> &ci, std::vector<float
 // Cheap pre-test on a sample of row blocks: share of sampled non-zeros that sit in blocks with
 // nnz >= min_reuse * distinct columns.  Lets "auto" skip the full plan build on matrices without
 // reuse (e.g. uniformly random columns).
-int sample_reuse(sextans_engine *h, int RB, int max_unique, double min_reuse, double *frac) {
+int64_t plan_key(const sextans_engine *h) { return h->opt_min_reuse_x100 * 100000 + h->opt_min_reuse_wide_x100; }
+
+int sample_reuse(sextans_engine *h, int RB, int max_unique, double min_reuse, double min_reuse2, double *frac, double *frac2) {
     const int nblk = (h->M + RB - 1) / RB;
     const int nsample = std::min(nblk, 512);
     std::vector<int> rp;
     if (int rc = read_back_row_ptr(h, rp)) return rc;
-    int64_t tot = 0, good = 0;
+    int64_t tot = 0, good = 0, good2 = 0;
     std::vector<int> cols;
     for (int sidx = 0; sidx < nsample; ++sidx) {
         const int b = (int)((int64_t)sidx * nblk / nsample);
@@ -440,9 +446,11 @@ int sample_reuse(sextans_engine *h, int RB, int max_unique, double min_reuse, do
         tot += j1 - j0;
         // a block larger than the panel is split by the real builder; its reuse ratio carries over
         if ((double)(j1 - j0) >= min_reuse * (double)distinct) good += j1 - j0;
+        if ((double)(j1 - j0) >= min_reuse2 * (double)distinct) good2 += j1 - j0;
         (void)max_unique;
     }
     *frac = tot ? (double)good / (double)tot : 0.0;
+    *frac2 = tot ? (double)good2 / (double)tot : 0.0;
     return SEXTANS_OK;
 }
 
@@ -451,7 +459,7 @@ int sample_reuse(sextans_engine *h, int RB, int max_unique, double min_reuse, do
 // per matrix ("upload once"), outside any timed region, like the reference's host-side scheduling
 // and packing (generate_edge_list_for_all_PEs + edge_list_64bit, sextans-host.cpp:114-148).
 int ensure_plan(sextans_engine *h, int lpr, bool force) {
-    if (h->ps.plan_lpr == lpr && h->ps.plan_min_reuse == h->opt_min_reuse_x100 && (h->ps.plan_built || !force))
+    if (h->ps.plan_lpr == lpr && h->ps.plan_min_reuse == plan_key(h) && (h->ps.plan_built || !force))
         return SEXTANS_OK;
     if (h->ps.plan_lpr != lpr) {   // park the active form, bring back the one for this lane count (if any)
         auto idx = [](int l) { return l == 2 ? 0 : l == 4 ? 1 : 2; };
@@ -461,7 +469,7 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
             std::swap(h->ps, h->plan_stash[idx(h->ps.plan_lpr)]);
             free_panel_state(h->ps);
         }
-        if (h->ps.plan_lpr == lpr && h->ps.plan_min_reuse == h->opt_min_reuse_x100 && (h->ps.plan_built || !force))
+        if (h->ps.plan_lpr == lpr && h->ps.plan_min_reuse == plan_key(h) && (h->ps.plan_built || !force))
             return SEXTANS_OK;
     }
     free_panel_state(h->ps);
@@ -476,14 +484,19 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
         h->device_matrix_checked = true;
     }
     const int RB = sx::kBlock / lpr;
-    const double min_reuse = (double)h->opt_min_reuse_x100 / 100.0;
+    // two thresholds: "panel_min_reuse_x100" decides for N <= 16, "panel_min_reuse_wide_x100" for N >= 32 (prepare()); the plan
+    // is built once, for the lower of the two, so that alternating N never rebuilds it
+    const double narrow = (double)h->opt_min_reuse_x100 / 100.0;
+    const double min_reuse = std::min(narrow, (double)h->opt_min_reuse_wide_x100 / 100.0);
+    double narrow_frac = 1.0;
     if (!force) {
         double frac = 0.0;
-        if (int rc = sample_reuse(h, RB, kPanelFloats / (4 * lpr), min_reuse, &frac)) return rc;
+        if (int rc = sample_reuse(h, RB, kPanelFloats / (4 * lpr), min_reuse, narrow, &frac, &narrow_frac)) return rc;
         if (frac < 0.5) {   // no reuse worth an LDS panel: remember the verdict, skip the build
             h->ps.plan_lpr = lpr;
-            h->ps.plan_min_reuse = h->opt_min_reuse_x100;
+            h->ps.plan_min_reuse = plan_key(h);
             h->ps.plan_panel_frac = frac * 0.999;
+            h->ps.plan_narrow_frac = narrow_frac * 0.999;
             h->ps.plan_built = false;
             return SEXTANS_OK;
         }
@@ -495,7 +508,8 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
     const int brc = sx::build_panel_plan_device(h->M, h->K, h->m_rp, h->m_ci, h->m_v, lpr, cap, min_reuse, dp, err);
     if (brc == 2) { g_last_error = err; sx::free_device_plan(dp); return SEXTANS_ERR_HIP; }
     h->ps.plan_lpr = lpr;
-    h->ps.plan_min_reuse = h->opt_min_reuse_x100;
+    h->ps.plan_min_reuse = plan_key(h);
+    h->ps.plan_narrow_frac = narrow_frac;
     if (brc == 1) {   // rows padded to 4 entries exceed 32-bit entry offsets: row-group kernel only
         h->ps.plan_panel_frac = 0.0;
         h->ps.plan_built = false;
@@ -765,6 +779,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "exact")) return &h->opt_exact;
     if (!strcmp(key, "profile")) return &h->opt_profile;
     if (!strcmp(key, "panel_min_reuse_x100")) return &h->opt_min_reuse_x100;
+    if (!strcmp(key, "panel_min_reuse_wide_x100")) return &h->opt_min_reuse_wide_x100;
     if (!strcmp(key, "phase_timing")) return &h->opt_phase_timing;
     if (!strcmp(key, "split_rows")) return &h->opt_split_rows;
     if (!strcmp(key, "bucket_rows")) return &h->opt_bucket_rows;
@@ -1247,7 +1262,7 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
     use_panel = false;
     if (h->opt_kernel != 1 && h->m_nnz > 0) {
         if (int rc = ensure_plan(h, lpr, h->opt_kernel == 2)) return rc;
-        use_panel = h->ps.plan_built && ((h->opt_kernel == 2) || h->ps.plan_panel_frac >= 0.5);
+        use_panel = h->ps.plan_built && ((h->opt_kernel == 2) || (h->ps.plan_panel_frac >= 0.5 && (N >= 32 || h->ps.plan_narrow_frac >= 0.5)));
     }
     if (!h->opt_lpr && !use_panel && N >= 32 && lpr != 8) { lpr = 8; tiles(); }
     // "kernel" 3 = K-windowed accumulator-resident kernel; auto picks it for matrices without B-row reuse

@@ -222,3 +222,40 @@ def test_small_matrix_forms_of_panel_v2(engine, oracle, max_len, spread):
         finally:
             engine.set_option("small_v2", 1)
             _set(engine)
+
+
+def test_panel_threshold_depends_on_n(engine, oracle, sx):
+    """A 2-D 5-point stencil has 1.65 non-zeros per distinct column in a 64-row block: below the N <= 16 threshold (2.0, gather
+    kernel), above the N >= 32 one (1.5, LDS panel; measured +14 % at N = 128).  One plan serves both (built for the lower
+    threshold), so alternating N does not rebuild anything; both kernels give the oracle's bits."""
+    from sextans_amd import api
+    nx = ny = 150
+    M = K = nx * ny
+    rp, ci, v = api.gen_stencil2d_host(nx, ny, 5, 1, 3)
+    for k, val in dict(lanes_per_row=0, kernel=0, panel_min_reuse_x100=200, panel_min_reuse_wide_x100=150, fuse_b=0, panel_v2=-1,
+                       cols_per_lane=0, tiles_per_wg=0, split_rows=0, bucket_rows=-1).items():
+        engine.set_option(k, val)
+    engine.set_matrix_csr(M, K, rp, ci, v)
+    rs = np.random.RandomState(11)
+    built = None
+    try:
+        for N, kern in ((16, "spmm_csr_rowgroup"), (32, "spmm_csr_panel_v2"), (16, "spmm_csr_rowgroup"), (64, "spmm_csr_panel_v2")):
+            B = rs.uniform(-1, 1, K * N).astype(np.float32)
+            C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+            want = C0.copy()
+            oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+            out = C0.copy()
+            engine.spmm(N, ALPHA, B, BETA, out)
+            assert engine.last_kernel() == kern, (N, engine.last_kernel())
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), N
+            if built is None:
+                built = engine.get_stat("plan_build_s")
+            assert engine.get_stat("plan_build_s") == built          # one plan, never rebuilt
+        engine.set_option("panel_min_reuse_wide_x100", 200)          # same threshold for every N: gather kernel at N = 32 too
+        out = C0.copy()
+        engine.spmm(64, ALPHA, B, BETA, out)
+        assert engine.last_kernel() == "spmm_csr_rowgroup"
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    finally:
+        engine.set_option("panel_min_reuse_wide_x100", 150)
+        _set(engine)

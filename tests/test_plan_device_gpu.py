@@ -61,6 +61,7 @@ def test_device_plan_is_byte_identical_to_the_host_builder(engine, sx, lanes, mi
         for what, (rp, ci, v, K) in _cases():
             M = len(rp) - 1
             engine.set_option("panel_min_reuse_x100", min_reuse)
+            engine.set_option("panel_min_reuse_wide_x100", min_reuse)   # (the plan is built for the lower of the two thresholds)
             engine.set_matrix_csr(M, K, rp, ci, v)
             dev = engine.export_plan(lanes)
             host = api.pack_csr(M, K, rp, ci, v, lanes, min_reuse)
@@ -69,7 +70,7 @@ def test_device_plan_is_byte_identical_to_the_host_builder(engine, sx, lanes, mi
         engine.set_matrix_csr(M, K, rp, ci, v)
         _same(engine.export_plan(lanes), api.pack_csr(M, K, rp, ci, v, lanes, min_reuse), ("nasa4704", lanes, min_reuse))
     finally:
-        for k, v in dict(kernel=0, bucket_rows=-1, exact_chain=1, panel_min_reuse_x100=200).items():
+        for k, v in dict(kernel=0, bucket_rows=-1, exact_chain=1, panel_min_reuse_x100=200, panel_min_reuse_wide_x100=150).items():
             engine.set_option(k, v)
 
 
@@ -91,7 +92,7 @@ def test_device_plan_of_a_device_resident_matrix_and_its_build_time(sx):
             built = e.get_stat("plan_build_s")
         hrp, hci, hv = api.gen_fem3d_host(*dims, 3)
         t0 = time.perf_counter()
-        host = api.pack_csr(M, K, hrp, hci, hv, 4, 200)
+        host = api.pack_csr(M, K, hrp, hci, hv, 4, 150)   # the engine's default: min(panel_min_reuse_x100, .._wide_x100)
         t_host = time.perf_counter() - t0
         print(f"device plan build {built * 1e3:.1f} ms (export incl. read-back {t_total:.2f} s); host builder {t_host:.2f} s; "
               f"{nnz} nnz, {dev['nblk']} blocks")
