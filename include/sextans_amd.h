@@ -243,9 +243,9 @@ int sextans_destroy(sextans_handle_t h);
  * nothing in parity), "split_rows" = 0 -- EVERY row is summed in strict CSR order and the result is bit-identical to
  * cpu_spmm_CSR unless the caller opts into re-association with "split_rows" = -1 or > 0 (power-law inputs with rows of
  * 10^5 entries may want that).  "exact_chain" (default 1): in strict-order mode a row longer than max(1024, nnz/16384)
- * is summed by the exact-chain kernels -- all rounded products formed in parallel, then ONE serial chain of rounded adds
- * per output column, bit-identical to cpu_spmm_CSR; 0 = such rows stay on the piece kernel (the same bits,
- * ~40x slower for a 400 000-entry row).  Matrices without long rows take none of this path.  "global_nnz": non-zeros of the WHOLE matrix when this engine holds a row range of it (multi-GPU);
+ * is summed by the exact-chain kernel -- producer wavefronts form all rounded products of the row, ONE serial chain of
+ * rounded adds per output column consumes them, bit-identical to cpu_spmm_CSR; 0 = such rows stay on the piece
+ * kernel (the same bits, ~20x slower for a 400 000-entry row).  Matrices without long rows take none of this path.  "global_nnz": non-zeros of the WHOLE matrix when this engine holds a row range of it (multi-GPU);
  * the automatic T is derived from it so that every rank cuts hub rows exactly as one GPU would; sextans_dist_spmm sets
  * it from an exchanged sum; 0 = this engine's matrix is the whole matrix),
  * "fuse_b" (1 = the panel kernel may stage B straight from column-major B when B is <= 16 MiB and every row block has a dictionary, saving the

@@ -151,14 +151,12 @@ struct sextans_engine {
     };
     PieceTable by_len, by_row;                // sorted by length (whole-matrix calls: balanced workgroups) / by row (row ranges)
     // exact chains (strict order, "exact_chain" = 1): rows longer than the automatic threshold leave the piece tables too
-    // and are summed by chain_products + chain_sum -- still one serial chain of rounded adds, bit-identical
+    // and are summed by chain_fused -- still one serial chain of rounded adds per (row, column), bit-identical
     int nchain = 0;
     int *d_chain_row = nullptr, *d_chain_beg = nullptr;
-    long long *d_chain_off = nullptr, *d_chain_offc = nullptr;   // prefix of the lengths / of the lengths padded to 64-entry chunks
+    long long *d_chain_off = nullptr;                   // prefix of the lengths
     std::vector<int> h_chain_row;
-    std::vector<long long> h_chain_off, h_chain_offc;
-    float *d_Pc = nullptr;
-    size_t Pc_cap = 0;
+    std::vector<long long> h_chain_off;
     int64_t chain_T = 0;
     int64_t chain_built_opt = -2;
     hipStream_t aux_stream = nullptr;         // the chain kernels need one or two wavefronts for ~1 ms: they run beside the main kernel
@@ -276,9 +274,9 @@ void free_split(sextans_engine *h) {   // long-row state: main matrix, skip flag
         (void)hipFree(t->d_vrp); (void)hipFree(t->d_vend); (void)hipFree(t->d_vfirst); (void)hipFree(t->d_row);
         *t = sextans_engine::PieceTable();
     }
-    (void)hipFree(h->d_chain_row); (void)hipFree(h->d_chain_beg); (void)hipFree(h->d_chain_off); (void)hipFree(h->d_chain_offc);
-    h->d_chain_row = h->d_chain_beg = nullptr; h->d_chain_off = h->d_chain_offc = nullptr;
-    h->nchain = 0; h->h_chain_row.clear(); h->h_chain_off.clear(); h->h_chain_offc.clear(); h->chain_T = 0; h->chain_built_opt = -2;
+    (void)hipFree(h->d_chain_row); (void)hipFree(h->d_chain_beg); (void)hipFree(h->d_chain_off);
+    h->d_chain_row = h->d_chain_beg = nullptr; h->d_chain_off = nullptr;
+    h->nchain = 0; h->h_chain_row.clear(); h->h_chain_off.clear(); h->chain_T = 0; h->chain_built_opt = -2;
     (void)hipFree(h->d_mrp); (void)hipFree(h->d_mci); (void)hipFree(h->d_mv); (void)hipFree(h->d_skip);
     h->d_mrp = h->d_mci = nullptr;
     h->d_mv = nullptr;
@@ -757,7 +755,6 @@ int sextans_destroy(sextans_handle_t h) {
     (void)hipFree(h->d_Bp); (void)hipFree(h->d_B); (void)hipFree(h->d_Cin); (void)hipFree(h->d_Cout);
     sextans_profile_reset(h);
     (void)hipFree(h->d_P);
-    (void)hipFree(h->d_Pc);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
@@ -912,12 +909,6 @@ struct Seg { int width, col0, ntiles; };
 //     parallel and folded in order (re-associated).  Measured on a 1M-row power-law matrix (33 M nnz, longest row
 //     399 302): T = 512 / 1024 / 2021 -> 0.81 / 0.74 / 0.77 ms with 4964 / 2190 / 978 rows re-associated (uniform
 //     matrix of the same size: 0.64 ms), so the larger threshold costs nothing and touches fewer rows.
-// Scratch rows (entries) one group of chain rows may hold: at least the longest chain row, at most 2 GiB of products.
-int64_t chain_group_cap(const sextans_engine *h, int N) {
-    int64_t longest = 0;
-    for (int k = 0; k < h->nchain; ++k) longest = std::max<int64_t>(longest, h->h_chain_offc[(size_t)k + 1] - h->h_chain_offc[(size_t)k]);
-    return std::max<int64_t>(longest, ((int64_t)1 << 29) / N);
-}
 
 int ensure_split(sextans_engine *h) {
     if (h->split_built_opt == h->opt_split_rows && h->bucket_built_opt == h->opt_bucket_rows &&
@@ -965,20 +956,17 @@ int ensure_split(sextans_engine *h) {
     for (int r : rows) ((int64_t)rp[(size_t)r + 1] - rp[(size_t)r] > Tc ? chain_rows : piece_rows).push_back(r);
     if (!chain_rows.empty()) {
         std::vector<int> beg;
-        std::vector<long long> off(1, 0), offc(1, 0);
+        std::vector<long long> off(1, 0);
         for (int r : chain_rows) {
             const long long len = rp[(size_t)r + 1] - rp[(size_t)r];
             beg.push_back(rp[(size_t)r]);
             off.push_back(off.back() + len);
-            offc.push_back(offc.back() + (len + sx::kChainCE - 1) / sx::kChainCE * sx::kChainCE);
         }
         if (int rc = upload(&h->d_chain_row, chain_rows)) return rc;
         if (int rc = upload(&h->d_chain_beg, beg)) return rc;
         if (int rc = upload(&h->d_chain_off, off)) return rc;
-        if (int rc = upload(&h->d_chain_offc, offc)) return rc;
         h->h_chain_row = chain_rows;
         h->h_chain_off = off;
-        h->h_chain_offc = offc;
         h->nchain = (int)chain_rows.size();
         h->chain_T = Tc;
     }
@@ -1227,8 +1215,6 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
     if (h->nhub > 0)
         if (int rc = ensure(&h->d_P, &h->P_cap, (size_t)h->split_nv * (size_t)N)) return rc;
     if (h->nchain > 0) {
-        const int64_t rows = std::min<int64_t>(h->h_chain_offc.back(), chain_group_cap(h, N));
-        if (int rc = ensure(&h->d_Pc, &h->Pc_cap, (size_t)rows * (size_t)N)) return rc;
         if (!h->aux_stream) {
             SX_HIP(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
             SX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -1320,43 +1306,31 @@ const char *kernel_name(int main, bool hubs, bool dense) {   // static strings f
     return names[main][hubs ? 1 : 0][dense ? 1 : 0];
 }
 
-// Exact chains of the chain rows [c0, c1) (see chain_products / chain_sum): products of a group of rows into the scratch
-// matrix from the repacked B panels (segment by segment, like the piece kernel), then one lane per (row, column) sums
-// them in order and applies the epilogue.
+// Exact chains of the chain rows [c0, c1) (chain_fused, spmm_csr_kernels.h): products from the repacked B panels (segment by
+// segment, like the piece kernel) and the serial sum of every (row, column) in one workgroup, epilogue included.
 void launch_chains(sextans_engine *h, const std::vector<Seg> &plan, const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc,
                    int N, int c0, int c1, int row_base, float alpha, float beta, hipStream_t s) {
-    const int64_t G = chain_group_cap(h, N);
-    for (int k = c0; k < c1;) {
-        int ke = k + 1;
-        while (ke < c1 && h->h_chain_offc[(size_t)ke + 1] - h->h_chain_offc[(size_t)k] <= G) ++ke;
-        const int64_t entries = h->h_chain_off[(size_t)ke] - h->h_chain_off[(size_t)k];
+    // one workgroup per (chain row, 16- or 8-column tile): chain_fused
+    {
         for (const Seg &g : plan) {
             const float *bp = h->d_Bp + (size_t)h->K * (size_t)g.col0;
-#define SX_CHAIN(L)                                                                                                    \
-    hipLaunchKernelGGL((sx::chain_products<L>), dim3((unsigned)((entries + 256 / L - 1) / (256 / L)) * (unsigned)g.ntiles),   \
-                       dim3(sx::kBlock), 0, s, h->d_chain_beg, h->d_chain_off, h->d_chain_offc, h->s_ci, h->s_v, bp,             \
-                       (int64_t)h->K * 4 * L, h->d_Pc, N, g.col0, g.ntiles, k, ke)
-            switch (g.width) {
-                case 32: SX_CHAIN(8); break;
-                case 16: SX_CHAIN(4); break;
-                default: SX_CHAIN(2); break;
-            }
-#undef SX_CHAIN
+            const int NT = g.width >= 16 ? 16 : 8;
+            const int ntiles = g.ntiles * (g.width / NT);
+            auto go = [&](auto kern, int lds, int threads) {
+                static bool attr_set = false;
+                if (!attr_set) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL(kern, dim3((unsigned)(c1 - c0) * (unsigned)ntiles), dim3((unsigned)threads), (size_t)lds, s, h->d_chain_row,
+                                   h->d_chain_beg, h->d_chain_off, h->s_ci, h->s_v, bp, (int64_t)h->K * g.width, g.width, dCin, ldc_in, dCout,
+                                   ldc, g.col0, ntiles, c0, row_base, alpha, beta);
+            };
+#define SX_FUSED(W) if (h->opt_exact) go(sx::chain_fused<W, true>, sx::chain_fused_lds_bytes(W), sx::chain_fused_threads(W)); \
+                    else go(sx::chain_fused<W, false>, sx::chain_fused_lds_bytes(W), sx::chain_fused_threads(W))
+            if (NT == 16) { SX_FUSED(16); } else { SX_FUSED(8); }
+#undef SX_FUSED
         }
-        // one workgroup per (chain row, block of NB columns); NB = the largest of 32 / 16 / 8 dividing N
-        const int NB = N % 32 == 0 ? 32 : N % 16 == 0 ? 16 : 8;
-        auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)(ke - k) * (unsigned)(N / NB)), dim3(sx::kBlock), 0, s, h->d_chain_row, h->d_chain_off,
-                               h->d_chain_offc, h->d_Pc, N, dCin, ldc_in, dCout, ldc, k, row_base, alpha, beta);
-        };
-#define SX_SUM(NBV) if (h->opt_exact) go(sx::chain_sum<NBV, true>); else go(sx::chain_sum<NBV, false>)
-        switch (NB) {
-            case 32: SX_SUM(32); break;
-            case 16: SX_SUM(16); break;
-            default: SX_SUM(8); break;
-        }
-#undef SX_SUM
-        k = ke;
     }
 }
 

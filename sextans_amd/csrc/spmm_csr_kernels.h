@@ -618,143 +618,209 @@ __global__ __launch_bounds__(kBlock) void fold_hub_pieces(const int *__restrict_
 // Exact chains for VERY long rows (hub rows of power-law matrices, border rows of arrow / KKT systems) in strict-order mode.
 // The reference's sum of a row is one serial chain of rounded adds (cpu_spmm_CSR, sparse_helper.h:279-289; the PEs
 // accumulate one entry at a time too, sextans.cpp:425-446): bit-identical results allow no re-association, so a 400 000-entry
-// row cannot be summed in parallel pieces.  What CAN be parallel is everything except the adds: chain_products forms all
-// rounded products a_j * B[col_j][n] of the row at full memory-level parallelism (every entry independent) into a scratch
-// matrix P; chain_sum then walks that matrix with one lane per output column: a dependent add every few cycles, the
-// products streamed through an LDS ring several chunks ahead (a first version with plain strided loads, 16 in flight per
-// lane, was bound by memory latency: 30 ns per entry).  400 000 entries x a few ns instead of ~32 ms through the piece
-// kernel, whose serial chain also contains the B-row gathers (~80 ns per entry).
+// row cannot be summed in parallel pieces.  What CAN be parallel is everything except the adds: all rounded products
+// a_j * B[col_j][n] of the row are formed at full memory-level parallelism (every entry independent) and only the adds walk the
+// row in order, one lane per output column: 400 000 entries x ~0.2 ns instead of ~32 ms through the piece kernel, whose serial
+// chain also contains the B-row gathers (~80 ns per entry).  Round 3 first did this in two launches through a scratch matrix
+// (chain_products + chain_sum: 2.66 ms on the power-law case); chain_fused below does it in one workgroup per row and N tile.
+constexpr int kChainCE = 64;   // entries per chunk
+
 // ------------------------------------------------------------------------------------------------
-// Scratch layout: chain row k owns ceil(len_k / 64) CHUNKS of 64 entries (coffc = prefix of the padded lengths); a chunk
-// is stored column-major, [N][64] floats, so that (1) the 64 x NB block a summing workgroup needs is one contiguous
-// NB * 256-byte run that LDS-DMA copies without touching registers, and (2) the lane that owns column n reads four
-// consecutive entries of its chain with one ds_read_b128.
-constexpr int kChainCE = 64;
-
-template <int LPR>
-__global__ __launch_bounds__(kBlock) void chain_products(const int *__restrict__ cbeg, const long long *__restrict__ coff,
-                                                         const long long *__restrict__ coffc, const int *__restrict__ col_idx,
-                                                         const float *__restrict__ val, const float *__restrict__ Bp,
-                                                         int64_t panel_stride, float *__restrict__ P, int N, int col0, int ntiles,
-                                                         int k0, int k1) {
-    // chain rows [k0, k1): entries cbeg[k] .. of the CSR arrays; flat entry index e over all of them
-    constexpr int NT = 4 * LPR;
-    constexpr int EB = kBlock / LPR;                       // entries per workgroup
-    const int tile = (int)(blockIdx.x % (unsigned)ntiles);
-    const long long e = (long long)(blockIdx.x / (unsigned)ntiles) * EB + threadIdx.x / LPR;
-    const int q = threadIdx.x % LPR;
-    const long long base = coff[k0], total = coff[k1] - base;
-    // chain row holding the workgroup's FIRST entry: one binary search per workgroup (a search per thread -- ten
-    // dependent loads each -- was most of this kernel's time); the other entries walk forward from there
-    __shared__ int s_row0;
-    if (threadIdx.x == 0) {
-        const long long e0 = (long long)(blockIdx.x / (unsigned)ntiles) * EB;
-        int lo0 = k0, hi0 = k1 - 1;
-        while (lo0 < hi0) { const int mid = (lo0 + hi0 + 1) >> 1; if (coff[mid] - base <= e0) lo0 = mid; else hi0 = mid - 1; }
-        s_row0 = lo0;
-    }
-    __syncthreads();
-    if (e >= total) return;
-    int lo = s_row0;
-    while (lo + 1 < k1 && coff[lo + 1] - base <= e) ++lo;
-    const long long er = e - (coff[lo] - base);            // entry inside the row
-    const int j = cbeg[lo] + (int)er;
-    const float a = val[j];
-    const float4 b = *reinterpret_cast<const float4 *>(Bp + (int64_t)tile * panel_stride + (int64_t)col_idx[j] * NT + 4 * q);
-    // chunk-major, column-major inside the chunk
-    float *dst = P + ((coffc[lo] - coffc[k0]) + (er / kChainCE) * kChainCE) * N + (int64_t)(col0 + tile * NT + 4 * q) * kChainCE +
-                 (er % kChainCE);
-    dst[0] = a * b.x;                                      // rounded products (-ffp-contract=off)
-    dst[kChainCE] = a * b.y;
-    dst[2 * kChainCE] = a * b.z;
-    dst[3 * kChainCE] = a * b.w;
+// chain_fused<NT, EXACT>: the exact chain of one very long row x one N tile (NT = 16 / 8 columns) in ONE workgroup, without the
+// scratch matrix: wavefront 0 CONSUMES -- lane n adds the rounded products of column n in order (ds_read_b128 = 4 entries, 4
+// dependent adds; the one part of the row that has to be serial: 4.5 cycles per entry, tools/valu_bench.hip) -- and the other
+// wavefronts PRODUCE them, 64 entries (one chunk) at a time, into an LDS ring.  chain_products + chain_sum above did the same
+// in two launches through global memory (the product pass sat in front of the longest row's chain).
+// No workgroup barrier in the steady state: a first fused version stepped all wavefronts through one barrier per chunk, and the
+// barrier + per-step bookkeeping cost the consumer as much as its 64 adds (700 cycles per chunk, 2.07 ms for a 399 302-entry row;
+// tools/chain_bench.hip: 16 reads + 64 dependent adds alone are 440 cycles; this kernel: 520).  Here every producer wavefront is a pipeline of its own:
+//   * two groups of GW producer wavefronts take turns, even chunks / odd chunks; inside a chunk a wavefront owns 64 / GW entries
+//     (all N-tile columns of them: one task = one entry x 4 columns per lane);
+//   * its val / col entries, its B rows and its requests are private (own LDS rings, own vmcnt): stage 1 requests val + col of
+//     chunk m + 2D (one dword LDS-DMA, addresses clamped to the row's last entry), stage 2 reads col and requests the B rows of
+//     chunk m + D (16-byte LDS-DMA), stage 3 multiplies chunk m into the shared product ring and publishes "m + 1 chunks done";
+//   * the consumer reads the eight progress words when it runs out of known-complete chunks and publishes how many chunks it has
+//     taken into registers; a producer looks at that word before it overwrites a ring slot.  (LDS operations of a wavefront are
+//     executed in order: data before flag on the writing side, flag before data on the reading side.)
+// ------------------------------------------------------------------------------------------------
+constexpr int kChainD = 7;                                  // producer steps between a request and its use (a step = two chunks of
+                                                            // consumer time, ~0.35 us; a random B-row gather ~2.5 us under load)
+constexpr int kChainNVC = 16, kChainNBR = 8, kChainNPR = 8; // per-wavefront val/col ring and B-row ring, shared product ring (chunks)
+constexpr int chain_fused_group_waves(int NT) { return NT >= 16 ? 4 : 2; }      // = tasks per chunk / 64
+constexpr int chain_fused_threads(int NT) { return 64 * (1 + 2 * chain_fused_group_waves(NT)); }
+constexpr int chain_fused_lds_bytes(int NT) {
+    return 2 * chain_fused_group_waves(NT) * (kChainNVC * 256 + kChainNBR * 1024) + kChainNPR * NT * (kChainCE + 4) * 4 + 64;
 }
+static_assert(kChainNVC >= 2 * kChainD + 1 && kChainNBR >= kChainD + 1 && kChainNPR >= 4, "ring sizes");
 
-// One workgroup = one chain row x NB output columns (NB = 32, 16 or 8).  All four wavefronts stream the row's chunks into
-// an LDS ring with LDS-DMA, requested kChainDepth chunks ahead (hand-counted vmcnt: inline-asm requests, one per
-// wavefront and chunk); the first NB lanes add the products of their column in order: ds_read_b128 = 4 entries, 4 adds.
-template <int NB, bool EXACT>
-__global__ __launch_bounds__(kBlock) void chain_sum(const int *__restrict__ crow, const long long *__restrict__ coff,
-                                                    const long long *__restrict__ coffc, const float *__restrict__ P, int N,
-                                                    const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc, int k0,
-                                                    int row_base, float alpha, float beta) {
-    constexpr int CHB = NB * kChainCE * 4;                 // bytes of one chunk slice
-    constexpr int kChainRing = 61440 / CHB;                // ring slots: 60 KiB of LDS, i.e. ~52 KiB of products in flight per
-    constexpr int kChainDepth = kChainRing - 2;            // workgroup (6 chunks of 4 KiB in flight were memory-latency bound)
-    constexpr int PIECES = CHB / 1024;                     // 1 KiB LDS-DMA pieces per chunk: NB / 4
-    static_assert(PIECES >= 1 && PIECES <= 8, "NB in 8 .. 32");
-    constexpr int PW = (PIECES + 3) / 4;                   // pieces per wavefront and chunk (the vmcnt unit)
-    __shared__ __attribute__((aligned(16))) char ring[kChainRing * CHB];
+template <int NT, bool EXACT>
+__global__ __launch_bounds__(chain_fused_threads(NT)) void chain_fused(
+    const int *__restrict__ crow, const int *__restrict__ cbeg, const long long *__restrict__ coff, const int *__restrict__ col_idx,
+    const float *__restrict__ val, const float *__restrict__ Bp, int64_t panel_stride, int panel_width, const float *Cin,
+    int64_t ldc_in, float *Cout, int64_t ldc, int col0, int ntiles, int k0, int row_base, float alpha, float beta) {
+    // (NT = 16 or 8 columns per workgroup: a 32-column panel is walked as two 16-column halves -- `ntiles` counts NT-column tiles,
+    // `panel_width` = floats per B row of the panel they live in)
+    static_assert(NT == 16 || NT == 8, "one task per producer lane and chunk");
+    constexpr int CE = kChainCE;                        // 64 entries per chunk
+    constexpr int QN = NT / 4;                          // tasks (lanes) per entry: one per 4 columns
+    constexpr int GW = chain_fused_group_waves(NT);     // producer wavefronts per group
+    constexpr int EPW = CE / GW;                        // entries of a chunk per producer wavefront (64 lanes = EPW entries x QN)
+    static_assert(EPW * QN == 64 && 2 * EPW <= 64, "a wavefront's tasks; val and col of its entries fit one dword request");
+    constexpr int D = kChainD, NVC = kChainNVC, NBR = kChainNBR, NPR = kChainNPR;
+    constexpr int PCS = CE + 4;                         // floats per product column (68: 16-byte rows for the consumer, 2-way banks for the writers)
+    constexpr int NPW = 2 * GW;
+    extern __shared__ __attribute__((aligned(16))) char chain_lds[];   // (more than the 64 KiB a static array may have)
+    // [per producer wavefront: val/col ring NVC x {64 dwords: val[EPW], col[EPW], unused}][B-row ring NBR x 64 x 16 B] [product ring] [flags]
+    constexpr int kWaveBytes = NVC * 256 + NBR * 1024;
+    float *s_pr = reinterpret_cast<float *>(chain_lds + NPW * kWaveBytes);                 // [NPR][NT][PCS]
+    typedef __attribute__((address_space(3))) volatile int lds_vint;   // (explicitly LDS: a generic volatile pointer captured by the lambdas below does not compile)
+    lds_vint *s_flag = (lds_vint *)((__attribute__((address_space(3))) char *)chain_lds + NPW * kWaveBytes + NPR * NT * PCS * 4);
+    // s_flag[0 .. NPW-1]: chunks done per producer wavefront; s_flag[NPW]: chunks taken by the consumer
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nblk = N / NB;
-    const int k = k0 + (int)(blockIdx.x / (unsigned)nblk), cb = (int)(blockIdx.x % (unsigned)nblk) * NB;
+    const int k = k0 + (int)(blockIdx.x / (unsigned)ntiles), tile = (int)(blockIdx.x % (unsigned)ntiles);
     const long long len = coff[k + 1] - coff[k];
-    const int nch = (int)((len + kChainCE - 1) / kChainCE);
-    const char *src0 = reinterpret_cast<const char *>(P + (coffc[k] - coffc[k0]) * N + (int64_t)cb * kChainCE) + lane * 16;
-    const unsigned ring0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)ring);
-    auto request = [&](int c, int slot) {                  // chunk c (clamped: counts stay constant) -> ring slot
-        const char *src = src0 + (int64_t)min(c, nch - 1) * kChainCE * N * 4;
+    const int nch = (int)((len + CE - 1) / CE);
+    const int nfull = (int)(len / CE);                  // chunks with all 64 entries
+    const int j0 = cbeg[k];
+    const int jlast = j0 + (int)len - 1;
+    if (tid <= NPW) s_flag[tid] = 0;
+    __syncthreads();                                    // (the only barrier)
+    if (wave == 0) {
+        // ---------------- consumer ----------------
+        float acc = 0.f;
+        if (tid < NT) {
+            f32x4 x[CE / 4], xn[CE / 4];
+            int avail = 0;                              // chunks 0 .. avail-1 are known to be complete in the product ring
+            auto wait_for = [&](int need) {             // until chunk `need - 1` is complete
+                while (avail < need) {
+                    int p0 = 0x7fffffff, p1 = 0x7fffffff;
 #pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            const int piece = min(wave * PW + i, PIECES - 1);   // (wavefronts beyond the chunk re-request its last piece)
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src + piece * 1024), "s"(ring0 + slot * CHB + piece * 1024) : "memory");
+                    for (int w = 0; w < GW; ++w) { p0 = min(p0, s_flag[w]); p1 = min(p1, s_flag[GW + w]); }
+                    avail = __builtin_amdgcn_readfirstlane(min(2 * p0, 2 * p1 + 1));   // (uniform: keep it in a scalar register)
+                    if (avail < need) __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+            };
+            auto load = [&](int ch, f32x4 (&dst)[CE / 4]) {
+                const f32x4 *np_ = reinterpret_cast<const f32x4 *>(s_pr + ((ch & (NPR - 1)) * NT + tid) * PCS);
+#pragma unroll
+                for (int u = 0; u < CE / 4; ++u) dst[u] = np_[u];
+            };
+            wait_for(1);
+            load(0, x);
+            // One chunk: `cur` = chunk c (already in registers), `nxt` <- chunk c + 1, then the 64 adds of chunk c.  The loop body is
+            // kept free of everything that is not these 16 reads and 64 adds -- a wavefront issues one instruction per ~4.5 cycles
+            // whatever it is, and a taken branch costs several of those:
+            //   * ONE register pin for all of `cur` (it was read a whole chunk ago: the compiler waits for it here, where that is free,
+            //     instead of in front of the first add; sixteen separate pins became fifteen s_waitcnt instructions);
+            //   * the "taken" word is written by every active lane (same value, same address: no exec juggling);
+            //   * the progress words are only read when the known-complete chunks run out (scalar compare, not taken).
+#define SX_PIN16(r) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), \
+                                      "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]))
+#define SX_CONSUME_FULL(c, cur, nxt)                                                                              \
+            {                                                                                                     \
+                SX_PIN16(cur);                                                                                    \
+                s_flag[NPW] = (c) + 1;                         /* chunks 0 .. c are in registers: their ring slots are free */ \
+                if (__builtin_expect((c) + 2 > avail, 0)) wait_for((c) + 2);                                      \
+                load((c) + 1, nxt);                                                                               \
+                asm volatile("" : "+v"(acc) : : "memory");   /* the reads are ISSUED before the adds start (memory clobber: the  */ \
+                                                             /* loads stay above; acc in/out: the adds stay below) ...          */ \
+                _Pragma("unroll") for (int u = 0; u < CE / 4; ++u) {                                              \
+                    acc = acc + cur[u].x; acc = acc + cur[u].y; acc = acc + cur[u].z; acc = acc + cur[u].w;        \
+                }                                                                                                 \
+                asm volatile("" : "+v"(acc));   /* ... and the next chunk's pin and flag write stay BEHIND them (volatile asm  */ \
+                                                /* statements keep their order): hoisted above, they would wait for the reads */ \
+            }
+            static_assert(CE / 4 == 16, "SX_PIN16");
+            const int nmain = min(nfull, nch - 1);          // chunks that are full AND have a successor
+            int c = 0;
+            for (; c + 2 <= nmain; c += 2) {
+                SX_CONSUME_FULL(c, x, xn)
+                SX_CONSUME_FULL(c + 1, xn, x)
+            }
+            for (; c < nch; ++c) {                          // the last one to three chunks: `x` is the current one
+                SX_PIN16(x);
+                s_flag[NPW] = c + 1;
+                if (c + 1 < nch) { wait_for(c + 2); load(c + 1, xn); }
+                if (c < nfull) {
+#pragma unroll
+                    for (int u = 0; u < CE / 4; ++u) { acc = acc + x[u].x; acc = acc + x[u].y; acc = acc + x[u].z; acc = acc + x[u].w; }
+                } else {   // the row's last, partial chunk: straight from the ring (nobody overwrites the last chunk's slot)
+                    const float *cf = s_pr + ((c & (NPR - 1)) * NT + tid) * PCS;
+                    const int cnt = (int)(len - (long long)nfull * CE);
+                    for (int u = 0; u < cnt; ++u) acc = acc + cf[u];
+                }
+                if (c + 1 < nch) {
+                    SX_PIN16(xn);
+#pragma unroll
+                    for (int u = 0; u < CE / 4; ++u) x[u] = xn[u];
+                }
+            }
+#undef SX_CONSUME_FULL
+#undef SX_PIN16
+            const int64_t r = (int64_t)(crow[k] - row_base);
+            const int64_t n = (int64_t)col0 + (int64_t)tile * NT + tid;
+            Cout[r + n * ldc] = epilogue<EXACT>(alpha, acc, beta, Cin[r + n * ldc_in]);
         }
+        return;
+    }
+    // ---------------- producers ----------------
+    const int pw = wave - 1;                            // producer number 0 .. NPW-1
+    const int grp = pw / GW, wl = pw % GW;              // group (0: even chunks, 1: odd chunks), wavefront inside the group
+    char *my = chain_lds + pw * kWaveBytes;             // private: val/col ring, then B-row ring
+    const unsigned my_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)my);
+    const int e_in_wave = lane / QN, q = lane % QN;     // my task: entry wl * EPW + e_in_wave of a chunk, columns 4q .. 4q+3 of the tile
+    const int sub_per_panel = panel_width / NT;
+    const float *bq = Bp + (int64_t)(tile / sub_per_panel) * panel_stride + (tile % sub_per_panel) * NT + 4 * q;
+    const int pofs = (4 * q) * PCS + wl * EPW + e_in_wave;
+    const int nmine = nch > grp ? (nch - grp + 1) / 2 : 0;   // chunks of my parity: grp, grp + 2, ...
+    auto dma4 = [](const void *g, unsigned lds_base) {      // 4 bytes per lane -> lds_base + 4 * lane
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(lds_base) : "memory");
     };
-    float acc = 0.f;
-    if (nch > 0) {
-#pragma unroll
-        for (int d = 0; d < kChainDepth; ++d) request(d, d);
-        const int nfull = (int)(len / kChainCE);               // chunks with all 64 entries
-        const char *mycol = ring + tid * (kChainCE * 4);
-        f32x4 x[kChainCE / 4], xn[kChainCE / 4];
-        // chunk 0 into registers
-        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PW * (kChainDepth - 1)) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (tid < NB) {
-#pragma unroll
-            for (int u = 0; u < kChainCE / 4; ++u) x[u] = reinterpret_cast<const f32x4 *>(mycol)[u];
+    auto dma16 = [](const void *g, unsigned lds_base) {     // 16 bytes per lane -> lds_base + 16 * lane
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(lds_base) : "memory");
+    };
+    int taken = 0;                                      // chunks the consumer is known to have taken into registers
+    // step m: stage 1 for my chunk number m + 2D, stage 2 for m + D, stage 3 for m (my chunk number i = chunk 2i + grp of the row)
+    for (int m = -2 * D; m < nmine; ++m) {
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * (D - 1)) : "memory");   // everything I requested D steps ago has landed
+        const int m1 = m + 2 * D, m2 = m + D;
+        // LDS reads first (the requests below are compiler barriers): col of stage 2, a and the B row of stage 3
+        int col = 0;
+        if (m2 >= 0) col = reinterpret_cast<const int *>(my + (m2 & (NVC - 1)) * 256)[EPW + e_in_wave];
+        float a = 0.f;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (m >= 0) {
+            a = reinterpret_cast<const float *>(my + (m & (NVC - 1)) * 256)[e_in_wave];
+            b = *reinterpret_cast<const f32x4 *>(my + NVC * 256 + (m & (NBR - 1)) * 1024 + lane * 16);
         }
-        // chunk c + 1 has landed (mine; after the barrier everybody's): its LDS reads are issued BEFORE the 64 dependent adds
-        // of chunk c, so neither the LDS round trip nor memory latency sits in the chain; ring slot (c - 2) is free for the
-        // request of chunk c + depth.  Two chunks per loop trip: the register sets swap roles without copies.
-#define SX_CHAIN_STEP(cc, cur, nxt)                                                                              \
-        {                                                                                                        \
-            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PW * (kChainDepth - 2)) : "memory");                       \
-            __builtin_amdgcn_s_barrier();                                                                        \
-            asm volatile("" ::: "memory");                                                                       \
-            request((cc) + kChainDepth, ((cc) + kChainDepth) % kChainRing);                                       \
-            if (tid < NB) {                                                                                      \
-                const f32x4 *np_ = reinterpret_cast<const f32x4 *>(mycol + (((cc) + 1) % kChainRing) * CHB);     \
-                _Pragma("unroll") for (int u = 0; u < kChainCE / 4; ++u) nxt[u] = np_[u];                        \
-                _Pragma("unroll") for (int u = 0; u < kChainCE / 4; ++u) {                                       \
-                    acc = acc + cur[u].x; acc = acc + cur[u].y; acc = acc + cur[u].z; acc = acc + cur[u].w;      \
-                }                                                                                                \
-            }                                                                                                    \
+        {   // stage 1: lanes 0 .. EPW-1 fetch val, EPW .. 2 EPW - 1 col of my entries of chunk m1 (the rest repeat)
+            const int ch = min(2 * m1 + grp, nch - 1);
+            const int j = min(j0 + ch * CE + wl * EPW + (lane % EPW), jlast);
+            const void *g = (lane / EPW) & 1 ? (const void *)(col_idx + j) : (const void *)(val + j);
+            dma4(g, my_lds + (m1 & (NVC - 1)) * 256);
         }
-        int c = 0;
-        for (; c + 2 <= nfull; c += 2) {
-            SX_CHAIN_STEP(c, x, xn)
-            SX_CHAIN_STEP(c + 1, xn, x)
-        }
-        if (c < nfull) SX_CHAIN_STEP(c, x, xn)
-#undef SX_CHAIN_STEP
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the over-requested chunks; the partial last chunk (if any)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (tid < NB && nfull < nch) {
-            const float *cf = reinterpret_cast<const float *>(mycol + (nfull % kChainRing) * CHB);
-            const int cnt = (int)(len - (long long)nfull * kChainCE);
-            for (int u = 0; u < cnt; ++u) acc = acc + cf[u];
+        // stage 2: B rows of chunk m2 (before the pipeline is full: row 0)
+        dma16(bq + (int64_t)col * panel_width, my_lds + NVC * 256 + (m2 & (NBR - 1)) * 1024);
+        if (m >= 0) {   // stage 3
+            const int ch = 2 * m + grp;
+            while (ch - taken >= NPR) {                 // the slot still holds a chunk the consumer has not taken
+                taken = s_flag[NPW];
+                if (ch - taken >= NPR) __builtin_amdgcn_s_sleep(4);
+            }
+            asm volatile("" ::: "memory");
+            float *d = s_pr + (ch & (NPR - 1)) * (NT * PCS) + pofs;
+            d[0] = a * b.x; d[PCS] = a * b.y; d[2 * PCS] = a * b.z; d[3 * PCS] = a * b.w;
+            asm volatile("" ::: "memory");
+            if (lane == 0) s_flag[pw] = m + 1;          // (after the products: LDS operations of a wavefront execute in order)
         }
     }
-    if (tid < NB) {
-        const int64_t r = (int64_t)(crow[k] - row_base);
-        Cout[r + (int64_t)(cb + tid) * ldc] = epilogue<EXACT>(alpha, acc, beta, Cin[r + (int64_t)(cb + tid) * ldc_in]);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the over-requested chunks: nothing may still target LDS when the wavefront ends
 }
 
 // ------------------------------------------------------------------------------------------------

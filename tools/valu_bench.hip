@@ -49,6 +49,12 @@ __global__ __launch_bounds__(1024) void k(float *out, long long *cycles, int ite
             asm volatile(REP8("v_pk_fma_f32 %0, %0, %8, %8\n v_pk_fma_f32 %1, %1, %8, %8\n v_pk_fma_f32 %2, %2, %8, %8\n v_pk_fma_f32 %3, %3, %8, %8\n"
                               "v_pk_fma_f32 %4, %4, %8, %8\n v_pk_fma_f32 %5, %5, %8, %8\n v_pk_fma_f32 %6, %6, %8, %8\n v_pk_fma_f32 %7, %7, %8, %8\n")
                          : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(q));
+        } else if constexpr (MODE == 8) {   // ONE dependent chain of 64 v_add_f32 (the exact-chain consumer's pattern)
+            asm volatile(REP64("v_add_f32 %0, %0, %1\n") : "+v"(a0) : "v"(b0));
+        } else if constexpr (MODE == 9) {   // the same chain with an independent ds-free VALU instruction between the adds
+            asm volatile(REP64("v_add_f32 %0, %0, %2\n v_mul_f32 %1, %1, %2\n") : "+v"(a0), "+v"(a1) : "v"(b0));
+        } else if constexpr (MODE == 10) {  // two independent chains interleaved
+            asm volatile(REP64("v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %2\n") : "+v"(a0), "+v"(a1) : "v"(b0));
         } else if constexpr (MODE == 7) {   // the kernel's pattern with scalar ops: 4 v_mul + 4 dependent v_add per 4 floats
             float t0_, t1_, t2_, t3_;
             asm volatile(REP8("v_mul_f32 %4, %8, %9\n v_mul_f32 %5, %8, %9\n v_mul_f32 %6, %8, %9\n v_mul_f32 %7, %8, %9\n"
@@ -91,6 +97,9 @@ int main() {
         run<3>("pk_mul,nop,pk_add one chain (x32)", threads, 64);
         run<7>("v_mul x4 + dep v_add x4 (x8)", threads, 64);
         run<4>("v_mov_b32_dpp x64", threads, 64);
+        run<8>("v_add_f32 x64, ONE dependent chain", threads, 64);
+        run<9>("dep v_add + indep v_mul (x64)", threads, 128);
+        run<10>("two dep v_add chains interleaved", threads, 128);
     }
     return 0;
 }
