@@ -153,7 +153,7 @@ struct sextans_engine {
     // exact chains (strict order, "exact_chain" = 1): rows longer than the automatic threshold leave the piece tables too
     // and are summed by chain_fused -- still one serial chain of rounded adds per (row, column), bit-identical
     int nchain = 0;
-    int *d_chain_row = nullptr, *d_chain_beg = nullptr;
+    int *d_chain_row = nullptr, *d_chain_beg = nullptr, *d_chain_perm = nullptr;   // perm: chain rows by length, longest first
     long long *d_chain_off = nullptr;                   // prefix of the lengths
     std::vector<int> h_chain_row;
     std::vector<long long> h_chain_off;
@@ -274,8 +274,8 @@ void free_split(sextans_engine *h) {   // long-row state: main matrix, skip flag
         (void)hipFree(t->d_vrp); (void)hipFree(t->d_vend); (void)hipFree(t->d_vfirst); (void)hipFree(t->d_row);
         *t = sextans_engine::PieceTable();
     }
-    (void)hipFree(h->d_chain_row); (void)hipFree(h->d_chain_beg); (void)hipFree(h->d_chain_off);
-    h->d_chain_row = h->d_chain_beg = nullptr; h->d_chain_off = nullptr;
+    (void)hipFree(h->d_chain_row); (void)hipFree(h->d_chain_beg); (void)hipFree(h->d_chain_off); (void)hipFree(h->d_chain_perm);
+    h->d_chain_row = h->d_chain_beg = h->d_chain_perm = nullptr; h->d_chain_off = nullptr;
     h->nchain = 0; h->h_chain_row.clear(); h->h_chain_off.clear(); h->chain_T = 0; h->chain_built_opt = -2;
     (void)hipFree(h->d_mrp); (void)hipFree(h->d_mci); (void)hipFree(h->d_mv); (void)hipFree(h->d_skip);
     h->d_mrp = h->d_mci = nullptr;
@@ -965,6 +965,12 @@ int ensure_split(sextans_engine *h) {
         if (int rc = upload(&h->d_chain_row, chain_rows)) return rc;
         if (int rc = upload(&h->d_chain_beg, beg)) return rc;
         if (int rc = upload(&h->d_chain_off, off)) return rc;
+        {   // launch order of whole-matrix calls: longest chain first (a workgroup lives as long as its row is; one per CU)
+            std::vector<int> perm(chain_rows.size());
+            for (size_t i = 0; i < perm.size(); ++i) perm[i] = (int)i;
+            std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return off[(size_t)a + 1] - off[(size_t)a] > off[(size_t)b + 1] - off[(size_t)b]; });
+            if (int rc = upload(&h->d_chain_perm, perm)) return rc;
+        }
         h->h_chain_row = chain_rows;
         h->h_chain_off = off;
         h->nchain = (int)chain_rows.size();
@@ -1216,7 +1222,7 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
         if (int rc = ensure(&h->d_P, &h->P_cap, (size_t)h->split_nv * (size_t)N)) return rc;
     if (h->nchain > 0) {
         if (!h->aux_stream) {
-            SX_HIP(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+            SX_HIP(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));   // (a high-priority stream was measured: no difference)
             SX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
             SX_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         }
@@ -1323,7 +1329,7 @@ void launch_chains(sextans_engine *h, const std::vector<Seg> &plan, const float 
                     attr_set = true;
                 }
                 hipLaunchKernelGGL(kern, dim3((unsigned)(c1 - c0) * (unsigned)ntiles), dim3((unsigned)threads), (size_t)lds, s, h->d_chain_row,
-                                   h->d_chain_beg, h->d_chain_off, h->s_ci, h->s_v, bp, (int64_t)h->K * g.width, g.width, dCin, ldc_in, dCout,
+                                   h->d_chain_beg, h->d_chain_off, (c0 == 0 && c1 == h->nchain) ? h->d_chain_perm : (const int *)nullptr, h->s_ci, h->s_v, bp, (int64_t)h->K * g.width, g.width, dCin, ldc_in, dCout,
                                    ldc, g.col0, ntiles, c0, row_base, alpha, beta);
             };
 #define SX_FUSED(W) if (h->opt_exact) go(sx::chain_fused<W, true>, sx::chain_fused_lds_bytes(W), sx::chain_fused_threads(W)); \

@@ -655,8 +655,8 @@ static_assert(kChainNVC >= 2 * kChainD + 1 && kChainNBR >= kChainD + 1 && kChain
 
 template <int NT, bool EXACT>
 __global__ __launch_bounds__(chain_fused_threads(NT)) void chain_fused(
-    const int *__restrict__ crow, const int *__restrict__ cbeg, const long long *__restrict__ coff, const int *__restrict__ col_idx,
-    const float *__restrict__ val, const float *__restrict__ Bp, int64_t panel_stride, int panel_width, const float *Cin,
+    const int *__restrict__ crow, const int *__restrict__ cbeg, const long long *__restrict__ coff, const int *__restrict__ perm,
+    const int *__restrict__ col_idx, const float *__restrict__ val, const float *__restrict__ Bp, int64_t panel_stride, int panel_width, const float *Cin,
     int64_t ldc_in, float *Cout, int64_t ldc, int col0, int ntiles, int k0, int row_base, float alpha, float beta) {
     // (NT = 16 or 8 columns per workgroup: a 32-column panel is walked as two 16-column halves -- `ntiles` counts NT-column tiles,
     // `panel_width` = floats per B row of the panel they live in)
@@ -678,7 +678,9 @@ __global__ __launch_bounds__(chain_fused_threads(NT)) void chain_fused(
     // s_flag[0 .. NPW-1]: chunks done per producer wavefront; s_flag[NPW]: chunks taken by the consumer
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int k = k0 + (int)(blockIdx.x / (unsigned)ntiles), tile = (int)(blockIdx.x % (unsigned)ntiles);
+    // (perm: whole-matrix launches walk the chain rows longest first; row-range launches take them as they come)
+    const int kr = (int)(blockIdx.x / (unsigned)ntiles), tile = (int)(blockIdx.x % (unsigned)ntiles);
+    const int k = perm ? perm[kr] : k0 + kr;
     const long long len = coff[k + 1] - coff[k];
     const int nch = (int)((len + CE - 1) / CE);
     const int nfull = (int)(len / CE);                  // chunks with all 64 entries
