@@ -251,6 +251,10 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
             av[b] = *reinterpret_cast<const f32x4 *>(pv + loff + b * BATCH);
             aw[b] = *reinterpret_cast<const uint2 *>(pi + loff + b * BATCH);
         }
+        // (Measured and NOT done: pinning all boff[] registers here so that the nine panel requests go out right behind the dictionary
+        // instead of piece 2..9 waiting -- behind a compiler-inserted vmcnt(0) at a control-flow join -- for the row entries: the
+        // 4M-row FEM matrix got slower, 687 -> 712 us at N = 16, 1063 -> 1172 us at N = 32: with 16 wavefronts per CU in their
+        // prologues the staggered requests are the better traffic shape; only the 74-workgroup nasa4704 loop gained, 3.88 -> 3.67 us.)
         if constexpr (DMA) dma_panel(st_begin); else load_panel(st_begin, true);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
