@@ -474,6 +474,15 @@ def powerlaw_secondary(api, torch, dev, stream):
     out.update(options="split_rows=-1 (opt-in re-association of hub rows)", piece_path_rows=int(e.get_stat("piece_path_rows")), reassociated_rows=int(e.get_stat("reassociated_rows")),
                matrix="powerlaw xmin 6, tail 1.2, max 400000, seed 7")
     e.close()
+    # the same matrix with NO option set: strict CSR order for every row, the 399 302-entry row summed by an exact chain
+    # (bit-identical to cpu_spmm_CSR)
+    e = api.Engine(dev.index)
+    e.set_matrix_csr_device(M, K, nnz, p, i, v)
+    d = _measure(api, torch, e, M, K, 16, nnz, dev, stream, 30)
+    out["default_strict_order"] = {"us_per_step": d["us_per_step"], "gflops": d["gflops"], "kernel": d["kernel"],
+                                   "exact_chain_rows": int(e.get_stat("exact_chain_rows")),
+                                   "reassociated_rows": int(e.get_stat("reassociated_rows"))}
+    e.close()
     for q in (p, i, v):
         api.device_free(dev.index, q)
     p, i, v, nnz_u = api.gen_csr_device(dev.index, M, K, nnz / M, 7)

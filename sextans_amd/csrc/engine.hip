@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <set>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -65,6 +66,8 @@ struct sextans_engine {
     bool owns_matrix = false;
     bool device_matrix_checked = false;   // a caller-provided device matrix has been validated (row_ptr monotone, columns < K)
     // workspaces
+    std::set<const void *> big_lds_kernels;   // kernels whose dynamic-LDS limit has been raised ON THIS ENGINE'S DEVICE (the
+                                              // attribute is per device: a process-wide flag breaks the second GPU of a process)
     float *d_Bp = nullptr;
     size_t Bp_cap = 0;              // floats
     int bp_layout = 0;              // main panel width of the last repack into d_Bp (0 = none)
@@ -565,6 +568,14 @@ void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_
     }
 }
 
+// Kernels that need more than the default 64 KiB of dynamic LDS: raise the limit once per (engine = device, kernel).
+int allow_big_lds(sextans_engine *h, const void *kern, int bytes) {
+    if (h->big_lds_kernels.count(kern)) return SEXTANS_OK;
+    SX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    h->big_lds_kernels.insert(kern);
+    return SEXTANS_OK;
+}
+
 // Wide-N form of the panel kernel (spmm_panel_v2.h): `nsuper` super tiles of 32 columns starting at the pointers
 // given; dictionary-only plans built for 4 lanes per row.
 template <int H>
@@ -583,11 +594,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     const int64_t pstride = bcol_ld > 0 ? bcol_ld : (int64_t)h->K * 16;
     const size_t lds = (size_t)H * sx::kWideHalfBytes;
     auto go = [&](auto kern) -> int {
-        static bool attr_set = false;   // one flag per instantiation (the lambda body is instantiated per kernel type)
-        if (!attr_set) {
-            SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        if (int rc = allow_big_lds(h, reinterpret_cast<const void *>(kern), (int)lds)) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)h->ps.d_row_off,
                            h->ps.d_lidx, h->ps.d_pval, h->ps.d_blk_row, h->ps.d_dict_ptr, h->ps.d_dict, h->ps.plan_dict_stride,
                            dBp, pstride, dCin, ldc_in, dCout, ldc, nsuper, tpw, nblk, alpha, beta, (int)h->opt_xcd,
@@ -1323,11 +1330,7 @@ void launch_chains(sextans_engine *h, const std::vector<Seg> &plan, const float 
             const int NT = g.width >= 16 ? 16 : 8;
             const int ntiles = g.ntiles * (g.width / NT);
             auto go = [&](auto kern, int lds, int threads) {
-                static bool attr_set = false;
-                if (!attr_set) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                    attr_set = true;
-                }
+                (void)allow_big_lds(h, reinterpret_cast<const void *>(kern), lds);
                 hipLaunchKernelGGL(kern, dim3((unsigned)(c1 - c0) * (unsigned)ntiles), dim3((unsigned)threads), (size_t)lds, s, h->d_chain_row,
                                    h->d_chain_beg, h->d_chain_off, (c0 == 0 && c1 == h->nchain) ? h->d_chain_perm : (const int *)nullptr, h->s_ci, h->s_v, bp, (int64_t)h->K * g.width, g.width, dCin, ldc_in, dCout,
                                    ldc, g.col0, ntiles, c0, row_base, alpha, beta);
@@ -1495,12 +1498,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         if (shared) {
             constexpr size_t lds = (size_t)sx::kShRing * sx::kShTileBytes + (size_t)(sx::kShMaxUnion + 8) * (sizeof(int) + sx::kShRows * sizeof(short)) +
                                    (size_t)sx::kShMaxRowCols * sizeof(int);
-            static bool attr_set = false;
-            if (!attr_set) {
-                SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sx::spmm_bell_mfma_shared),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set = true;
-            }
+            if (int rc = allow_big_lds(h, reinterpret_cast<const void *>(sx::spmm_bell_mfma_shared), (int)lds)) return rc;
             hipLaunchKernelGGL(sx::spmm_bell_mfma_shared, dim3((unsigned)((h->dense_mb + sx::kShRows - 1) / sx::kShRows)),
                                dim3(sx::kShThreads), lds, s, h->d_dense_col, Af, Bf, d_C_in, ldc_in, d_C_out, ldc, h->dense_mb, h->dense_W,
                                alpha, beta, 0);
@@ -1940,12 +1938,7 @@ int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint1
         if (shared) {
             constexpr size_t lds = (size_t)sx::kShRing * sx::kShTileBytes + (size_t)(sx::kShMaxUnion + 8) * (sizeof(int) + sx::kShRows * sizeof(short)) +
                                   (size_t)sx::kShMaxRowCols * sizeof(int);
-            static bool attr_set = false;
-            if (!attr_set) {
-                SX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sx::spmm_bell_mfma_shared),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set = true;
-            }
+            if (int rc = allow_big_lds(h, reinterpret_cast<const void *>(sx::spmm_bell_mfma_shared), (int)lds)) return rc;
             hipLaunchKernelGGL(sx::spmm_bell_mfma_shared, dim3((unsigned)((mblocks + sx::kShRows - 1) / sx::kShRows)), dim3(sx::kShThreads), lds,
                                s, h->d_bell_col, Af, Bf, d_C_in, ldc, d_C_out, ldc, mblocks, h->bell_W, alpha, beta, (int)h->opt_bell_debug);
             h->last_kernel = "spmm_bell_mfma_shared";
