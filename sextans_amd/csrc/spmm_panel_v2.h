@@ -251,10 +251,17 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
             av[b] = *reinterpret_cast<const f32x4 *>(pv + loff + b * BATCH);
             aw[b] = *reinterpret_cast<const uint2 *>(pi + loff + b * BATCH);
         }
-        // (Measured and NOT done: pinning all boff[] registers here so that the nine panel requests go out right behind the dictionary
-        // instead of piece 2..9 waiting -- behind a compiler-inserted vmcnt(0) at a control-flow join -- for the row entries: the
-        // 4M-row FEM matrix got slower, 687 -> 712 us at N = 16, 1063 -> 1172 us at N = 32: with 16 wavefronts per CU in their
-        // prologues the staggered requests are the better traffic shape; only the 74-workgroup nasa4704 loop gained, 3.88 -> 3.67 us.)
+        // All dictionary indices are waited for HERE, in one counted wait behind which the row loads above stay in flight.  Left to
+        // itself the compiler waits for boff[1] after the first (conditional) panel request -- and after a control-flow join its
+        // wait-count bookkeeping can only say vmcnt(0): the row entries and the first piece had to land before pieces 2..9 were even
+        // requested, one extra memory round trip in every workgroup's prologue.  Same-box A/B on the 4M-row FEM matrix (tools/ab.py):
+        // N = 16 720 -> 695 us (a first comparison ACROSS boxes had said 687 -> 712: box-to-box spread is +-4 %).
+        static_assert(MAXD == 9 || MAXD == 5, "the pin below names every boff register");
+        if constexpr (MAXD == 9)
+            asm volatile("" : "+v"(boff[0]), "+v"(boff[1]), "+v"(boff[2]), "+v"(boff[3]), "+v"(boff[4]), "+v"(boff[5]), "+v"(boff[6]),
+                              "+v"(boff[7]), "+v"(boff[8]));
+        else
+            asm volatile("" : "+v"(boff[0]), "+v"(boff[1]), "+v"(boff[2]), "+v"(boff[3]), "+v"(boff[4]));
         if constexpr (DMA) dma_panel(st_begin); else load_panel(st_begin, true);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
@@ -283,21 +290,25 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
     long long t_rows = 0;
     for (int st = st_begin; st < st_end; ++st) {
         const int64_t col0 = (int64_t)st * NTT;
-        // ---- requests that fly under this super tile's row loop: its C_in, the next panel
+        // ---- the panel of this tile (LDS-DMA form), then the requests that fly under its row loop: its C_in, the next panel
+        // (register form).  C_in is requested AFTER the panel has landed: the compiler drains everything outstanding before the
+        // barrier that publishes the panel, and C_in (always an HBM miss) in front of that drain added its latency to the panel's
+        // (mostly L2 hits) at the top of every tile; behind it, it has the whole row loop to arrive.
+        if constexpr (DMA) {
+            if (st != st_begin) {
+                __syncthreads();               // every wave is done reading the previous panel
+                dma_panel(st);
+                __syncthreads();               // (the compiler drains the DMA before the barrier)
+            }
+        }
         if (st != st_begin) {
 #pragma unroll
             for (int h = 0; h < H; ++h)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) aload1(cin[h][j], Cin + (col0 + h * 16 + j) * ldc_in, cvoff_in);
         }
-        if constexpr (DMA) {
-            if (st != st_begin) {
-                __syncthreads();               // every wave is done reading the previous panel
-                dma_panel(st);
-                __syncthreads();               // (the compiler drains the DMA, and with it C_in, before the barrier)
-            }
-        } else if (st + 1 < st_end) {
-            load_panel(st + 1, false);
+        if constexpr (!DMA) {
+            if (st + 1 < st_end) load_panel(st + 1, false);
         }
         f32x4 acc[H];
 #pragma unroll

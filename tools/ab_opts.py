@@ -1,0 +1,31 @@
+"""Option sets compared on ONE box, round-robin: tools/ab_opts.py <fem dims AxBxCxD> <N> <iters> "k=v,k=v" "k=v" ...  (kernel us per launch)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from sextans_amd import api
+dims = [int(x) for x in sys.argv[1].split("x")]; N = int(sys.argv[2]); iters = int(sys.argv[3])
+sets = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.split(",") if kv) for a in sys.argv[4:]]
+M = K = dims[0] * dims[1] * dims[2] * dims[3]
+p = api.gen_fem3d_device(0, *dims, 3)
+st = torch.cuda.current_stream().cuda_stream
+B = torch.empty(K * N, device="cuda"); Cin = torch.empty(M * N, device="cuda"); Cout = torch.empty(M * N, device="cuda")
+api.gen_uniform_device(0, B.data_ptr(), K * N, 41, st); api.gen_uniform_device(0, Cin.data_ptr(), M * N, 42, st)
+engines = []
+for o in sets:
+    e = api.Engine(0)
+    for k, v in o.items():
+        e.set_option(k, v)
+    e.set_matrix_csr_device(M, K, p[3], *p[:3])
+    engines.append(e)
+for rnd in range(3):
+    out = []
+    for o, e in zip(sets, engines):
+        f = lambda: e.spmm_device(N, 0.85, B.data_ptr(), K, -2.06, Cin.data_ptr(), Cout.data_ptr(), M, st)
+        for _ in range(3): f()
+        e.set_option("profile", 1); e.profile_reset()
+        for _ in range(iters): f()
+        torch.cuda.synchronize()
+        k_ns, n, r_ns = e.profile_read(); e.set_option("profile", 0)
+        out.append(f"{o}: {k_ns / 1e3:.1f} ({e.last_kernel()})")
+    print(f"N={N} round {rnd}: " + " | ".join(out), flush=True)
