@@ -1,4 +1,4 @@
-"""A/B timing on ONE box: tools/ab.py <workload> <N-list> lib1.so lib2.so ... -- each library in its own subprocess, round-robin, several rounds."""
+"""A/B timing on ONE box: tools/ab.py <fem dims AxBxCxD | synth:spec> <N-list> <iters> lib1.so lib2.so ... -- each library in its own subprocess, round-robin, several rounds."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if sys.argv[1] == "--child":
@@ -6,10 +6,15 @@ if sys.argv[1] == "--child":
     import sextans_amd.api as api
     api.LIB_PATH = os.path.join(ROOT, sys.argv[2])
     import torch
-    dims = [int(x) for x in sys.argv[3].split("x")]
     Ns = [int(x) for x in sys.argv[4].split(",")]
-    M = K = dims[0] * dims[1] * dims[2] * dims[3]
-    p = api.gen_fem3d_device(0, *dims, 3)
+    if sys.argv[3].startswith("synth:"):
+        from sextans_amd import sweep
+        M, K, p0, p1, p2, nnz = sweep._synth(sys.argv[3], 0)
+        p = (p0, p1, p2, nnz)
+    else:
+        dims = [int(x) for x in sys.argv[3].split("x")]
+        M = K = dims[0] * dims[1] * dims[2] * dims[3]
+        p = api.gen_fem3d_device(0, *dims, 3)
     e = api.Engine(0); e.set_matrix_csr_device(M, K, p[3], *p[:3])
     st = torch.cuda.current_stream().cuda_stream
     res = []
