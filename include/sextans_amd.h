@@ -254,6 +254,8 @@ int sextans_destroy(sextans_handle_t h);
  * N >= 32, default 150: with more columns per B row the panel pays earlier; the packed plan is built once, for the lower
  * of the two), "panel_v2" (-1 auto / 0 / 1: the register-resident form of the panel
  * kernel, spmm_csr_panel_v2), "tiles_per_wg" (N tiles one workgroup of that kernel walks; 0 = auto),
+ * "small_v2" (default 1: small matrices staged from column-major B size the launch's dictionary capacity and register-resident
+ * batches from the plan; 0 = the full-capacity form, for measurements),
  * "cols_per_lane" (0/4 = 16-column tiles at 4 workgroups per CU, the default; 8 = 32-column super tiles at 2 per CU),
  * "bell_shared" (blocked-ELL, N = 256: -1 = use the union-walk kernel spmm_bell_mfma_shared when 8 consecutive block rows
  * share block columns, stat "bell_share" >= 1.5; 0 never; 1 whenever the unions fit), "bell_debug" (measurements only:
