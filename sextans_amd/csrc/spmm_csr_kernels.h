@@ -737,6 +737,31 @@ __global__ __launch_bounds__(chain_fused_threads(NT)) void chain_fused(
             static_assert(CE / 4 == 16, "SX_PIN16");
             const int nmain = min(nfull, nch - 1);          // chunks that are full AND have a successor
             int c = 0;
+            // Eight chunks per trip: the ring slot of every read is a compile-time constant (ds_read immediate offsets from one
+            // base register, no address arithmetic), the "taken" word is written every other chunk.
+            static_assert(NPR == 8, "the unrolled loop walks the product ring once per trip");
+            const f32x4 *ring_me = reinterpret_cast<const f32x4 *>(s_pr + tid * PCS);
+#define SX_CONSUME8(i, cur, nxt)                                                                                  \
+            {                                                                                                     \
+                SX_PIN16(cur);                                                                                    \
+                if (((i) & 1) == 0) s_flag[NPW] = c + (i) + 1;                                                    \
+                if (__builtin_expect(c + (i) + 2 > avail, 0)) wait_for(c + (i) + 2);                              \
+                {                                                                                                 \
+                    const f32x4 *np_ = ring_me + (((i) + 1) & (NPR - 1)) * (NT * PCS / 4);                        \
+                    _Pragma("unroll") for (int u = 0; u < CE / 4; ++u) nxt[u] = np_[u];                           \
+                }                                                                                                 \
+                asm volatile("" : "+v"(acc) : : "memory");                                                        \
+                _Pragma("unroll") for (int u = 0; u < CE / 4; ++u) {                                              \
+                    acc = acc + cur[u].x; acc = acc + cur[u].y; acc = acc + cur[u].z; acc = acc + cur[u].w;        \
+                }                                                                                                 \
+                asm volatile("" : "+v"(acc));                                                                     \
+            }
+            static_assert((NT * PCS) % 4 == 0, "ring slots are whole f32x4");
+            for (; c + 8 <= nmain; c += 8) {
+                SX_CONSUME8(0, x, xn) SX_CONSUME8(1, xn, x) SX_CONSUME8(2, x, xn) SX_CONSUME8(3, xn, x)
+                SX_CONSUME8(4, x, xn) SX_CONSUME8(5, xn, x) SX_CONSUME8(6, x, xn) SX_CONSUME8(7, xn, x)
+            }
+#undef SX_CONSUME8
             for (; c + 2 <= nmain; c += 2) {
                 SX_CONSUME_FULL(c, x, xn)
                 SX_CONSUME_FULL(c + 1, xn, x)
