@@ -28,6 +28,7 @@
 #include "chan_kernels.h"
 #include "panel_plan.h"
 #include "plan_device.h"
+#include "row_cluster.h"
 #include "sextans_amd.h"
 #include "spmm_csr_kernels.h"
 #include "spmm_panel_v2.h"
@@ -101,6 +102,13 @@ struct sextans_engine {
         bool plan_built = false;        // false: only the sampled verdict exists (no packed stream)
     };
     PanelState ps;                      // active
+    // The same plan over the rows in CLUSTERED order (row_cluster.hip: brick by brick for grid-stencil matrices), 4 lanes per row,
+    // used by spmm_csr_panel_v2 for whole-matrix calls; row-range calls and every other kernel keep the natural-order plan above.
+    PanelState psc;
+    int *d_slot_row = nullptr;          // psc: row of the main matrix per (block, slot)
+    int cluster_state = 0;              // 0 not evaluated, 1 in use, -1 rejected (no grid structure / no gain)
+    int64_t cluster_s2 = 0, cluster_s3 = 0;
+    int64_t plan_total_dict = 0, cluster_total_dict = 0;   // sum of the block dictionaries: natural order / clustered order
     PanelState plan_stash[3];           // parked, indexed by lanes_per_row 2 / 4 / 8 -> 0 / 1 / 2
     // K-windowed accumulator-resident plan (spmm_csr_window; built lazily)
     uint2 *d_wstream = nullptr;
@@ -185,6 +193,9 @@ struct sextans_engine {
     int64_t opt_cols_per_lane = 0;      // LDS-panel kernel: output columns per lane.  4 (= 0, the default) = 16-column tiles;
                                         // 8 = register-blocked 32-column super tiles (spmm_csr_panel_v2<2>: 2 workgroups per
                                         // CU -- measured slower than 4 columns per lane at 4 workgroups per CU)
+    int64_t opt_cluster_shape = 0;      // measurement switch: brick shape run_rows * 10000 + lines * 100 + planes (0 = 16 x 2 x 2 / 16 x 4)
+    int64_t opt_cluster_group = 3;      // bricks are laid out in groups of g x g brick columns (A/B on the 4M-row FEM matrix: g = 3)
+    int64_t opt_row_cluster = -1;       // clustered-order plan for spmm_csr_panel_v2 (ensure_cluster_plan): -1 auto, 0 never, 1 whenever found
     int64_t opt_small_v2 = 1;           // measurement switch: 0 = small matrices keep the full-capacity, 4-deep form of spmm_csr_panel_v2
     int64_t opt_panel_v2 = -1;          // 16-column tiles on the register-resident form (spmm_csr_panel_v2<1>: row entries
                                         // loaded once per block, panels by LDS-DMA, tile loop inside the workgroup, C stored
@@ -255,6 +266,12 @@ void free_panel_state(sextans_engine::PanelState &p) {
 void free_plan(sextans_engine *h) {   // every packed form of the current main matrix
     free_panel_state(h->ps);
     for (auto &p : h->plan_stash) free_panel_state(p);
+    free_panel_state(h->psc);
+    (void)hipFree(h->d_slot_row);
+    h->d_slot_row = nullptr;
+    h->cluster_state = 0;
+    h->cluster_s2 = h->cluster_s3 = 0;
+    h->plan_total_dict = h->cluster_total_dict = 0;
 }
 
 void free_window(sextans_engine *h) {
@@ -530,6 +547,89 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
     h->ps.plan_max_row = dp.max_row_len;
     h->ps.plan_pad_row = cap;
     h->ps.plan_built = true;
+    if (lpr == 4) h->plan_total_dict = dp.total_dict;
+    return SEXTANS_OK;
+}
+
+// Clustered-order plan (see PanelState psc): built once per matrix, after the natural-order plan for 4 lanes per row exists and is
+// dictionary-only.  Option "row_cluster": -1 = when the matrix has grid-stencil structure AND the clustered plan copies at least
+// 15 % fewer B rows into LDS; 1 = whenever the structure is found; 0 = never.
+int ensure_cluster_plan(sextans_engine *h) {
+    if (h->cluster_state != 0) return SEXTANS_OK;
+    h->cluster_state = -1;
+    if (h->opt_row_cluster == 0 || !h->ps.plan_built || h->ps.plan_lpr != 4 || h->ps.plan_mixed || h->M < 4096) return SEXTANS_OK;
+    PlanTimer timer(h);
+    // ---- grid strides from the columns of ~128 rows out of the middle half of the matrix
+    std::vector<int> rp;
+    if (int rc = read_back_row_ptr(h, rp)) return rc;
+    std::vector<int> rows;
+    std::vector<std::vector<int>> cols;
+    const int nsample = 128;
+    for (int k = 0; k < nsample; ++k) {
+        const int r = (int)((int64_t)h->M / 4 + (int64_t)k * (h->M / 2) / nsample);
+        const int j0 = rp[(size_t)r], j1 = rp[(size_t)r + 1];
+        if (j1 <= j0 || j1 - j0 > 4096) continue;
+        std::vector<int> c((size_t)(j1 - j0));
+        SX_HIP(hipMemcpy(c.data(), h->m_ci + j0, sizeof(int) * c.size(), hipMemcpyDeviceToHost));
+        rows.push_back(r);
+        cols.push_back(std::move(c));
+    }
+    sx::GridStrides gs;
+    if (!sx::detect_grid_strides(h->M, rows, cols, &gs)) return SEXTANS_OK;
+    h->cluster_s2 = gs.s2;
+    h->cluster_s3 = gs.s3;
+    // ---- bricks of <= 64 rows = one row block each: a run of 15 / 16 rows of a grid line x 2 lines x 2 planes (3-D), x 4 lines (2-D).
+    // Runs of consecutive rows keep a wavefront's C accesses (its 16 row slots) on consecutive rows -- 64-byte runs per column as in
+    // natural order (12-row runs gave away half of the gain at N = 128, where C is half of the traffic); the plan builder starts a
+    // block at every brick (`cut`), so blocks and bricks coincide.
+    int run_rows = 16, b2 = gs.s3 > 0 ? 2 : 4, b3 = gs.s3 > 0 ? 2 : 1;
+    if (h->opt_cluster_shape > 0) {   // EXPERIMENT: run_rows * 10000 + b2 * 100 + b3
+        run_rows = (int)(h->opt_cluster_shape / 10000); b2 = (int)(h->opt_cluster_shape / 100 % 100); b3 = (int)(h->opt_cluster_shape % 100);
+    }
+    std::string err;
+    int *d_perm = nullptr, *prp = nullptr, *pci = nullptr;
+    unsigned char *d_cut = nullptr;
+    float *pv = nullptr;
+    auto drop = [&]() { (void)hipFree(d_perm); (void)hipFree(d_cut); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv); };
+    if (sx::build_brick_order_device(h->M, gs, run_rows, b2, b3, (int)h->opt_cluster_group, &d_perm, &d_cut, err)) { g_last_error = err; drop(); return SEXTANS_ERR_HIP; }
+    if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_perm, &prp, &pci, &pv, err)) {
+        g_last_error = err; drop(); return SEXTANS_ERR_HIP;
+    }
+    sx::DevicePlan dp;
+    const int lpr = 4, RB = sx::kBlock / lpr, cap = kPanelFloats / (4 * lpr);
+    const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;
+    const int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, min_reuse, dp, err, d_cut);
+    (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv); (void)hipFree(d_cut);
+    prp = pci = nullptr; pv = nullptr; d_cut = nullptr;
+    if (brc == 2) { g_last_error = err; sx::free_device_plan(dp); drop(); return SEXTANS_ERR_HIP; }
+    h->cluster_total_dict = dp.total_dict;
+    const bool gain = (double)dp.total_dict <= 0.85 * (double)h->plan_total_dict;
+    if (brc != 0 || dp.mixed || dp.dict_stride > 9 * RB || dp.max_dict > sx::kWideMaxDict || (h->opt_row_cluster < 0 && !gain)) {
+        sx::free_device_plan(dp); drop();
+        return SEXTANS_OK;
+    }
+    if (sx::build_slot_rows_device(dp.nblk, RB, dp.d_blk_row, d_perm, &h->d_slot_row, err)) {
+        g_last_error = err; sx::free_device_plan(dp); drop(); return SEXTANS_ERR_HIP;
+    }
+    (void)hipFree(d_perm);
+    sextans_engine::PanelState &c = h->psc;
+    c.plan_lpr = lpr;
+    c.plan_min_reuse = plan_key(h);
+    c.plan_nblk = dp.nblk;
+    c.plan_dict_stride = dp.dict_stride;
+    c.plan_mixed = false;
+    c.d_blk_row = dp.d_blk_row; c.d_dict_ptr = dp.d_dict_cnt; c.d_dict = dp.d_dict; c.d_row_off = dp.d_slot_info;
+    c.d_lidx = dp.d_idx16; c.d_pcol32 = dp.d_col32; c.d_pval = dp.d_val;
+    c.h_blk_row.swap(dp.h_blk_row);
+    c.plan_stream_len = dp.stream_len;
+    c.plan_panel_frac = h->ps.plan_panel_frac;
+    c.plan_narrow_frac = h->ps.plan_narrow_frac;
+    c.plan_nnz_panel = dp.nnz_in_panel_blocks;
+    c.plan_max_dict = dp.max_dict;
+    c.plan_max_row = dp.max_row_len;
+    c.plan_pad_row = cap;
+    c.plan_built = true;
+    h->cluster_state = 1;
     return SEXTANS_OK;
 }
 
@@ -581,7 +681,10 @@ int allow_big_lds(sextans_engine *h, const void *kern, int bytes) {
 template <int H>
 int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc,
                       int nsuper, float alpha, float beta, hipStream_t s, int64_t bcol_ld, int blk_begin, int blk_end,
-                      int row_base) {
+                      int row_base, bool clustered = false) {
+    // (clustered: the plan over the rows in brick order, whole-matrix calls only; its slot -> row table addresses C)
+    const sextans_engine::PanelState &P = clustered ? h->psc : h->ps;
+    const int *slot_row = clustered ? h->d_slot_row : nullptr;
     const int nblk = blk_end - blk_begin;
     if (nblk <= 0 || nsuper <= 0) return SEXTANS_OK;
     int tpw = (int)h->opt_tiles_per_wg;
@@ -595,10 +698,10 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     const size_t lds = (size_t)H * sx::kWideHalfBytes;
     auto go = [&](auto kern) -> int {
         if (int rc = allow_big_lds(h, reinterpret_cast<const void *>(kern), (int)lds)) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)h->ps.d_row_off,
-                           h->ps.d_lidx, h->ps.d_pval, h->ps.d_blk_row, h->ps.d_dict_ptr, h->ps.d_dict, h->ps.plan_dict_stride,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)P.d_row_off,
+                           P.d_lidx, P.d_pval, P.d_blk_row, P.d_dict_ptr, P.d_dict, P.plan_dict_stride,
                            dBp, pstride, dCin, ldc_in, dCout, ldc, nsuper, tpw, nblk, alpha, beta, (int)h->opt_xcd,
-                           h->ps.plan_pad_row, blk_begin, row_base, (const unsigned char *)h->d_skip, (long long *)h->d_dbg);
+                           P.plan_pad_row, blk_begin, row_base, (const unsigned char *)h->d_skip, (long long *)h->d_dbg, slot_row);
         return SEXTANS_OK;
     };
     // register-resident batches (16 entries each) per row: from the mean row length of the main matrix, so that matrices
@@ -608,7 +711,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     {   // ... corrected by the longest row: no more batches than any row has, and one more when that makes EVERY row
         // register-resident (nasa4704: mean 22, longest 42 -- a quarter of the wavefronts otherwise finish a row from the
         // stream, one L2 round trip per 16 entries, and their workgroup waits for them)
-        const int nb_max = std::max(1, (h->ps.plan_max_row + 15) / 16);
+        const int nb_max = std::max(1, (P.plan_max_row + 15) / 16);
         if (nb_max <= nb) nb = nb_max <= 2 ? 2 : nb_max <= 3 ? 3 : nb_max <= 4 ? 4 : 6;
         else if (nb == 2 && nb_max == 3) nb = 3;
     }
@@ -617,7 +720,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
         return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, false>) : go(sx::spmm_csr_panel_v2<H, 6, false, false>);
     } else {
         // small matrices staged from column-major B: dictionary capacity from the plan (5 x 64 covers nasa4704's 300)
-        const bool small_dict = bcol_ld > 0 && h->ps.plan_max_dict <= 5 * 64;
+        const bool small_dict = bcol_ld > 0 && P.plan_max_dict <= 5 * 64;
         if (h->opt_phase_timing && h->d_dbg && h->opt_exact) {   // diagnostic instantiations: the forms the dispatcher uses most
             if (small_dict && nb == 3 && h->opt_small_v2 != 0) return go(sx::spmm_csr_panel_v2<H, 3, true, true, true, 5>);
             if (bcol_ld > 0) return go(sx::spmm_csr_panel_v2<H, 2, true, true, true>);
@@ -794,6 +897,9 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "tiles_per_wg")) return &h->opt_tiles_per_wg;
     if (!strcmp(key, "panel_v2")) return &h->opt_panel_v2;
     if (!strcmp(key, "small_v2")) return &h->opt_small_v2;
+    if (!strcmp(key, "row_cluster")) return &h->opt_row_cluster;
+    if (!strcmp(key, "cluster_shape")) return &h->opt_cluster_shape;
+    if (!strcmp(key, "cluster_group")) return &h->opt_cluster_group;
     if (!strcmp(key, "window_rows")) return &h->opt_win_rows;
     if (!strcmp(key, "window_cols")) return &h->opt_win_cols;
     if (!strcmp(key, "window_unroll")) return &h->opt_win_unroll;
@@ -820,6 +926,13 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
     if ((slot == &h->opt_win_rows || slot == &h->opt_win_cols) && *slot != value) {
         (void)hipSetDevice(h->device);
         free_window(h);   // the stream is built for one (rows per wavefront, window) pair
+    }
+    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
+        (void)hipSetDevice(h->device);   // the clustered-order plan is (re)considered under the new setting
+        free_panel_state(h->psc);
+        (void)hipFree(h->d_slot_row);
+        h->d_slot_row = nullptr;
+        h->cluster_state = 0;
     }
     if (*slot != value) h->dist_cut_key.clear();   // chunk cuts are aligned to the packed forms the options select (all
                                                    // ranks of a partition must change options together: the cut
@@ -1261,6 +1374,9 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
     use_panel = false;
     if (h->opt_kernel != 1 && h->m_nnz > 0) {
         if (int rc = ensure_plan(h, lpr, h->opt_kernel == 2)) return rc;
+        // (here, not at launch time: prepare() runs before a hipGraph capture starts, and the builder copies to the host)
+        if (lpr == 4 && h->ps.plan_built)
+            if (int rc = ensure_cluster_plan(h)) return rc;
         use_panel = h->ps.plan_built && ((h->opt_kernel == 2) || (h->ps.plan_panel_frac >= 0.5 && (N >= 32 || h->ps.plan_narrow_frac >= 0.5)));
     }
     if (!h->opt_lpr && !use_panel && N >= 32 && lpr != 8) { lpr = 8; tiles(); }
@@ -1379,6 +1495,11 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "dense_tile_fraction")) *value = h->nnz > 0 ? (double)h->dense_nnz / (double)h->nnz : 0.0;
     else if (!strcmp(key, "dense_tiles_on_mfma")) *value = h->dense_W > 0 ? 1.0 : 0.0;
     else if (!strcmp(key, "bell_share")) *value = h->bell_share;
+    else if (!strcmp(key, "row_cluster")) *value = (double)h->cluster_state;          // 1 in use, -1 rejected, 0 not evaluated yet
+    else if (!strcmp(key, "grid_stride_line")) *value = (double)h->cluster_s2;
+    else if (!strcmp(key, "grid_stride_plane")) *value = (double)h->cluster_s3;
+    else if (!strcmp(key, "panel_rows_natural")) *value = (double)h->plan_total_dict;  // B rows copied into LDS per N tile, natural order
+    else if (!strcmp(key, "panel_rows_clustered")) *value = (double)h->cluster_total_dict;
     else if (!strcmp(key, "panel_fraction")) *value = h->ps.plan_panel_frac;
     else if (!strcmp(key, "panel_blocks")) *value = (double)h->ps.plan_nblk;
     else return SEXTANS_ERR_INVALID;
@@ -1631,7 +1752,10 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             // 128 registers together with a panel in registers)
             const bool short_rows = h->M > 0 && h->m_nnz / h->M + 8 <= 32;
             if (panel_here && g.width == 16 && !h->ps.plan_mixed && h->opt_panel_v2 != 0 && (!fuse_b || short_rows) && wide_ok) {
-                if (int rc = launch_panel_v2<1>(h, bsrc, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, bld, blk0, blk1, row_begin))
+                // whole-matrix calls on repacked panels: the plan over the rows in clustered (brick) order when the matrix has one
+                const bool clustered = whole && !fuse_b && h->cluster_state == 1;
+                if (int rc = launch_panel_v2<1>(h, bsrc, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, bld, clustered ? 0 : blk0,
+                                                clustered ? h->psc.plan_nblk : blk1, row_begin, clustered))
                     return rc;
                 v2_used = true;
                 if (hubs) launch_hub_pieces<4>(h, pt, bp, g.ntiles, g.col0, v0, v1, s);

@@ -26,6 +26,7 @@ struct DevicePlan {                   // device arrays in exactly the form the L
     int max_row_len = 0;              // longest row of the matrix the plan was built from
     bool mixed = false;
     int64_t nnz_in_panel_blocks = 0;
+    int64_t total_dict = 0;           // sum of the block dictionaries (B rows copied into LDS per N tile)
     std::vector<int> h_blk_row;
 };
 
@@ -33,6 +34,6 @@ struct DevicePlan {                   // device arrays in exactly the form the L
 int validate_csr_device(int M, int K, int64_t nnz, const int *d_rp, const int *d_ci, int *bad, std::string &err);
 void free_device_plan(DevicePlan &d);
 int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, const float *d_v, int lpr, int max_unique,
-                            double min_reuse, DevicePlan &out, std::string &err);
+                            double min_reuse, DevicePlan &out, std::string &err, const unsigned char *d_cut = nullptr);
 
 }  // namespace sx

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void plan_row_off(const int *__restrict__ rp, 
 // ---- pass B: block formation, one workgroup per part
 __global__ __launch_bounds__(256) void plan_blocks(const int *__restrict__ rp, const int *__restrict__ ci, int M, int PR, int RB,
                                                    int cap, double min_reuse, int *__restrict__ pb_row, int *__restrict__ pb_cnt,
-                                                   int *__restrict__ part_nblk) {
+                                                   int *__restrict__ part_nblk, const unsigned char *__restrict__ cut) {
+    // cut (may be null): rows at which a block MUST start (brick boundaries of the clustered row order, row_cluster.hip)
     __shared__ int keys[kHT], stamp[kHT];
     __shared__ int s_count;
     const int tid = threadIdx.x;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void plan_blocks(const int *__restrict__ rp, c
         __syncthreads();
         int e = r, uniq = 0;
         bool fits = true;
-        while (e < part_end && e - r < RB) {
+        while (e < part_end && e - r < RB && !(cut && e > r && cut[e])) {
             const int before = uniq;
             bool over = false;
             const int j1 = rp[e + 1];
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void plan_blocks(const int *__restrict__ rp, c
         const long long n = (long long)rp[e] - rp[r];
         // (a block cut short by the end of its part is judged by fit alone: a one-row remnant has no reuse of its own,
         // and a single direct block would push the whole matrix onto the slower mixed kernel instantiation)
-        const bool remnant = e == part_end && e - r < RB;
+        const bool remnant = (e == part_end || (cut && e < part_end && cut[e])) && e - r < RB;   // (a forced cut counts as one)
         const bool use_dict = fits && uniq > 0 && ((double)n >= min_reuse * (double)uniq || remnant);
         if (tid == 0) { pb_row[(long long)p * PR + nb] = r; pb_cnt[(long long)p * PR + nb] = use_dict ? uniq : 0; }
         ++nb;
@@ -135,11 +136,11 @@ __global__ __launch_bounds__(256) void plan_compact(const int *__restrict__ rp, 
                                                     const int *__restrict__ pb_cnt, const int *__restrict__ part_nblk,
                                                     const int *__restrict__ part_blk_base, int nblk, int *__restrict__ blk_row,
                                                     int *__restrict__ dict_cnt, int *stats /* max_dict, mixed, longest row */,
-                                                    unsigned long long *nnz_panel) {
+                                                    unsigned long long *nnz_panel /* [0] covered non-zeros, [1] sum of the dictionaries */) {
     const int p = blockIdx.x;
     const int nb = part_nblk[p], base = part_blk_base[p];
     int mx = 0, mixed = 0;
-    unsigned long long covered = 0;
+    unsigned long long covered = 0, dsum = 0;
     for (int i = threadIdx.x; i < nb; i += 256) {
         const int r0 = pb_row[(long long)p * PR + i];
         const int r1 = i + 1 < nb ? pb_row[(long long)p * PR + i + 1] : min(M, (p + 1) * PR);
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void plan_compact(const int *__restrict__ rp, 
         dict_cnt[base + i] = c;
         const long long n = (long long)rp[r1] - rp[r0];
         mx = max(mx, c);
+        dsum += (unsigned long long)c;
         if (c > 0) covered += (unsigned long long)n;
         else if (n > 0) mixed = 1;
     }
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(256) void plan_compact(const int *__restrict__ rp, 
     if (mx) atomicMax(&stats[0], mx);
     if (mixed) atomicOr(&stats[1], 1);
     if (covered) atomicAdd(nnz_panel, covered);
+    if (dsum) atomicAdd(nnz_panel + 1, dsum);
 }
 
 // ---- pass C: one workgroup per block
@@ -292,7 +295,7 @@ void free_device_plan(DevicePlan &d) {
 // 0 = built; 1 = not representable (padded stream exceeds 32-bit entry offsets): caller keeps the row-group kernel;
 // 2 = HIP error (err set)
 int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, const float *d_v, int lpr, int max_unique,
-                            double min_reuse, DevicePlan &out, std::string &err) {
+                            double min_reuse, DevicePlan &out, std::string &err, const unsigned char *d_cut) {
     (void)K;
     free_device_plan(out);
     const int RB = 256 / lpr;
@@ -342,7 +345,7 @@ int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, cons
     PD_HIP(tmp.alloc(&d_part_nblk, (size_t)nparts));
     PD_HIP(tmp.alloc(&d_part_blk_base, (size_t)nparts));
     hipLaunchKernelGGL(plan_blocks, dim3((unsigned)nparts), dim3(256), 0, nullptr, d_rp, d_ci, M, PR, RB, max_unique, min_reuse,
-                       d_pb_row, d_pb_cnt, d_part_nblk);
+                       d_pb_row, d_pb_cnt, d_part_nblk, d_cut);
     std::vector<int> h_nblk((size_t)nparts), h_bbase((size_t)nparts);
     PD_HIP(hipMemcpy(h_nblk.data(), d_part_nblk, sizeof(int) * (size_t)nparts, hipMemcpyDeviceToHost));
     long long nblk = 0;
@@ -352,21 +355,22 @@ int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, cons
     int *d_stats = nullptr;
     unsigned long long *d_cov = nullptr;
     PD_HIP(tmp.alloc(&d_stats, 3));
-    PD_HIP(tmp.alloc(&d_cov, 1));
+    PD_HIP(tmp.alloc(&d_cov, 2));
     PD_HIP(hipMemset(d_stats, 0, 3 * sizeof(int)));
-    PD_HIP(hipMemset(d_cov, 0, sizeof(unsigned long long)));
+    PD_HIP(hipMemset(d_cov, 0, 2 * sizeof(unsigned long long)));
     PD_HIP(hipMalloc((void **)&out.d_blk_row, sizeof(int) * ((size_t)nblk + 1)));
     PD_HIP(hipMalloc((void **)&out.d_dict_cnt, sizeof(int) * (size_t)nblk));
     hipLaunchKernelGGL(plan_compact, dim3((unsigned)nparts), dim3(256), 0, nullptr, d_rp, M, PR, d_pb_row, d_pb_cnt, d_part_nblk,
                        d_part_blk_base, (int)nblk, out.d_blk_row, out.d_dict_cnt, d_stats, d_cov);
     int h_stats[3] = {0, 0, 0};
-    unsigned long long h_cov = 0;
+    unsigned long long h_cov[2] = {0, 0};
     PD_HIP(hipMemcpy(h_stats, d_stats, sizeof h_stats, hipMemcpyDeviceToHost));
-    PD_HIP(hipMemcpy(&h_cov, d_cov, sizeof h_cov, hipMemcpyDeviceToHost));
+    PD_HIP(hipMemcpy(h_cov, d_cov, sizeof h_cov, hipMemcpyDeviceToHost));
     out.max_dict = h_stats[0];
     out.mixed = h_stats[1] != 0;
     out.max_row_len = h_stats[2];
-    out.nnz_in_panel_blocks = (int64_t)h_cov;
+    out.nnz_in_panel_blocks = (int64_t)h_cov[0];
+    out.total_dict = (int64_t)h_cov[1];
     out.h_blk_row.resize((size_t)nblk + 1);
     PD_HIP(hipMemcpy(out.h_blk_row.data(), out.d_blk_row, sizeof(int) * ((size_t)nblk + 1), hipMemcpyDeviceToHost));
     // ---- pass C

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
     const int *__restrict__ blk_row, const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
     const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc,
     int nsuper, int tpw, int nblk, float alpha, float beta, int use_xcd_remap, int pad_row, int blk_begin, int row_base,
-    const unsigned char *__restrict__ skip, long long *dbg) {
+    const unsigned char *__restrict__ skip, long long *dbg, const int *__restrict__ slot_row) {
     long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, w0 = 0;
     if constexpr (TIMED) { t0 = clock64(); w0 = wall_clock64(); }
     constexpr int LPR = 4;
@@ -170,7 +170,9 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
     const unsigned short *pi = p_idx16 + wbase;
     const unsigned loff = (len > 0 ? (unsigned)(si.x - wbase) : 0u) + 4u * (unsigned)q;
     // C: this lane's row (clamped for the loads) and whether it is written
-    const int myrow = min(row0 + slot, row1 - 1);
+    // (slot_row: the plan walks the rows in clustered order -- row_cluster.hip -- and this table, at an address that depends on the
+    // block number only, says which row of the matrix a slot is; without it blocks are runs of consecutive rows)
+    const int myrow = slot_row ? slot_row[(int64_t)blk * RB + slot] : min(row0 + slot, row1 - 1);
     const unsigned coff = (unsigned)(myrow - row_base);
     const bool cwrite = row0 + slot < row1 && !(skip && skip[myrow]);
     const char *pq = lds + 16 * q;

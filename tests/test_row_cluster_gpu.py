@@ -1,0 +1,138 @@
+"""Clustered-order plan (csrc/row_cluster.hip, engine option row_cluster): for matrices with grid-stencil structure the LDS-panel plan
+visits the rows brick by brick (a run of <= 16 rows of a grid line x 2 lines x 2 planes), so that a 64-row block needs ~30 % fewer B
+rows in its panel.  Rows are independent: every sum keeps its order, results stay bit-identical to cpu_spmm_CSR.  Row-range calls,
+8-column tiles and column-major staging keep the natural-order plan."""
+import numpy as np
+import pytest
+
+from util import ALPHA, BETA, random_csr
+
+pytestmark = pytest.mark.gpu
+
+OPTS = dict(lanes_per_row=0, kernel=0, fuse_b=0, panel_v2=-1, cols_per_lane=0, tiles_per_wg=0, split_rows=0, bucket_rows=-1,
+            panel_min_reuse_x100=200, panel_min_reuse_wide_x100=150, row_cluster=-1, cluster_group=3, cluster_shape=0)
+
+
+def _set(engine, **kw):
+    d = dict(OPTS)
+    d.update(kw)
+    for k, v in d.items():
+        engine.set_option(k, v)
+
+
+def _cases():
+    from sextans_amd import api
+    yield "fem 3 dof", api.gen_fem3d_host(16, 15, 14, 3, 7), 16 * 15 * 14 * 3, (48, 720)
+    yield "fem 1 dof", api.gen_fem3d_host(30, 28, 26, 1, 7), 30 * 28 * 26, (30, 840)
+    yield "2-D 9-point, 2 dof", api.gen_stencil2d_host(120, 110, 9, 2, 3), 120 * 110 * 2, (240, 0)
+    yield "2-D 5-point", api.gen_stencil2d_host(130, 90, 5, 1, 3), 130 * 90, (130, 0)
+
+
+@pytest.mark.parametrize("N", [16, 40, 128])
+def test_clustered_plan_is_bit_identical_and_smaller(engine, oracle, N):
+    for name, (rp, ci, v), M, strides in _cases():
+        K = M
+        rs = np.random.RandomState(N)
+        B = rs.uniform(-1, 1, K * N).astype(np.float32)
+        C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+        want = C0.copy()
+        oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+        try:
+            for rc in (1, -1, 0):
+                _set(engine, row_cluster=rc)
+                engine.set_matrix_csr(M, K, rp, ci, v)
+                for rp_time in (1, 4):                      # (4: the hipGraph replay of the repeat loop)
+                    out = C0.copy()
+                    engine.spmm(N, ALPHA, B, BETA, out, rp_time=rp_time)
+                    assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (name, N, rc, rp_time, engine.last_kernel())
+                if engine.last_kernel().startswith("spmm_csr_panel"):      # (the 5-point stencil at N = 16 stays on the gather kernel)
+                    state = int(engine.get_stat("row_cluster"))
+                    if rc == 0:
+                        assert state == -1
+                    else:
+                        assert (int(engine.get_stat("grid_stride_line")), int(engine.get_stat("grid_stride_plane"))) == strides, name
+                        nat, clu = engine.get_stat("panel_rows_natural"), engine.get_stat("panel_rows_clustered")
+                        assert clu < 0.85 * nat, (name, nat, clu)
+                        assert state == 1
+        finally:
+            _set(engine)
+
+
+def test_no_structure_no_clustering(engine, oracle, sx):
+    """Random columns inside a band (reuse, but no grid strides) and a KKT system (different stencils per section): the detector
+    declines, the natural-order plan runs, same bits."""
+    from sextans_amd import api
+    rs = np.random.RandomState(3)
+    cases = []
+    M = 6000
+    rp, ci, v = random_csr(rs, M, M, 12)
+    band = np.clip(np.repeat(np.arange(M), np.diff(rp)) + rs.randint(-40, 41, size=len(ci)), 0, M - 1).astype(np.int32)
+    order = np.lexsort((band, np.repeat(np.arange(M), np.diff(rp))))
+    cases.append(("banded random", rp, band[order], v[order], M))
+    n = 3000
+    krp, kci, kv = api.gen_kkt_host(n, 2, 3)
+    cases.append(("kkt", krp, kci, kv, api.kkt_rows(n, 2)))
+    try:
+        for name, rp, ci, v, M in cases:
+            _set(engine, row_cluster=1, kernel=2)
+            engine.set_matrix_csr(M, M, rp, ci, v)
+            N = 32
+            B = rs.uniform(-1, 1, M * N).astype(np.float32)
+            C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+            want = C0.copy()
+            oracle.spmm(M, N, M, ALPHA, rp, ci, v, B, BETA, want)
+            out = C0.copy()
+            engine.spmm(N, ALPHA, B, BETA, out)
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), name
+            assert int(engine.get_stat("row_cluster")) == -1, name
+    finally:
+        _set(engine)
+
+
+def test_row_ranges_and_long_rows_with_a_clustered_plan(engine, oracle):
+    """Whole-matrix calls use the clustered plan, row-range calls (the chunks of the multi-GPU pipeline) the natural one; rows that
+    leave the main matrix (long rows -> piece path / exact chains) are skipped through the slot -> row table.  All bit-identical."""
+    import torch
+    from sextans_amd import api
+    rp, ci, v = api.gen_fem3d_host(16, 15, 14, 3, 7)
+    M = K = 16 * 15 * 14 * 3
+    # make a few rows long (they leave the main matrix): append random extra entries to rows 100, 2000, 9000
+    rs = np.random.RandomState(5)
+    rows = np.repeat(np.arange(M), np.diff(rp))
+    extra_r, extra_c, extra_v = [], [], []
+    for r, n in ((100, 700), (2000, 1500), (9000, 2600)):
+        cols = np.setdiff1d(rs.choice(K, size=n, replace=False), ci[rp[r]:rp[r + 1]])
+        extra_r.append(np.full(len(cols), r)); extra_c.append(cols); extra_v.append(rs.uniform(-1, 1, len(cols)))
+    rows = np.concatenate([rows] + extra_r); cols = np.concatenate([ci] + extra_c); vals = np.concatenate([v] + extra_v).astype(np.float32)
+    order = np.lexsort((cols, rows))
+    rows, ci2, v2 = rows[order], cols[order].astype(np.int32), vals[order]
+    rp2 = np.zeros(M + 1, dtype=np.int32); np.add.at(rp2, rows + 1, 1); rp2 = np.cumsum(rp2).astype(np.int32)
+    N = 32
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp2, ci2, v2, B, BETA, want)
+    try:
+        _set(engine, row_cluster=1)
+        engine.set_matrix_csr(M, K, rp2, ci2, v2)
+        out = C0.copy()
+        engine.spmm(N, ALPHA, B, BETA, out)
+        assert engine.get_stat("piece_path_rows") >= 3 and int(engine.get_stat("row_cluster")) == 1
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+        st = torch.cuda.current_stream().cuda_stream
+        dB = torch.from_numpy(B).cuda(); dCin = torch.from_numpy(C0).cuda()
+        got = torch.full((M * N,), float("nan"), device="cuda")
+        cuts = [0, engine.align_row(N, 3000), engine.align_row(N, 7000), M]
+        for i in range(3):
+            c0, c1 = cuts[i], cuts[i + 1]
+            slab = torch.full(((c1 - c0) * N,), float("nan"), device="cuda")
+            engine.spmm_device_rows(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr() + 4 * c0, M, slab.data_ptr(), c1 - c0, c0, c1,
+                                    reuse_b_panels=i > 0, stream=st)
+            got.view(N, M)[:, c0:c1] = slab.view(N, c1 - c0)
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        out = C0.copy()                                   # and a whole-matrix call again
+        engine.spmm(N, ALPHA, B, BETA, out)
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    finally:
+        _set(engine)

@@ -1,13 +1,19 @@
-"""Option sets compared on ONE box, round-robin: tools/ab_opts.py <fem dims AxBxCxD> <N> <iters> "k=v,k=v" "k=v" ...  (kernel us per launch)"""
+"""Option sets compared on ONE box, round-robin: tools/ab_opts.py <fem dims AxBxCxD | synth:spec> <N> <iters> "k=v,k=v" "k=v" ...  (kernel us per launch)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from sextans_amd import api
-dims = [int(x) for x in sys.argv[1].split("x")]; N = int(sys.argv[2]); iters = int(sys.argv[3])
+N = int(sys.argv[2]); iters = int(sys.argv[3])
 sets = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.split(",") if kv) for a in sys.argv[4:]]
-M = K = dims[0] * dims[1] * dims[2] * dims[3]
-p = api.gen_fem3d_device(0, *dims, 3)
+if sys.argv[1].startswith("synth:"):
+    from sextans_amd import sweep
+    M, K, p0, p1, p2, nnz = sweep._synth(sys.argv[1], 0)
+    p = (p0, p1, p2, nnz)
+else:
+    dims = [int(x) for x in sys.argv[1].split("x")]
+    M = K = dims[0] * dims[1] * dims[2] * dims[3]
+    p = api.gen_fem3d_device(0, *dims, 3)
 st = torch.cuda.current_stream().cuda_stream
 B = torch.empty(K * N, device="cuda"); Cin = torch.empty(M * N, device="cuda"); Cout = torch.empty(M * N, device="cuda")
 api.gen_uniform_device(0, B.data_ptr(), K * N, 41, st); api.gen_uniform_device(0, Cin.data_ptr(), M * N, 42, st)
