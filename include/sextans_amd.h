@@ -254,6 +254,13 @@ int sextans_destroy(sextans_handle_t h);
  * N >= 32, default 150: with more columns per B row the panel pays earlier; the packed plan is built once, for the lower
  * of the two), "panel_v2" (-1 auto / 0 / 1: the register-resident form of the panel
  * kernel, spmm_csr_panel_v2), "tiles_per_wg" (N tiles one workgroup of that kernel walks; 0 = auto),
+ * "row_cluster" (-1 auto / 0 never / 1 whenever the structure is found: for matrices with Cartesian-grid stencil structure in
+ * natural ordering -- strides inferred from the column offsets of sampled rows -- the LDS-panel plan visits the rows brick by brick
+ * instead of in runs of consecutive rows, so that a 64-row block needs ~30 % fewer B rows in its panel; rows are
+ * independent, every sum keeps its order: bit-identical.  Auto uses it when the clustered plan copies >= 15 % fewer B rows;
+ * whole-matrix calls of spmm_csr_panel_v2 only, row-range calls keep the natural-order plan.  "cluster_group" (default 3) /
+ * "cluster_shape" (0 = default bricks): layout tunables of that order, for measurements; stats "row_cluster" (1 in use, -1
+ * declined), "grid_stride_line", "grid_stride_plane", "panel_rows_natural", "panel_rows_clustered"),
  * "small_v2" (default 1: small matrices staged from column-major B size the launch's dictionary capacity and register-resident
  * batches from the plan; 0 = the full-capacity form, for measurements),
  * "cols_per_lane" (0/4 = 16-column tiles at 4 workgroups per CU, the default; 8 = 32-column super tiles at 2 per CU),
