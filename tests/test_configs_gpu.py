@@ -51,6 +51,38 @@ def test_config3_pcrystk02_standin_n128(engine, oracle, kernel, lpr):
     _set(engine)
 
 
+@pytest.mark.parametrize("row_cluster", [-1, 1, 0])
+@pytest.mark.parametrize("tiles_per_wg", [0, 1, 3])
+def test_config3_standin_on_the_round3_kernel_forms(engine, oracle, row_cluster, tiles_per_wg):
+    """The same matrix through the round-3 instantiations: spmm_csr_panel_v2 on repacked panels (fuse_b = 0) with every way of
+    walking the 8 N tiles, natural-order and clustered-order plans, plus the hipGraph repeat loop.  Bit-identical to cpu_spmm_CSR."""
+    from sextans_amd import api
+    rp, ci, v = api.gen_fem3d_host(35, 19, 7, 3, 2)
+    M = K = 35 * 19 * 7 * 3
+    N = 128
+    rs = np.random.RandomState(4)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    try:
+        _set(engine, kernel=0, lanes_per_row=0, fuse_b=0)
+        engine.set_option("row_cluster", row_cluster)
+        engine.set_option("tiles_per_wg", tiles_per_wg)
+        engine.set_matrix_csr(M, K, rp, ci, v)
+        for rp_time in (1, 5):
+            out = C0.copy()
+            engine.spmm(N, ALPHA, B, BETA, out, rp_time=rp_time)
+            assert engine.last_kernel() == "spmm_csr_panel_v2"
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (row_cluster, tiles_per_wg, rp_time)
+        if row_cluster == 1:
+            assert (int(engine.get_stat("grid_stride_line")), int(engine.get_stat("grid_stride_plane"))) == (105, 1995)
+    finally:
+        engine.set_option("row_cluster", -1)
+        engine.set_option("tiles_per_wg", 0)
+        _set(engine)
+
+
 @pytest.mark.parametrize("kernel", [0, 3])
 def test_config4_full_size(engine, oracle, kernel):
     """kernel 0 = what the dispatcher picks for this matrix (the gather kernel: no B-row reuse), 3 = the
