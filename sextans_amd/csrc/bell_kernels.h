@@ -479,16 +479,33 @@ __global__ __launch_bounds__(kShThreads, 2) void spmm_bell_mfma_shared(
 }
 
 // Sharing factor of a blocked-ELL matrix: sum over groups of kShRows block rows of |union of their block columns|
-// (one thread per group; the rows are sorted ascending with -1 = empty: a k-way merge).
+// (one thread per group; rows sorted strictly ascending with -1 = empty: a k-way merge; anything else sets *irregular).
 __global__ __launch_bounds__(256) void bell_union_count(const int *__restrict__ block_col, int mblocks, int ell_width,
                                                         unsigned long long *total_union, unsigned long long *total_blocks,
-                                                        unsigned long long *max_union) {
+                                                        unsigned long long *max_union, unsigned long long *irregular) {
     const int g = blockIdx.x * 256 + threadIdx.x;
     const int br0 = g * kShRows;
     if (br0 >= mblocks) return;
     int pos[kShRows];
 #pragma unroll
     for (int r = 0; r < kShRows; ++r) pos[r] = 0;
+    // The union walk (and spmm_bell_mfma_shared, which keeps ONE ELL slot per (block row, union position)) needs every block row's
+    // block columns strictly ascending.  sextans_set_matrix_bell* does not demand that -- the per-wavefront kernels sum duplicate
+    // and unsorted slots like any others -- so a row that lists a column twice or out of order marks the matrix irregular and the
+    // engine keeps it off the shared kernel.
+    for (int r = 0; r < kShRows; ++r) {
+        if (br0 + r >= mblocks) continue;
+        const int *row = block_col + (int64_t)(br0 + r) * ell_width;
+        int prev = -1;
+        bool bad = false;
+        for (int i = 0; i < ell_width; ++i) {
+            const int c = row[i];
+            if (c < 0) continue;
+            bad |= c <= prev;
+            prev = c;
+        }
+        if (bad) { atomicMax(irregular, 1ull); return; }
+    }
     unsigned long long uni = 0, blocks = 0;
     while (true) {
         int best = 0x7fffffff;

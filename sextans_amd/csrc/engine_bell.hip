@@ -1,0 +1,335 @@
+// engine_bell.hip -- the matrix-core side of the engine: blocked-ELL bf16 SpMM (BASELINE config 5, bell_kernels.h) and
+// "MFMA only where a tile is actually dense" (ensure_dense: 32x32 tiles of a CSR matrix cut out into a blocked-ELL side matrix).
+// No analogue in the reference (scalar fp32 PEs): parity unpinned by it, see DESIGN.md 4.5 / 4.7.
+#include <algorithm>
+#include <cstring>
+
+#include "bell_kernels.h"
+#include "engine_state.h"
+
+namespace sxe {
+
+void free_bell(sextans_engine *h) {
+    (void)hipFree(h->d_bell_col_owned); (void)hipFree(h->d_bell_Af);
+    h->d_bell_col_owned = nullptr; h->d_bell_col = nullptr; h->d_bell_Af = nullptr;
+    h->bell_M = h->bell_K = h->bell_W = 0;
+}
+
+// "MFMA only where a tile is actually dense" (north_star).  Counts the 32x32 tiles of the main matrix whose fill
+// reaches the threshold (always: get_stat "dense_tile_fraction" = share of the non-zeros sitting in such tiles) and,
+// when the caller has opted into bf16 for them ("mfma_dense_tiles" = 1), cuts them out of the main matrix into a
+// blocked-ELL bf16 side matrix for spmm_bell_mfma; the CSR kernels keep the remainder in fp32.  Only full 32-row
+// block rows are searched; at most 256 dense tiles per block row (the densest columns first come first served).
+int ensure_dense(sextans_engine *h) {
+    if (h->dense_built_mfma == h->opt_mfma_dense && h->dense_built_fill == h->opt_dense_fill_x100) return SEXTANS_OK;
+    if (h->dense_W > 0 || h->opt_mfma_dense) {   // the source matrix may change: everything downstream starts again
+        free_plan(h);
+        free_window(h);
+    }
+    const bool had_tiles = h->dense_W > 0;
+    if (had_tiles || h->opt_mfma_dense) free_dense(h);
+    else { h->dense_tiles = h->dense_nnz = 0; }
+    h->dense_built_mfma = h->opt_mfma_dense;
+    h->dense_built_fill = h->opt_dense_fill_x100;
+    const int mb = h->M / 32;
+    if (mb == 0 || h->nnz == 0) return SEXTANS_OK;
+    const int64_t thr = std::max<int64_t>(1, (h->opt_dense_fill_x100 * 1024 + 99) / 100);
+    if (h->nnz < thr) return SEXTANS_OK;
+    PlanTimer timer(h);
+    std::vector<int> rp, ci;
+    std::vector<float> va;
+    if (int rc = read_back_row_ptr(h, rp, 0)) return rc;
+    {   // cheap exit: a block row with fewer than `thr` entries cannot hold a dense tile
+        bool any = false;
+        for (int br = 0; br < mb && !any; ++br) any = (int64_t)rp[(size_t)br * 32 + 32] - rp[(size_t)br * 32] >= thr;
+        if (!any) return SEXTANS_OK;
+    }
+    if (!h->opt_mfma_dense) {
+        // report only: estimate from a sample of block rows (a few small copies instead of reading the matrix back)
+        const int nsample = std::min(mb, 512);
+        int64_t tot = 0, in_dense = 0, tiles = 0;
+        std::vector<int> cols;
+        for (int sidx = 0; sidx < nsample; ++sidx) {
+            const int br = (int)((int64_t)sidx * mb / nsample);
+            const int j0 = rp[(size_t)br * 32], j1 = rp[(size_t)br * 32 + 32];
+            tot += j1 - j0;
+            if (j1 - j0 < thr) continue;
+            cols.resize((size_t)(j1 - j0));
+            SX_HIP(hipMemcpy(cols.data(), h->d_ci + j0, sizeof(int) * cols.size(), hipMemcpyDeviceToHost));
+            for (int &c : cols) {
+                if ((unsigned)c >= (unsigned)h->K) return SEXTANS_ERR_INDEX;
+                c >>= 5;
+            }
+            std::sort(cols.begin(), cols.end());
+            for (size_t a = 0; a < cols.size();) {
+                size_t b = a;
+                while (b < cols.size() && cols[b] == cols[a]) ++b;
+                if ((int64_t)(b - a) >= thr) { in_dense += (int64_t)(b - a); ++tiles; }
+                a = b;
+            }
+        }
+        // scaled to the whole matrix
+        h->dense_nnz = tot ? (int64_t)((double)in_dense / (double)tot * (double)h->nnz) : 0;
+        h->dense_tiles = (int64_t)((double)tiles * (double)mb / (double)nsample);
+        return SEXTANS_OK;
+    }
+    if (int rc = read_back_entries(h, ci, va, 0)) return rc;
+    // pass 1: dense tile columns per block row
+    std::vector<std::vector<int>> dense((size_t)mb);
+    std::vector<int> cols;
+    int W = 0;
+    for (int br = 0; br < mb; ++br) {
+        const int j0 = rp[(size_t)br * 32], j1 = rp[(size_t)br * 32 + 32];
+        if (j1 - j0 < thr) continue;
+        cols.assign(ci.begin() + j0, ci.begin() + j1);
+        for (int &c : cols) c >>= 5;
+        std::sort(cols.begin(), cols.end());
+        for (size_t a = 0; a < cols.size();) {
+            size_t b = a;
+            while (b < cols.size() && cols[b] == cols[a]) ++b;
+            if ((int64_t)(b - a) >= thr && dense[(size_t)br].size() < 256) {
+                dense[(size_t)br].push_back(cols[a]);
+                h->dense_nnz += (int64_t)(b - a);
+            }
+            a = b;
+        }
+        h->dense_tiles += (int64_t)dense[(size_t)br].size();
+        W = std::max(W, (int)dense[(size_t)br].size());
+    }
+    if (W == 0) return SEXTANS_OK;   // nothing to route
+    // The device form is blocked-ELL (mb x W slots of 2 KiB): one crowded block row sets W for all of them, so bound
+    // the padded size; a matrix that would need more keeps its dense tiles on the fp32 kernels (reported, not routed).
+    if ((int64_t)mb * W * 2048 > ((int64_t)8 << 30)) {
+        g_last_error = "mfma_dense_tiles: blocked-ELL form of the dense tiles would exceed 8 GiB; tiles stay on the fp32 kernels";
+        return SEXTANS_OK;
+    }
+    // pass 2: tile values, stored COMPACTLY on the host (one 32x32 fp32 tile per dense tile, not per ELL slot: fp32 sums
+    // of duplicates, rounded to bf16 once) + the remainder as the new main matrix
+    std::vector<int64_t> tile0((size_t)mb + 1, 0);   // first compact tile of every block row
+    for (int br = 0; br < mb; ++br) tile0[(size_t)br + 1] = tile0[(size_t)br] + (int64_t)dense[(size_t)br].size();
+    std::vector<int> bcol((size_t)mb * W, -1);
+    std::vector<float> blk((size_t)tile0[(size_t)mb] * 1024, 0.0f);
+    std::vector<int> mrp((size_t)h->M + 1, 0);
+    size_t w = 0;
+    for (int r = 0; r < h->M; ++r) {
+        const int br = r >> 5;
+        const std::vector<int> *d = br < mb ? &dense[(size_t)br] : nullptr;
+        for (int j = rp[(size_t)r]; j < rp[(size_t)r + 1]; ++j) {
+            int slot = -1;
+            if (d && !d->empty()) {
+                const auto it = std::lower_bound(d->begin(), d->end(), ci[(size_t)j] >> 5);
+                if (it != d->end() && *it == (ci[(size_t)j] >> 5)) slot = (int)(it - d->begin());
+            }
+            if (slot >= 0) {
+                blk[(((size_t)tile0[(size_t)br] + (size_t)slot) * 32 + (size_t)(r & 31)) * 32 + (size_t)(ci[(size_t)j] & 31)] += va[(size_t)j];
+            } else {
+                ci[w] = ci[(size_t)j]; va[w] = va[(size_t)j]; ++w;
+            }
+        }
+        mrp[(size_t)r + 1] = (int)w;
+    }
+    for (int br = 0; br < mb; ++br)
+        for (size_t sl = 0; sl < dense[(size_t)br].size(); ++sl) bcol[(size_t)br * W + sl] = dense[(size_t)br][sl];
+    std::vector<uint16_t> bval((size_t)mb * W * 1024, 0);   // ELL slots without a tile stay +0.0
+    for (int br = 0; br < mb; ++br)
+        for (size_t sl = 0; sl < dense[(size_t)br].size(); ++sl) {
+            const float *src = blk.data() + ((size_t)tile0[(size_t)br] + sl) * 1024;
+            uint16_t *dst = bval.data() + ((size_t)br * W + sl) * 1024;
+            for (int i = 0; i < 1024; ++i) {
+                uint32_t u;
+                memcpy(&u, &src[i], 4);
+                if ((u & 0x7fffffffu) > 0x7f800000u) { dst[i] = (uint16_t)((u >> 16) | 0x40u); continue; }
+                u += 0x7fffu + ((u >> 16) & 1u);
+                dst[i] = (uint16_t)(u >> 16);
+            }
+        }
+    std::vector<float>().swap(blk);
+    ci.resize(w ? w : 1); va.resize(w ? w : 1);
+    // the remainder becomes the source matrix of the long-row split (which has not run yet for this source)
+    if (int rc = upload(&h->d_srp, mrp)) return rc;
+    if (int rc = upload(&h->d_sci, ci)) return rc;
+    if (int rc = upload(&h->d_sv, va)) return rc;
+    h->s_rp = h->d_srp; h->s_ci = h->d_sci; h->s_v = h->d_sv; h->s_nnz = (int64_t)w;
+    h->m_rp = h->s_rp; h->m_ci = h->s_ci; h->m_v = h->s_v; h->m_nnz = h->s_nnz;
+    if (int rc = upload(&h->d_dense_col, bcol)) return rc;
+    uint16_t *d_val = nullptr;
+    SX_HIP(hipMalloc((void **)&d_val, bval.size() * 2));
+    SX_HIP(hipMemcpy(d_val, bval.data(), bval.size() * 2, hipMemcpyHostToDevice));
+    const int64_t nslots = (int64_t)mb * W;
+    SX_HIP(hipMalloc(&h->d_dense_Af, (size_t)nslots * 2048));
+    hipLaunchKernelGGL(sx::bell_repack_a, dim3((unsigned)((nslots * 128 + 255) / 256)), dim3(256), 0, nullptr, d_val,
+                       (sx::u32x4 *)h->d_dense_Af, nslots);
+    SX_HIP(hipDeviceSynchronize());
+    (void)hipFree(d_val);
+    h->dense_mb = mb;
+    h->dense_W = W;
+    {   // do neighbouring block rows share tile columns (block-diagonal / banded dense structure)?  Then N = 256 runs the
+        // LDS-shared MFMA kernel
+        unsigned long long *d_cnt = nullptr, h_cnt[4] = {0, 0, 0, 0};
+        SX_HIP(hipMalloc((void **)&d_cnt, 4 * sizeof(unsigned long long)));
+        SX_HIP(hipMemset(d_cnt, 0, 4 * sizeof(unsigned long long)));
+        const int groups = (mb + sx::kShRows - 1) / sx::kShRows;
+        hipLaunchKernelGGL(sx::bell_union_count, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, nullptr, h->d_dense_col, mb, W,
+                           d_cnt, d_cnt + 1, d_cnt + 2, d_cnt + 3);
+        const hipError_t e = hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost);
+        (void)hipFree(d_cnt);
+        SX_HIP(e);
+        h->dense_share = h_cnt[0] ? (double)h_cnt[1] / (double)h_cnt[0] : 0.0;
+        h->dense_max_union = h_cnt[3] ? 0x7fffffff : (int)h_cnt[2];
+    }
+    return SEXTANS_OK;
+}
+
+int launch_dense_tiles(sextans_engine *h, int N, float alpha, const float *d_B, int64_t ldb, float beta, const float *d_C_in,
+                       int64_t ldc_in, float *d_C_out, int64_t ldc, hipStream_t s) {
+        const int kblocks = (h->K + 31) / 32, ntiles = N / 32;
+        const int64_t threads = (int64_t)kblocks * ntiles * 128;
+        hipLaunchKernelGGL(sx::bell_repack_b_f32, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_B, ldb, h->K,
+                           (sx::u32x4 *)h->d_bell_Bf, kblocks, ntiles);
+        const auto *Af = (const sx::bf16x8 *)h->d_dense_Af;
+        const auto *Bf = (const sx::bf16x8 *)h->d_bell_Bf;
+#define SX_BELL(NSUB)                                                                                               \
+    {                                                                                                               \
+        const int64_t waves = (int64_t)h->dense_mb * (ntiles / NSUB);                                               \
+        hipLaunchKernelGGL((sx::spmm_bell_mfma<NSUB>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, h->d_dense_col, \
+                           Af, Bf, d_C_in, ldc_in, d_C_out, ldc, h->dense_mb, h->dense_W, ntiles, alpha, beta);            \
+    }
+        const bool shared = ntiles == 8 && h->opt_bell_shared != 0 && sx::kShRows * h->dense_W <= sx::kShMaxRowCols &&
+                            h->dense_max_union <= sx::kShMaxUnion && (h->opt_bell_shared == 1 || h->dense_share >= 1.5);
+        if (shared) {
+            constexpr size_t lds = (size_t)sx::kShRing * sx::kShTileBytes + (size_t)(sx::kShMaxUnion + 8) * (sizeof(int) + sx::kShRows * sizeof(short)) +
+                                   (size_t)sx::kShMaxRowCols * sizeof(int);
+            if (int rc = allow_big_lds(h, reinterpret_cast<const void *>(sx::spmm_bell_mfma_shared), (int)lds)) return rc;
+            hipLaunchKernelGGL(sx::spmm_bell_mfma_shared, dim3((unsigned)((h->dense_mb + sx::kShRows - 1) / sx::kShRows)),
+                               dim3(sx::kShThreads), lds, s, h->d_dense_col, Af, Bf, d_C_in, ldc_in, d_C_out, ldc, h->dense_mb, h->dense_W,
+                               alpha, beta, 0);
+        } else if (ntiles % 4 == 0) SX_BELL(4) else if (ntiles % 2 == 0) SX_BELL(2) else SX_BELL(1)
+#undef SX_BELL
+        const int row0 = h->dense_mb * 32;
+        if (row0 < h->M) {
+            const int64_t tot = (int64_t)(h->M - row0) * N;
+            hipLaunchKernelGGL(sx::scale_tail_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, d_C_in, ldc_in,
+                               d_C_out, ldc, row0, h->M, N, alpha, beta);
+        }
+    return SEXTANS_OK;
+}
+
+}  // namespace sxe
+
+using namespace sxe;
+
+extern "C" {
+
+int sextans_set_matrix_bell_device(sextans_handle_t h, int M, int K, int ell_width,
+                                   const int *d_block_col, const uint16_t *d_block_val) {
+    if (!h || M <= 0 || K <= 0 || (M % 32) || (K % 32) || ell_width <= 0 || !d_block_col || !d_block_val)
+        return SEXTANS_ERR_INVALID;
+    SX_HIP(hipSetDevice(h->device));
+    free_bell(h);
+    const int64_t nslots = (int64_t)(M / 32) * ell_width;
+    SX_HIP(hipMalloc(&h->d_bell_Af, (size_t)nslots * 2048));
+    const int64_t threads = nslots * 128;
+    hipLaunchKernelGGL(sx::bell_repack_a, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, nullptr,
+                       d_block_val, (sx::u32x4 *)h->d_bell_Af, nslots);
+    SX_HIP(hipDeviceSynchronize());
+    h->d_bell_col = d_block_col;
+    h->bell_M = M; h->bell_K = K; h->bell_W = ell_width;
+    {   // do the block rows of a workgroup share block columns?  (decides between the per-wavefront kernels and the
+        // LDS-shared one, "MFMA only where a tile is actually dense" + reuse)
+        unsigned long long *d_cnt = nullptr, h_cnt[4] = {0, 0, 0, 0};
+        SX_HIP(hipMalloc((void **)&d_cnt, 4 * sizeof(unsigned long long)));
+        SX_HIP(hipMemset(d_cnt, 0, 4 * sizeof(unsigned long long)));
+        const int groups = (M / 32 + sx::kShRows - 1) / sx::kShRows;
+        hipLaunchKernelGGL(sx::bell_union_count, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, nullptr, d_block_col, M / 32,
+                           ell_width, d_cnt, d_cnt + 1, d_cnt + 2, d_cnt + 3);
+        const hipError_t e = hipMemcpy(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost);
+        (void)hipFree(d_cnt);
+        SX_HIP(e);
+        h->bell_share = h_cnt[0] ? (double)h_cnt[1] / (double)h_cnt[0] : 0.0;
+        h->bell_max_union = h_cnt[3] ? 0x7fffffff : (int)h_cnt[2];   // duplicate / unsorted block columns: never the shared kernel
+        if (h_cnt[3]) h->bell_share = 0.0;
+    }
+    return SEXTANS_OK;
+}
+
+int sextans_set_matrix_bell(sextans_handle_t h, int M, int K, int ell_width, const int *block_col,
+                            const uint16_t *block_val) {
+    if (!h || M <= 0 || K <= 0 || (M % 32) || (K % 32) || ell_width <= 0 || !block_col || !block_val)
+        return SEXTANS_ERR_INVALID;
+    SX_HIP(hipSetDevice(h->device));
+    const size_t nslots = (size_t)(M / 32) * (size_t)ell_width;
+    int *d_col = nullptr;
+    uint16_t *d_val = nullptr;
+    SX_HIP(hipMalloc((void **)&d_col, nslots * sizeof(int)));
+    SX_HIP(hipMalloc((void **)&d_val, nslots * 2048));
+    SX_HIP(hipMemcpy(d_col, block_col, nslots * sizeof(int), hipMemcpyHostToDevice));
+    SX_HIP(hipMemcpy(d_val, block_val, nslots * 2048, hipMemcpyHostToDevice));
+    int rc = sextans_set_matrix_bell_device(h, M, K, ell_width, d_col, d_val);
+    (void)hipFree(d_val);
+    if (rc) { (void)hipFree(d_col); return rc; }
+    h->d_bell_col_owned = d_col;
+    return SEXTANS_OK;
+}
+
+int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint16_t *d_B, int64_t ldb,
+                             float beta, const float *d_C_in, float *d_C_out, int64_t ldc, void *stream) {
+    if (!h || N <= 0 || (N % 32) || !d_B || !d_C_in || !d_C_out) return SEXTANS_ERR_INVALID;
+    if (!h->d_bell_Af) return SEXTANS_ERR_STATE;
+    if (ldb < h->bell_K || (ldb % 8) || ldc < h->bell_M) return SEXTANS_ERR_INVALID;
+    SX_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int kblocks = h->bell_K / 32, mblocks = h->bell_M / 32, ntiles = N / 32;
+    const size_t need = (size_t)h->bell_K * (size_t)N * 2;
+    if (h->bell_Bf_cap < need) {
+        if (h->d_bell_Bf) SX_HIP(hipFree(h->d_bell_Bf));
+        h->d_bell_Bf = nullptr; h->bell_Bf_cap = 0;
+        SX_HIP(hipMalloc(&h->d_bell_Bf, need));
+        h->bell_Bf_cap = need;
+    }
+    {
+        Prof p(h, &h->ev_repack, s);
+        const int64_t threads = (int64_t)kblocks * ntiles * 128;
+        hipLaunchKernelGGL(sx::bell_repack_b, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_B,
+                           ldb, (sx::u32x4 *)h->d_bell_Bf, kblocks, ntiles);
+    }
+    {
+        Prof p(h, &h->ev_kernel, s);
+        const auto *Af = (const sx::bf16x8 *)h->d_bell_Af;
+        const auto *Bf = (const sx::bf16x8 *)h->d_bell_Bf;
+#define SX_BELL(NSUB)                                                                                  \
+    {                                                                                                  \
+        const int64_t waves = (int64_t)mblocks * (ntiles / NSUB);                                      \
+        hipLaunchKernelGGL((sx::spmm_bell_mfma<NSUB>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, \
+                           h->d_bell_col, Af, Bf, d_C_in, ldc, d_C_out, ldc, mblocks, h->bell_W, ntiles,    \
+                           alpha, beta);                                                                      \
+    }
+        const bool shared = ntiles == 8 && h->opt_bell_shared != 0 && sx::kShRows * h->bell_W <= sx::kShMaxRowCols &&
+                            h->bell_max_union <= sx::kShMaxUnion &&
+                            (h->opt_bell_shared == 1 || h->bell_share >= 1.5);
+        if (shared) {
+            constexpr size_t lds = (size_t)sx::kShRing * sx::kShTileBytes + (size_t)(sx::kShMaxUnion + 8) * (sizeof(int) + sx::kShRows * sizeof(short)) +
+                                  (size_t)sx::kShMaxRowCols * sizeof(int);
+            if (int rc = allow_big_lds(h, reinterpret_cast<const void *>(sx::spmm_bell_mfma_shared), (int)lds)) return rc;
+            hipLaunchKernelGGL(sx::spmm_bell_mfma_shared, dim3((unsigned)((mblocks + sx::kShRows - 1) / sx::kShRows)), dim3(sx::kShThreads), lds,
+                               s, h->d_bell_col, Af, Bf, d_C_in, ldc, d_C_out, ldc, mblocks, h->bell_W, alpha, beta, (int)h->opt_bell_debug);
+            h->last_kernel = "spmm_bell_mfma_shared";
+            SX_HIP(hipGetLastError());
+            return SEXTANS_OK;
+        } else if (ntiles == 8 && h->opt_bell_wide) {
+            // "bell_generation" = G > 0: launches of G block rows, so that the wavefronts of a launch start at block
+            // column 0 together and sweep K side by side (experiment: does the Infinity Cache then serve the B tiles?)
+            const int G = h->opt_bell_gen > 0 ? (int)h->opt_bell_gen : mblocks;
+            for (int b0 = 0; b0 < mblocks; b0 += G) {
+                const int nb = std::min(G, mblocks - b0);
+                hipLaunchKernelGGL(sx::spmm_bell_mfma_n256, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, s, h->d_bell_col, Af,
+                                   Bf, d_C_in, ldc, d_C_out, ldc, std::min(mblocks, b0 + nb), h->bell_W, alpha, beta, b0);
+            }
+        } else if (ntiles % 4 == 0) SX_BELL(4) else if (ntiles % 2 == 0) SX_BELL(2) else SX_BELL(1)
+#undef SX_BELL
+        h->last_kernel = "spmm_bell_mfma";
+    }
+    SX_HIP(hipGetLastError());
+    return SEXTANS_OK;
+}
+
+}  // extern "C"

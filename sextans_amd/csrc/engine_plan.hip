@@ -1,0 +1,608 @@
+// engine_plan.hip -- what the engine prepares ONCE per matrix, outside every timed region, like the reference's host-side
+// scheduling and packing (generate_edge_list_for_all_PEs + edge_list_64bit, sextans-host.cpp:114-148): the long-row split
+// (bucketed rows, hub pieces, exact chains), the packed row-bucketed plans of the LDS-panel kernels (natural and clustered
+// row order; built on the device, plan_device.hip / row_cluster.hip), the K-window stream, and prepare(), which brings all
+// of that up to date for an N-column SpMM.
+#include <algorithm>
+#include <cstring>
+
+#include "engine_state.h"
+#include "panel_plan.h"
+#include "plan_device.h"
+#include "row_cluster.h"
+#include "spmm_csr_kernels.h"
+#include "spmm_panel_v2.h"
+#include "spmm_window_kernel.h"
+#include "window_plan.h"
+
+namespace sxe {
+
+void free_panel_state(sextans_engine::PanelState &p) {
+    (void)hipFree(p.d_dict_ptr); (void)hipFree(p.d_dict); (void)hipFree(p.d_lidx); (void)hipFree(p.d_blk_row);
+    (void)hipFree(p.d_row_off); (void)hipFree(p.d_pcol32); (void)hipFree(p.d_pval);
+    p = sextans_engine::PanelState();
+}
+
+void free_plan(sextans_engine *h) {   // every packed form of the current main matrix
+    free_panel_state(h->ps);
+    for (auto &p : h->plan_stash) free_panel_state(p);
+    free_panel_state(h->psc);
+    (void)hipFree(h->d_slot_row);
+    h->d_slot_row = nullptr;
+    h->cluster_state = 0;
+    h->cluster_s2 = h->cluster_s3 = 0;
+    h->plan_total_dict = h->cluster_total_dict = 0;
+}
+
+void free_window(sextans_engine *h) {
+    (void)hipFree(h->d_wstream); (void)hipFree(h->d_wstep0);
+    h->d_wstream = nullptr; h->d_wstep0 = nullptr;
+    h->win_nwaves = h->win_rw = 0;
+    h->win_padded = 0;
+    h->win_state = 0;
+    h->win_built_rows = h->win_built_cols = -1;
+}
+
+void free_split(sextans_engine *h) {   // long-row state: main matrix, skip flags, piece tables (built from the source)
+    for (auto *t : {&h->by_len, &h->by_row}) {
+        (void)hipFree(t->d_vrp); (void)hipFree(t->d_vend); (void)hipFree(t->d_vfirst); (void)hipFree(t->d_row);
+        *t = sextans_engine::PieceTable();
+    }
+    (void)hipFree(h->d_chain_row); (void)hipFree(h->d_chain_beg); (void)hipFree(h->d_chain_off); (void)hipFree(h->d_chain_perm);
+    h->d_chain_row = h->d_chain_beg = h->d_chain_perm = nullptr; h->d_chain_off = nullptr;
+    h->nchain = 0; h->h_chain_row.clear(); h->h_chain_off.clear(); h->chain_T = 0; h->chain_built_opt = -2;
+    (void)hipFree(h->d_mrp); (void)hipFree(h->d_mci); (void)hipFree(h->d_mv); (void)hipFree(h->d_skip);
+    h->d_mrp = h->d_mci = nullptr;
+    h->d_mv = nullptr;
+    h->d_skip = nullptr;
+    h->h_split_rows.clear();
+    h->nhub = h->split_nv = 0;
+    h->split_T = h->bucket_L0 = 0;
+    h->split_built_opt = h->bucket_built_opt = h->split_built_gnnz = -2;
+    h->m_rp = h->s_rp; h->m_ci = h->s_ci; h->m_v = h->s_v; h->m_nnz = h->s_nnz;
+}
+
+void free_dense(sextans_engine *h) {   // dense-tile state and everything downstream of the source matrix
+    (void)hipFree(h->d_dense_col); (void)hipFree(h->d_dense_Af);
+    h->d_dense_col = nullptr; h->d_dense_Af = nullptr;
+    h->dense_mb = h->dense_W = 0;
+    h->dense_tiles = h->dense_nnz = 0;
+    h->dense_built_mfma = h->dense_built_fill = -2;
+    (void)hipFree(h->d_srp); (void)hipFree(h->d_sci); (void)hipFree(h->d_sv);
+    h->d_srp = h->d_sci = nullptr;
+    h->d_sv = nullptr;
+    h->s_rp = h->d_rp; h->s_ci = h->d_ci; h->s_v = h->d_v; h->s_nnz = h->nnz;
+    free_split(h);
+}
+
+void free_matrix(sextans_engine *h) {
+    free_plan(h);
+    free_dense(h);
+    free_window(h);
+    h->plan_build_s = 0.0;
+    if (h->owns_matrix) {
+        (void)hipFree((void *)h->d_rp);
+        (void)hipFree((void *)h->d_ci);
+        (void)hipFree((void *)h->d_v);
+    }
+    h->d_rp = h->d_ci = nullptr;
+    h->d_v = nullptr;
+    h->owns_matrix = false;
+    h->device_matrix_checked = false;
+    h->m_rp = h->m_ci = h->s_rp = h->s_ci = nullptr; h->m_v = h->s_v = nullptr; h->m_nnz = h->s_nnz = 0;
+    h->dist_cut_key.clear();   // chunk cuts are aligned to the packed forms of one matrix
+    h->bp_layout = 0;          // B panels belong to one (K, B)
+}
+
+int ensure(float **p, size_t *cap, size_t need) {
+    if (*cap >= need && *p) return SEXTANS_OK;
+    if (*p) SX_HIP(hipFree(*p));
+    *p = nullptr; *cap = 0;
+    SX_HIP(hipMalloc((void **)p, (need ? need : 1) * sizeof(float)));
+    *cap = need;
+    return SEXTANS_OK;
+}
+
+// Device copy of the CSR arrays -> host, validated: the host-side plan builders index arrays of size K with
+// the column indices and trust row_ptr to be monotonic (a matrix handed over with
+// sextans_set_matrix_csr_device has not been looked at by anybody yet).
+// (level 2: the main matrix the kernels work on; 1: the source of the long-row split; 0: the matrix as the caller set it)
+int read_back_row_ptr(sextans_engine *h, std::vector<int> &rp, int level) {
+    rp.resize((size_t)h->M + 1);
+    const int *src = level == 2 ? h->m_rp : level == 1 ? h->s_rp : h->d_rp;
+    SX_HIP(hipMemcpy(rp.data(), src, sizeof(int) * ((size_t)h->M + 1), hipMemcpyDeviceToHost));
+    if (rp[0] != 0 || (int64_t)rp[(size_t)h->M] != (level == 2 ? h->m_nnz : level == 1 ? h->s_nnz : h->nnz)) return SEXTANS_ERR_INVALID;
+    for (int r = 0; r < h->M; ++r)
+        if (rp[(size_t)r + 1] < rp[(size_t)r]) return SEXTANS_ERR_INVALID;
+    return SEXTANS_OK;
+}
+int read_back_entries(sextans_engine *h, std::vector<int> &ci, std::vector<float> &va, int level) {
+    const int64_t nnz = level == 2 ? h->m_nnz : level == 1 ? h->s_nnz : h->nnz;
+    const size_t n1 = (size_t)(nnz ? nnz : 1);
+    ci.assign(n1, 0); va.assign(n1, 0.f);
+    if (nnz) {
+        SX_HIP(hipMemcpy(ci.data(), level == 2 ? h->m_ci : level == 1 ? h->s_ci : h->d_ci, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost));
+        SX_HIP(hipMemcpy(va.data(), level == 2 ? h->m_v : level == 1 ? h->s_v : h->d_v, sizeof(float) * (size_t)nnz, hipMemcpyDeviceToHost));
+    }
+    const unsigned K = (unsigned)h->K;
+    unsigned bad = 0;
+    for (int64_t j = 0; j < nnz; ++j) bad |= (unsigned)((unsigned)ci[(size_t)j] >= K);
+    return bad ? SEXTANS_ERR_INDEX : SEXTANS_OK;
+}
+
+// Build (or reuse) the packed row-bucketed form of A for `lpr` lanes per row.  The CSR arrays are read
+// back from the device copy, so this works for host- and device-provided matrices alike; it runs once
+// per matrix ("upload once"), outside any timed region, like the reference's host-side scheduling
+// and packing (generate_edge_list_for_all_PEs + edge_list_64bit, sextans-host.cpp:114-148).
+// Cheap pre-test on a sample of row blocks: share of sampled non-zeros that sit in blocks with
+// nnz >= min_reuse * distinct columns.  Lets "auto" skip the full plan build on matrices without
+// reuse (e.g. uniformly random columns).
+int64_t plan_key(const sextans_engine *h) { return h->opt_min_reuse_x100 * 100000 + h->opt_min_reuse_wide_x100; }
+
+int sample_reuse(sextans_engine *h, int RB, int max_unique, double min_reuse, double min_reuse2, double *frac, double *frac2) {
+    const int nblk = (h->M + RB - 1) / RB;
+    const int nsample = std::min(nblk, 512);
+    std::vector<int> rp;
+    if (int rc = read_back_row_ptr(h, rp)) return rc;
+    int64_t tot = 0, good = 0, good2 = 0;
+    std::vector<int> cols;
+    for (int sidx = 0; sidx < nsample; ++sidx) {
+        const int b = (int)((int64_t)sidx * nblk / nsample);
+        const int r0 = b * RB, r1 = std::min(h->M, r0 + RB);
+        const int j0 = rp[(size_t)r0], j1 = rp[(size_t)r1];
+        if (j1 <= j0) continue;
+        cols.resize((size_t)(j1 - j0));
+        SX_HIP(hipMemcpy(cols.data(), h->m_ci + j0, sizeof(int) * cols.size(), hipMemcpyDeviceToHost));
+        std::sort(cols.begin(), cols.end());
+        const int64_t distinct = std::unique(cols.begin(), cols.end()) - cols.begin();
+        tot += j1 - j0;
+        // a block larger than the panel is split by the real builder; its reuse ratio carries over
+        if ((double)(j1 - j0) >= min_reuse * (double)distinct) good += j1 - j0;
+        if ((double)(j1 - j0) >= min_reuse2 * (double)distinct) good2 += j1 - j0;
+        (void)max_unique;
+    }
+    *frac = tot ? (double)good / (double)tot : 0.0;
+    *frac2 = tot ? (double)good2 / (double)tot : 0.0;
+    return SEXTANS_OK;
+}
+
+// Build (or reuse) the packed row-bucketed form of A for `lpr` lanes per row.  The CSR arrays are read
+// back from the device copy, so this works for host- and device-provided matrices alike; it runs once
+// per matrix ("upload once"), outside any timed region, like the reference's host-side scheduling
+// and packing (generate_edge_list_for_all_PEs + edge_list_64bit, sextans-host.cpp:114-148).
+int ensure_plan(sextans_engine *h, int lpr, bool force) {
+    if (h->ps.plan_lpr == lpr && h->ps.plan_min_reuse == plan_key(h) && (h->ps.plan_built || !force))
+        return SEXTANS_OK;
+    if (h->ps.plan_lpr != lpr) {   // park the active form, bring back the one for this lane count (if any)
+        auto idx = [](int l) { return l == 2 ? 0 : l == 4 ? 1 : 2; };
+        if (h->ps.plan_lpr) std::swap(h->ps, h->plan_stash[idx(h->ps.plan_lpr)]);
+        if (h->ps.plan_lpr != lpr) std::swap(h->ps, h->plan_stash[idx(lpr)]);
+        if (h->ps.plan_lpr && h->ps.plan_lpr != lpr) {   // displaced a third form: park it in its own slot
+            std::swap(h->ps, h->plan_stash[idx(h->ps.plan_lpr)]);
+            free_panel_state(h->ps);
+        }
+        if (h->ps.plan_lpr == lpr && h->ps.plan_min_reuse == plan_key(h) && (h->ps.plan_built || !force))
+            return SEXTANS_OK;
+    }
+    free_panel_state(h->ps);
+    PlanTimer timer(h);
+    // A matrix handed over with sextans_set_matrix_csr_device has not been looked at by anybody yet: the kernels gather B
+    // rows by column index and the builders trust row_ptr to be monotone, so it is validated once, on the device.
+    if (!h->owns_matrix && !h->device_matrix_checked) {
+        int bad = 0;
+        std::string verr;
+        if (sx::validate_csr_device(h->M, h->K, h->nnz, h->d_rp, h->d_ci, &bad, verr)) { g_last_error = verr; return SEXTANS_ERR_HIP; }
+        if (bad) return (bad & 1) ? SEXTANS_ERR_INVALID : SEXTANS_ERR_INDEX;
+        h->device_matrix_checked = true;
+    }
+    const int RB = sx::kBlock / lpr;
+    // two thresholds: "panel_min_reuse_x100" decides for N <= 16, "panel_min_reuse_wide_x100" for N >= 32 (prepare()); the plan
+    // is built once, for the lower of the two, so that alternating N never rebuilds it
+    const double narrow = (double)h->opt_min_reuse_x100 / 100.0;
+    const double min_reuse = std::min(narrow, (double)h->opt_min_reuse_wide_x100 / 100.0);
+    double narrow_frac = 1.0;
+    if (!force) {
+        double frac = 0.0;
+        if (int rc = sample_reuse(h, RB, kPanelFloats / (4 * lpr), min_reuse, narrow, &frac, &narrow_frac)) return rc;
+        if (frac < 0.5) {   // no reuse worth an LDS panel: remember the verdict, skip the build
+            h->ps.plan_lpr = lpr;
+            h->ps.plan_min_reuse = plan_key(h);
+            h->ps.plan_panel_frac = frac * 0.999;
+            h->ps.plan_narrow_frac = narrow_frac * 0.999;
+            h->ps.plan_built = false;
+            return SEXTANS_OK;
+        }
+    }
+    // The packed form is built on the device (plan_device.hip): the CSR arrays never leave HBM.
+    sx::DevicePlan dp;
+    std::string err;
+    const int cap = kPanelFloats / (4 * lpr);
+    const int brc = sx::build_panel_plan_device(h->M, h->K, h->m_rp, h->m_ci, h->m_v, lpr, cap, min_reuse, dp, err);
+    if (brc == 2) { g_last_error = err; sx::free_device_plan(dp); return SEXTANS_ERR_HIP; }
+    h->ps.plan_lpr = lpr;
+    h->ps.plan_min_reuse = plan_key(h);
+    h->ps.plan_narrow_frac = narrow_frac;
+    if (brc == 1) {   // rows padded to 4 entries exceed 32-bit entry offsets: row-group kernel only
+        h->ps.plan_panel_frac = 0.0;
+        h->ps.plan_built = false;
+        return SEXTANS_OK;
+    }
+    if (dp.dict_stride > 9 * RB) { sx::free_device_plan(dp); return SEXTANS_ERR_STATE; }   // capacity = 9 * RB by construction
+    h->ps.plan_nblk = dp.nblk;
+    h->ps.plan_dict_stride = dp.dict_stride;
+    h->ps.plan_mixed = dp.mixed;
+    h->ps.d_blk_row = dp.d_blk_row; h->ps.d_dict_ptr = dp.d_dict_cnt; h->ps.d_dict = dp.d_dict; h->ps.d_row_off = dp.d_slot_info;
+    h->ps.d_lidx = dp.d_idx16; h->ps.d_pcol32 = dp.d_col32; h->ps.d_pval = dp.d_val;
+    h->ps.h_blk_row.swap(dp.h_blk_row);
+    h->ps.plan_stream_len = dp.stream_len;
+    h->ps.plan_panel_frac = h->m_nnz ? (double)dp.nnz_in_panel_blocks / (double)h->m_nnz : 0.0;
+    h->ps.plan_nnz_panel = dp.nnz_in_panel_blocks;
+    h->ps.plan_max_dict = dp.max_dict;
+    h->ps.plan_max_row = dp.max_row_len;
+    h->ps.plan_pad_row = cap;
+    h->ps.plan_built = true;
+    if (lpr == 4) h->plan_total_dict = dp.total_dict;
+    return SEXTANS_OK;
+}
+
+// Clustered-order plan (see PanelState psc): built once per matrix, after the natural-order plan for 4 lanes per row exists and is
+// dictionary-only.  Option "row_cluster": -1 = when the matrix has grid-stencil structure AND the clustered plan copies at least
+// 15 % fewer B rows into LDS; 1 = whenever the structure is found; 0 = never.
+int ensure_cluster_plan(sextans_engine *h) {
+    if (h->cluster_state != 0) return SEXTANS_OK;
+    h->cluster_state = -1;
+    if (h->opt_row_cluster == 0 || !h->ps.plan_built || h->ps.plan_lpr != 4 || h->ps.plan_mixed || h->M < 4096) return SEXTANS_OK;
+    PlanTimer timer(h);
+    // ---- grid strides from the columns of ~128 rows out of the middle half of the matrix
+    std::vector<int> rp;
+    if (int rc = read_back_row_ptr(h, rp)) return rc;
+    std::vector<int> rows;
+    std::vector<std::vector<int>> cols;
+    const int nsample = 128;
+    for (int k = 0; k < nsample; ++k) {
+        const int r = (int)((int64_t)h->M / 4 + (int64_t)k * (h->M / 2) / nsample);
+        const int j0 = rp[(size_t)r], j1 = rp[(size_t)r + 1];
+        if (j1 <= j0 || j1 - j0 > 4096) continue;
+        std::vector<int> c((size_t)(j1 - j0));
+        SX_HIP(hipMemcpy(c.data(), h->m_ci + j0, sizeof(int) * c.size(), hipMemcpyDeviceToHost));
+        rows.push_back(r);
+        cols.push_back(std::move(c));
+    }
+    sx::GridStrides gs;
+    if (!sx::detect_grid_strides(h->M, rows, cols, &gs)) return SEXTANS_OK;
+    h->cluster_s2 = gs.s2;
+    h->cluster_s3 = gs.s3;
+    // ---- bricks of <= 64 rows = one row block each: a run of 15 / 16 rows of a grid line x 2 lines x 2 planes (3-D), x 4 lines (2-D).
+    // Runs of consecutive rows keep a wavefront's C accesses (its 16 row slots) on consecutive rows -- 64-byte runs per column as in
+    // natural order (12-row runs gave away half of the gain at N = 128, where C is half of the traffic); the plan builder starts a
+    // block at every brick (`cut`), so blocks and bricks coincide.
+    int run_rows = 16, b2 = gs.s3 > 0 ? 2 : 4, b3 = gs.s3 > 0 ? 2 : 1;
+    if (h->opt_cluster_shape > 0) {   // EXPERIMENT: run_rows * 10000 + b2 * 100 + b3
+        run_rows = (int)(h->opt_cluster_shape / 10000); b2 = (int)(h->opt_cluster_shape / 100 % 100); b3 = (int)(h->opt_cluster_shape % 100);
+    }
+    std::string err;
+    int *d_perm = nullptr, *prp = nullptr, *pci = nullptr;
+    unsigned char *d_cut = nullptr;
+    float *pv = nullptr;
+    auto drop = [&]() { (void)hipFree(d_perm); (void)hipFree(d_cut); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv); };
+    if (sx::build_brick_order_device(h->M, gs, run_rows, b2, b3, (int)h->opt_cluster_group, &d_perm, &d_cut, err)) { g_last_error = err; drop(); return SEXTANS_ERR_HIP; }
+    if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_perm, &prp, &pci, &pv, err)) {
+        g_last_error = err; drop(); return SEXTANS_ERR_HIP;
+    }
+    sx::DevicePlan dp;
+    const int lpr = 4, RB = sx::kBlock / lpr, cap = kPanelFloats / (4 * lpr);
+    const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;
+    const int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, min_reuse, dp, err, d_cut);
+    (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv); (void)hipFree(d_cut);
+    prp = pci = nullptr; pv = nullptr; d_cut = nullptr;
+    if (brc == 2) { g_last_error = err; sx::free_device_plan(dp); drop(); return SEXTANS_ERR_HIP; }
+    h->cluster_total_dict = dp.total_dict;
+    const bool gain = (double)dp.total_dict <= 0.85 * (double)h->plan_total_dict;
+    if (brc != 0 || dp.mixed || dp.dict_stride > 9 * RB || dp.max_dict > sx::kWideMaxDict || (h->opt_row_cluster < 0 && !gain)) {
+        sx::free_device_plan(dp); drop();
+        return SEXTANS_OK;
+    }
+    if (sx::build_slot_rows_device(dp.nblk, RB, dp.d_blk_row, d_perm, &h->d_slot_row, err)) {
+        g_last_error = err; sx::free_device_plan(dp); drop(); return SEXTANS_ERR_HIP;
+    }
+    (void)hipFree(d_perm);
+    sextans_engine::PanelState &c = h->psc;
+    c.plan_lpr = lpr;
+    c.plan_min_reuse = plan_key(h);
+    c.plan_nblk = dp.nblk;
+    c.plan_dict_stride = dp.dict_stride;
+    c.plan_mixed = false;
+    c.d_blk_row = dp.d_blk_row; c.d_dict_ptr = dp.d_dict_cnt; c.d_dict = dp.d_dict; c.d_row_off = dp.d_slot_info;
+    c.d_lidx = dp.d_idx16; c.d_pcol32 = dp.d_col32; c.d_pval = dp.d_val;
+    c.h_blk_row.swap(dp.h_blk_row);
+    c.plan_stream_len = dp.stream_len;
+    c.plan_panel_frac = h->ps.plan_panel_frac;
+    c.plan_narrow_frac = h->ps.plan_narrow_frac;
+    c.plan_nnz_panel = dp.nnz_in_panel_blocks;
+    c.plan_max_dict = dp.max_dict;
+    c.plan_max_row = dp.max_row_len;
+    c.plan_pad_row = cap;
+    c.plan_built = true;
+    h->cluster_state = 1;
+    return SEXTANS_OK;
+}
+
+// Kernels that need more than the default 64 KiB of dynamic LDS: raise the limit once per (engine = device, kernel).
+int allow_big_lds(sextans_engine *h, const void *kern, int bytes) {
+    if (h->big_lds_kernels.count(kern)) return SEXTANS_OK;
+    SX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    h->big_lds_kernels.insert(kern);
+    return SEXTANS_OK;
+}
+
+// Traffic model behind the automatic choice between the gather kernel and the window kernel for matrices
+// without B-row reuse (bytes crossing the L2 <-> memory fabric per SpMM):
+//   gather: every non-zero pulls max(128, 4 * tile width) bytes of B (a 64-byte B row still costs a
+//           128-byte line) + the 8-byte CSR entry per N tile;
+//   window: every XCD streams the whole 8-column panel once per sweep, sweeps = rows / rows whose partial
+//           sums the chip holds in LDS at once (at least 1), + the 8-byte stream entry, per 8-column tile.
+bool window_pays(const sextans_engine *h, int N, int64_t padded) {
+    // Measured on MI355X (profiles/r02_window_kernel_*.txt): the model below counts fabric BYTES, but both
+    // kernels are bound by line REQUESTS (~57 G/s beyond L2, ~135 G/s from L2), the sweep issues two 32-byte
+    // row reads per non-zero at N = 16 where the gather issues one 64-byte read, and without a chip-wide
+    // window barrier the wavefronts drift apart by more than the 4 MiB L2 holds (L2 hit rate 20 %).  The
+    // window kernel never won a measurement, so "auto" only considers it when option "window_auto" is set.
+    if (!h->opt_win_auto) return false;
+    if (N > 24 || h->m_nnz == 0) return false;
+    const double K = (double)h->K, nnz = (double)h->m_nnz, M = (double)h->M;
+    if (K * N * 4.0 <= 48.0 * 1048576.0) return false;   // B (nearly) fits the L2s: gathers stay on chip
+    double gather = 0.0;
+    int rest = N;
+    for (int w : {16, 8}) { const int nt = rest / w; gather += nt * nnz * (std::max(128.0, 4.0 * w) + 8.0); rest -= nt * w; }
+    const double live = (double)h->num_cus * 16.0 * (double)h->opt_win_rows;
+    const double sweeps = std::max(1.0, M / live);
+    const double window = (N / 8) * (sweeps * 8.0 * K * 32.0 + 8.0 * (double)padded);
+    return window < 0.75 * gather;
+}
+
+// Build (or reuse) the K-windowed stream of A.  force: "kernel" = 3 (no pay-off / skew test).
+int ensure_window(sextans_engine *h, bool force) {
+    if (h->win_state != 0 && h->win_built_rows == h->opt_win_rows && h->win_built_cols == h->opt_win_cols &&
+        (h->win_state == 1 || !force))
+        return SEXTANS_OK;
+    free_window(h);
+    PlanTimer timer(h);
+    h->win_built_rows = h->opt_win_rows;
+    h->win_built_cols = h->opt_win_cols;
+    h->win_state = -1;
+    const int RW = (int)h->opt_win_rows;
+    if (RW < 1 || RW > sx::kWinMaxRowsPerWave || h->opt_win_cols < 1 || h->opt_win_cols > 0x7fffffff ||
+        (int64_t)h->K > ((int64_t)1 << sx::kWinColBits) || h->m_nnz == 0)
+        return SEXTANS_OK;
+    std::vector<int> rp, ci;
+    std::vector<float> va;
+    if (int rc = read_back_row_ptr(h, rp)) return rc;
+    if (!force && (double)sx::window_plan_padded_lower_bound(h->M, rp.data(), RW) > 1.3 * (double)h->m_nnz)
+        return SEXTANS_OK;   // skewed rows: one row per step would be mostly padding
+    if (int rc = read_back_entries(h, ci, va)) return rc;
+    sx::WindowPlan plan;
+    if (!sx::build_window_plan(h->M, h->K, rp.data(), ci.data(), va.data(), RW, (int)h->opt_win_cols, plan))
+        return SEXTANS_OK;
+    if (!force && (double)plan.padded > 1.35 * (double)h->m_nnz) return SEXTANS_OK;
+    static_assert(sizeof(sx::WinEntry) == sizeof(uint2), "stream entries are loaded as uint2");
+    SX_HIP(hipMalloc((void **)&h->d_wstream, sizeof(uint2) * plan.stream.size()));
+    SX_HIP(hipMemcpy(h->d_wstream, plan.stream.data(), sizeof(uint2) * plan.stream.size(), hipMemcpyHostToDevice));
+    if (int rc = upload(&h->d_wstep0, plan.wave_step0)) return rc;
+    h->win_nwaves = plan.nwaves;
+    h->win_rw = RW;
+    h->win_padded = plan.padded;
+    h->win_state = 1;
+    return SEXTANS_OK;
+}
+
+// Long-row test + piece tables (see the engine struct).  Thresholds:
+//   L0 ("bucket_rows"; -1 = max(32, 2 * mean row length)): a workgroup of the row-group / panel kernels owns 32-128
+//     consecutive rows and lives as long as its longest row, so one 100-entry row among 15-entry rows wastes 85 % of
+//     the workgroup; rows above L0 are processed in a second launch in order of length instead.  Regular matrices
+//     (Poisson, FEM, nasa4704) have no such rows and take none of this path.
+//   T ("split_rows"; -1 = max(1024, nnz / 16384); 0 = never): the adds of one row are a serial chain and its B
+//     rows arrive at best ~16 per memory round trip, i.e. ~0.05-0.1 us per entry: a 400 000-entry hub row would hold
+//     one row group for tens of milliseconds.  Rows above T are cut into pieces of T entries that are summed in
+//     parallel and folded in order (re-associated).  Measured on a 1M-row power-law matrix (33 M nnz, longest row
+//     399 302): T = 512 / 1024 / 2021 -> 0.81 / 0.74 / 0.77 ms with 4964 / 2190 / 978 rows re-associated (uniform
+//     matrix of the same size: 0.64 ms), so the larger threshold costs nothing and touches fewer rows.
+
+int ensure_split(sextans_engine *h) {
+    if (h->split_built_opt == h->opt_split_rows && h->bucket_built_opt == h->opt_bucket_rows &&
+        h->split_built_gnnz == h->opt_global_nnz && h->chain_built_opt == h->opt_exact_chain)
+        return SEXTANS_OK;
+    free_split(h);
+    free_plan(h);      // the packed forms are built from the main matrix
+    free_window(h);
+    h->split_built_opt = h->opt_split_rows;
+    h->bucket_built_opt = h->opt_bucket_rows;
+    h->split_built_gnnz = h->opt_global_nnz;
+    h->chain_built_opt = h->opt_exact_chain;
+    if (h->M == 0 || h->s_nnz == 0) return SEXTANS_OK;
+    int64_t T = h->opt_split_rows, L0 = h->opt_bucket_rows;
+    // strict order: rows above the automatic threshold become exact chains instead of one-piece rows
+    const int64_t Tc = (h->opt_split_rows == 0 && h->opt_exact_chain)
+                           ? std::max<int64_t>(1024, std::max<int64_t>(h->opt_global_nnz, h->s_nnz) / 16384) : INT64_MAX;
+    // the automatic threshold follows the non-zeros of the whole matrix: a rank of a row-partitioned SpMM ("global_nnz")
+    // then cuts a hub row into the same pieces as a single GPU holding all rows => bitwise equal results
+    if (T < 0) T = std::max<int64_t>(1024, std::max<int64_t>(h->opt_global_nnz, h->s_nnz) / 16384);
+    if (L0 < 0) L0 = std::max<int64_t>(32, 2 * (h->s_nnz / h->M));
+    if (T == 0) T = INT64_MAX;                 // never split
+    if (L0 == 0) L0 = std::min(T, Tc);         // no bucketing: only rows that must be split / chained leave
+    if (L0 > std::min(T, Tc)) L0 = std::min(T, Tc);
+    if (L0 == INT64_MAX) return SEXTANS_OK;
+    PlanTimer timer(h);
+    std::vector<int> rp;
+    if (int rc = read_back_row_ptr(h, rp, 1)) return rc;
+    std::vector<int> rows;                     // ascending
+    for (int r = 0; r < h->M; ++r)
+        if ((int64_t)rp[(size_t)r + 1] - rp[(size_t)r] > L0) rows.push_back(r);
+    if (rows.empty()) return SEXTANS_OK;
+    {   // bucketing alone (no row that must be split) is only worth three extra launches when the long rows carry
+        // a visible share of the work: a handful of rows just above L0 in a regular matrix stay where they are
+        int64_t long_nnz = 0, longest = 0;
+        for (int r : rows) {
+            const int64_t len = (int64_t)rp[(size_t)r + 1] - rp[(size_t)r];
+            long_nnz += len;
+            longest = std::max(longest, len);
+        }
+        if (longest <= std::min(T, Tc) && h->opt_bucket_rows < 0 && long_nnz * 50 < h->s_nnz) return SEXTANS_OK;
+    }
+    // chain rows leave the piece tables
+    std::vector<int> chain_rows, piece_rows;
+    for (int r : rows) ((int64_t)rp[(size_t)r + 1] - rp[(size_t)r] > Tc ? chain_rows : piece_rows).push_back(r);
+    if (!chain_rows.empty()) {
+        std::vector<int> beg;
+        std::vector<long long> off(1, 0);
+        for (int r : chain_rows) {
+            const long long len = rp[(size_t)r + 1] - rp[(size_t)r];
+            beg.push_back(rp[(size_t)r]);
+            off.push_back(off.back() + len);
+        }
+        if (int rc = upload(&h->d_chain_row, chain_rows)) return rc;
+        if (int rc = upload(&h->d_chain_beg, beg)) return rc;
+        if (int rc = upload(&h->d_chain_off, off)) return rc;
+        {   // launch order of whole-matrix calls: longest chain first (a workgroup lives as long as its row is; one per CU)
+            std::vector<int> perm(chain_rows.size());
+            for (size_t i = 0; i < perm.size(); ++i) perm[i] = (int)i;
+            std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return off[(size_t)a + 1] - off[(size_t)a] > off[(size_t)b + 1] - off[(size_t)b]; });
+            if (int rc = upload(&h->d_chain_perm, perm)) return rc;
+        }
+        h->h_chain_row = chain_rows;
+        h->h_chain_off = off;
+        h->nchain = (int)chain_rows.size();
+        h->chain_T = Tc;
+    }
+    std::vector<int> ci;
+    std::vector<float> va;
+    if (int rc = read_back_entries(h, ci, va, 1)) return rc;
+    // piece tables in two row orders
+    auto build = [&](const std::vector<int> &order, sextans_engine::PieceTable &t) -> int {
+        std::vector<int> vrp, vend, vfirst;
+        for (int r : order) {
+            vfirst.push_back((int)vrp.size());
+            const int64_t j0 = rp[(size_t)r], j1 = rp[(size_t)r + 1];
+            const int64_t step = (j1 - j0 > T) ? T : (j1 - j0);
+            for (int64_t j = j0; j < j1; j += step) { vrp.push_back((int)j); vend.push_back((int)std::min(j + step, j1)); }
+        }
+        vfirst.push_back((int)vrp.size());
+        if (int rc = upload(&t.d_vrp, vrp)) return rc;
+        if (int rc = upload(&t.d_vend, vend)) return rc;
+        if (int rc = upload(&t.d_vfirst, vfirst)) return rc;
+        if (int rc = upload(&t.d_row, order)) return rc;
+        t.h_row = order;
+        t.h_vfirst = vfirst;
+        return SEXTANS_OK;
+    };
+    std::vector<int> by_len = piece_rows;
+    std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b) {
+        return rp[(size_t)a + 1] - rp[(size_t)a] > rp[(size_t)b + 1] - rp[(size_t)b];
+    });
+    if (int rc = build(by_len, h->by_len)) return rc;
+    if (int rc = build(piece_rows, h->by_row)) return rc;
+    // main matrix: long rows emptied; skip flags
+    std::vector<int> mrp((size_t)h->M + 1, 0);
+    std::vector<unsigned char> skip((size_t)h->M, 0);
+    {
+        size_t k = 0, w = 0;
+        for (int r = 0; r < h->M; ++r) {
+            const int j0 = rp[(size_t)r], j1 = rp[(size_t)r + 1];
+            if (k < rows.size() && rows[k] == r) {
+                skip[(size_t)r] = 1;
+                if ((int64_t)j1 - j0 > T) h->h_split_rows.push_back(r);
+                ++k;
+            } else {
+                if (w != (size_t)j0) {
+                    std::copy(ci.begin() + j0, ci.begin() + j1, ci.begin() + (ptrdiff_t)w);
+                    std::copy(va.begin() + j0, va.begin() + j1, va.begin() + (ptrdiff_t)w);
+                }
+                w += (size_t)(j1 - j0);
+            }
+            mrp[(size_t)r + 1] = (int)w;
+        }
+        ci.resize(w ? w : 1); va.resize(w ? w : 1);
+        h->m_nnz = (int64_t)w;
+    }
+    if (int rc = upload(&h->d_mrp, mrp)) return rc;
+    if (int rc = upload(&h->d_mci, ci)) return rc;
+    if (int rc = upload(&h->d_mv, va)) return rc;
+    if (int rc = upload(&h->d_skip, skip)) return rc;
+    h->m_rp = h->d_mrp; h->m_ci = h->d_mci; h->m_v = h->d_mv;
+    h->nhub = (int)piece_rows.size();
+    h->split_nv = h->by_len.h_vfirst.back();
+    h->split_T = T == INT64_MAX ? 0 : T;
+    h->bucket_L0 = L0;
+    return SEXTANS_OK;
+}
+
+// Everything that may allocate or run host-side preprocessing for an N-column SpMM: B-panel workspace,
+// N-tile plan, and (for kernel != 1) the packed row-bucketed form of A.  Idempotent; called by
+// sextans_spmm_device2 and, ahead of the timed region, by sextans_spmm_host.
+int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_panel, bool &use_window) {
+    if (int rc = ensure_dense(h)) return rc;   // first the dense tiles leave (when the caller routes them to MFMA) ...
+    if (int rc = ensure_split(h)) return rc;   // ... then the long rows; the packed forms below are built from what remains
+    if (h->dense_W > 0 && N % 32 == 0) {
+        const size_t need = (size_t)((h->K + 31) / 32) * 32 * (size_t)N * 2;
+        if (h->bell_Bf_cap < need) {
+            if (h->d_bell_Bf) SX_HIP(hipFree(h->d_bell_Bf));
+            h->d_bell_Bf = nullptr; h->bell_Bf_cap = 0;
+            SX_HIP(hipMalloc(&h->d_bell_Bf, need));
+            h->bell_Bf_cap = need;
+        }
+    }
+    if (h->nhub > 0)
+        if (int rc = ensure(&h->d_P, &h->P_cap, (size_t)h->split_nv * (size_t)N)) return rc;
+    if (h->nchain > 0) {
+        if (!h->aux_stream) {
+            SX_HIP(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));   // (a high-priority stream was measured: no difference)
+            SX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            SX_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
+    }
+    if (h->Bp_cap < (size_t)h->K * (size_t)N || !h->d_Bp) h->bp_layout = 0;   // new workspace: nothing to reuse
+    if (int rc = ensure(&h->d_Bp, &h->Bp_cap, (size_t)h->K * (size_t)N)) return rc;
+    // main tile width: 4*lanes_per_row, but never wider than N itself (N = 8 -> 2 lanes per row); then
+    // 16- and 8-wide tiles for the remainder (N is a multiple of 8, the reference's N-tile
+    // granularity: sextans.cpp:57-60).
+    // "lanes_per_row" 0 = auto: 4 lanes (16-column tiles) for the panel kernel -- measured best on the FEM class
+    // (config 3, N=128: 23 us with 4 lanes, 31 us with 8) -- and 8 lanes (32-column tiles) for the gather kernel
+    // once N >= 32: a 128-byte B row is one fabric request where two 64-byte tiles are two (uniform 4M matrix,
+    // N = 32/64/128: 3.15/6.9/15.2 ms with 8 lanes against 6.1/12.6/27.7 ms with 4).
+    int lpr = h->opt_lpr ? (int)h->opt_lpr : 4;
+    auto tiles = [&]() {
+        while (lpr > 2 && 4 * lpr > N) lpr /= 2;
+        W = 4 * lpr;
+        plan.clear();
+        int col = 0;
+        for (int w : {W, 16, 8}) {
+            if (w > W) continue;
+            const int nt = (N - col) / w;
+            if (nt > 0) { plan.push_back({w, col, nt}); col += nt * w; }
+        }
+    };
+    tiles();
+    // Kernel choice: "kernel" 1 = row-group gather, 2 = LDS panel, 0 = auto (panel when at least half
+    // of the non-zeros sit in row blocks whose B rows are reused -- "only where a tile has reuse").
+    use_panel = false;
+    if (h->opt_kernel != 1 && h->m_nnz > 0) {
+        if (int rc = ensure_plan(h, lpr, h->opt_kernel == 2)) return rc;
+        // (here, not at launch time: prepare() runs before a hipGraph capture starts, and the builder copies to the host)
+        if (lpr == 4 && h->ps.plan_built)
+            if (int rc = ensure_cluster_plan(h)) return rc;
+        use_panel = h->ps.plan_built && ((h->opt_kernel == 2) || (h->ps.plan_panel_frac >= 0.5 && (N >= 32 || h->ps.plan_narrow_frac >= 0.5)));
+    }
+    if (!h->opt_lpr && !use_panel && N >= 32 && lpr != 8) { lpr = 8; tiles(); }
+    // "kernel" 3 = K-windowed accumulator-resident kernel; auto picks it for matrices without B-row reuse
+    // whose B does not fit the L2s when the traffic model says the sweep moves fewer bytes than the gather.
+    use_window = false;
+    if (h->m_nnz > 0 && (h->opt_kernel == 3 || (h->opt_kernel == 0 && !use_panel))) {
+        const bool force = h->opt_kernel == 3;
+        if (force || (h->win_state >= 0 && window_pays(h, N, h->win_state == 1 ? h->win_padded : h->m_nnz))) {
+            if (int rc = ensure_window(h, force)) return rc;
+            use_window = h->win_state == 1 && (force || window_pays(h, N, h->win_padded));
+        }
+    }
+    return SEXTANS_OK;
+}
+
+}  // namespace sxe

@@ -89,7 +89,8 @@ __device__ __forceinline__ void glds16(const float *gsrc, char *lds_dst) {
 // and protects registers it recycles as address temporaries) put full-drain waits -- including waits for the previous
 // tile's STORES to be acknowledged -- at the top of every super tile: 12 k of 16 k cycles per tile were spent waiting.
 // Rules (cdna_hip_programming.md, inline-asm section): a destination counts as written at the asm statement, so
-// nothing may read it before the matching drain(); drain() names every such register as an in/out operand.
+// nothing may read it before the matching drain; the drain (the s_waitcnt after the row loop and the pins right behind it)
+// names every such register as an in/out operand.
 __device__ __forceinline__ void aload4(f32x4 &dst, const float *sbase, unsigned voff_bytes) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
 }
@@ -128,7 +129,6 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
     constexpr int NTT = 16 * H;               // columns per super tile
     constexpr int BATCH = 16;
     constexpr int MAXD = DCAP;                // dictionary capacity of this launch = MAXD * RB (<= 9 * RB, the plan's limit)
-    constexpr int PFT = 3;                    // batches of the row in flight beyond the current one
     extern __shared__ __attribute__((aligned(16))) int smem[];
     char *lds = reinterpret_cast<char *>(smem);
 
@@ -358,6 +358,18 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
         } else {
             static_assert(H == 1 || H == 2, "the drain names the C_in registers explicitly");
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(cin[0][0]), "+v"(cin[0][1]), "+v"(cin[0][2]), "+v"(cin[0][3]) : : "memory");
+        }
+        // The same wait also covers the NEXT panel's B rows (load_panel(st + 1, false) wrote bv / bs behind the compiler's back): name
+        // every one of those registers in a volatile asm right behind the wait (volatile asms keep their order), so that no use of
+        // them -- e.g. the copies that pack bs[u][h][0..3] into the 16-byte operand of store_panel -- can be scheduled above it.
+        if constexpr (!DMA) {
+#pragma unroll
+            for (int u = 0; u < MAXD; ++u)
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    if constexpr (BCOL) asm volatile("" : "+v"(bs[u][h][0]), "+v"(bs[u][h][1]), "+v"(bs[u][h][2]), "+v"(bs[u][h][3]));
+                    else asm volatile("" : "+v"(bv[u][h]));
+                }
         }
         // ---- C straight from the accumulators
         if (cwrite) {

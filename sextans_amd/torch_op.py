@@ -33,21 +33,29 @@ def clear_cache():
 def _engine_for(A, dev):
     """One engine per sparse matrix, at most _MAX_ENGINES of them (LRU: every entry pins an engine with its device
     workspaces).  The key holds the addresses AND the version counters of A's three tensors, so an in-place update
-    of A gets a fresh engine (the packed forms snapshot the values).  The entry also keeps A's own tensors alive:
+    of A gets a fresh engine (the packed forms snapshot the values); tensors without version counters (inference mode)
+    get a fresh engine every time.  The entry also keeps A's own tensors alive:
     as long as it exists their storage cannot be freed and handed to a different matrix, so equal addresses always
     mean the same matrix."""
     crow, col, val = A.crow_indices(), A.col_indices(), A.values()
     M, K = A.shape
-    def ver(t):   # inference-mode tensors have no version counter: address-only key (the entry pins the tensors)
+    def ver(t):   # inference-mode tensors have no version counter
         try:
             return t._version
         except RuntimeError:
-            return -1
-    key = (dev, crow.data_ptr(), col.data_ptr(), val.data_ptr(), ver(crow), ver(col), ver(val), M, K, val.numel())
+            return None
+    vers = (ver(crow), ver(col), ver(val))
+    key = (dev, crow.data_ptr(), col.data_ptr(), val.data_ptr(), vers, M, K, val.numel())
+    # Without version counters an in-place update of A (same storage, same addresses) cannot be told from no update, and the
+    # packed forms snapshot the values: such matrices are never served from the cache -- a stale entry under the same
+    # addresses is dropped and the engine is rebuilt on every call.
+    cacheable = None not in vers
     ent = _cache.get(key)
     if ent is not None:
-        _cache.move_to_end(key)
-        return ent[0]
+        if cacheable:
+            _cache.move_to_end(key)
+            return ent[0]
+        _evict(key)
     crow32, col32 = crow.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
     val32 = val.to(torch.float32).contiguous()
     eng = api.Engine(dev)
