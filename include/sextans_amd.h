@@ -254,19 +254,28 @@ int sextans_destroy(sextans_handle_t h);
  * N >= 32, default 150: with more columns per B row the panel pays earlier; the packed plan is built once, for the lower
  * of the two), "panel_v2" (-1 auto / 0 / 1: the register-resident form of the panel
  * kernel, spmm_csr_panel_v2), "tiles_per_wg" (N tiles one workgroup of that kernel walks; 0 = auto),
- * "row_cluster" (-1 auto / 0 never / 1 whenever the structure is found: for matrices with Cartesian-grid stencil structure in
- * natural ordering -- strides inferred from the column offsets of sampled rows -- the LDS-panel plan visits the rows brick by brick
- * instead of in runs of consecutive rows, so that a 64-row block needs ~30 % fewer B rows in its panel; rows are
- * independent, every sum keeps its order: bit-identical.  Auto uses it when the clustered plan copies >= 15 % fewer B rows;
- * whole-matrix calls of spmm_csr_panel_v2 only, row-range calls keep the natural-order plan.  "cluster_group" (default 3) /
- * "cluster_shape" (0 = default bricks): layout tunables of that order, for measurements; stats "row_cluster" (1 in use, -1
- * declined), "grid_stride_line", "grid_stride_plane", "panel_rows_natural", "panel_rows_clustered"),
+ * "row_cluster" (-1 auto / 0 never / 1 whenever a clustered plan can be built / 2 graph clustering also for grids): the plan of
+ *   spmm_csr_panel_v2 may visit the rows in a clustered order on whole-matrix calls -- the rows of a matrix are independent, so
+ *   every sum keeps its order and the result stays bit-identical to cpu_spmm_CSR.  Two forms: (1) matrices with Cartesian-grid
+ *   stencil structure in natural ordering are visited brick by brick (csrc/row_cluster.hip; stats "grid_stride_line",
+ *   "grid_stride_plane"); (2) matrices whose numbering has no locality but whose graph has (meshes in an arbitrary node order) are
+ *   aggregated over the matrix graph on the device (csrc/graph_cluster.hip), their columns relabelled in first-touch order, and the
+ *   SpMM runs in its REORDERED form: B repacked into permuted panels, C staged block-major (two extra passes over C inside the call;
+ *   sextans_last_kernel = "spmm_csr_panel_v2_reordered").  Needs M == K and no rows on the long-row path.  Stats: "row_cluster"
+ *   (1 grid bricks / 2 graph clustering in use, -1 declined, 0 not evaluated yet -- it is evaluated by the first whole-matrix
+ *   SpMM with N >= 16), "panel_rows_natural", "panel_rows_clustered" (B rows copied into LDS per 16-column tile), "panel_blocks",
+ *   "panel_blocks_clustered", "cluster_shared_fraction" (sampled pre-test of form 2).  The same reason the reference schedules its
+ *   non-zeros: keeping the on-chip B window hot (sparse_helper.h:345-403).
+ * "cluster_group" (default 3), "cluster_shape" (0 = default bricks): layout tunables of form (1); measurement switches (below).
  * "small_v2" (default 1: small matrices staged from column-major B size the launch's dictionary capacity and register-resident
  * batches from the plan; 0 = the full-capacity form, for measurements),
  * "cols_per_lane" (0/4 = 16-column tiles at 4 workgroups per CU, the default; 8 = 32-column super tiles at 2 per CU),
  * "bell_shared" (blocked-ELL, N = 256: -1 = use the union-walk kernel spmm_bell_mfma_shared when 8 consecutive block rows
  * share block columns, stat "bell_share" >= 1.5; 0 never; 1 whenever the unions fit), "bell_debug" (measurements only:
- * ablation bits of that kernel, results are wrong when non-zero).  Unknown keys -> SEXTANS_ERR_INVALID. */
+ * ablation bits of that kernel, results are wrong when non-zero).  Unknown keys -> SEXTANS_ERR_INVALID.
+ * MEASUREMENT SWITCHES -- "bell_debug", "cluster_shape", "cluster_group", "phase_timing" -- are not part of the drop-in surface:
+ * setting one to anything but its default returns SEXTANS_ERR_INVALID unless the process runs with SEXTANS_DEBUG_OPTIONS=1 in
+ * its environment (tools/ do; "bell_debug" corrupts C on purpose). */
 /* "mfma_dense_tiles" / "dense_tile_fill_x100": north_star's "MFMA only where a tile is actually dense".  The engine
  * always counts the 32x32 tiles of A whose fill reaches dense_tile_fill_x100 % (default 50) -- sextans_get_stat
  * "dense_tiles", "dense_tile_fraction" (share of the non-zeros in such tiles; estimated from a sample of up to 512
@@ -292,7 +301,8 @@ int sextans_export_plan(sextans_handle_t h, int lanes_per_row, struct sextans_pa
  * region like the reference's scheduling/packing, sextans-host.cpp:114-148), "window_padded_entries",
  * "window_state" (0 not evaluated, 1 built, -1 rejected), "panel_fraction", "panel_blocks", "piece_path_rows",
  * "reassociated_rows", "bucket_threshold", "split_threshold", "dense_tiles", "dense_tile_fraction",
- * "dense_tiles_on_mfma". */
+ * "dense_tiles_on_mfma", "row_cluster" and the other clustering figures listed with that option, "device_bytes" (bytes of
+ * device memory the engine holds right now: matrix copies, packed plans, workspaces). */
 int sextans_get_stat(sextans_handle_t h, const char *key, double *value);
 
 /* Upload a CSR matrix (host pointers) once; later spmm calls reuse the device copy.  This is
@@ -414,6 +424,8 @@ int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint1
  * dominant SpMM kernel launches since the last reset, and how many were timed. */
 int sextans_profile_read(sextans_handle_t h, double *mean_kernel_ns, int64_t *launches,
                          double *mean_repack_ns);
+/* Mean duration of what a call launches BEHIND its SpMM kernel (the reordered form's C staging -> C pass); 0 launches otherwise. */
+int sextans_profile_read_post(sextans_handle_t h, double *mean_post_ns, int64_t *launches);
 int sextans_profile_reset(sextans_handle_t h);
 
 /* Debug aid (option "phase_timing" = 1): wave cycles of the panel kernel's phases summed over a 1/128

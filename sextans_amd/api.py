@@ -160,6 +160,7 @@ def lib():
                                    _f32p, _f32p, C.c_float, _f32p]
     L.sextans_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                        C.POINTER(C.c_double)]
+    L.sextans_profile_read_post.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.sextans_profile_reset.argtypes = [C.c_void_p]
     L.sextans_phase_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.sextans_last_kernel.restype = C.c_char_p
@@ -624,6 +625,12 @@ class Engine:
         _check(lib().sextans_profile_read(self._h, C.byref(k), C.byref(n), C.byref(r)),
                "profile_read")
         return k.value, n.value, r.value
+
+    def profile_read_post(self):
+        """(mean ns, launches) of what calls launched behind their SpMM kernel (the reordered form's C staging -> C pass)."""
+        k, n = C.c_double(), C.c_int64()
+        _check(lib().sextans_profile_read_post(self._h, C.byref(k), C.byref(n)), "profile_read_post")
+        return k.value, n.value
 
     def phase_timing_read(self):
         out = (C.c_int64 * 8)()

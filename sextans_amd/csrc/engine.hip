@@ -17,6 +17,7 @@
 
 #include "chan_kernels.h"
 #include "engine_state.h"
+#include "reorder_kernels.h"
 #include "spmm_csr_kernels.h"
 #include "spmm_panel_v2.h"
 #include "spmm_window_kernel.h"
@@ -117,10 +118,13 @@ void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_
 template <int H>
 int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc,
                       int nsuper, float alpha, float beta, hipStream_t s, int64_t bcol_ld, int blk_begin, int blk_end,
-                      int row_base, bool clustered = false) {
-    // (clustered: the plan over the rows in brick order, whole-matrix calls only; its slot -> row table addresses C)
-    const sextans_engine::PanelState &P = clustered ? h->psc : h->ps;
-    const int *slot_row = clustered ? h->d_slot_row : nullptr;
+                      int row_base, int mode = 0) {
+    // mode 1 (grid bricks): the plan over the rows in brick order, whole-matrix calls only; its slot -> row table addresses C.
+    // mode 2 (graph clustering, the reordered form): dBp = permuted panels, dCin == dCout == the block-major staging buffer,
+    // ldc_in == ldc == floats per tile.
+    const sextans_engine::PanelState &P = mode ? h->psc : h->ps;
+    const int *slot_row = mode == 1 ? h->d_slot_row : nullptr;
+    const unsigned char *skip = mode == 2 ? nullptr : (const unsigned char *)h->d_skip;
     const int nblk = blk_end - blk_begin;
     if (nblk <= 0 || nsuper <= 0) return SEXTANS_OK;
     int tpw = (int)h->opt_tiles_per_wg;
@@ -137,7 +141,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)P.d_row_off,
                            P.d_lidx, P.d_pval, P.d_blk_row, P.d_dict_ptr, P.d_dict, P.plan_dict_stride,
                            dBp, pstride, dCin, ldc_in, dCout, ldc, nsuper, tpw, nblk, alpha, beta, (int)h->opt_xcd,
-                           P.plan_pad_row, blk_begin, row_base, (const unsigned char *)h->d_skip, (long long *)h->d_dbg, slot_row);
+                           P.plan_pad_row, blk_begin, row_base, skip, (long long *)h->d_dbg, slot_row);
         return SEXTANS_OK;
     };
     // register-resident batches (16 entries each) per row: from the mean row length of the main matrix, so that matrices
@@ -167,6 +171,12 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
             return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, true, false, 5>) : go(sx::spmm_csr_panel_v2<H, 2, false, true, false, 5>);
         }
         if (bcol_ld > 0) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, true>) : go(sx::spmm_csr_panel_v2<H, 2, false, true>);
+        if (mode == 2) {   // block-major C staging
+            if (nb == 3) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 3, true, false, false, 9, true>) : go(sx::spmm_csr_panel_v2<H, 3, false, false, false, 9, true>);
+            if (nb == 2) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false, false, 9, true>) : go(sx::spmm_csr_panel_v2<H, 2, false, false, false, 9, true>);
+            if (nb == 4) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 4, true, false, false, 9, true>) : go(sx::spmm_csr_panel_v2<H, 4, false, false, false, 9, true>);
+            return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, false, false, 9, true>) : go(sx::spmm_csr_panel_v2<H, 6, false, false, false, 9, true>);
+        }
         if (nb == 3) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 3, true, false>) : go(sx::spmm_csr_panel_v2<H, 3, false, false>);
         if (nb == 2) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false>) : go(sx::spmm_csr_panel_v2<H, 2, false, false>);
         if (nb == 4) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 4, true, false>) : go(sx::spmm_csr_panel_v2<H, 4, false, false>);
@@ -238,7 +248,7 @@ int sextans_destroy(sextans_handle_t h) {
     free_matrix(h);
     free_bell(h);
     (void)hipFree(h->d_bell_Bf);
-    (void)hipFree(h->d_Bp); (void)hipFree(h->d_B); (void)hipFree(h->d_Cin); (void)hipFree(h->d_Cout);
+    (void)hipFree(h->d_Bp); (void)hipFree(h->d_B); (void)hipFree(h->d_Cin); (void)hipFree(h->d_Cout); (void)hipFree(h->d_Cs);
     sextans_profile_reset(h);
     (void)hipFree(h->d_P);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -322,10 +332,7 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
     }
     if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
         (void)hipSetDevice(h->device);   // the clustered-order plan is (re)considered under the new setting
-        free_panel_state(h->psc);
-        (void)hipFree(h->d_slot_row);
-        h->d_slot_row = nullptr;
-        h->cluster_state = 0;
+        free_cluster_plan(h);
     }
     if (*slot != value) h->dist_cut_key.clear();   // chunk cuts are aligned to the packed forms the options select (all
                                                    // ranks of a partition must change options together: the cut
@@ -415,7 +422,7 @@ int sextans_align_row(sextans_handle_t h, int N, int row, int *aligned) {
     std::vector<Seg> plan;
     int W = 0;
     bool use_panel = false, use_window = false;
-    if (int rc = prepare(h, N, plan, W, use_panel, use_window)) return rc;
+    if (int rc = prepare(h, N, plan, W, use_panel, use_window, false)) return rc;
     *aligned = row;
     if (row == h->M) return SEXTANS_OK;
     if (use_window) *aligned = row / h->win_rw * h->win_rw;
@@ -509,7 +516,10 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "dense_tile_fraction")) *value = h->nnz > 0 ? (double)h->dense_nnz / (double)h->nnz : 0.0;
     else if (!strcmp(key, "dense_tiles_on_mfma")) *value = h->dense_W > 0 ? 1.0 : 0.0;
     else if (!strcmp(key, "bell_share")) *value = h->bell_share;
-    else if (!strcmp(key, "row_cluster")) *value = (double)h->cluster_state;          // 1 in use, -1 rejected, 0 not evaluated yet
+    else if (!strcmp(key, "row_cluster")) *value = (double)h->cluster_state;          // 1 grid bricks / 2 graph clustering in use, -1 declined, 0 not evaluated yet
+    else if (!strcmp(key, "cluster_shared_fraction")) *value = h->cluster_shared;
+    else if (!strcmp(key, "panel_blocks_clustered")) *value = (double)h->psc.plan_nblk;
+    else if (!strcmp(key, "device_bytes")) *value = (double)device_bytes(h);
     else if (!strcmp(key, "grid_stride_line")) *value = (double)h->cluster_s2;
     else if (!strcmp(key, "grid_stride_plane")) *value = (double)h->cluster_s3;
     else if (!strcmp(key, "panel_rows_natural")) *value = (double)h->plan_total_dict;  // B rows copied into LDS per N tile, natural order
@@ -607,7 +617,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     std::vector<Seg> plan;
     int W = 0;
     bool use_panel = false, use_window = false;
-    if (int rc = prepare(h, N, plan, W, use_panel, use_window)) return rc;
+    if (int rc = prepare(h, N, plan, W, use_panel, use_window, whole)) return rc;
     if (h->dense_W > 0) {
         // Dense tiles first, on the matrix cores: C_out = alpha * (A_dense * bf16(B)) + beta * C_in for the full block
         // rows (and alpha * 0 + beta * C_in below them); the CSR kernels then add alpha * (A_rest * B) on top
@@ -684,19 +694,38 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
                         (size_t)h->K * (size_t)N * sizeof(float) <= ((size_t)16 << 20);
     // (a reuse request is honoured only if the panels in the workspace have this layout: row-range calls of
     // one pipelined SpMM may alternate between the window kernel's 8-column panels and these)
-    const bool skip_repack = fuse_b || ((flags & SEXTANS_ROWS_REUSE_B_PANELS) != 0 && h->bp_layout == W);
+    // The reordered form (graph-clustered plan, ensure_cluster_plan): whole-matrix calls, 16-column tiles.  Its B panels hold the
+    // rows of B in the plan's column order and C goes through the block-major staging buffer (reorder_kernels.h); an 8-column
+    // remainder tile keeps the natural-order kernels and panels.  (Layout tag -W: such panels are never reused by a row-range call.)
+    const bool reordered = whole && h->cluster_state == 2 && h->opt_kernel != 1 && h->opt_kernel != 3 && W == 16 && !fuse_b && !hubs &&
+                           !chains && h->dense_W == 0 && h->d_Cs && N >= 16;
+    const int64_t cs_tile = reordered ? (int64_t)h->psc.plan_nblk * 64 * 16 : 0;   // floats per 16-column tile of the staging buffer
+    const int layout = reordered ? -W : W;
+    const bool skip_repack = fuse_b || ((flags & SEXTANS_ROWS_REUSE_B_PANELS) != 0 && h->bp_layout == layout);
 
-    if (!skip_repack) {
-        h->bp_layout = W;
+    if (!skip_repack || reordered) {
         Prof p(h, &h->ev_repack, s);
-        for (const Seg &g : plan) {
-            float *dst = h->d_Bp + (size_t)h->K * (size_t)g.col0;
-            switch (g.width) {
-                case 32: launch_repack<32>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s); break;
-                case 16: launch_repack<16>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s); break;
-                default: launch_repack<8>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s); break;
+        if (!skip_repack) {
+            h->bp_layout = layout;
+            for (const Seg &g : plan) {
+                float *dst = h->d_Bp + (size_t)h->K * (size_t)g.col0;
+                if (reordered && g.width == 16) {
+                    hipLaunchKernelGGL(sx::repack_b_panels_perm, dim3((unsigned)((h->K + sx::kBlock - 1) / sx::kBlock), (unsigned)g.ntiles),
+                                       dim3(sx::kBlock), 0, s, d_B, ldb, dst, h->K, g.col0, h->d_colpos);
+                    continue;
+                }
+                switch (g.width) {
+                    case 32: launch_repack<32>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s); break;
+                    case 16: launch_repack<16>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s); break;
+                    default: launch_repack<8>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s); break;
+                }
             }
         }
+        if (reordered)
+            for (const Seg &g : plan)
+                if (g.width == 16)
+                    hipLaunchKernelGGL(sx::permute_c_in, dim3((unsigned)((h->M + sx::kBlock - 1) / sx::kBlock), (unsigned)g.ntiles),
+                                       dim3(sx::kBlock), 0, s, d_C_in, ldc_in, h->d_Cs, cs_tile, h->d_cpos, h->M, g.col0);
     }
     {
         Prof p(h, &h->ev_kernel, s);
@@ -713,6 +742,12 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             const float *bp = h->d_Bp + (size_t)h->K * (size_t)g.col0;
             const float *cin = d_C_in + (int64_t)g.col0 * ldc_in;
             float *cout = d_C_out + (int64_t)g.col0 * ldc;
+            if (reordered && g.width == 16) {
+                if (int rc = launch_panel_v2<1>(h, bp, h->d_Cs, cs_tile, h->d_Cs, cs_tile, g.ntiles, alpha, beta, s, 0, 0, h->psc.plan_nblk, 0, 2))
+                    return rc;
+                v2_used = true;
+                continue;
+            }
             const bool panel_here = use_panel && g.width == W;   // the plan is built for width W
             const float *bsrc = fuse_b ? d_B + (int64_t)g.col0 * ldb : bp;
             const int64_t bld = fuse_b ? ldb : 0;
@@ -741,7 +776,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
                 // whole-matrix calls on repacked panels: the plan over the rows in clustered (brick) order when the matrix has one
                 const bool clustered = whole && !fuse_b && h->cluster_state == 1;
                 if (int rc = launch_panel_v2<1>(h, bsrc, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, bld, clustered ? 0 : blk0,
-                                                clustered ? h->psc.plan_nblk : blk1, row_begin, clustered))
+                                                clustered ? h->psc.plan_nblk : blk1, row_begin, clustered ? 1 : 0))
                     return rc;
                 v2_used = true;
                 if (hubs) launch_hub_pieces<4>(h, pt, bp, g.ntiles, g.col0, v0, v1, s);
@@ -761,7 +796,14 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         }
         if (hubs) fold();
         if (chains) SX_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
-        h->last_kernel = kernel_name(v2_used ? 3 : use_panel ? 1 : 0, hubs || chains, h->dense_W > 0);
+        h->last_kernel = reordered ? "spmm_csr_panel_v2_reordered" : kernel_name(v2_used ? 3 : use_panel ? 1 : 0, hubs || chains, h->dense_W > 0);
+    }
+    if (reordered) {
+        Prof p(h, &h->ev_post, s);
+        for (const Seg &g : plan)
+            if (g.width == 16)
+                hipLaunchKernelGGL(sx::permute_c_out, dim3((unsigned)((h->M + sx::kBlock - 1) / sx::kBlock), (unsigned)g.ntiles),
+                                   dim3(sx::kBlock), 0, s, h->d_Cs, cs_tile, d_C_out, ldc, h->d_cpos, h->M, g.col0);
     }
     SX_HIP(hipGetLastError());
     return SEXTANS_OK;
@@ -962,7 +1004,7 @@ int sextans_spmm_csr(int M, int N, int K, int NNZ, float ALPHA, const int *CSRRo
 
 int sextans_profile_reset(sextans_handle_t h) {
     if (!h) return SEXTANS_ERR_INVALID;
-    for (auto *vec : {&h->ev_kernel, &h->ev_repack}) {
+    for (auto *vec : {&h->ev_kernel, &h->ev_repack, &h->ev_post}) {
         for (auto &ep : *vec) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
         vec->clear();
     }
@@ -987,6 +1029,21 @@ int sextans_profile_read(sextans_handle_t h, double *mean_kernel_ns, int64_t *la
     if (int rc = mean(h->ev_kernel, mean_kernel_ns)) return rc;
     if (int rc = mean(h->ev_repack, mean_repack_ns)) return rc;
     if (launches) *launches = (int64_t)h->ev_kernel.size();
+    return SEXTANS_OK;
+}
+
+int sextans_profile_read_post(sextans_handle_t h, double *mean_post_ns, int64_t *launches) {
+    if (!h) return SEXTANS_ERR_INVALID;
+    SX_HIP(hipSetDevice(h->device));
+    double tot = 0.0;
+    for (auto &ep : h->ev_post) {
+        SX_HIP(hipEventSynchronize(ep.b));
+        float ms = 0.f;
+        SX_HIP(hipEventElapsedTime(&ms, ep.a, ep.b));
+        tot += (double)ms * 1e6;
+    }
+    if (mean_post_ns) *mean_post_ns = h->ev_post.empty() ? 0.0 : tot / (double)h->ev_post.size();
+    if (launches) *launches = (int64_t)h->ev_post.size();
     return SEXTANS_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "engine_state.h"
+#include "graph_cluster.h"
 #include "panel_plan.h"
 #include "plan_device.h"
 #include "row_cluster.h"
@@ -23,15 +24,46 @@ void free_panel_state(sextans_engine::PanelState &p) {
     p = sextans_engine::PanelState();
 }
 
+void free_cluster_plan(sextans_engine *h) {   // the clustered-order plan and its tables; it is reconsidered at the next whole-matrix call
+    free_panel_state(h->psc);
+    (void)hipFree(h->d_slot_row); (void)hipFree(h->d_colpos); (void)hipFree(h->d_cpos);
+    h->d_slot_row = h->d_colpos = h->d_cpos = nullptr;
+    h->cluster_state = 0;
+    h->cluster_total_dict = 0;
+    h->cluster_shared = 0.0;
+}
+
 void free_plan(sextans_engine *h) {   // every packed form of the current main matrix
     free_panel_state(h->ps);
     for (auto &p : h->plan_stash) free_panel_state(p);
-    free_panel_state(h->psc);
-    (void)hipFree(h->d_slot_row);
-    h->d_slot_row = nullptr;
-    h->cluster_state = 0;
+    free_cluster_plan(h);
     h->cluster_s2 = h->cluster_s3 = 0;
     h->plan_total_dict = h->cluster_total_dict = 0;
+}
+
+int64_t device_bytes(const sextans_engine *h) {
+    auto plan_bytes = [](const sextans_engine::PanelState &p) -> int64_t {
+        if (!p.plan_built || !p.plan_lpr) return 0;
+        const int64_t rb = sx::kBlock / p.plan_lpr;
+        return (int64_t)p.plan_nblk * (4 * (2 + p.plan_dict_stride + 2 * rb)) + p.plan_stream_len * 6 + (p.plan_mixed ? p.plan_stream_len * 4 : 4);
+    };
+    int64_t b = 0;
+    const int64_t rows = (int64_t)h->M + 1;
+    if (h->owns_matrix) b += rows * 4 + h->nnz * 8;
+    if (h->d_srp) b += rows * 4 + h->s_nnz * 8;
+    if (h->d_mrp) b += rows * 4 + h->m_nnz * 8 + h->M;
+    b += ((int64_t)h->split_nv * 8 + (int64_t)h->nhub * 8) * 2 + (int64_t)h->nchain * 24;
+    b += plan_bytes(h->ps) + plan_bytes(h->psc);
+    for (const auto &p : h->plan_stash) b += plan_bytes(p);
+    if (h->d_slot_row) b += (int64_t)h->psc.plan_nblk * 64 * 4;
+    if (h->d_colpos) b += (int64_t)h->K * 4;
+    if (h->d_cpos) b += (int64_t)h->M * 4;
+    if (h->d_wstream) b += h->win_padded * 8 + (int64_t)h->win_nwaves * 4;
+    if (h->d_dense_Af) b += (int64_t)h->dense_mb * h->dense_W * (2048 + 4);
+    if (h->d_bell_Af) b += (int64_t)(h->bell_M / 32) * h->bell_W * (2048 + (h->d_bell_col_owned ? 4 : 0));
+    b += (int64_t)h->bell_Bf_cap;
+    b += 4 * (int64_t)(h->Bp_cap + h->B_cap + (h->d_Cin ? h->C_cap : 0) + h->C_cap + h->P_cap + h->stage_cap + h->chB_cap + h->chC_cap + h->Cs_cap);
+    return b;
 }
 
 void free_window(sextans_engine *h) {
@@ -139,6 +171,25 @@ int read_back_entries(sextans_engine *h, std::vector<int> &ci, std::vector<float
 // reuse (e.g. uniformly random columns).
 int64_t plan_key(const sextans_engine *h) { return h->opt_min_reuse_x100 * 100000 + h->opt_min_reuse_wide_x100; }
 
+// DevicePlan -> PanelState (the arrays change owner)
+void adopt_device_plan(sextans_engine::PanelState &c, sx::DevicePlan &dp, const sextans_engine *h, int lpr, int cap) {
+    c.plan_lpr = lpr;
+    c.plan_min_reuse = plan_key(h);
+    c.plan_nblk = dp.nblk;
+    c.plan_dict_stride = dp.dict_stride;
+    c.plan_mixed = dp.mixed;
+    c.d_blk_row = dp.d_blk_row; c.d_dict_ptr = dp.d_dict_cnt; c.d_dict = dp.d_dict; c.d_row_off = dp.d_slot_info;
+    c.d_lidx = dp.d_idx16; c.d_pcol32 = dp.d_col32; c.d_pval = dp.d_val;
+    c.h_blk_row.swap(dp.h_blk_row);
+    c.plan_stream_len = dp.stream_len;
+    c.plan_nnz_panel = dp.nnz_in_panel_blocks;
+    c.plan_max_dict = dp.max_dict;
+    c.plan_max_row = dp.max_row_len;
+    c.plan_pad_row = cap;
+    c.plan_built = true;
+    dp = sx::DevicePlan();
+}
+
 int sample_reuse(sextans_engine *h, int RB, int max_unique, double min_reuse, double min_reuse2, double *frac, double *frac2) {
     const int nblk = (h->M + RB - 1) / RB;
     const int nsample = std::min(nblk, 512);
@@ -245,17 +296,25 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
     return SEXTANS_OK;
 }
 
-// Clustered-order plan (see PanelState psc): built once per matrix, after the natural-order plan for 4 lanes per row exists and is
-// dictionary-only.  Option "row_cluster": -1 = when the matrix has grid-stencil structure AND the clustered plan copies at least
-// 15 % fewer B rows into LDS; 1 = whenever the structure is found; 0 = never.
-int ensure_cluster_plan(sextans_engine *h) {
-    if (h->cluster_state != 0) return SEXTANS_OK;
-    h->cluster_state = -1;
-    if (h->opt_row_cluster == 0 || !h->ps.plan_built || h->ps.plan_lpr != 4 || h->ps.plan_mixed || h->M < 4096) return SEXTANS_OK;
-    PlanTimer timer(h);
+// Clustered-order plan (see PanelState psc): built once per matrix, on the first WHOLE-matrix call that could use it.  Two forms:
+//   cluster_state 1  grid bricks (row_cluster.hip): matrices with Cartesian-grid stencil structure in natural ordering; strides
+//                    inferred from sampled rows, rows sorted brick by brick; C addressed through a slot -> row table, B untouched.
+//                    A fast path: one radix sort, and hand-shaped bricks beat the general clustering by ~10 % in panel rows.
+//   cluster_state 2  graph clustering (graph_cluster.hip) for everything else that has neighbourhood structure but not in its
+//                    numbering: multilevel pairwise aggregation of the rows over the matrix graph, columns relabelled in
+//                    first-touch order, B repacked into permuted panels and C staged block-major (reorder_kernels.h).
+// Option "row_cluster": -1 = automatic (grid: when the clustered plan copies >= 15 % fewer B rows into LDS; graph: when the
+// natural-order plan is missing or its blocks are cut short by the panel capacity, the sampled rows share neighbourhoods, and the
+// reordered plan copies >= 40 % fewer B rows -- it pays two extra passes over C); 1 = whenever a clustered plan can be built;
+// 2 = graph clustering even for grids; 0 = never.
+// It is an optimisation: whatever goes wrong in here (allocation failures included) declines it and the SpMM runs on the
+// natural-order forms it already has.
+namespace {
+int cluster_grid(sextans_engine *h) {   // 0 = in use, 1 = declined
+    if (!h->ps.plan_built || h->ps.plan_lpr != 4 || h->ps.plan_mixed) return 1;
     // ---- grid strides from the columns of ~128 rows out of the middle half of the matrix
     std::vector<int> rp;
-    if (int rc = read_back_row_ptr(h, rp)) return rc;
+    if (read_back_row_ptr(h, rp)) return 1;
     std::vector<int> rows;
     std::vector<std::vector<int>> cols;
     const int nsample = 128;
@@ -264,12 +323,12 @@ int ensure_cluster_plan(sextans_engine *h) {
         const int j0 = rp[(size_t)r], j1 = rp[(size_t)r + 1];
         if (j1 <= j0 || j1 - j0 > 4096) continue;
         std::vector<int> c((size_t)(j1 - j0));
-        SX_HIP(hipMemcpy(c.data(), h->m_ci + j0, sizeof(int) * c.size(), hipMemcpyDeviceToHost));
+        if (hipMemcpy(c.data(), h->m_ci + j0, sizeof(int) * c.size(), hipMemcpyDeviceToHost) != hipSuccess) return 1;
         rows.push_back(r);
         cols.push_back(std::move(c));
     }
     sx::GridStrides gs;
-    if (!sx::detect_grid_strides(h->M, rows, cols, &gs)) return SEXTANS_OK;
+    if (!sx::detect_grid_strides(h->M, rows, cols, &gs)) return 1;
     h->cluster_s2 = gs.s2;
     h->cluster_s3 = gs.s3;
     // ---- bricks of <= 64 rows = one row block each: a run of 15 / 16 rows of a grid line x 2 lines x 2 planes (3-D), x 4 lines (2-D).
@@ -277,53 +336,85 @@ int ensure_cluster_plan(sextans_engine *h) {
     // natural order (12-row runs gave away half of the gain at N = 128, where C is half of the traffic); the plan builder starts a
     // block at every brick (`cut`), so blocks and bricks coincide.
     int run_rows = 16, b2 = gs.s3 > 0 ? 2 : 4, b3 = gs.s3 > 0 ? 2 : 1;
-    if (h->opt_cluster_shape > 0) {   // EXPERIMENT: run_rows * 10000 + b2 * 100 + b3
+    if (h->opt_cluster_shape > 0) {   // measurement switch (SEXTANS_DEBUG_OPTIONS): run_rows * 10000 + b2 * 100 + b3, validated by set_option
         run_rows = (int)(h->opt_cluster_shape / 10000); b2 = (int)(h->opt_cluster_shape / 100 % 100); b3 = (int)(h->opt_cluster_shape % 100);
+        if (run_rows < 1 || b2 < 1 || b3 < 1) return 1;
     }
     std::string err;
     int *d_perm = nullptr, *prp = nullptr, *pci = nullptr;
     unsigned char *d_cut = nullptr;
     float *pv = nullptr;
-    auto drop = [&]() { (void)hipFree(d_perm); (void)hipFree(d_cut); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv); };
-    if (sx::build_brick_order_device(h->M, gs, run_rows, b2, b3, (int)h->opt_cluster_group, &d_perm, &d_cut, err)) { g_last_error = err; drop(); return SEXTANS_ERR_HIP; }
-    if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_perm, &prp, &pci, &pv, err)) {
-        g_last_error = err; drop(); return SEXTANS_ERR_HIP;
-    }
     sx::DevicePlan dp;
+    auto drop = [&]() { (void)hipFree(d_perm); (void)hipFree(d_cut); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv); sx::free_device_plan(dp); return 1; };
+    if (sx::build_brick_order_device(h->M, gs, run_rows, b2, b3, (int)h->opt_cluster_group, &d_perm, &d_cut, err)) return drop();
+    if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_perm, &prp, &pci, &pv, err)) return drop();
     const int lpr = 4, RB = sx::kBlock / lpr, cap = kPanelFloats / (4 * lpr);
     const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;
     const int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, min_reuse, dp, err, d_cut);
     (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv); (void)hipFree(d_cut);
     prp = pci = nullptr; pv = nullptr; d_cut = nullptr;
-    if (brc == 2) { g_last_error = err; sx::free_device_plan(dp); drop(); return SEXTANS_ERR_HIP; }
+    if (brc != 0) return drop();
     h->cluster_total_dict = dp.total_dict;
     const bool gain = (double)dp.total_dict <= 0.85 * (double)h->plan_total_dict;
-    if (brc != 0 || dp.mixed || dp.dict_stride > 9 * RB || dp.max_dict > sx::kWideMaxDict || (h->opt_row_cluster < 0 && !gain)) {
-        sx::free_device_plan(dp); drop();
-        return SEXTANS_OK;
-    }
-    if (sx::build_slot_rows_device(dp.nblk, RB, dp.d_blk_row, d_perm, &h->d_slot_row, err)) {
-        g_last_error = err; sx::free_device_plan(dp); drop(); return SEXTANS_ERR_HIP;
-    }
+    if (dp.mixed || dp.dict_stride > 9 * RB || dp.max_dict > sx::kWideMaxDict || (h->opt_row_cluster < 0 && !gain)) return drop();
+    if (sx::build_slot_rows_device(dp.nblk, RB, dp.d_blk_row, d_perm, &h->d_slot_row, err)) return drop();
     (void)hipFree(d_perm);
-    sextans_engine::PanelState &c = h->psc;
-    c.plan_lpr = lpr;
-    c.plan_min_reuse = plan_key(h);
-    c.plan_nblk = dp.nblk;
-    c.plan_dict_stride = dp.dict_stride;
-    c.plan_mixed = false;
-    c.d_blk_row = dp.d_blk_row; c.d_dict_ptr = dp.d_dict_cnt; c.d_dict = dp.d_dict; c.d_row_off = dp.d_slot_info;
-    c.d_lidx = dp.d_idx16; c.d_pcol32 = dp.d_col32; c.d_pval = dp.d_val;
-    c.h_blk_row.swap(dp.h_blk_row);
-    c.plan_stream_len = dp.stream_len;
-    c.plan_panel_frac = h->ps.plan_panel_frac;
-    c.plan_narrow_frac = h->ps.plan_narrow_frac;
-    c.plan_nnz_panel = dp.nnz_in_panel_blocks;
-    c.plan_max_dict = dp.max_dict;
-    c.plan_max_row = dp.max_row_len;
-    c.plan_pad_row = cap;
-    c.plan_built = true;
-    h->cluster_state = 1;
+    adopt_device_plan(h->psc, dp, h, lpr, cap);
+    h->psc.plan_panel_frac = h->ps.plan_panel_frac;
+    h->psc.plan_narrow_frac = h->ps.plan_narrow_frac;
+    return 0;
+}
+
+int cluster_graph(sextans_engine *h) {   // 0 = in use, 1 = declined
+    if (h->M != h->K || h->m_nnz <= 0 || h->d_skip || h->nhub > 0 || h->nchain > 0 || h->dense_W > 0) return 1;
+    if ((int64_t)h->K * 64 >= ((int64_t)1 << 32)) return 1;   // 32-bit byte offsets into a K x 16 panel
+    const int lpr = 4, RB = sx::kBlock / lpr, cap = kPanelFloats / (4 * lpr);
+    std::string err;
+    if (h->opt_row_cluster < 0) {
+        // worth trying?  Not when the natural-order plan already fills its blocks (numberings with locality: the grid path or
+        // nothing), and not when neighbouring rows do not share neighbourhoods (random columns: there is nothing to find)
+        if (h->ps.plan_built && !h->ps.plan_mixed && h->ps.plan_nblk > 0 && (double)h->M / h->ps.plan_nblk >= 40.0) return 1;
+        double shared = 0.0;
+        if (sx::probe_shared_neighbourhood_device(h->M, h->m_rp, h->m_ci, 256, &shared, err)) return 1;
+        h->cluster_shared = shared;
+        if (shared < 0.2) return 1;
+    }
+    int *d_order = nullptr, *d_colpos = nullptr, *d_cpos = nullptr, *prp = nullptr, *pci = nullptr;
+    float *pv = nullptr;
+    sx::DevicePlan dp;
+    auto drop = [&]() { (void)hipFree(d_order); (void)hipFree(d_colpos); (void)hipFree(d_cpos); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
+                        sx::free_device_plan(dp); return 1; };
+    if (sx::cluster_rows_graph_device(h->M, h->K, h->m_nnz, h->m_rp, h->m_ci, 4096, &d_order, err)) return drop();
+    if (sx::column_first_touch_order_device(h->M, h->K, h->m_rp, h->m_ci, d_order, &d_colpos, err)) return drop();
+    if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_order, &prp, &pci, &pv, err)) return drop();
+    if (sx::relabel_columns_device(h->m_nnz, pci, d_colpos, err)) return drop();
+    const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;
+    const int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, min_reuse, dp, err, nullptr);
+    (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
+    prp = pci = nullptr; pv = nullptr;
+    if (brc != 0) return drop();
+    h->cluster_total_dict = dp.total_dict;
+    if (dp.mixed || dp.dict_stride > 9 * RB || dp.max_dict > sx::kWideMaxDict || (int64_t)dp.nblk * RB * 64 >= ((int64_t)1 << 32)) return drop();
+    if (h->opt_row_cluster < 0 && h->ps.plan_built && (double)dp.total_dict > 0.6 * (double)h->plan_total_dict) return drop();
+    if (sx::build_row_slots_device(h->M, dp.nblk, RB, dp.d_blk_row, d_order, &d_cpos, err)) return drop();
+    (void)hipFree(d_order);
+    adopt_device_plan(h->psc, dp, h, lpr, cap);
+    h->psc.plan_panel_frac = h->m_nnz ? (double)dp.nnz_in_panel_blocks / (double)h->m_nnz : 0.0;
+    h->psc.plan_narrow_frac = h->psc.plan_panel_frac;
+    h->d_colpos = d_colpos;
+    h->d_cpos = d_cpos;
+    return 0;
+}
+}  // namespace
+
+int ensure_cluster_plan(sextans_engine *h) {
+    if (h->cluster_state != 0) return SEXTANS_OK;
+    h->cluster_state = -1;
+    if (h->opt_row_cluster == 0 || h->M < 4096) return SEXTANS_OK;
+    PlanTimer timer(h);
+    if (h->opt_row_cluster != 2 && cluster_grid(h) == 0) h->cluster_state = 1;
+    else if (cluster_graph(h) == 0) h->cluster_state = 2;
+    (void)hipGetLastError();   // a failure in here (out of memory for the sort buffers, ...) only declines the clustered plan
     return SEXTANS_OK;
 }
 
@@ -538,7 +629,7 @@ int ensure_split(sextans_engine *h) {
 // Everything that may allocate or run host-side preprocessing for an N-column SpMM: B-panel workspace,
 // N-tile plan, and (for kernel != 1) the packed row-bucketed form of A.  Idempotent; called by
 // sextans_spmm_device2 and, ahead of the timed region, by sextans_spmm_host.
-int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_panel, bool &use_window) {
+int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_panel, bool &use_window, bool whole) {
     if (int rc = ensure_dense(h)) return rc;   // first the dense tiles leave (when the caller routes them to MFMA) ...
     if (int rc = ensure_split(h)) return rc;   // ... then the long rows; the packed forms below are built from what remains
     if (h->dense_W > 0 && N % 32 == 0) {
@@ -586,12 +677,19 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
     use_panel = false;
     if (h->opt_kernel != 1 && h->m_nnz > 0) {
         if (int rc = ensure_plan(h, lpr, h->opt_kernel == 2)) return rc;
-        // (here, not at launch time: prepare() runs before a hipGraph capture starts, and the builder copies to the host)
-        if (lpr == 4 && h->ps.plan_built)
+        // (here, not at launch time: prepare() runs before a hipGraph capture starts, and the builders copy to the host and
+        // allocate.  Only for whole-matrix calls: engines that serve row ranges -- the chunks of the multi-GPU pipeline -- never
+        // use the clustered plan and do not pay for it.)
+        if (lpr == 4 && whole && h->opt_kernel != 3) {
             if (int rc = ensure_cluster_plan(h)) return rc;
+            if (h->cluster_state == 2 && N >= 16)   // block-major C staging of the reordered form: N / 16 tiles x 64 slots per block
+                if (int rc = ensure(&h->d_Cs, &h->Cs_cap, (size_t)(N / 16) * (size_t)h->psc.plan_nblk * 64 * 16)) return rc;
+        }
         use_panel = h->ps.plan_built && ((h->opt_kernel == 2) || (h->ps.plan_panel_frac >= 0.5 && (N >= 32 || h->ps.plan_narrow_frac >= 0.5)));
     }
-    if (!h->opt_lpr && !use_panel && N >= 32 && lpr != 8) { lpr = 8; tiles(); }
+    // (the reordered form of a graph-clustered matrix runs 16-column tiles whether or not a natural-order plan exists)
+    const bool reorder = whole && h->cluster_state == 2 && h->opt_kernel != 1 && h->opt_kernel != 3 && lpr == 4;
+    if (!h->opt_lpr && !use_panel && !reorder && N >= 32 && lpr != 8) { lpr = 8; tiles(); }
     // "kernel" 3 = K-windowed accumulator-resident kernel; auto picks it for matrices without B-row reuse
     // whose B does not fit the L2s when the traffic model says the sweep moves fewer bytes than the gather.
     use_window = false;

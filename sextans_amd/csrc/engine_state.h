@@ -90,8 +90,13 @@ struct sextans_engine {
     // The same plan over the rows in CLUSTERED order (row_cluster.hip: brick by brick for grid-stencil matrices), 4 lanes per row,
     // used by spmm_csr_panel_v2 for whole-matrix calls; row-range calls and every other kernel keep the natural-order plan above.
     PanelState psc;
-    int *d_slot_row = nullptr;          // psc: row of the main matrix per (block, slot)
-    int cluster_state = 0;              // 0 not evaluated, 1 in use, -1 rejected (no grid structure / no gain)
+    int *d_slot_row = nullptr;          // psc, grid bricks: row of the main matrix per (block, slot)
+    int *d_colpos = nullptr;            // psc, graph clustering: row of the permuted B panels that holds column c (K ints)
+    int *d_cpos = nullptr;              //   ... and the slot of every row in the block-major C staging buffer (M ints)
+    float *d_Cs = nullptr;              //   ... that buffer: [N / 16][blocks x 64][16] floats
+    size_t Cs_cap = 0;
+    double cluster_shared = 0.0;        // sampled share of a neighbour row's columns a row has too (graph clustering pre-test)
+    int cluster_state = 0;              // 0 not evaluated, 1 grid bricks in use, 2 graph clustering (reordered form) in use, -1 declined
     int64_t cluster_s2 = 0, cluster_s3 = 0;
     int64_t plan_total_dict = 0, cluster_total_dict = 0;   // sum of the block dictionaries: natural order / clustered order
     PanelState plan_stash[3];           // parked, indexed by lanes_per_row 2 / 4 / 8 -> 0 / 1 / 2
@@ -180,7 +185,8 @@ struct sextans_engine {
                                         // CU -- measured slower than 4 columns per lane at 4 workgroups per CU)
     int64_t opt_cluster_shape = 0;      // measurement switch: brick shape run_rows * 10000 + lines * 100 + planes (0 = 16 x 2 x 2 / 16 x 4)
     int64_t opt_cluster_group = 3;      // bricks are laid out in groups of g x g brick columns (A/B on the 4M-row FEM matrix: g = 3)
-    int64_t opt_row_cluster = -1;       // clustered-order plan for spmm_csr_panel_v2 (ensure_cluster_plan): -1 auto, 0 never, 1 whenever found
+    int64_t opt_row_cluster = -1;       // clustered-order plan for spmm_csr_panel_v2 (ensure_cluster_plan): -1 auto, 0 never, 1 whenever one
+                                        // can be built, 2 = graph clustering (reordered form) also where the grid bricks would apply
     int64_t opt_small_v2 = 1;           // measurement switch: 0 = small matrices keep the full-capacity, 4-deep form of spmm_csr_panel_v2
     int64_t opt_panel_v2 = -1;          // 16-column tiles on the register-resident form (spmm_csr_panel_v2<1>: row entries
                                         // loaded once per block, panels by LDS-DMA, tile loop inside the workgroup, C stored
@@ -220,7 +226,7 @@ struct sextans_engine {
                                         // of those tiles and of B for them); 0: they are only counted (get_stat)
     int64_t opt_dense_fill_x100 = 50;   // a tile is dense when it holds >= this percentage of its 1024 positions
     // profiling
-    std::vector<sxe::EventPair> ev_kernel, ev_repack;
+    std::vector<sxe::EventPair> ev_kernel, ev_repack, ev_post;   // ev_post: passes behind the kernel (C staging -> C)
     const char *last_kernel = "none";
 };
 
@@ -229,6 +235,9 @@ namespace sxe {
 int check_device(int device);
 void free_panel_state(sextans_engine::PanelState &p);
 void free_plan(sextans_engine *h);
+void free_cluster_plan(sextans_engine *h);
+int64_t plan_key(const sextans_engine *h);
+int64_t device_bytes(const sextans_engine *h);   // what the engine holds in HBM right now (stat "device_bytes")
 void free_window(sextans_engine *h);
 void free_bell(sextans_engine *h);
 void free_split(sextans_engine *h);
@@ -244,7 +253,7 @@ int ensure_window(sextans_engine *h, bool force);
 bool window_pays(const sextans_engine *h, int N, int64_t padded);
 int ensure_split(sextans_engine *h);
 int ensure_dense(sextans_engine *h);                       // engine_bell.hip
-int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_panel, bool &use_window);
+int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_panel, bool &use_window, bool whole = true);
 // dense 32x32 tiles on the matrix cores (engine_bell.hip): C_out = alpha * (A_dense * bf16(B)) + beta * C_in for the full block rows
 int launch_dense_tiles(sextans_engine *h, int N, float alpha, const float *d_B, int64_t ldb, float beta, const float *d_C_in,
                        int64_t ldc_in, float *d_C_out, int64_t ldc, hipStream_t s);

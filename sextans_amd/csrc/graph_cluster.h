@@ -1,0 +1,36 @@
+// graph_cluster.h -- structure-agnostic row clustering for the LDS-panel plan (csrc/graph_cluster.hip).
+//
+// The reference schedules the non-zeros of ANY matrix for its on-chip B window (generate_edge_list_for_all_PEs,
+// sparse_helper.h:345-403).  The round-3 clustered plan of this engine (row_cluster.hip) needs Cartesian-grid structure in natural
+// ordering; this is the general form: a multilevel pairwise aggregation of the rows over the matrix graph, built on the device.
+#pragma once
+#include <cstdint>
+#include <string>
+
+namespace sx {
+
+// Share of a sampled row's columns that a neighbouring row (one of its own column indices, read as a row) has too, averaged
+// over `nsample` rows spread over the matrix: ~0 for matrices with random columns, 0.3 .. 0.7 for mesh / stencil matrices in
+// ANY numbering.  Needs M == K.  Returns non-zero on a HIP error.
+int probe_shared_neighbourhood_device(int M, const int *d_rp, const int *d_ci, int nsample, double *shared_fraction, std::string &err);
+
+// order[i] = row of the matrix at position i of the clustered order (M ints on the device, caller frees).
+// Rows are merged pairwise, level by level (cluster sizes 1 -> 2 -> 4 ... -> max_cluster_rows), each cluster with the unmatched
+// neighbouring cluster it shares the most neighbourhood with; a merged pair's rows become contiguous, so the final order is the
+// leaf order of the merge tree: any run of consecutive rows is a graph-compact set.  M == K required (a column index is read as
+// the row of the neighbour).  Returns 0 = built, 1 = declined (not square, empty), 2 = HIP error (err set).
+int cluster_rows_graph_device(int M, int K, int64_t nnz, const int *d_rp, const int *d_ci, int max_cluster_rows, int **d_order,
+                              std::string &err);
+
+// colpos[c] = new position of column c: columns in the order in which the rows of `order` first touch them (untouched columns
+// last), so that the dictionary of a run of consecutive rows is (mostly) a run of consecutive new positions -- whole cache lines
+// of the relabelled B panel.  K ints on the device, caller frees.
+int column_first_touch_order_device(int M, int K, const int *d_rp, const int *d_ci, const int *d_order, int **d_colpos, std::string &err);
+
+// in place: ci[j] = colpos[ci[j]]
+int relabel_columns_device(int64_t nnz, int *d_ci, const int *d_colpos, std::string &err);
+
+// cpos[order[blk_row[b] + s]] = b * RB + s: the slot of every row in the block-major C staging buffer (M ints, caller frees)
+int build_row_slots_device(int M, int nblk, int RB, const int *d_blk_row, const int *d_order, int **d_cpos, std::string &err);
+
+}  // namespace sx

@@ -1,0 +1,436 @@
+// graph_cluster.hip -- structure-agnostic row clustering for the LDS-panel plan, built on the device.
+//
+// Why: a row block's LDS panel is as large as the block's dictionary (its distinct columns) and is copied once per 16-column N
+// tile, and a block is a run of CONSECUTIVE rows of the plan's row order.  When the numbering of the matrix has no locality (an
+// arbitrary node ordering of a mesh: SuiteSparse files carry whatever order their generator wrote) 64 consecutive rows share
+// nothing: 22 rows fill the 576-row panel, every dictionary row is a separate 128-byte fabric request for 64 useful bytes, and the
+// kernel runs at a third of its speed.  The rows of a matrix are independent -- ANY order of the rows gives the same sums, bit for
+// bit -- so the plan may visit them in an order in which consecutive rows are neighbours in the matrix graph.  The reference
+// schedules its non-zeros for the same purpose, keeping the on-chip B window hot (generate_edge_list_for_all_PEs,
+// sparse_helper.h:345-403: row % 64 interleaving over PEs, 4096-column windows).
+//
+// How (cluster_rows_graph_device): multilevel pairwise aggregation, the coarsening half of a multilevel graph partitioner.
+//   weights   t(r, c) = 1 + |cols(r) & cols(c)| for every non-zero (r, c), c read as a row (M == K): the neighbourhood two
+//             adjacent rows share ("triangles on the edge").  With unit weights every neighbour of a stencil row ties and the
+//             pairs are random (face / edge / corner neighbours alike): measured on a randomly renumbered 3-dof 27-point mesh,
+//             9.8 dictionary rows per matrix row against 7.1 with these weights (natural grid order: 9.3; hand-made bricks: 6.2).
+//   level     every cluster accumulates, in an LDS hash table, the weight of its non-zeros towards each neighbouring cluster
+//             that still fits (size(A) + size(B) <= 2, 4, 8 ... rows) and keeps its four best partners by
+//             weight / sqrt(size(B)); five handshake rounds then pair clusters that choose each other (first still-unmatched
+//             candidate each round); a pair's rows become contiguous in the order.  Sizes double per level, so 64-row blocks
+//             take six levels and the order keeps refining up to `max_cluster_rows` (neighbouring blocks of the order are
+//             neighbours in the graph: they run on one XCD at about the same time and share B lines in its L2).
+//   cost      one pass over the non-zeros per level; 12 levels + the weights: ~0.2 s for 318 M non-zeros (plan time, outside every
+//             timed region like the reference's scheduling).
+// Everything is integer arithmetic on the device; ties are broken by a hash of the (unordered) pair, so the order is a
+// deterministic function of the matrix.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "graph_cluster.h"
+
+namespace sx {
+namespace {
+
+#define GC_HIP(x)                                                                                       \
+    do {                                                                                                \
+        hipError_t e_ = (x);                                                                            \
+        if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return 2; }       \
+    } while (0)
+
+struct Scratch {   // device allocations freed on every exit path (keep() hands one over to the caller)
+    std::vector<void *> p;
+    ~Scratch() { for (void *q : p) (void)hipFree(q); }
+    template <class T> hipError_t alloc(T **out, size_t n) {
+        hipError_t e = hipMalloc((void **)out, sizeof(T) * (n ? n : 1));
+        if (e == hipSuccess) p.push_back(*out);
+        return e;
+    }
+    void keep(void *q) { p.erase(std::remove(p.begin(), p.end(), q), p.end()); }
+};
+
+constexpr int kTriMaxLen = 256;   // rows longer than this: unit weights (their neighbourhoods are not compared)
+constexpr int kTriHT = 512;       // hash slots per wavefront for one row's columns (load <= 0.5)
+constexpr int kNbHT = 512;        // hash slots per wavefront for a cluster's neighbouring clusters
+constexpr int kCand = 4;          // partners kept per cluster and level
+
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ void set_insert(int *tab, int c) {
+    unsigned h = mix32((unsigned)c) & (kTriHT - 1);
+    for (int probe = 0; probe < kTriHT; ++probe) {
+        const int prev = atomicCAS(&tab[h], -1, c);
+        if (prev == -1 || prev == c) return;
+        h = (h + 1) & (kTriHT - 1);
+    }
+}
+__device__ __forceinline__ bool set_has(const int *tab, int c) {
+    unsigned h = mix32((unsigned)c) & (kTriHT - 1);
+    for (int probe = 0; probe < kTriHT; ++probe) {
+        const int k = tab[h];
+        if (k == c) return true;
+        if (k == -1) return false;
+        h = (h + 1) & (kTriHT - 1);
+    }
+    return false;
+}
+
+// One wavefront per row r: t[j] = min(255, 1 + |cols(r) & cols(c_j)|) for every entry j of the row whose column c_j is a row
+// (c_j < M, != r) of at most kTriMaxLen entries; 1 otherwise.
+__global__ __launch_bounds__(256) void tri_weights(int M, const int *__restrict__ rp, const int *__restrict__ ci, unsigned char *__restrict__ t) {
+    __shared__ int tabs[4][kTriHT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= M) return;                       // (no workgroup barrier below: wavefronts are independent)
+    int *tab = tabs[wave];
+    const int j0 = rp[r], len = rp[r + 1] - j0;
+    if (len > kTriMaxLen) {
+        for (int e = lane; e < len; e += 64) t[j0 + e] = 1;
+        return;
+    }
+    for (int i = lane; i < kTriHT; i += 64) tab[i] = -1;
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < len; e += 64) set_insert(tab, ci[j0 + e]);
+    __builtin_amdgcn_wave_barrier();
+    for (int e0 = 0; e0 < len; e0 += 64) {
+        const int e = e0 + lane;
+        int k0 = 0, lc = 0;
+        if (e < len) {
+            const int c = ci[j0 + e];
+            if ((unsigned)c < (unsigned)M && c != r) { k0 = rp[c]; lc = min(rp[c + 1] - k0, kTriMaxLen); }
+        }
+        const int n_here = min(64, len - e0);
+        unsigned mine = 0;
+        for (int i = 0; i < n_here; ++i) {
+            const int ck0 = __shfl(k0, i), clc = __shfl(lc, i);   // wave-uniform
+            unsigned cnt = 0;
+            for (int k = 0; k < clc; k += 64) {
+                const bool hit = (k + lane < clc) && set_has(tab, ci[ck0 + k + lane]);
+                cnt += (unsigned)__popcll(__ballot(hit));
+            }
+            if (lane == i) mine = cnt;
+        }
+        if (e < len) t[j0 + e] = (unsigned char)min(255u, 1u + mine);
+    }
+}
+
+// Sampled version of the same count: the share of a neighbour row's columns that the sampled row has too.
+__global__ __launch_bounds__(256) void probe_shared(int M, const int *__restrict__ rp, const int *__restrict__ ci, int nsample,
+                                                    unsigned long long *acc /* [0] shared, [1] compared */) {
+    __shared__ int tabs[4][kTriHT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + wave;
+    if (s >= nsample) return;
+    const int r = (int)((long long)M / 8 + (long long)s * (3LL * M / 4) / nsample);
+    int *tab = tabs[wave];
+    const int j0 = rp[r], len = rp[r + 1] - j0;
+    if (len < 2 || len > kTriMaxLen) return;
+    for (int i = lane; i < kTriHT; i += 64) tab[i] = -1;
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < len; e += 64) set_insert(tab, ci[j0 + e]);
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long shared = 0, compared = 0;
+    for (int q = 0; q < 8; ++q) {                          // eight neighbours spread over the row
+        const int c = ci[j0 + (int)((long long)q * len / 8)];
+        if ((unsigned)c >= (unsigned)M || c == r) continue;
+        const int k0 = rp[c], lc = min(rp[c + 1] - k0, kTriMaxLen);
+        for (int k = 0; k < lc; k += 64) {
+            const bool hit = (k + lane < lc) && set_has(tab, ci[k0 + k + lane]);
+            shared += (unsigned long long)__popcll(__ballot(hit));
+        }
+        compared += (unsigned long long)lc;
+    }
+    if (lane == 0 && compared) { atomicAdd(&acc[0], shared); atomicAdd(&acc[1], compared); }
+}
+
+// ---- one aggregation level -----------------------------------------------------------------------------------------------
+// Clusters are numbered in the current order: cluster A = rows ord[cstart[A] .. cstart[A + 1]); cinfo[row] = {cluster, its size}.
+// One wavefront per cluster: weights towards every neighbouring cluster that still fits under `limit` rows, then the kCand best.
+__global__ __launch_bounds__(256) void level_candidates(int nc, int M, const int *__restrict__ cstart, const int *__restrict__ ord,
+                                                        const int2 *__restrict__ cinfo, const int *__restrict__ rp,
+                                                        const int *__restrict__ ci, const unsigned char *__restrict__ t, int limit,
+                                                        unsigned salt, int *__restrict__ cand) {
+    __shared__ int keys[4][kNbHT];
+    __shared__ unsigned vals[4][kNbHT];
+    __shared__ int sizes[4][kNbHT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int A = blockIdx.x * 4 + wave;
+    if (A >= nc) return;
+    int *kk = keys[wave];
+    unsigned *vv = vals[wave];
+    int *ss = sizes[wave];
+    const int s0 = cstart[A], s1 = cstart[A + 1], sizeA = s1 - s0;
+    if (sizeA >= limit) {                                   // nothing fits any more
+        if (lane < kCand) cand[(long long)A * kCand + lane] = -1;
+        return;
+    }
+    for (int i = lane; i < kNbHT; i += 64) { kk[i] = -1; vv[i] = 0u; }
+    __builtin_amdgcn_wave_barrier();
+    for (int p = s0; p < s1; ++p) {
+        const int r = ord[p];
+        const int j0 = rp[r], len = rp[r + 1] - j0;
+        for (int e = lane; e < len; e += 64) {
+            const int c = ci[j0 + e];
+            if ((unsigned)c >= (unsigned)M) continue;
+            const int2 inf = cinfo[c];
+            if (inf.x == A || sizeA + inf.y > limit) continue;
+            unsigned h = mix32((unsigned)inf.x) & (kNbHT - 1);
+            for (int probe = 0; probe < kNbHT; ++probe) {   // (a full table drops the entry: a heuristic loses a candidate)
+                const int prev = atomicCAS(&kk[h], -1, inf.x);
+                if (prev == -1 || prev == inf.x) { atomicAdd(&vv[h], (unsigned)t[j0 + e]); ss[h] = inf.y; break; }
+                h = (h + 1) & (kNbHT - 1);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // score = weight / sqrt(partner size) (equal weights: the smaller partner, which keeps the sizes balanced), ties by a hash
+    // of the unordered pair (both ends see the same value, so mutual choices are likely)
+    constexpr int PER = kNbHT / 64;
+    unsigned long long sc[PER];
+    int id[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int slot = lane + 64 * i;
+        id[i] = kk[slot];
+        sc[i] = 0ull;
+        if (id[i] >= 0) {
+            const float f = (float)vv[slot] * __frsqrt_rn((float)ss[slot]);
+            const unsigned lo = (unsigned)min(A, id[i]), hi = (unsigned)max(A, id[i]);
+            const unsigned tie = mix32(lo * 0x9E3779B1u + mix32(hi + salt));
+            sc[i] = ((unsigned long long)__float_as_uint(f) << 32) | tie;
+        }
+    }
+    for (int k = 0; k < kCand; ++k) {
+        unsigned long long best = 0ull;
+        int bid = -1;
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            if (sc[i] > best) { best = sc[i]; bid = id[i]; }
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned olo = __shfl_xor((unsigned)(best & 0xffffffffull), off), ohi = __shfl_xor((unsigned)(best >> 32), off);
+            const int oid = __shfl_xor(bid, off);
+            const unsigned long long other = ((unsigned long long)ohi << 32) | olo;
+            if (other > best || (other == best && oid > bid)) { best = other; bid = oid; }
+        }
+        if (lane == 0) cand[(long long)A * kCand + k] = best ? bid : -1;
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            if (id[i] == bid) sc[i] = 0ull;
+    }
+}
+
+__global__ __launch_bounds__(256) void level_reset(int nc, int *matched, int *mate) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a < nc) { matched[a] = 0; mate[a] = -1; }
+}
+__global__ __launch_bounds__(256) void level_propose(int nc, const int *__restrict__ cand, const int *__restrict__ matched, int *__restrict__ want) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= nc) return;
+    int w = -1;
+    if (!matched[a])
+        for (int k = 0; k < kCand && w < 0; ++k) {
+            const int b = cand[(long long)a * kCand + k];
+            if (b >= 0 && !matched[b]) w = b;
+        }
+    want[a] = w;
+}
+__global__ __launch_bounds__(256) void level_accept(int nc, const int *__restrict__ want, int *matched, int *mate) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= nc) return;
+    const int b = want[a];
+    if (b > a && want[b] == a) { matched[a] = 1; matched[b] = 1; mate[a] = b; mate[b] = a; }
+}
+// leader of a pair = its member that comes first in the order; new cluster sizes at the leaders
+__global__ __launch_bounds__(256) void level_leaders(int nc, const int *__restrict__ mate, const int *__restrict__ cstart, int *is_leader,
+                                                     int *new_size) {
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a > nc) return;
+    if (a == nc) { is_leader[a] = 0; new_size[a] = 0; return; }   // (scans run over nc + 1 elements: the last one yields the totals)
+    const int m = mate[a];
+    const bool lead = m < 0 || m > a;
+    is_leader[a] = lead ? 1 : 0;
+    new_size[a] = lead ? (cstart[a + 1] - cstart[a]) + (m >= 0 ? cstart[m + 1] - cstart[m] : 0) : 0;
+}
+__global__ __launch_bounds__(256) void level_move(int M, int nc, const int *__restrict__ ord, const int2 *__restrict__ cinfo,
+                                                  const int *__restrict__ cstart, const int *__restrict__ mate, const int *__restrict__ new_idx,
+                                                  const int *__restrict__ new_start, int *__restrict__ ord2, int2 *__restrict__ cinfo2,
+                                                  int *__restrict__ cstart2) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= M) return;
+    const int r = ord[p];
+    const int a = cinfo[r].x;
+    const int m = mate[a];
+    const int lead = (m >= 0 && m < a) ? m : a;
+    const int o = p - cstart[a];
+    const int lead_size = cstart[lead + 1] - cstart[lead];
+    const int total = lead_size + ((m >= 0) ? (lead == a ? cstart[m + 1] - cstart[m] : cstart[a + 1] - cstart[a]) : 0);
+    const int np = new_start[lead] + (lead == a ? o : lead_size + o);
+    ord2[np] = r;
+    cinfo2[r] = make_int2(new_idx[lead], total);
+    if (lead == a && o == 0) cstart2[new_idx[lead]] = new_start[lead];
+    if (p == 0) cstart2[new_idx[nc]] = M;   // new_idx[nc] = number of new clusters (exclusive scan over nc + 1 elements)
+}
+
+__global__ __launch_bounds__(256) void init_level0(int M, int *ord, int2 *cinfo, int *cstart) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < M) { ord[r] = r; cinfo[r] = make_int2(r, 1); cstart[r] = r; }
+    if (r == M) cstart[r] = M;
+}
+
+// ---- column order ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void first_touch(int M, const int *__restrict__ rp, const int *__restrict__ ci, const int *__restrict__ ord,
+                                                   int *first) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= M) return;
+    const int r = ord[p], j0 = rp[r], len = rp[r + 1] - j0;
+    for (int e = lane; e < len; e += 64) atomicMin(&first[ci[j0 + e]], p);
+}
+__global__ __launch_bounds__(256) void iota_fill(int n, int *v, int *w, int fill) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { v[i] = i; if (w) w[i] = fill; }
+}
+__global__ __launch_bounds__(256) void invert_perm(int n, const int *__restrict__ order, int *__restrict__ pos) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) pos[order[i]] = i;
+}
+__global__ __launch_bounds__(256) void relabel(long long nnz, int *ci, const int *__restrict__ colpos) {
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j < nnz) ci[j] = colpos[ci[j]];
+}
+__global__ __launch_bounds__(256) void row_slots(int nblk, int RB, const int *__restrict__ blk_row, const int *__restrict__ order,
+                                                 int *__restrict__ cpos) {
+    const long long tt = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tt >= (long long)nblk * RB) return;
+    const int b = (int)(tt / RB), s = (int)(tt % RB);
+    const int i = blk_row[b] + s;
+    if (i < blk_row[b + 1]) cpos[order[i]] = b * RB + s;
+}
+
+inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+int probe_shared_neighbourhood_device(int M, const int *d_rp, const int *d_ci, int nsample, double *shared_fraction, std::string &err) {
+    *shared_fraction = 0.0;
+    if (M < 16 || nsample < 1) return 0;
+    Scratch tmp;
+    unsigned long long *d_acc = nullptr, h_acc[2] = {0, 0};
+    GC_HIP(tmp.alloc(&d_acc, 2));
+    GC_HIP(hipMemset(d_acc, 0, sizeof h_acc));
+    hipLaunchKernelGGL(probe_shared, dim3(blocks_for(nsample, 4)), dim3(256), 0, nullptr, M, d_rp, d_ci, nsample, d_acc);
+    GC_HIP(hipMemcpy(h_acc, d_acc, sizeof h_acc, hipMemcpyDeviceToHost));
+    if (h_acc[1]) *shared_fraction = (double)h_acc[0] / (double)h_acc[1];
+    return 0;
+}
+
+int cluster_rows_graph_device(int M, int K, int64_t nnz, const int *d_rp, const int *d_ci, int max_cluster_rows, int **d_order,
+                              std::string &err) {
+    *d_order = nullptr;
+    if (M != K || M < 2 || nnz <= 0) return 1;
+    Scratch tmp;
+    unsigned char *t = nullptr;
+    int *ord[2] = {nullptr, nullptr}, *cstart[2] = {nullptr, nullptr};
+    int2 *cinfo[2] = {nullptr, nullptr};
+    int *cand = nullptr, *matched = nullptr, *want = nullptr, *mate = nullptr, *is_leader = nullptr, *new_idx = nullptr, *new_size = nullptr,
+        *new_start = nullptr;
+    GC_HIP(tmp.alloc(&t, (size_t)nnz));
+    for (int i = 0; i < 2; ++i) {
+        GC_HIP(tmp.alloc(&ord[i], (size_t)M));
+        GC_HIP(tmp.alloc(&cstart[i], (size_t)M + 1));
+        GC_HIP(tmp.alloc(&cinfo[i], (size_t)M));
+    }
+    GC_HIP(tmp.alloc(&cand, (size_t)M * kCand));
+    GC_HIP(tmp.alloc(&matched, (size_t)M));
+    GC_HIP(tmp.alloc(&want, (size_t)M));
+    GC_HIP(tmp.alloc(&mate, (size_t)M));
+    GC_HIP(tmp.alloc(&is_leader, (size_t)M + 1));
+    GC_HIP(tmp.alloc(&new_idx, (size_t)M + 1));
+    GC_HIP(tmp.alloc(&new_size, (size_t)M + 1));
+    GC_HIP(tmp.alloc(&new_start, (size_t)M + 1));
+    void *scan_tmp = nullptr;
+    size_t scan_bytes = 0;
+    GC_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, is_leader, new_idx, M + 1, nullptr));
+    GC_HIP(tmp.alloc((char **)&scan_tmp, scan_bytes));
+
+    hipLaunchKernelGGL(tri_weights, dim3(blocks_for(M, 4)), dim3(256), 0, nullptr, M, d_rp, d_ci, t);
+    hipLaunchKernelGGL(init_level0, dim3(blocks_for((long long)M + 1, 256)), dim3(256), 0, nullptr, M, ord[0], cinfo[0], cstart[0]);
+    int nc = M, cur = 0, level = 0;
+    for (long long limit = 2; limit <= (long long)max_cluster_rows && nc > 1; limit *= 2, ++level) {
+        hipLaunchKernelGGL(level_candidates, dim3(blocks_for(nc, 4)), dim3(256), 0, nullptr, nc, M, cstart[cur], ord[cur], cinfo[cur], d_rp,
+                           d_ci, t, (int)limit, (unsigned)level * 0x632BE5ABu, cand);
+        hipLaunchKernelGGL(level_reset, dim3(blocks_for(nc, 256)), dim3(256), 0, nullptr, nc, matched, mate);
+        for (int round = 0; round < 5; ++round) {
+            hipLaunchKernelGGL(level_propose, dim3(blocks_for(nc, 256)), dim3(256), 0, nullptr, nc, cand, matched, want);
+            hipLaunchKernelGGL(level_accept, dim3(blocks_for(nc, 256)), dim3(256), 0, nullptr, nc, want, matched, mate);
+        }
+        hipLaunchKernelGGL(level_leaders, dim3(blocks_for((long long)nc + 1, 256)), dim3(256), 0, nullptr, nc, mate, cstart[cur], is_leader,
+                           new_size);
+        GC_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, is_leader, new_idx, nc + 1, nullptr));
+        GC_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, new_size, new_start, nc + 1, nullptr));
+        hipLaunchKernelGGL(level_move, dim3(blocks_for(M, 256)), dim3(256), 0, nullptr, M, nc, ord[cur], cinfo[cur], cstart[cur], mate,
+                           new_idx, new_start, ord[cur ^ 1], cinfo[cur ^ 1], cstart[cur ^ 1]);
+        int nc_new = 0;
+        GC_HIP(hipMemcpy(&nc_new, new_idx + nc, sizeof(int), hipMemcpyDeviceToHost));
+        cur ^= 1;
+        if (nc_new <= 0 || nc_new > nc) { err = "graph clustering: inconsistent level"; return 2; }
+        const bool stalled = nc_new == nc;
+        nc = nc_new;
+        if (stalled && limit >= 64) break;   // nothing merges any more (disconnected pieces)
+    }
+    GC_HIP(hipDeviceSynchronize());
+    GC_HIP(hipGetLastError());
+    tmp.keep(ord[cur]);
+    *d_order = ord[cur];
+    return 0;
+}
+
+int column_first_touch_order_device(int M, int K, const int *d_rp, const int *d_ci, const int *d_order, int **d_colpos, std::string &err) {
+    *d_colpos = nullptr;
+    if (K <= 0) return 1;
+    Scratch tmp;
+    int *first = nullptr, *first_sorted = nullptr, *cols = nullptr, *cols_sorted = nullptr, *pos = nullptr;
+    GC_HIP(tmp.alloc(&first, (size_t)K));
+    GC_HIP(tmp.alloc(&first_sorted, (size_t)K));
+    GC_HIP(tmp.alloc(&cols, (size_t)K));
+    GC_HIP(tmp.alloc(&cols_sorted, (size_t)K));
+    GC_HIP(tmp.alloc(&pos, (size_t)K));
+    hipLaunchKernelGGL(iota_fill, dim3(blocks_for(K, 256)), dim3(256), 0, nullptr, K, cols, first, 0x7fffffff);
+    if (M > 0) hipLaunchKernelGGL(first_touch, dim3(blocks_for(M, 4)), dim3(256), 0, nullptr, M, d_rp, d_ci, d_order, first);
+    void *sort_tmp = nullptr;
+    size_t bytes = 0;
+    GC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, first, first_sorted, cols, cols_sorted, K, 0, 32, nullptr));
+    GC_HIP(tmp.alloc((char **)&sort_tmp, bytes));
+    GC_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp, bytes, first, first_sorted, cols, cols_sorted, K, 0, 32, nullptr));   // stable: ties by column
+    hipLaunchKernelGGL(invert_perm, dim3(blocks_for(K, 256)), dim3(256), 0, nullptr, K, cols_sorted, pos);
+    GC_HIP(hipDeviceSynchronize());
+    GC_HIP(hipGetLastError());
+    tmp.keep(pos);
+    *d_colpos = pos;
+    return 0;
+}
+
+int relabel_columns_device(int64_t nnz, int *d_ci, const int *d_colpos, std::string &err) {
+    if (nnz > 0) hipLaunchKernelGGL(relabel, dim3(blocks_for(nnz, 256)), dim3(256), 0, nullptr, (long long)nnz, d_ci, d_colpos);
+    GC_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
+int build_row_slots_device(int M, int nblk, int RB, const int *d_blk_row, const int *d_order, int **d_cpos, std::string &err) {
+    *d_cpos = nullptr;
+    int *cpos = nullptr;
+    GC_HIP(hipMalloc((void **)&cpos, sizeof(int) * (size_t)std::max(1, M)));
+    if (nblk > 0) hipLaunchKernelGGL(row_slots, dim3(blocks_for((long long)nblk * RB, 256)), dim3(256), 0, nullptr, nblk, RB, d_blk_row, d_order, cpos);
+    const hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipFree(cpos); err = hipGetErrorString(e); return 2; }
+    *d_cpos = cpos;
+    return 0;
+}
+
+}  // namespace sx

@@ -100,6 +100,9 @@ __device__ __forceinline__ void aload1(float &dst, const float *sbase, unsigned 
 __device__ __forceinline__ void astore1(float *sbase, unsigned voff_bytes, float val) {
     asm volatile("global_store_dword %0, %1, %2" : : "v"(voff_bytes), "v"(val), "s"(sbase) : "memory");
 }
+__device__ __forceinline__ void astore4(float *sbase, unsigned voff_bytes, const f32x4 &val) {
+    asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(voff_bytes), "v"(val), "s"(sbase) : "memory");
+}
 
 // BCOL: Bp is the caller's column-major B (panel_stride = its leading dimension), staged with 4-byte loads; else Bp
 // holds row-major K x 16 panels at stride panel_stride floats.
@@ -115,13 +118,17 @@ __device__ __forceinline__ void astore1(float *sbase, unsigned voff_bytes, float
 // plan's actual maximum, so that a block with 235 dictionary rows does not issue the loads and LDS writes of 576).
 // (8 instead of 4 B rows in flight per lane for launches that cannot fill the chip -- one wavefront per SIMD -- was measured on
 // nasa4704: row loop 2833 vs 2829 cycles, not kept.)
-template <int H, int NB, bool EXACT, bool BCOL, bool TIMED = false, int DCAP = 9>
+// CROW (the REORDERED form, reorder_kernels.h): Cin == Cout == the block-major staging buffer Cs[tile][blk * 64 + slot][16]
+// (ldc_in == ldc == floats per tile): C_in of a tile is ONE 16-byte load per lane and C_out one 16-byte store, whatever rows of the
+// matrix the block's slots are; blk_dict then holds RELABELLED columns (rows of the permuted B panels).
+template <int H, int NB, bool EXACT, bool BCOL, bool TIMED = false, int DCAP = 9, bool CROW = false>
 __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
     const int2 *__restrict__ slot_info, const unsigned short *__restrict__ p_idx16, const float *__restrict__ p_val,
     const int *__restrict__ blk_row, const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
     const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc,
     int nsuper, int tpw, int nblk, float alpha, float beta, int use_xcd_remap, int pad_row, int blk_begin, int row_base,
     const unsigned char *__restrict__ skip, long long *dbg, const int *__restrict__ slot_row) {
+    static_assert(!CROW || (H == 1 && !BCOL), "the block-major C staging exists for 16-column tiles on repacked panels");
     long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, w0 = 0;
     if constexpr (TIMED) { t0 = clock64(); w0 = wall_clock64(); }
     constexpr int LPR = 4;
@@ -274,13 +281,19 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
     // C: column (col0 + 16h + 4q + j) of this lane = uniform column base (col0 + 16h + j) + a per-lane byte offset
     const unsigned cvoff_in = (4u * (unsigned)q * (unsigned)ldc_in + coff) * 4u;
     const unsigned cvoff_out = (4u * (unsigned)q * (unsigned)ldc + coff) * 4u;
+    const unsigned cvoff_row = ((unsigned)(blk * RB + slot) * 16u + 4u * (unsigned)q) * 4u;   // CROW: my 16 bytes of the tile
     // C_in of the FIRST super tile is requested here, in the same round trip as the panel and the row entries (for a
     // matrix of a few thousand rows the whole kernel is three round trips: one more is 15 % of its time)
     float cin[H][4];
+    f32x4 cinv = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (CROW) {
+        aload4(cinv, Cin + (int64_t)st_begin * ldc_in, cvoff_row);
+    } else {
 #pragma unroll
-    for (int h = 0; h < H; ++h)
+        for (int h = 0; h < H; ++h)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) aload1(cin[h][j], Cin + ((int64_t)st_begin * NTT + h * 16 + j) * ldc_in, cvoff_in);
+            for (int j = 0; j < 4; ++j) aload1(cin[h][j], Cin + ((int64_t)st_begin * NTT + h * 16 + j) * ldc_in, cvoff_in);
+    }
     if constexpr (!DMA) store_panel();
     // (a use of the row registers HERE makes the compiler wait for their loads before the loop; otherwise its wait
     // bookkeeping carries them into the loop as "possibly pending" and every batch waits for younger loads)
@@ -304,10 +317,14 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
             }
         }
         if (st != st_begin) {
+            if constexpr (CROW) {
+                aload4(cinv, Cin + (int64_t)st * ldc_in, cvoff_row);
+            } else {
 #pragma unroll
-            for (int h = 0; h < H; ++h)
+                for (int h = 0; h < H; ++h)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) aload1(cin[h][j], Cin + (col0 + h * 16 + j) * ldc_in, cvoff_in);
+                    for (int j = 0; j < 4; ++j) aload1(cin[h][j], Cin + (col0 + h * 16 + j) * ldc_in, cvoff_in);
+            }
         }
         if constexpr (!DMA) {
             if (st + 1 < st_end) load_panel(st + 1, false);
@@ -355,6 +372,8 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
                            "+v"(cin[1][2]), "+v"(cin[1][3])
                          :
                          : "memory");
+        } else if constexpr (CROW) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cinv) : : "memory");
         } else {
             static_assert(H == 1 || H == 2, "the drain names the C_in registers explicitly");
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(cin[0][0]), "+v"(cin[0][1]), "+v"(cin[0][2]), "+v"(cin[0][3]) : : "memory");
@@ -372,7 +391,13 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
                 }
         }
         // ---- C straight from the accumulators
-        if (cwrite) {
+        if constexpr (CROW) {
+            if (cwrite) {
+                const f32x4 o = {epilogue<EXACT>(alpha, acc[0].x, beta, cinv.x), epilogue<EXACT>(alpha, acc[0].y, beta, cinv.y),
+                                 epilogue<EXACT>(alpha, acc[0].z, beta, cinv.z), epilogue<EXACT>(alpha, acc[0].w, beta, cinv.w)};
+                astore4(Cout + (int64_t)st * ldc, cvoff_row, o);
+            }
+        } else if (cwrite) {
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 const float a4[4] = {acc[h].x, acc[h].y, acc[h].z, acc[h].w};

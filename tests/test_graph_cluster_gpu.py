@@ -1,0 +1,184 @@
+"""Graph clustering of the rows (csrc/graph_cluster.hip) and the REORDERED form of the LDS-panel SpMM (csrc/reorder_kernels.h,
+spmm_csr_panel_v2<..., CROW>): matrices whose graph has locality but whose numbering does not -- a 3-dof FEM matrix under a random
+node permutation, the same under reverse Cuthill-McKee, an unstructured jittered-point mesh -- are aggregated over the matrix graph
+on the device, their columns relabelled, B repacked into permuted panels and C staged block-major.  The rows of a matrix are
+independent and every row keeps its CSR entry order, so the result stays BIT-IDENTICAL to cpu_spmm_CSR (sparse_helper.h:262-290).
+What the reference does for the same purpose: generate_edge_list_for_all_PEs schedules any matrix for its on-chip B window
+(sparse_helper.h:345-403)."""
+import numpy as np
+import pytest
+
+from util import ALPHA, BETA, random_csr
+
+pytestmark = pytest.mark.gpu
+
+OPTS = dict(lanes_per_row=0, kernel=0, fuse_b=1, panel_v2=-1, cols_per_lane=0, tiles_per_wg=0, split_rows=0, bucket_rows=-1,
+            panel_min_reuse_x100=200, panel_min_reuse_wide_x100=150, row_cluster=-1, exact=1)
+
+
+def _set(engine, **kw):
+    d = dict(OPTS)
+    d.update(kw)
+    for k, v in d.items():
+        engine.set_option(k, v)
+
+
+def _fem(nx, ny, nz, dof, seed=7):
+    from sextans_amd import api
+    rp, ci, v = api.gen_fem3d_host(nx, ny, nz, dof, seed)
+    return rp, ci, v, nx * ny * nz * dof
+
+
+def _classes():
+    """name, (rp, ci, v, M), the state "row_cluster" must report under the automatic setting"""
+    from sextans_amd import meshgen
+    rp, ci, v, M = _fem(18, 17, 16, 3)
+    yield "fem 3 dof, random node order", (*meshgen.permute_symmetric(rp, ci, v, M, meshgen.node_permutation(M // 3, 3, 11)), M), 2
+    yield "fem 3 dof, RCM", (*meshgen.permute_symmetric(rp, ci, v, M, meshgen.rcm_node_permutation(rp, ci, M, 3)), M), None
+    rp1, ci1, v1, M1 = _fem(30, 28, 26, 1)
+    yield "fem 1 dof, random node order", (*meshgen.permute_symmetric(rp1, ci1, v1, M1, meshgen.node_permutation(M1, 1, 5)), M1), 2
+    yield "jittered mesh, 3 dof, random order", meshgen.jittered_mesh3d(18, 16, 15, 3, numbering="random", dof=3), 2
+    yield "jittered mesh, 1 dof, sweep order", meshgen.jittered_mesh3d(28, 26, 24, 4, numbering="sweep"), None
+
+
+def _operands(rs, M, K, N):
+    return rs.uniform(-1, 1, K * N).astype(np.float32), rs.uniform(-1, 1, M * N).astype(np.float32)
+
+
+@pytest.mark.parametrize("N", [16, 24, 128])
+def test_reordered_form_is_bit_identical(engine, oracle, N):
+    for name, (rp, ci, v, M), auto_state in _classes():
+        rs = np.random.RandomState(N + M % 97)
+        B, C0 = _operands(rs, M, M, N)
+        want = C0.copy()
+        oracle.spmm(M, N, M, ALPHA, rp, ci, v, B, BETA, want)
+        try:
+            for rc in (2, -1, 0):
+                _set(engine, row_cluster=rc)
+                engine.set_matrix_csr(M, M, rp, ci, v)
+                for rp_time in (1, 4):                      # (4: the hipGraph replay of the repeat loop, B panels reused)
+                    out = C0.copy()
+                    engine.spmm(N, ALPHA, B, BETA, out, rp_time=rp_time)
+                    assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (name, N, rc, rp_time, engine.last_kernel())
+                state = int(engine.get_stat("row_cluster"))
+                if rc == 2:
+                    assert state == 2 and engine.last_kernel() == "spmm_csr_panel_v2_reordered", (name, state, engine.last_kernel())
+                    assert engine.get_stat("panel_rows_clustered") > 0
+                elif rc == 0:
+                    assert state == -1 and "reordered" not in engine.last_kernel()
+                elif auto_state is not None:
+                    assert state == auto_state, (name, state, engine.get_stat("cluster_shared_fraction"))
+        finally:
+            _set(engine)
+
+
+def test_clustering_quality(engine):
+    """What the clustering is for: far fewer B rows copied into LDS, full row blocks.  (Natural order of the randomly renumbered 3-dof
+    matrix: ~22 rows fill the 576-row panel; clustered: >= 48 rows per block and < 45 % of the panel rows.)"""
+    from sextans_amd import meshgen
+    rp, ci, v, M = _fem(20, 20, 20, 3)
+    prp, pci, pv = meshgen.permute_symmetric(rp, ci, v, M, meshgen.node_permutation(M // 3, 3, 1))
+    try:
+        _set(engine, row_cluster=-1)
+        engine.set_matrix_csr(M, M, prp, pci, pv)
+        N = 16
+        B = np.ones(M * N, np.float32); C = np.zeros(M * N, np.float32)
+        engine.spmm(N, ALPHA, B, BETA, C)
+        assert int(engine.get_stat("row_cluster")) == 2
+        nat, clu = engine.get_stat("panel_rows_natural"), engine.get_stat("panel_rows_clustered")
+        blocks = engine.get_stat("panel_blocks_clustered")
+        assert clu < 0.45 * nat, (nat, clu)
+        assert M / blocks >= 48, (M, blocks)
+        assert engine.get_stat("cluster_shared_fraction") > 0.3
+        assert engine.get_stat("device_bytes") > 8 * len(pci)
+    finally:
+        _set(engine)
+
+
+def test_declined_inputs(engine, oracle):
+    """Random columns (nothing to find: the sampled pre-test says so), rectangular matrices, matrices with rows on the long-row
+    path: the graph clustering declines, also when forced, and the natural-order kernels run -- same bits."""
+    rs = np.random.RandomState(9)
+    cases = []
+    M = 8192
+    rp, ci, v = random_csr(rs, M, M, 24)
+    cases.append(("uniform random", M, M, rp, ci, v, -1))
+    rp, ci, v = random_csr(rs, M, M + 512, 24)
+    cases.append(("rectangular", M, M + 512, rp, ci, v, 2))
+    rp, ci, v = random_csr(rs, M, M, 40, long_rows=3)        # 1600-entry rows: exact chains
+    cases.append(("long rows", M, M, rp, ci, v, 2))
+    try:
+        for name, M, K, rp, ci, v, rc in cases:
+            _set(engine, row_cluster=rc)
+            engine.set_matrix_csr(M, K, rp, ci, v)
+            N = 32
+            B, C0 = _operands(rs, M, K, N)
+            want = C0.copy()
+            oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+            out = C0.copy()
+            engine.spmm(N, ALPHA, B, BETA, out)
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), name
+            assert int(engine.get_stat("row_cluster")) == -1, name
+    finally:
+        _set(engine)
+
+
+def test_device_calls_alias_ranges_and_options(engine, oracle):
+    """Device-resident calls on the reordered form: C_in == C_out, leading dimensions, alpha / beta special values, exact = 0 within
+    the stated bound; row-range calls in between keep the natural-order forms (and never reuse the permuted B panels)."""
+    import torch
+    from sextans_amd import meshgen
+    rp, ci, v, M = _fem(17, 16, 15, 3)
+    rp, ci, v = meshgen.permute_symmetric(rp, ci, v, M, meshgen.node_permutation(M // 3, 3, 2))
+    rs = np.random.RandomState(1)
+    N = 40
+    ldb, ldc = M + 24, M + 8
+    Bf = rs.uniform(-1, 1, ldb * N).astype(np.float32)
+    Cf = rs.uniform(-1, 1, ldc * N).astype(np.float32)
+    B = np.ascontiguousarray(Bf.reshape(N, ldb)[:, :M]).reshape(-1)
+    C0 = np.ascontiguousarray(Cf.reshape(N, ldc)[:, :M]).reshape(-1)
+    st = torch.cuda.current_stream().cuda_stream
+    try:
+        _set(engine, row_cluster=2)
+        engine.set_matrix_csr(M, M, rp, ci, v)
+        dB = torch.from_numpy(Bf).cuda()
+        for alpha, beta in ((ALPHA, BETA), (np.float32(1), np.float32(0)), (np.float32(0), np.float32(1)), (np.float32(-2.5), np.float32(1))):
+            want = C0.copy()
+            oracle.spmm(M, N, M, alpha, rp, ci, v, B, beta, want)
+            dC = torch.from_numpy(Cf).cuda()
+            engine.spmm_device(N, float(alpha), dB.data_ptr(), ldb, float(beta), dC.data_ptr(), dC.data_ptr(), ldc, st)   # in place
+            torch.cuda.synchronize()
+            got = dC.cpu().numpy().reshape(N, ldc)
+            assert engine.last_kernel() == "spmm_csr_panel_v2_reordered"
+            assert np.array_equal(np.ascontiguousarray(got[:, :M]).reshape(-1).view(np.uint32), want.view(np.uint32)), (alpha, beta)
+            assert np.array_equal(got[:, M:], Cf.reshape(N, ldc)[:, M:])          # the padding rows of C are untouched
+        # row ranges between whole-matrix calls
+        want = C0.copy()
+        oracle.spmm(M, N, M, ALPHA, rp, ci, v, B, BETA, want)
+        dCin = torch.from_numpy(C0).cuda()
+        dBc = torch.from_numpy(B).cuda()
+        got = torch.full((M * N,), float("nan"), device="cuda")
+        cuts = [0, engine.align_row(N, M // 3), engine.align_row(N, 2 * M // 3), M]
+        for i in range(3):
+            c0, c1 = cuts[i], cuts[i + 1]
+            slab = torch.full(((c1 - c0) * N,), float("nan"), device="cuda")
+            engine.spmm_device_rows(N, ALPHA, dBc.data_ptr(), M, BETA, dCin.data_ptr() + 4 * c0, M, slab.data_ptr(), c1 - c0, c0, c1,
+                                    reuse_b_panels=i > 0, stream=st)
+            assert "reordered" not in engine.last_kernel()
+            got.view(N, M)[:, c0:c1] = slab.view(N, c1 - c0)
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        out = C0.copy()
+        engine.spmm(N, ALPHA, B, BETA, out)
+        assert engine.last_kernel() == "spmm_csr_panel_v2_reordered"
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+        # exact = 0 (FMA): the stated tolerance |d| <= 1e-4 (|alpha| sum |a b| + |beta c|)
+        _set(engine, row_cluster=2, exact=0)
+        out = C0.copy()
+        engine.spmm(N, ALPHA, B, BETA, out)
+        import scipy.sparse as sp
+        A = sp.csr_matrix((np.abs(v), ci, rp), shape=(M, M))
+        bound = 1e-4 * (abs(ALPHA) * (A @ np.abs(B.reshape(N, M).T)).T.reshape(-1) + np.abs(BETA * C0))
+        assert np.all(np.abs(out.astype(np.float64) - want) <= bound + 1e-30)
+    finally:
+        _set(engine)
