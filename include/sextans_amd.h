@@ -467,6 +467,11 @@ int sextans_gen_stencil2d_host(int nx, int ny, int points, int dof, uint64_t see
                                float **val, int64_t *nnz);
 int sextans_gen_stencil2d_device(int device, int nx, int ny, int points, int dof, uint64_t seed, int r0, int r1, int **d_row_ptr,
                                  int **d_col_idx, float **d_val, int64_t *nnz);
+/* P A P^T of a device-resident CSR matrix (measurement infrastructure for meshes in arbitrary node orders): row / column i becomes
+ * row / column new_of_old[i] (host array, a permutation of 0 .. M-1), columns ascending per row, values travel with their entries.
+ * New device arrays (sextans_device_free).  Rows of up to 4096 entries. */
+int sextans_csr_permute_symmetric_device(int device, int M, int64_t nnz, const int *d_row_ptr, const int *d_col_idx, const float *d_val,
+                                         const int *new_of_old, int **o_row_ptr, int **o_col_idx, float **o_val);
 int sextans_gen_kkt_host(int n, int arrow, uint64_t seed, int r0, int r1, int **row_ptr, int **col_idx, float **val, int64_t *nnz);
 int sextans_gen_kkt_device(int device, int n, int arrow, uint64_t seed, int r0, int r1, int **d_row_ptr, int **d_col_idx,
                            float **d_val, int64_t *nnz);

@@ -690,6 +690,18 @@ def gen_fem3d_host(nx, ny, nz, dof, seed, r0=0, r1=None):
     return out
 
 
+def permute_symmetric_device(device, M, nnz, d_rp, d_ci, d_v, new_of_old):
+    """P A P^T on the device (row / column i -> new_of_old[i]); returns new device pointers (rp, ci, v) -- free with device_free."""
+    p, i, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    no = np.ascontiguousarray(new_of_old, np.int32)
+    L = lib()
+    L.sextans_csr_permute_symmetric_device.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                       C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    _check(L.sextans_csr_permute_symmetric_device(device, M, nnz, d_rp, d_ci, d_v, no.ctypes.data, C.byref(p), C.byref(i), C.byref(v)),
+           "csr_permute_symmetric_device")
+    return p.value, i.value, v.value
+
+
 def gen_fem3d_device(device, nx, ny, nz, dof, seed, r0=0, r1=None):
     r1 = nx * ny * nz * dof if r1 is None else r1
     p, i, v = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -518,6 +518,7 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "bell_share")) *value = h->bell_share;
     else if (!strcmp(key, "row_cluster")) *value = (double)h->cluster_state;          // 1 grid bricks / 2 graph clustering in use, -1 declined, 0 not evaluated yet
     else if (!strcmp(key, "cluster_shared_fraction")) *value = h->cluster_shared;
+    else if (!strcmp(key, "cluster_decline")) *value = (double)h->cluster_decline;
     else if (!strcmp(key, "panel_blocks_clustered")) *value = (double)h->psc.plan_nblk;
     else if (!strcmp(key, "device_bytes")) *value = (double)device_bytes(h);
     else if (!strcmp(key, "grid_stride_line")) *value = (double)h->cluster_s2;

@@ -29,6 +29,7 @@ void free_cluster_plan(sextans_engine *h) {   // the clustered-order plan and it
     (void)hipFree(h->d_slot_row); (void)hipFree(h->d_colpos); (void)hipFree(h->d_cpos);
     h->d_slot_row = h->d_colpos = h->d_cpos = nullptr;
     h->cluster_state = 0;
+    h->cluster_decline = 0;
     h->cluster_total_dict = 0;
     h->cluster_shared = 0.0;
 }
@@ -365,38 +366,43 @@ int cluster_grid(sextans_engine *h) {   // 0 = in use, 1 = declined
     return 0;
 }
 
-int cluster_graph(sextans_engine *h) {   // 0 = in use, 1 = declined
-    if (h->M != h->K || h->m_nnz <= 0 || h->d_skip || h->nhub > 0 || h->nchain > 0 || h->dense_W > 0) return 1;
-    if ((int64_t)h->K * 64 >= ((int64_t)1 << 32)) return 1;   // 32-bit byte offsets into a K x 16 panel
+int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reason (stat "cluster_decline")
+    if (h->M != h->K || h->m_nnz <= 0) return 1;                                        // 1: not square
+    if (h->d_skip || h->nhub > 0 || h->nchain > 0 || h->dense_W > 0) return 2;           // 2: rows on the long-row / dense-tile paths
+    if ((int64_t)h->K * 64 >= ((int64_t)1 << 32)) return 3;   // 3: 32-bit byte offsets into a K x 16 panel
     const int lpr = 4, RB = sx::kBlock / lpr, cap = kPanelFloats / (4 * lpr);
     std::string err;
     if (h->opt_row_cluster < 0) {
         // worth trying?  Not when the natural-order plan already fills its blocks (numberings with locality: the grid path or
         // nothing), and not when neighbouring rows do not share neighbourhoods (random columns: there is nothing to find)
-        if (h->ps.plan_built && !h->ps.plan_mixed && h->ps.plan_nblk > 0 && (double)h->M / h->ps.plan_nblk >= 40.0) return 1;
+        if (h->ps.plan_built && !h->ps.plan_mixed && h->ps.plan_nblk > 0 && (double)h->M / h->ps.plan_nblk >= 50.0) return 4;   // 4: natural blocks are full
         double shared = 0.0;
-        if (sx::probe_shared_neighbourhood_device(h->M, h->m_rp, h->m_ci, 256, &shared, err)) return 1;
+        if (sx::probe_shared_neighbourhood_device(h->M, h->m_rp, h->m_ci, 256, &shared, err)) return 5;
         h->cluster_shared = shared;
-        if (shared < 0.2) return 1;
+        if (shared < 0.2) return 5;                                                                                               // 5: no shared neighbourhoods
     }
     int *d_order = nullptr, *d_colpos = nullptr, *d_cpos = nullptr, *prp = nullptr, *pci = nullptr;
     float *pv = nullptr;
     sx::DevicePlan dp;
-    auto drop = [&]() { (void)hipFree(d_order); (void)hipFree(d_colpos); (void)hipFree(d_cpos); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
-                        sx::free_device_plan(dp); return 1; };
-    if (sx::cluster_rows_graph_device(h->M, h->K, h->m_nnz, h->m_rp, h->m_ci, 4096, &d_order, err)) return drop();
-    if (sx::column_first_touch_order_device(h->M, h->K, h->m_rp, h->m_ci, d_order, &d_colpos, err)) return drop();
-    if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_order, &prp, &pci, &pv, err)) return drop();
-    if (sx::relabel_columns_device(h->m_nnz, pci, d_colpos, err)) return drop();
+    auto drop = [&](int why) { (void)hipFree(d_order); (void)hipFree(d_colpos); (void)hipFree(d_cpos); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
+                               sx::free_device_plan(dp); return why; };
+    if (sx::cluster_rows_graph_device(h->M, h->K, h->m_nnz, h->m_rp, h->m_ci, 4096, &d_order, err)) return drop(6);   // 6 .. 9: a builder failed
+    if (sx::column_first_touch_order_device(h->M, h->K, h->m_rp, h->m_ci, d_order, &d_colpos, err)) return drop(7);
+    if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_order, &prp, &pci, &pv, err)) return drop(8);
+    if (sx::relabel_columns_device(h->m_nnz, pci, d_colpos, err)) return drop(8);
+    // Every block that fits gets a dictionary (threshold 0): the tail of the order holds the rows nothing wanted to merge with, and
+    // ONE block of such rows without reuse would make the whole plan "mixed".  The reuse test is made on the plan as a whole below.
     const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;
-    const int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, min_reuse, dp, err, nullptr);
+    const int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, 0.0, dp, err, nullptr);
     (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
     prp = pci = nullptr; pv = nullptr;
-    if (brc != 0) return drop();
+    if (brc != 0) return drop(9);
     h->cluster_total_dict = dp.total_dict;
-    if (dp.mixed || dp.dict_stride > 9 * RB || dp.max_dict > sx::kWideMaxDict || (int64_t)dp.nblk * RB * 64 >= ((int64_t)1 << 32)) return drop();
-    if (h->opt_row_cluster < 0 && h->ps.plan_built && (double)dp.total_dict > 0.6 * (double)h->plan_total_dict) return drop();
-    if (sx::build_row_slots_device(h->M, dp.nblk, RB, dp.d_blk_row, d_order, &d_cpos, err)) return drop();
+    // 10: a row wider than the panel / limits of the 32-bit offsets; 11: the reordered plan has no reuse either; 12: not enough gain
+    if (dp.mixed || dp.dict_stride > 9 * RB || dp.max_dict > sx::kWideMaxDict || (int64_t)dp.nblk * RB * 64 >= ((int64_t)1 << 32)) return drop(10);
+    if ((double)h->m_nnz < min_reuse * (double)dp.total_dict) return drop(11);
+    if (h->opt_row_cluster < 0 && h->ps.plan_built && (double)dp.total_dict > 0.6 * (double)h->plan_total_dict) return drop(12);
+    if (sx::build_row_slots_device(h->M, dp.nblk, RB, dp.d_blk_row, d_order, &d_cpos, err)) return drop(9);
     (void)hipFree(d_order);
     adopt_device_plan(h->psc, dp, h, lpr, cap);
     h->psc.plan_panel_frac = h->m_nnz ? (double)dp.nnz_in_panel_blocks / (double)h->m_nnz : 0.0;
@@ -413,7 +419,7 @@ int ensure_cluster_plan(sextans_engine *h) {
     if (h->opt_row_cluster == 0 || h->M < 4096) return SEXTANS_OK;
     PlanTimer timer(h);
     if (h->opt_row_cluster != 2 && cluster_grid(h) == 0) h->cluster_state = 1;
-    else if (cluster_graph(h) == 0) h->cluster_state = 2;
+    else if ((h->cluster_decline = cluster_graph(h)) == 0) h->cluster_state = 2;
     (void)hipGetLastError();   // a failure in here (out of memory for the sort buffers, ...) only declines the clustered plan
     return SEXTANS_OK;
 }

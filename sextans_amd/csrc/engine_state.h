@@ -95,6 +95,7 @@ struct sextans_engine {
     int *d_cpos = nullptr;              //   ... and the slot of every row in the block-major C staging buffer (M ints)
     float *d_Cs = nullptr;              //   ... that buffer: [N / 16][blocks x 64][16] floats
     size_t Cs_cap = 0;
+    int cluster_decline = 0;            // why the graph clustering was declined (engine_plan.hip: cluster_graph), 0 = it was not
     double cluster_shared = 0.0;        // sampled share of a neighbour row's columns a row has too (graph clustering pre-test)
     int cluster_state = 0;              // 0 not evaluated, 1 grid bricks in use, 2 graph clustering (reordered form) in use, -1 declined
     int64_t cluster_s2 = 0, cluster_s3 = 0;

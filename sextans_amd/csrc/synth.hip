@@ -17,8 +17,11 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
+#include "graph_cluster.h"
+#include "row_cluster.h"
 #include "sextans_amd.h"
 
 #define SX_HD __host__ __device__ __forceinline__
@@ -246,6 +249,51 @@ __global__ void k_uniform(float *dst, int64_t n, uint64_t seed) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) dst[i] = u01m1(rnd(seed, (uint64_t)i, 0x51));
+}
+
+// ---- P A P^T on the device (measurement infrastructure: meshes in arbitrary node orders, sextans_amd/meshgen.py) ----------------
+// rows already gathered in the new order and columns relabelled: sort every row's entries by column (values travel along).
+// One wavefront per row of <= 256 entries (bitonic network over 256 LDS slots), one workgroup per longer row (<= 4096).
+template <int P, int T>   // P slots, T threads cooperating on one row
+__device__ __forceinline__ void sort_row_lds(int *key, float *val, int n, int t) {
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < P; i += T) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int a = key[i], b = key[ixj];
+                    if ((a > b) == ((i & k) == 0)) {
+                        key[i] = b; key[ixj] = a;
+                        const float va = val[i]; val[i] = val[ixj]; val[ixj] = va;
+                    }
+                }
+            }
+            if (T == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+        }
+    (void)n;
+}
+__global__ __launch_bounds__(256) void k_sort_rows_wave(int M, const int *__restrict__ rp, int *ci, float *va) {
+    __shared__ int key[4][256];
+    __shared__ float val[4][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= M) return;
+    const int j0 = rp[r], n = rp[r + 1] - j0;
+    if (n < 2 || n > 256) return;
+    for (int i = lane; i < 256; i += 64) { key[wave][i] = i < n ? ci[j0 + i] : 0x7fffffff; val[wave][i] = i < n ? va[j0 + i] : 0.f; }
+    __builtin_amdgcn_wave_barrier();
+    sort_row_lds<256, 64>(key[wave], val[wave], n, lane);
+    for (int i = lane; i < n; i += 64) { ci[j0 + i] = key[wave][i]; va[j0 + i] = val[wave][i]; }
+}
+__global__ __launch_bounds__(256) void k_sort_rows_wg(const int *__restrict__ rows, const int *__restrict__ rp, int *ci, float *va) {
+    __shared__ int key[4096];
+    __shared__ float val[4096];
+    const int r = rows[blockIdx.x], t = threadIdx.x;
+    const int j0 = rp[r], n = rp[r + 1] - j0;
+    for (int i = t; i < 4096; i += 256) { key[i] = i < n ? ci[j0 + i] : 0x7fffffff; val[i] = i < n ? va[j0 + i] : 0.f; }
+    __syncthreads();
+    sort_row_lds<4096, 256>(key, val, n, t);
+    for (int i = t; i < n; i += 256) { ci[j0 + i] = key[i]; va[j0 + i] = val[i]; }
 }
 
 #define SY_HIP(call) do { if ((call) != hipSuccess) return SEXTANS_ERR_HIP; } while (0)
@@ -601,6 +649,46 @@ int sextans_gen_uniform_device(int device, float *d_dst, int64_t n, uint64_t see
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(k_uniform, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_dst, n, seed);
     SY_HIP(hipGetLastError());
+    return SEXTANS_OK;
+}
+
+int sextans_csr_permute_symmetric_device(int device, int M, int64_t nnz, const int *d_row_ptr, const int *d_col_idx, const float *d_val,
+                                         const int *new_of_old, int **o_row_ptr, int **o_col_idx, float **o_val) {
+    if (M < 0 || nnz < 0 || !d_row_ptr || !new_of_old || !o_row_ptr || !o_col_idx || !o_val) return SEXTANS_ERR_INVALID;
+    SY_HIP(hipSetDevice(device));
+    std::vector<int> old_of_new((size_t)M, -1), rp((size_t)M + 1);
+    for (int i = 0; i < M; ++i) {
+        const int p = new_of_old[i];
+        if (p < 0 || p >= M || old_of_new[(size_t)p] != -1) return SEXTANS_ERR_INVALID;   // not a permutation
+        old_of_new[(size_t)p] = i;
+    }
+    int *d_order = nullptr, *d_new = nullptr, *d_long = nullptr;
+    auto drop = [&]() { (void)hipFree(d_order); (void)hipFree(d_new); (void)hipFree(d_long); };
+    std::string err;
+    if (hipMalloc((void **)&d_order, sizeof(int) * (size_t)(M ? M : 1)) != hipSuccess || hipMalloc((void **)&d_new, sizeof(int) * (size_t)(M ? M : 1)) != hipSuccess) { drop(); return SEXTANS_ERR_HIP; }
+    if (M && (hipMemcpy(d_order, old_of_new.data(), sizeof(int) * (size_t)M, hipMemcpyHostToDevice) != hipSuccess ||
+              hipMemcpy(d_new, new_of_old, sizeof(int) * (size_t)M, hipMemcpyHostToDevice) != hipSuccess)) { drop(); return SEXTANS_ERR_HIP; }
+    int *nrp = nullptr, *nci = nullptr;
+    float *nva = nullptr;
+    auto fail = [&](int rc) { drop(); (void)hipFree(nrp); (void)hipFree(nci); (void)hipFree(nva); return rc; };
+    if (sx::permute_csr_rows_device(M, nnz, d_row_ptr, d_col_idx, d_val, d_order, &nrp, &nci, &nva, err)) return fail(SEXTANS_ERR_HIP);
+    if (sx::relabel_columns_device(nnz, nci, d_new, err)) return fail(SEXTANS_ERR_HIP);
+    if (hipMemcpy(rp.data(), nrp, sizeof(int) * ((size_t)M + 1), hipMemcpyDeviceToHost) != hipSuccess) return fail(SEXTANS_ERR_HIP);
+    std::vector<int> long_rows;
+    for (int r = 0; r < M; ++r) {
+        const int n = rp[(size_t)r + 1] - rp[(size_t)r];
+        if (n > 4096) return fail(SEXTANS_ERR_INVALID);      // (this tool sorts rows of up to 4096 entries)
+        if (n > 256) long_rows.push_back(r);
+    }
+    if (M) hipLaunchKernelGGL(k_sort_rows_wave, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, 0, M, nrp, nci, nva);
+    if (!long_rows.empty()) {
+        if (hipMalloc((void **)&d_long, sizeof(int) * long_rows.size()) != hipSuccess ||
+            hipMemcpy(d_long, long_rows.data(), sizeof(int) * long_rows.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(SEXTANS_ERR_HIP);
+        hipLaunchKernelGGL(k_sort_rows_wg, dim3((unsigned)long_rows.size()), dim3(256), 0, 0, d_long, nrp, nci, nva);
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return fail(SEXTANS_ERR_HIP);
+    drop();
+    *o_row_ptr = nrp; *o_col_idx = nci; *o_val = nva;
     return SEXTANS_OK;
 }
 

@@ -67,7 +67,8 @@ def test_reordered_form_is_bit_identical(engine, oracle, N):
                 elif rc == 0:
                     assert state == -1 and "reordered" not in engine.last_kernel()
                 elif auto_state is not None:
-                    assert state == auto_state, (name, state, engine.get_stat("cluster_shared_fraction"))
+                    assert state == auto_state, (name, state, engine.get_stat("cluster_shared_fraction"), engine.get_stat("cluster_decline"),
+                                                 engine.get_stat("panel_blocks"), engine.get_stat("panel_rows_natural"), engine.get_stat("panel_rows_clustered"))
         finally:
             _set(engine)
 
@@ -182,3 +183,30 @@ def test_device_calls_alias_ranges_and_options(engine, oracle):
         assert np.all(np.abs(out.astype(np.float64) - want) <= bound + 1e-30)
     finally:
         _set(engine)
+
+
+def test_device_permutation_tool_matches_the_host_one():
+    """sextans_csr_permute_symmetric_device (what tools/ use to renumber the 4M-row matrices in HBM) == meshgen.permute_symmetric."""
+    import ctypes
+    from sextans_amd import api, meshgen
+    nx, ny, nz, dof = 13, 12, 11, 3
+    M = nx * ny * nz * dof
+    rp, ci, v = api.gen_fem3d_host(nx, ny, nz, dof, 5)
+    perm = meshgen.node_permutation(M // dof, dof, 4)
+    want = meshgen.permute_symmetric(rp, ci, v, M, perm)
+    d = api.gen_fem3d_device(0, nx, ny, nz, dof, 5)
+    p = api.permute_symmetric_device(0, M, d[3], *d[:3], perm)
+    import torch
+    nnz = d[3]
+
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def fetch(ptr, n, dt):
+        out = np.empty(n, np.int32 if dt == torch.int32 else np.float32)
+        assert hip.hipMemcpy(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(out.nbytes), 2) == 0   # device -> host
+        return out
+    got = (fetch(p[0], M + 1, torch.int32), fetch(p[1], nnz, torch.int32), fetch(p[2], nnz, torch.float32))
+    for a, b in zip(got, want):
+        assert np.array_equal(a.view(np.uint32), np.asarray(b).view(np.uint32))
+    for q in list(d[:3]) + list(p):
+        api.device_free(0, q)
