@@ -120,10 +120,10 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
                       int nsuper, float alpha, float beta, hipStream_t s, int64_t bcol_ld, int blk_begin, int blk_end,
                       int row_base, int mode = 0) {
     // mode 1 (grid bricks): the plan over the rows in brick order, whole-matrix calls only; its slot -> row table addresses C.
-    // mode 2 (graph clustering, the reordered form): dBp = permuted panels, dCin == dCout == the block-major staging buffer,
-    // ldc_in == ldc == floats per tile.
+    // mode 2 (graph clustering, the reordered form): dBp = permuted panels, dCin == dCout == the row-major staging buffer,
+    // ldc_in == ldc == floats per tile; the same slot -> row table addresses the staging rows.
     const sextans_engine::PanelState &P = mode ? h->psc : h->ps;
-    const int *slot_row = mode == 1 ? h->d_slot_row : nullptr;
+    const int *slot_row = mode ? h->d_slot_row : nullptr;
     const unsigned char *skip = mode == 2 ? nullptr : (const unsigned char *)h->d_skip;
     const int nblk = blk_end - blk_begin;
     if (nblk <= 0 || nsuper <= 0) return SEXTANS_OK;
@@ -700,7 +700,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     // remainder tile keeps the natural-order kernels and panels.  (Layout tag -W: such panels are never reused by a row-range call.)
     const bool reordered = whole && h->cluster_state == 2 && h->opt_kernel != 1 && h->opt_kernel != 3 && W == 16 && !fuse_b && !hubs &&
                            !chains && h->dense_W == 0 && h->d_Cs && N >= 16;
-    const int64_t cs_tile = reordered ? (int64_t)h->psc.plan_nblk * 64 * 16 : 0;   // floats per 16-column tile of the staging buffer
+    const int64_t cs_tile = reordered ? (int64_t)h->M * 16 : 0;   // floats per 16-column tile of the staging buffer
     const int layout = reordered ? -W : W;
     const bool skip_repack = fuse_b || ((flags & SEXTANS_ROWS_REUSE_B_PANELS) != 0 && h->bp_layout == layout);
 
@@ -725,8 +725,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         if (reordered)
             for (const Seg &g : plan)
                 if (g.width == 16)
-                    hipLaunchKernelGGL(sx::permute_c_in, dim3((unsigned)((h->M + sx::kBlock - 1) / sx::kBlock), (unsigned)g.ntiles),
-                                       dim3(sx::kBlock), 0, s, d_C_in, ldc_in, h->d_Cs, cs_tile, h->d_cpos, h->M, g.col0);
+                    launch_repack<16>(d_C_in, ldc_in, h->d_Cs, h->M, g.col0, g.ntiles, s);   // C_in -> row-major tiles
     }
     {
         Prof p(h, &h->ev_kernel, s);
@@ -803,8 +802,8 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         Prof p(h, &h->ev_post, s);
         for (const Seg &g : plan)
             if (g.width == 16)
-                hipLaunchKernelGGL(sx::permute_c_out, dim3((unsigned)((h->M + sx::kBlock - 1) / sx::kBlock), (unsigned)g.ntiles),
-                                   dim3(sx::kBlock), 0, s, h->d_Cs, cs_tile, d_C_out, ldc, h->d_cpos, h->M, g.col0);
+                hipLaunchKernelGGL(sx::tiles_to_colmajor, dim3((unsigned)((h->M + sx::kBlock - 1) / sx::kBlock), (unsigned)g.ntiles),
+                                   dim3(sx::kBlock), 0, s, h->d_Cs, d_C_out, ldc, h->M, g.col0);
     }
     SX_HIP(hipGetLastError());
     return SEXTANS_OK;

@@ -26,8 +26,8 @@ void free_panel_state(sextans_engine::PanelState &p) {
 
 void free_cluster_plan(sextans_engine *h) {   // the clustered-order plan and its tables; it is reconsidered at the next whole-matrix call
     free_panel_state(h->psc);
-    (void)hipFree(h->d_slot_row); (void)hipFree(h->d_colpos); (void)hipFree(h->d_cpos);
-    h->d_slot_row = h->d_colpos = h->d_cpos = nullptr;
+    (void)hipFree(h->d_slot_row); (void)hipFree(h->d_colpos);
+    h->d_slot_row = h->d_colpos = nullptr;
     h->cluster_state = 0;
     h->cluster_decline = 0;
     h->cluster_total_dict = 0;
@@ -58,7 +58,6 @@ int64_t device_bytes(const sextans_engine *h) {
     for (const auto &p : h->plan_stash) b += plan_bytes(p);
     if (h->d_slot_row) b += (int64_t)h->psc.plan_nblk * 64 * 4;
     if (h->d_colpos) b += (int64_t)h->K * 4;
-    if (h->d_cpos) b += (int64_t)h->M * 4;
     if (h->d_wstream) b += h->win_padded * 8 + (int64_t)h->win_nwaves * 4;
     if (h->d_dense_Af) b += (int64_t)h->dense_mb * h->dense_W * (2048 + 4);
     if (h->d_bell_Af) b += (int64_t)(h->bell_M / 32) * h->bell_W * (2048 + (h->d_bell_col_owned ? 4 : 0));
@@ -381,10 +380,10 @@ int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reaso
         h->cluster_shared = shared;
         if (shared < 0.2) return 5;                                                                                               // 5: no shared neighbourhoods
     }
-    int *d_order = nullptr, *d_colpos = nullptr, *d_cpos = nullptr, *prp = nullptr, *pci = nullptr;
+    int *d_order = nullptr, *d_colpos = nullptr, *prp = nullptr, *pci = nullptr;
     float *pv = nullptr;
     sx::DevicePlan dp;
-    auto drop = [&](int why) { (void)hipFree(d_order); (void)hipFree(d_colpos); (void)hipFree(d_cpos); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
+    auto drop = [&](int why) { (void)hipFree(d_order); (void)hipFree(d_colpos); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
                                sx::free_device_plan(dp); return why; };
     if (sx::cluster_rows_graph_device(h->M, h->K, h->m_nnz, h->m_rp, h->m_ci, 4096, &d_order, err)) return drop(6);   // 6 .. 9: a builder failed
     if (sx::column_first_touch_order_device(h->M, h->K, h->m_rp, h->m_ci, d_order, &d_colpos, err)) return drop(7);
@@ -399,16 +398,15 @@ int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reaso
     if (brc != 0) return drop(9);
     h->cluster_total_dict = dp.total_dict;
     // 10: a row wider than the panel / limits of the 32-bit offsets; 11: the reordered plan has no reuse either; 12: not enough gain
-    if (dp.mixed || dp.dict_stride > 9 * RB || dp.max_dict > sx::kWideMaxDict || (int64_t)dp.nblk * RB * 64 >= ((int64_t)1 << 32)) return drop(10);
+    if (dp.mixed || dp.dict_stride > 9 * RB || dp.max_dict > sx::kWideMaxDict || (int64_t)h->M * 64 >= ((int64_t)1 << 32)) return drop(10);
     if ((double)h->m_nnz < min_reuse * (double)dp.total_dict) return drop(11);
     if (h->opt_row_cluster < 0 && h->ps.plan_built && (double)dp.total_dict > 0.6 * (double)h->plan_total_dict) return drop(12);
-    if (sx::build_row_slots_device(h->M, dp.nblk, RB, dp.d_blk_row, d_order, &d_cpos, err)) return drop(9);
+    if (sx::build_slot_rows_device(dp.nblk, RB, dp.d_blk_row, d_order, &h->d_slot_row, err)) return drop(9);
     (void)hipFree(d_order);
     adopt_device_plan(h->psc, dp, h, lpr, cap);
     h->psc.plan_panel_frac = h->m_nnz ? (double)dp.nnz_in_panel_blocks / (double)h->m_nnz : 0.0;
     h->psc.plan_narrow_frac = h->psc.plan_panel_frac;
     h->d_colpos = d_colpos;
-    h->d_cpos = d_cpos;
     return 0;
 }
 }  // namespace
@@ -688,8 +686,8 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
         // use the clustered plan and do not pay for it.)
         if (lpr == 4 && whole && h->opt_kernel != 3) {
             if (int rc = ensure_cluster_plan(h)) return rc;
-            if (h->cluster_state == 2 && N >= 16)   // block-major C staging of the reordered form: N / 16 tiles x 64 slots per block
-                if (int rc = ensure(&h->d_Cs, &h->Cs_cap, (size_t)(N / 16) * (size_t)h->psc.plan_nblk * 64 * 16)) return rc;
+            if (h->cluster_state == 2 && N >= 16)   // row-major C staging of the reordered form: N / 16 tiles of M x 16
+                if (int rc = ensure(&h->d_Cs, &h->Cs_cap, (size_t)(N / 16) * (size_t)h->M * 16)) return rc;
         }
         use_panel = h->ps.plan_built && ((h->opt_kernel == 2) || (h->ps.plan_panel_frac >= 0.5 && (N >= 32 || h->ps.plan_narrow_frac >= 0.5)));
     }

@@ -90,10 +90,9 @@ struct sextans_engine {
     // The same plan over the rows in CLUSTERED order (row_cluster.hip: brick by brick for grid-stencil matrices), 4 lanes per row,
     // used by spmm_csr_panel_v2 for whole-matrix calls; row-range calls and every other kernel keep the natural-order plan above.
     PanelState psc;
-    int *d_slot_row = nullptr;          // psc, grid bricks: row of the main matrix per (block, slot)
+    int *d_slot_row = nullptr;          // psc: row of the main matrix per (block, slot)
     int *d_colpos = nullptr;            // psc, graph clustering: row of the permuted B panels that holds column c (K ints)
-    int *d_cpos = nullptr;              //   ... and the slot of every row in the block-major C staging buffer (M ints)
-    float *d_Cs = nullptr;              //   ... that buffer: [N / 16][blocks x 64][16] floats
+    float *d_Cs = nullptr;              //   ... and the row-major C staging buffer of the reordered form: [N / 16][M][16] floats
     size_t Cs_cap = 0;
     int cluster_decline = 0;            // why the graph clustering was declined (engine_plan.hip: cluster_graph), 0 = it was not
     double cluster_shared = 0.0;        // sampled share of a neighbour row's columns a row has too (graph clustering pre-test)

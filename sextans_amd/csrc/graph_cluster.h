@@ -30,7 +30,4 @@ int column_first_touch_order_device(int M, int K, const int *d_rp, const int *d_
 // in place: ci[j] = colpos[ci[j]]
 int relabel_columns_device(int64_t nnz, int *d_ci, const int *d_colpos, std::string &err);
 
-// cpos[order[blk_row[b] + s]] = b * RB + s: the slot of every row in the block-major C staging buffer (M ints, caller frees)
-int build_row_slots_device(int M, int nblk, int RB, const int *d_blk_row, const int *d_order, int **d_cpos, std::string &err);
-
 }  // namespace sx

@@ -304,15 +304,6 @@ __global__ __launch_bounds__(256) void relabel(long long nnz, int *ci, const int
     const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
     if (j < nnz) ci[j] = colpos[ci[j]];
 }
-__global__ __launch_bounds__(256) void row_slots(int nblk, int RB, const int *__restrict__ blk_row, const int *__restrict__ order,
-                                                 int *__restrict__ cpos) {
-    const long long tt = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (tt >= (long long)nblk * RB) return;
-    const int b = (int)(tt / RB), s = (int)(tt % RB);
-    const int i = blk_row[b] + s;
-    if (i < blk_row[b + 1]) cpos[order[i]] = b * RB + s;
-}
-
 inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
@@ -419,17 +410,6 @@ int column_first_touch_order_device(int M, int K, const int *d_rp, const int *d_
 int relabel_columns_device(int64_t nnz, int *d_ci, const int *d_colpos, std::string &err) {
     if (nnz > 0) hipLaunchKernelGGL(relabel, dim3(blocks_for(nnz, 256)), dim3(256), 0, nullptr, (long long)nnz, d_ci, d_colpos);
     GC_HIP(hipDeviceSynchronize());
-    return 0;
-}
-
-int build_row_slots_device(int M, int nblk, int RB, const int *d_blk_row, const int *d_order, int **d_cpos, std::string &err) {
-    *d_cpos = nullptr;
-    int *cpos = nullptr;
-    GC_HIP(hipMalloc((void **)&cpos, sizeof(int) * (size_t)std::max(1, M)));
-    if (nblk > 0) hipLaunchKernelGGL(row_slots, dim3(blocks_for((long long)nblk * RB, 256)), dim3(256), 0, nullptr, nblk, RB, d_blk_row, d_order, cpos);
-    const hipError_t e = hipDeviceSynchronize();
-    if (e != hipSuccess) { (void)hipFree(cpos); err = hipGetErrorString(e); return 2; }
-    *d_cpos = cpos;
     return 0;
 }
 

@@ -118,9 +118,10 @@ __device__ __forceinline__ void astore4(float *sbase, unsigned voff_bytes, const
 // plan's actual maximum, so that a block with 235 dictionary rows does not issue the loads and LDS writes of 576).
 // (8 instead of 4 B rows in flight per lane for launches that cannot fill the chip -- one wavefront per SIMD -- was measured on
 // nasa4704: row loop 2833 vs 2829 cycles, not kept.)
-// CROW (the REORDERED form, reorder_kernels.h): Cin == Cout == the block-major staging buffer Cs[tile][blk * 64 + slot][16]
-// (ldc_in == ldc == floats per tile): C_in of a tile is ONE 16-byte load per lane and C_out one 16-byte store, whatever rows of the
-// matrix the block's slots are; blk_dict then holds RELABELLED columns (rows of the permuted B panels).
+// CROW (the REORDERED form, reorder_kernels.h): Cin == Cout == the row-major staging buffer Cs[tile][row][16] (ldc_in == ldc ==
+// floats per tile = 16 M): C_in of a tile is ONE 16-byte load per lane and C_out one 16-byte store -- the four lanes of a slot cover
+// the 64 contiguous bytes of row slot_row[slot], whatever row of the matrix that is; blk_dict then holds RELABELLED columns (rows
+// of the permuted B panels).
 template <int H, int NB, bool EXACT, bool BCOL, bool TIMED = false, int DCAP = 9, bool CROW = false>
 __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
     const int2 *__restrict__ slot_info, const unsigned short *__restrict__ p_idx16, const float *__restrict__ p_val,
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
     // C: column (col0 + 16h + 4q + j) of this lane = uniform column base (col0 + 16h + j) + a per-lane byte offset
     const unsigned cvoff_in = (4u * (unsigned)q * (unsigned)ldc_in + coff) * 4u;
     const unsigned cvoff_out = (4u * (unsigned)q * (unsigned)ldc + coff) * 4u;
-    const unsigned cvoff_row = ((unsigned)(blk * RB + slot) * 16u + 4u * (unsigned)q) * 4u;   // CROW: my 16 bytes of the tile
+    const unsigned cvoff_row = ((unsigned)myrow * 16u + 4u * (unsigned)q) * 4u;   // CROW: my 16 bytes of the tile (row-major staging)
     // C_in of the FIRST super tile is requested here, in the same round trip as the panel and the row entries (for a
     // matrix of a few thousand rows the whole kernel is three round trips: one more is 15 % of its time)
     float cin[H][4];

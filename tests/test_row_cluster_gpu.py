@@ -59,8 +59,10 @@ def test_clustered_plan_is_bit_identical_and_smaller(engine, oracle, N):
 
 
 def test_no_structure_no_clustering(engine, oracle, sx):
-    """Random columns inside a band (reuse, but no grid strides) and a KKT system (different stencils per section): the detector
-    declines, the natural-order plan runs, same bits."""
+    """Random columns inside a band (reuse, but no grid strides; its natural-order blocks are full) and a KKT system (different
+    stencils per section, border rows on the exact-chain path): under the automatic setting neither the grid detector nor the graph
+    clustering (tests/test_graph_cluster_gpu.py) takes them and the natural-order plan runs; forced (row_cluster = 1) the banded
+    matrix may get a graph-clustered plan -- same bits either way."""
     from sextans_amd import api
     rs = np.random.RandomState(3)
     cases = []
@@ -74,17 +76,21 @@ def test_no_structure_no_clustering(engine, oracle, sx):
     cases.append(("kkt", krp, kci, kv, api.kkt_rows(n, 2)))
     try:
         for name, rp, ci, v, M in cases:
-            _set(engine, row_cluster=1, kernel=2)
-            engine.set_matrix_csr(M, M, rp, ci, v)
-            N = 32
-            B = rs.uniform(-1, 1, M * N).astype(np.float32)
-            C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
-            want = C0.copy()
-            oracle.spmm(M, N, M, ALPHA, rp, ci, v, B, BETA, want)
-            out = C0.copy()
-            engine.spmm(N, ALPHA, B, BETA, out)
-            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), name
-            assert int(engine.get_stat("row_cluster")) == -1, name
+            for rc in (-1, 1):
+                _set(engine, row_cluster=rc, kernel=2)
+                engine.set_matrix_csr(M, M, rp, ci, v)
+                N = 32
+                B = rs.uniform(-1, 1, M * N).astype(np.float32)
+                C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+                want = C0.copy()
+                oracle.spmm(M, N, M, ALPHA, rp, ci, v, B, BETA, want)
+                out = C0.copy()
+                engine.spmm(N, ALPHA, B, BETA, out)
+                assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (name, rc)
+                state = int(engine.get_stat("row_cluster"))
+                assert state != 1, name                                   # never the grid bricks
+                if rc == -1 or name == "kkt":
+                    assert state == -1, (name, rc, engine.get_stat("cluster_decline"))
     finally:
         _set(engine)
 

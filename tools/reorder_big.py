@@ -51,9 +51,8 @@ def host_classes():
     for num in ("sweep", "random"):
         if "mesh_" + num in classes:
             t = time.time()
-            m = int(round(n * (dof ** (1 / 3))))          # about as many rows as the FEM matrix, 1 dof
-            rp, ci, v, M = meshgen.jittered_mesh3d(m, m, m, 5, numbering=num)
-            print(f"# jittered mesh {m}^3, numbering {num}: M={M} nnz={rp[-1]} ({time.time() - t:.1f} s on the host)", flush=True)
+            rp, ci, v, M = meshgen.jittered_mesh3d(n, n, n, 5, numbering=num, dof=dof)
+            print(f"# jittered mesh {n}^3 x {dof} dof, numbering {num}: M={M} nnz={rp[-1]} ({time.time() - t:.1f} s on the host)", flush=True)
             yield "mesh_" + num, M, int(rp[-1]), (rp, ci, v)
 
 
