@@ -375,10 +375,14 @@ int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reaso
         // worth trying?  Not when the natural-order plan already fills its blocks (numberings with locality: the grid path or
         // nothing), and not when neighbouring rows do not share neighbourhoods (random columns: there is nothing to find)
         if (h->ps.plan_built && !h->ps.plan_mixed && h->ps.plan_nblk > 0 && (double)h->M / h->ps.plan_nblk >= 50.0) return 4;   // 4: natural blocks are full
-        double shared = 0.0;
-        if (sx::probe_shared_neighbourhood_device(h->M, h->m_rp, h->m_ci, 256, &shared, err)) return 5;
+        double shared = 0.0, near = 0.0;
+        if (sx::probe_shared_neighbourhood_device(h->M, h->m_rp, h->m_ci, 256, &shared, &near, err)) return 5;
         h->cluster_shared = shared;
         if (shared < 0.2) return 5;                                                                                               // 5: no shared neighbourhoods
+        // 13: short rows in a numbering that has locality -- per row the two extra passes over C move more bytes than the row's
+        // non-zeros, and the gather kernel finds its B rows in L2 (2-D 5-point stencils, 1-dof meshes in sweep order: measured equal
+        // or slower per step); without locality in the numbering the reordered form wins even there (1-dof mesh, random order: 1.7x)
+        if (h->m_nnz / h->M < 20 && near >= 0.5) return 13;
     }
     int *d_order = nullptr, *d_colpos = nullptr, *prp = nullptr, *pci = nullptr;
     float *pv = nullptr;
@@ -647,7 +651,9 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
     }
     if (h->nhub > 0)
         if (int rc = ensure(&h->d_P, &h->P_cap, (size_t)h->split_nv * (size_t)N)) return rc;
-    if (h->nchain > 0) {
+    if (h->nchain > 0 || (N >= 32 && h->opt_pipeline_tiles != 0)) {
+        if (!h->ev_pipe[0])
+            for (hipEvent_t &e : h->ev_pipe) SX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         if (!h->aux_stream) {
             SX_HIP(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));   // (a high-priority stream was measured: no difference)
             SX_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));

@@ -162,6 +162,7 @@ struct sextans_engine {
     int64_t chain_built_opt = -2;
     hipStream_t aux_stream = nullptr;         // the chain kernels need one or two wavefronts for ~1 ms: they run beside the main kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_pipe[4] = {nullptr, nullptr, nullptr, nullptr};   // tile-group pipelining (engine.hip): fork / second-group passes done / first kernel done / side stream done
     std::vector<int> h_split_rows;            // ascending: rows cut into more than one piece
     int nhub = 0;                             // long rows (bucketed + split)
     int split_nv = 0;                         // pieces of all long rows
@@ -187,6 +188,10 @@ struct sextans_engine {
     int64_t opt_cluster_group = 3;      // bricks are laid out in groups of g x g brick columns (A/B on the 4M-row FEM matrix: g = 3)
     int64_t opt_row_cluster = -1;       // clustered-order plan for spmm_csr_panel_v2 (ensure_cluster_plan): -1 auto, 0 never, 1 whenever one
                                         // can be built, 2 = graph clustering (reordered form) also where the grid bricks would apply
+    int64_t opt_pipeline_tiles = 0;     // N >= 32 on spmm_csr_panel_v2: 1 = the 16-column tiles run as two groups and the layout passes of the second
+                                        // group go to the side stream under the first group's kernel.  Built and measured: the second
+                                        // pass over the packed A stream costs more than the hidden repack saves (FEM 4M, N = 128: 3.94 -> 4.09 ms
+                                        // per step, N = 32: 1.12 -> 1.52 ms), so the default is 0 = one launch over all tiles
     int64_t opt_small_v2 = 1;           // measurement switch: 0 = small matrices keep the full-capacity, 4-deep form of spmm_csr_panel_v2
     int64_t opt_panel_v2 = -1;          // 16-column tiles on the register-resident form (spmm_csr_panel_v2<1>: row entries
                                         // loaded once per block, panels by LDS-DMA, tile loop inside the workgroup, C stored

@@ -11,8 +11,10 @@ namespace sx {
 
 // Share of a sampled row's columns that a neighbouring row (one of its own column indices, read as a row) has too, averaged
 // over `nsample` rows spread over the matrix: ~0 for matrices with random columns, 0.3 .. 0.7 for mesh / stencil matrices in
-// ANY numbering.  Needs M == K.  Returns non-zero on a HIP error.
-int probe_shared_neighbourhood_device(int M, const int *d_rp, const int *d_ci, int nsample, double *shared_fraction, std::string &err);
+// ANY numbering.  *near_fraction = share of the sampled rows' entries within M / 64 of the diagonal (does the numbering have
+// locality?).  Needs M == K.  Returns non-zero on a HIP error.
+int probe_shared_neighbourhood_device(int M, const int *d_rp, const int *d_ci, int nsample, double *shared_fraction, double *near_fraction,
+                                      std::string &err);
 
 // order[i] = row of the matrix at position i of the clustered order (M ints on the device, caller frees).
 // Rows are merged pairwise, level by level (cluster sizes 1 -> 2 -> 4 ... -> max_cluster_rows), each cluster with the unmatched

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void tri_weights(int M, const int *__restrict_
 
 // Sampled version of the same count: the share of a neighbour row's columns that the sampled row has too.
 __global__ __launch_bounds__(256) void probe_shared(int M, const int *__restrict__ rp, const int *__restrict__ ci, int nsample,
-                                                    unsigned long long *acc /* [0] shared, [1] compared */) {
+                                                    unsigned long long *acc /* [0] shared, [1] compared, [2] near entries, [3] entries */) {
     __shared__ int tabs[4][kTriHT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + wave;
@@ -135,6 +135,15 @@ __global__ __launch_bounds__(256) void probe_shared(int M, const int *__restrict
     __builtin_amdgcn_wave_barrier();
     for (int e = lane; e < len; e += 64) set_insert(tab, ci[j0 + e]);
     __builtin_amdgcn_wave_barrier();
+    {   // locality of the numbering: entries within M / 64 of the diagonal
+        unsigned long long near = 0;
+        for (int e = lane; e < len; e += 64) {
+            const long long d = (long long)ci[j0 + e] - r;
+            near += (d < 0 ? -d : d) < (long long)M / 64 + 1 ? 1u : 0u;
+        }
+        for (int off = 32; off > 0; off >>= 1) near += __shfl_xor((unsigned)near, off);
+        if (lane == 0) { atomicAdd(&acc[2], near); atomicAdd(&acc[3], (unsigned long long)len); }
+    }
     unsigned long long shared = 0, compared = 0;
     for (int q = 0; q < 8; ++q) {                          // eight neighbours spread over the row
         const int c = ci[j0 + (int)((long long)q * len / 8)];
@@ -308,16 +317,19 @@ inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 
 
 }  // namespace
 
-int probe_shared_neighbourhood_device(int M, const int *d_rp, const int *d_ci, int nsample, double *shared_fraction, std::string &err) {
+int probe_shared_neighbourhood_device(int M, const int *d_rp, const int *d_ci, int nsample, double *shared_fraction, double *near_fraction,
+                                      std::string &err) {
     *shared_fraction = 0.0;
+    *near_fraction = 0.0;
     if (M < 16 || nsample < 1) return 0;
     Scratch tmp;
-    unsigned long long *d_acc = nullptr, h_acc[2] = {0, 0};
-    GC_HIP(tmp.alloc(&d_acc, 2));
+    unsigned long long *d_acc = nullptr, h_acc[4] = {0, 0, 0, 0};
+    GC_HIP(tmp.alloc(&d_acc, 4));
     GC_HIP(hipMemset(d_acc, 0, sizeof h_acc));
     hipLaunchKernelGGL(probe_shared, dim3(blocks_for(nsample, 4)), dim3(256), 0, nullptr, M, d_rp, d_ci, nsample, d_acc);
     GC_HIP(hipMemcpy(h_acc, d_acc, sizeof h_acc, hipMemcpyDeviceToHost));
     if (h_acc[1]) *shared_fraction = (double)h_acc[0] / (double)h_acc[1];
+    if (h_acc[3]) *near_fraction = (double)h_acc[2] / (double)h_acc[3];
     return 0;
 }
 

@@ -252,10 +252,12 @@ def test_panel_threshold_depends_on_n(engine, oracle, sx):
                 built = engine.get_stat("plan_build_s")
             assert engine.get_stat("plan_build_s") == built          # one plan, never rebuilt
         engine.set_option("panel_min_reuse_wide_x100", 200)          # same threshold for every N: gather kernel at N = 32 too
+        engine.set_option("row_cluster", 0)                          # (and no graph-clustered plan in its place: test_graph_cluster_gpu.py)
         out = C0.copy()
         engine.spmm(64, ALPHA, B, BETA, out)
         assert engine.last_kernel() == "spmm_csr_rowgroup"
         assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
     finally:
         engine.set_option("panel_min_reuse_wide_x100", 150)
+        engine.set_option("row_cluster", -1)
         _set(engine)

@@ -1,5 +1,5 @@
 """Option sets compared on ONE box, round-robin: tools/ab_opts.py <fem dims AxBxCxD | synth:spec> <N> <iters> "k=v,k=v" "k=v" ...  (kernel us per launch)"""
-import os, sys
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -30,8 +30,9 @@ for rnd in range(3):
         f = lambda: e.spmm_device(N, 0.85, B.data_ptr(), K, -2.06, Cin.data_ptr(), Cout.data_ptr(), M, st)
         for _ in range(3): f()
         e.set_option("profile", 1); e.profile_reset()
+        torch.cuda.synchronize(); t0 = time.time()
         for _ in range(iters): f()
-        torch.cuda.synchronize()
-        k_ns, n, r_ns = e.profile_read(); e.set_option("profile", 0)
-        out.append(f"{o}: {k_ns / 1e3:.1f} ({e.last_kernel()})")
+        torch.cuda.synchronize(); wall = (time.time() - t0) / iters
+        k_ns, n, r_ns = e.profile_read(); p_ns, _ = e.profile_read_post(); e.set_option("profile", 0)
+        out.append(f"{o}: kernel {k_ns / 1e3:.1f} pre {r_ns / 1e3:.1f} post {p_ns / 1e3:.1f} wall {wall * 1e6:.1f} ({e.last_kernel()})")
     print(f"N={N} round {rnd}: " + " | ".join(out), flush=True)
