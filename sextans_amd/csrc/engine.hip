@@ -18,6 +18,7 @@
 #include "chan_kernels.h"
 #include "engine_state.h"
 #include "reorder_kernels.h"
+#include "spmm_colwise_kernel.h"
 #include "spmm_csr_kernels.h"
 #include "spmm_panel_v2.h"
 #include "spmm_window_kernel.h"
@@ -286,6 +287,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "small_v2")) return &h->opt_small_v2;
     if (!strcmp(key, "row_cluster")) return &h->opt_row_cluster;
     if (!strcmp(key, "pipeline_tiles")) return &h->opt_pipeline_tiles;
+    if (!strcmp(key, "colwise_max_len")) return &h->opt_colwise_max_len;
     if (!strcmp(key, "cluster_shape")) return &h->opt_cluster_shape;
     if (!strcmp(key, "cluster_group")) return &h->opt_cluster_group;
     if (!strcmp(key, "window_rows")) return &h->opt_win_rows;
@@ -336,6 +338,7 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
         (void)hipSetDevice(h->device);   // the clustered-order plan is (re)considered under the new setting
         free_cluster_plan(h);
     }
+    if (slot == &h->opt_colwise_max_len && *slot != value) h->colwise_state = 0;
     if (*slot != value) h->dist_cut_key.clear();   // chunk cuts are aligned to the packed forms the options select (all
                                                    // ranks of a partition must change options together: the cut
                                                    // exchange is a collective)
@@ -521,6 +524,8 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "row_cluster")) *value = (double)h->cluster_state;          // 1 grid bricks / 2 graph clustering in use, -1 declined, 0 not evaluated yet
     else if (!strcmp(key, "cluster_shared_fraction")) *value = h->cluster_shared;
     else if (!strcmp(key, "cluster_decline")) *value = (double)h->cluster_decline;
+    else if (!strcmp(key, "colwise")) *value = (double)h->colwise_state;
+    else if (!strcmp(key, "row_coherence")) *value = h->row_coherence;
     else if (!strcmp(key, "panel_blocks_clustered")) *value = (double)h->psc.plan_nblk;
     else if (!strcmp(key, "device_bytes")) *value = (double)device_bytes(h);
     else if (!strcmp(key, "grid_stride_line")) *value = (double)h->cluster_s2;
@@ -690,11 +695,30 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         SX_HIP(hipGetLastError());
         return SEXTANS_OK;
     }
+    // Short rows in a numbering with locality (or "kernel" = 4): one lane per row on the caller's column-major operands -- no B
+    // repack, no LDS (spmm_colwise_kernel.h).  Rows on the long-row paths need the repacked panels: then the other kernels run.
+    if ((h->opt_kernel == 4 || (h->opt_kernel == 0 && h->colwise_state == 1)) && !hubs && !chains && h->dense_W == 0 && h->m_nnz > 0) {
+        Prof p(h, &h->ev_kernel, s);
+        const int nrowblk = (nrows + sx::kBlock - 1) / sx::kBlock;
+        auto go = [&](auto kern, int col0, int ntiles) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)nrowblk, (unsigned)ntiles), dim3(sx::kBlock), 0, s, h->m_rp, h->m_ci, h->m_v, d_B, ldb, d_C_in,
+                               ldc_in, d_C_out, ldc, row_begin, row_end, nrowblk, col0, alpha, beta, (int)h->opt_xcd, (const unsigned char *)h->d_skip);
+        };
+        const int n16 = N / 16;
+        if (n16 > 0) { if (h->opt_exact) go(sx::spmm_csr_colwise<true, 16>, 0, n16); else go(sx::spmm_csr_colwise<false, 16>, 0, n16); }
+        if (N % 16) { if (h->opt_exact) go(sx::spmm_csr_colwise<true, 8>, n16 * 16, 1); else go(sx::spmm_csr_colwise<false, 8>, n16 * 16, 1); }
+        h->last_kernel = "spmm_csr_colwise";
+        SX_HIP(hipGetLastError());
+        return SEXTANS_OK;
+    }
     // Small B (fits the L2s), dictionary-only plan, one N segment: the panel kernel stages straight from the
     // caller's column-major B and the repack launch disappears.
     const bool fuse_b = use_panel && !h->ps.plan_mixed && h->opt_fuse_b && !(flags & kRowsNoFuseB) && plan.size() == 1 &&
                         plan[0].width == W && !hubs && !chains &&
                         (size_t)h->K * (size_t)N * sizeof(float) <= ((size_t)16 << 20);
+    // (Staging from column-major B for LARGE matrices -- no repack launch at all -- was measured in round 4 and loses everywhere: 4M-row
+    // 3-dof FEM N = 16 kernel 660 -> 872 us against 83 us of repack saved; 1-dof 27-point 379 -> 577; 2-D 9-point 296 -> 427;
+    // 5-point 270 -> 412: 36 four-byte loads per lane and panel through registers instead of nine LDS-DMA requests.)
     // (a reuse request is honoured only if the panels in the workspace have this layout: row-range calls of
     // one pipelined SpMM may alternate between the window kernel's 8-column panels and these)
     // The reordered form (graph-clustered plan, ensure_cluster_plan): whole-matrix calls, 16-column tiles.  Its B panels hold the

@@ -29,6 +29,8 @@ void free_cluster_plan(sextans_engine *h) {   // the clustered-order plan and it
     (void)hipFree(h->d_slot_row); (void)hipFree(h->d_colpos);
     h->d_slot_row = h->d_colpos = nullptr;
     h->cluster_state = 0;
+    h->colwise_state = 0;
+    h->row_coherence = 0.0;
     h->cluster_decline = 0;
     h->cluster_total_dict = 0;
     h->cluster_shared = 0.0;
@@ -415,6 +417,19 @@ int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reaso
 }
 }  // namespace
 
+// Short rows in a numbering with locality: the lane-per-row kernel on the caller's column-major B (spmm_colwise_kernel.h).
+int ensure_colwise(sextans_engine *h) {
+    if (h->colwise_state != 0) return SEXTANS_OK;
+    h->colwise_state = -1;
+    if (h->M < 2 || h->m_nnz <= 0 || h->m_nnz / h->M > h->opt_colwise_max_len) return SEXTANS_OK;
+    std::string err;
+    double close = 0.0;
+    if (sx::probe_row_coherence_device(h->M, h->m_rp, h->m_ci, 4096, &close, err)) { (void)hipGetLastError(); return SEXTANS_OK; }
+    h->row_coherence = close;
+    if (close >= 0.7) h->colwise_state = 1;
+    return SEXTANS_OK;
+}
+
 int ensure_cluster_plan(sextans_engine *h) {
     if (h->cluster_state != 0) return SEXTANS_OK;
     h->cluster_state = -1;
@@ -685,7 +700,10 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
     // Kernel choice: "kernel" 1 = row-group gather, 2 = LDS panel, 0 = auto (panel when at least half
     // of the non-zeros sit in row blocks whose B rows are reused -- "only where a tile has reuse").
     use_panel = false;
-    if (h->opt_kernel != 1 && h->m_nnz > 0) {
+    if ((h->opt_kernel == 0 || h->opt_kernel == 4) && h->m_nnz > 0)
+        if (int rc = ensure_colwise(h)) return rc;
+    const bool colwise = h->opt_kernel == 4 || (h->opt_kernel == 0 && h->colwise_state == 1);
+    if (h->opt_kernel != 1 && h->opt_kernel != 4 && h->m_nnz > 0 && !(colwise && h->nhub == 0 && h->nchain == 0 && h->dense_W == 0)) {
         if (int rc = ensure_plan(h, lpr, h->opt_kernel == 2)) return rc;
         // (here, not at launch time: prepare() runs before a hipGraph capture starts, and the builders copy to the host and
         // allocate.  Only for whole-matrix calls: engines that serve row ranges -- the chunks of the multi-GPU pipeline -- never

@@ -94,6 +94,8 @@ struct sextans_engine {
     int *d_colpos = nullptr;            // psc, graph clustering: row of the permuted B panels that holds column c (K ints)
     float *d_Cs = nullptr;              //   ... and the row-major C staging buffer of the reordered form: [N / 16][M][16] floats
     size_t Cs_cap = 0;
+    int colwise_state = 0;              // spmm_csr_colwise for this matrix: 0 not evaluated, 1 short rows in a numbering with locality, -1 no
+    double row_coherence = 0.0;         // sampled share of consecutive rows' entries with neighbouring columns
     int cluster_decline = 0;            // why the graph clustering was declined (engine_plan.hip: cluster_graph), 0 = it was not
     double cluster_shared = 0.0;        // sampled share of a neighbour row's columns a row has too (graph clustering pre-test)
     int cluster_state = 0;              // 0 not evaluated, 1 grid bricks in use, 2 graph clustering (reordered form) in use, -1 declined
@@ -180,6 +182,8 @@ struct sextans_engine {
     std::vector<int> dist_meta;     // {first row, rows} per (chunk, rank) as last uploaded, and where
     const int *dist_meta_at = nullptr;
     // options
+    int64_t opt_colwise_max_len = 6;    // spmm_csr_colwise is considered for matrices whose mean row length is at most this (5- and 7-point
+                                        // stencils; measured on 4M-row matrices: 5 entries per row 361 -> 259 us per step at N = 16, 9 entries 368 -> 407)
     int64_t opt_kernel = 0, opt_lpr = 0, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;   // opt_lpr 0 = auto
     int64_t opt_cols_per_lane = 0;      // LDS-panel kernel: output columns per lane.  4 (= 0, the default) = 16-column tiles;
                                         // 8 = register-blocked 32-column super tiles (spmm_csr_panel_v2<2>: 2 workgroups per
@@ -254,6 +258,7 @@ int read_back_row_ptr(sextans_engine *h, std::vector<int> &rp, int level = 2);
 int read_back_entries(sextans_engine *h, std::vector<int> &ci, std::vector<float> &va, int level = 2);
 int ensure_plan(sextans_engine *h, int lpr, bool force);
 int ensure_cluster_plan(sextans_engine *h);
+int ensure_colwise(sextans_engine *h);
 int ensure_window(sextans_engine *h, bool force);
 bool window_pays(const sextans_engine *h, int N, int64_t padded);
 int ensure_split(sextans_engine *h);

@@ -16,6 +16,10 @@ namespace sx {
 int probe_shared_neighbourhood_device(int M, const int *d_rp, const int *d_ci, int nsample, double *shared_fraction, double *near_fraction,
                                       std::string &err);
 
+// Share of the j-th entries of sampled consecutive rows (r, r + 1) whose columns differ by at most 32: ~1 for stencil / banded /
+// generator-ordered mesh matrices, ~0 for random columns or random numberings (dispatcher test of spmm_csr_colwise).
+int probe_row_coherence_device(int M, const int *d_rp, const int *d_ci, int nsample, double *close_fraction, std::string &err);
+
 // order[i] = row of the matrix at position i of the clustered order (M ints on the device, caller frees).
 // Rows are merged pairwise, level by level (cluster sizes 1 -> 2 -> 4 ... -> max_cluster_rows), each cluster with the unmatched
 // neighbouring cluster it shares the most neighbourhood with; a merged pair's rows become contiguous, so the final order is the

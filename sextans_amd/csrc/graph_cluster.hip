@@ -158,6 +158,23 @@ __global__ __launch_bounds__(256) void probe_shared(int M, const int *__restrict
     if (lane == 0 && compared) { atomicAdd(&acc[0], shared); atomicAdd(&acc[1], compared); }
 }
 
+// Do consecutive rows have neighbouring columns?  Pairs (r, r + 1) sampled over the matrix: share of their j-th entries whose
+// columns differ by at most 32 (what makes the B loads of spmm_csr_colwise coalesce).
+__global__ __launch_bounds__(256) void probe_coherence(int M, const int *__restrict__ rp, const int *__restrict__ ci, int nsample,
+                                                       unsigned long long *acc /* [0] close pairs, [1] pairs */) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= nsample || M < 2) return;
+    const int r = (int)((long long)s * (M - 1) / nsample);
+    const int a0 = rp[r], a1 = rp[r + 1], b1 = rp[r + 2];
+    const int n = min(min(a1 - a0, b1 - a1), 64);
+    unsigned long long close = 0;
+    for (int j = 0; j < n; ++j) {
+        const long long d = (long long)ci[a1 + j] - ci[a0 + j];
+        close += (d < 0 ? -d : d) <= 32 ? 1u : 0u;
+    }
+    if (n > 0) { atomicAdd(&acc[0], close); atomicAdd(&acc[1], (unsigned long long)n); }
+}
+
 // ---- one aggregation level -----------------------------------------------------------------------------------------------
 // Clusters are numbered in the current order: cluster A = rows ord[cstart[A] .. cstart[A + 1]); cinfo[row] = {cluster, its size}.
 // One wavefront per cluster: weights towards every neighbouring cluster that still fits under `limit` rows, then the kCand best.
@@ -330,6 +347,19 @@ int probe_shared_neighbourhood_device(int M, const int *d_rp, const int *d_ci, i
     GC_HIP(hipMemcpy(h_acc, d_acc, sizeof h_acc, hipMemcpyDeviceToHost));
     if (h_acc[1]) *shared_fraction = (double)h_acc[0] / (double)h_acc[1];
     if (h_acc[3]) *near_fraction = (double)h_acc[2] / (double)h_acc[3];
+    return 0;
+}
+
+int probe_row_coherence_device(int M, const int *d_rp, const int *d_ci, int nsample, double *close_fraction, std::string &err) {
+    *close_fraction = 0.0;
+    if (M < 2 || nsample < 1) return 0;
+    Scratch tmp;
+    unsigned long long *d_acc = nullptr, h_acc[2] = {0, 0};
+    GC_HIP(tmp.alloc(&d_acc, 2));
+    GC_HIP(hipMemset(d_acc, 0, sizeof h_acc));
+    hipLaunchKernelGGL(probe_coherence, dim3(blocks_for(nsample, 256)), dim3(256), 0, nullptr, M, d_rp, d_ci, nsample, d_acc);
+    GC_HIP(hipMemcpy(h_acc, d_acc, sizeof h_acc, hipMemcpyDeviceToHost));
+    if (h_acc[1]) *close_fraction = (double)h_acc[0] / (double)h_acc[1];
     return 0;
 }
 

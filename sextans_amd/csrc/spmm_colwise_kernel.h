@@ -1,0 +1,73 @@
+// spmm_colwise_kernel.h -- short-row form of the SpMM for matrices whose NUMBERING has locality: one lane per row, the B and C
+// accesses of a wavefront coalesce along the rows of the column-major operands.
+//
+// The reference packs short rows back to back into each PE's list (sparse_helper.h:292-343) so that a PE never idles on them;
+// what costs time here is different: for a 2-D 5-point stencil at N = 16 a row has 40 bytes of non-zeros against 64 bytes of B and
+// 128 bytes of C, so the row-group / LDS-panel kernels spend the step on what surrounds the non-zeros -- the B repack into row-major
+// panels (512 MB moved, 81 us for K = 4 M: 22 % of the step), the C tile transposes, a per-row prologue and epilogue for five
+// multiply-adds per column.  This kernel has none of that:
+//   * thread = row r, 16 accumulators = the 16 columns of one N tile; a wavefront = 64 CONSECUTIVE rows;
+//   * B is read where the caller left it (column-major, leading dimension ldb): the j-th entries of 64 consecutive rows have
+//     columns c_j(r) that move with r in a stencil / banded / mesh-in-generator-order matrix, so the 64 four-byte loads of
+//     B[c_j(r) + n ldb] fall into one or two 128-byte lines per column n -- no repack launch, no LDS;
+//   * C_in / C_out column-major: 64 consecutive rows of one column are one 256-byte run.
+// Every row is summed in ascending CSR order by one lane per output element, product rounded before the add when EXACT: the order
+// and rounding of cpu_spmm_CSR (sparse_helper.h:279-289), bit-identical.
+// It pays only for SHORT rows (the per-entry cost is 1 + 16 vector-memory instructions per lane; the LDS-panel kernel needs
+// 1 LDS read per 4 columns) in numberings WITH locality (else every one of those loads touches 64 lines): the dispatcher uses it
+// when the mean row length is <= 6 and sampled consecutive rows have neighbouring columns (engine_plan.hip: ensure_colwise).
+// Measured (4M rows, same-box A/B, us per step): 5-point stencil N = 16 361 -> 259, N = 32 592 -> 484, N = 128 2011 -> 1859; 9-point
+// (9 per row) 368 -> 407: already a loss; 27-point 450 -> 2489; banded random columns 530 -> 1836 (no coherence between rows).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "spmm_csr_kernels.h"
+
+namespace sx {
+
+// rows [row_begin, row_end); C pointers address row_begin as their row 0; grid = (row blocks of 256) x tiles of NC columns from col_base, row blocks
+// spread over the XCDs in contiguous chunks (neighbouring row blocks share B lines in L2).
+template <bool EXACT, int NC>   // NC = columns of a tile: 16, or 8 for a remainder tile
+__global__ __launch_bounds__(kBlock) void spmm_csr_colwise(const int *__restrict__ rp, const int *__restrict__ ci, const float *__restrict__ va,
+                                                           const float *__restrict__ B, int64_t ldb, const float *Cin, int64_t ldc_in, float *Cout,
+                                                           int64_t ldc, int row_begin, int row_end, int nrowblk, int col_base, float alpha, float beta,
+                                                           int use_xcd_remap, const unsigned char *__restrict__ skip) {
+    unsigned wg = blockIdx.x;
+    if (use_xcd_remap) wg = xcd_remap(wg, (unsigned)nrowblk);
+    const int r = row_begin + (int)wg * kBlock + (int)threadIdx.x;
+    if (r >= row_end) return;
+    const int tile = blockIdx.y;
+    const int col0 = col_base + tile * NC;
+    const float *b = B + (int64_t)col0 * ldb;
+    int j = rp[r];
+    const int j1 = rp[r + 1];
+    float acc[NC];
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[n] = 0.f;
+    // C_in early: its 16 loads fly under the row loop
+    const int64_t lr = r - row_begin;
+    float cin[NC];
+#pragma unroll
+    for (int n = 0; n < NC; ++n) cin[n] = Cin[lr + (int64_t)(col0 + n) * ldc_in];
+    if (j < j1) {
+        int c = ci[j];
+        float a = va[j];
+        while (true) {
+            float bv[NC];
+#pragma unroll
+            for (int n = 0; n < NC; ++n) bv[n] = b[c + (int64_t)n * ldb];
+            const float a0 = a;
+            ++j;
+            if (j < j1) { c = ci[j]; a = va[j]; }          // the next entry is requested before this one's products are formed
+#pragma unroll
+            for (int n = 0; n < NC; ++n) acc[n] = mac<EXACT>(acc[n], a0, bv[n]);
+            if (j >= j1) break;
+        }
+    }
+    if (skip && skip[r]) return;
+#pragma unroll
+    for (int n = 0; n < NC; ++n) Cout[lr + (int64_t)(col0 + n) * ldc] = epilogue<EXACT>(alpha, acc[n], beta, cin[n]);
+}
+
+}  // namespace sx
