@@ -82,13 +82,14 @@ void launch_rowgroup(sextans_engine *h, const int *rp, const int *rend, const in
 // dBp: repacked panel (bcol_ld == 0) or the caller's column-major B at this segment's first column with its
 // leading dimension bcol_ld (dictionary-only plans, small B: no repack launch).
 template <int LPR>
-void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout,
+int launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout,
                   int64_t ldc, int ntiles, float alpha, float beta, hipStream_t s, int64_t bcol_ld, int blk_begin,
                   int blk_end, int row_base) {
     constexpr int RB = sx::kBlock / LPR;
     constexpr int NT = 4 * LPR;
     const int nblk = blk_end - blk_begin;
-    if (nblk <= 0) return;
+    if (nblk <= 0) return SEXTANS_OK;
+    if (int rc = restore_plan_streams(h)) return rc;   // (released while a clustered plan served the whole-matrix calls)
     const unsigned nwg = (unsigned)nblk * (unsigned)ntiles;
     const int64_t pstride = bcol_ld > 0 ? bcol_ld : (int64_t)h->K * NT;
     const int xcd = (int)h->opt_xcd;
@@ -112,6 +113,7 @@ void launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_
         if (h->opt_exact) go(sx::spmm_csr_panel<LPR, true, false>);
         else go(sx::spmm_csr_panel<LPR, false, false>);
     }
+    return SEXTANS_OK;
 }
 
 // Wide-N form of the panel kernel (spmm_panel_v2.h): `nsuper` super tiles of 32 columns starting at the pointers
@@ -128,6 +130,8 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     const unsigned char *skip = mode == 2 ? nullptr : (const unsigned char *)h->d_skip;
     const int nblk = blk_end - blk_begin;
     if (nblk <= 0 || nsuper <= 0) return SEXTANS_OK;
+    if (mode == 0)
+        if (int rc = restore_plan_streams(h)) return rc;   // (released while a clustered plan served the whole-matrix calls)
     int tpw = (int)h->opt_tiles_per_wg;
     if (tpw <= 0) {   // all of N in one workgroup while that still leaves >= 4 rounds of workgroups (2 per CU)
         const int64_t rounds = (int64_t)nblk * nsuper / ((int64_t)8 * h->num_cus);
@@ -546,6 +550,7 @@ int sextans_export_plan(sextans_handle_t h, int lanes_per_row, sextans_packed *o
     if (int rc = ensure_split(h)) return rc;
     if (int rc = ensure_plan(h, lanes_per_row, true)) return rc;
     if (!h->ps.plan_built) return SEXTANS_ERR_STATE;
+    if (int rc = restore_plan_streams(h)) return rc;
     const auto &ps = h->ps;
     const int M = h->M, nblk = ps.plan_nblk, RB = sx::kBlock / lanes_per_row;
     const size_t L = (size_t)ps.plan_stream_len;
@@ -868,8 +873,9 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
                     return rc;
                 if (g.ntiles & 1) {
                     const int64_t c0 = (int64_t)nsuper * 32;
-                    launch_panel<4>(h, fuse_b ? bsrc + c0 * ldb : bsrc + c0 * (int64_t)h->K, cin + c0 * ldc_in, ldc_in, cout + c0 * ldc,
-                                    ldc, 1, alpha, beta, s, bld, blk0, blk1, row_begin);
+                    if (int rc = launch_panel<4>(h, fuse_b ? bsrc + c0 * ldb : bsrc + c0 * (int64_t)h->K, cin + c0 * ldc_in, ldc_in,
+                                                 cout + c0 * ldc, ldc, 1, alpha, beta, s, bld, blk0, blk1, row_begin))
+                        return rc;
                 }
                 v2_used = true;
                 if (hubs) launch_hub_pieces<4>(h, pt, bp, g.ntiles, g.col0, v0, v1, s);
@@ -889,7 +895,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
                 continue;
             }
 #define SX_SEG(L)                                                                                                       \
-    if (panel_here) launch_panel<L>(h, bsrc, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, bld, blk0, blk1, row_begin);  \
+    if (panel_here) { if (int rc = launch_panel<L>(h, bsrc, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, bld, blk0, blk1, row_begin)) return rc; }  \
     else launch_rowgroup<L>(h, h->m_rp, h->m_rp + 1, h->m_ci, h->m_v, false, h->d_skip, bp, cin, ldc_in, cout, ldc, row_begin, row_end, \
                             g.ntiles, alpha, beta, s);                                                                   \
     if (hubs) launch_hub_pieces<L>(h, pt, bp, g.ntiles, g.col0, v0, v1, s);

@@ -48,7 +48,8 @@ int64_t device_bytes(const sextans_engine *h) {
     auto plan_bytes = [](const sextans_engine::PanelState &p) -> int64_t {
         if (!p.plan_built || !p.plan_lpr) return 0;
         const int64_t rb = sx::kBlock / p.plan_lpr;
-        return (int64_t)p.plan_nblk * (4 * (2 + p.plan_dict_stride + 2 * rb)) + p.plan_stream_len * 6 + (p.plan_mixed ? p.plan_stream_len * 4 : 4);
+        return (int64_t)p.plan_nblk * (4 * (2 + p.plan_dict_stride + 2 * rb)) +
+               (p.stream_released ? 0 : p.plan_stream_len * 6 + (p.plan_mixed ? p.plan_stream_len * 4 : 4));
     };
     int64_t b = 0;
     const int64_t rows = (int64_t)h->M + 1;
@@ -430,6 +431,42 @@ int ensure_colwise(sextans_engine *h) {
     return SEXTANS_OK;
 }
 
+// The natural-order plan (4 lanes per row) keeps its meta data -- block boundaries for sextans_align_row, dictionary sizes --
+// but its packed stream, 6 bytes per non-zero (1.9 GB for the 318 M-nnz FEM matrix), is only read by row-range calls and by
+// whole-matrix calls that cannot use the clustered plan (column-major staging of small B).  Once a clustered plan serves the
+// whole-matrix calls of a matrix too large for that staging, the stream is handed back; the first launch that needs it again
+// rebuilds it (the builder is deterministic: the same bytes; 75 ms for that matrix) -- a row-range call issued inside the caller's
+// own hipGraph capture right after a whole-matrix call would therefore allocate inside the capture: issue one outside first.
+void release_plan_streams(sextans_engine *h) {
+    sextans_engine::PanelState &p = h->ps;
+    if (!p.plan_built || p.stream_released || p.plan_lpr != 4) return;
+    if ((size_t)h->K * 16 * sizeof(float) <= ((size_t)16 << 20)) return;   // column-major staging may still pick the natural-order plan
+    (void)hipFree(p.d_lidx); (void)hipFree(p.d_pval); (void)hipFree(p.d_pcol32);
+    p.d_lidx = nullptr; p.d_pval = nullptr; p.d_pcol32 = nullptr;
+    p.stream_released = true;
+}
+
+int restore_plan_streams(sextans_engine *h) {
+    sextans_engine::PanelState &p = h->ps;
+    if (!p.stream_released) return SEXTANS_OK;
+    PlanTimer timer(h);
+    sx::DevicePlan dp;
+    std::string err;
+    const int lpr = p.plan_lpr, cap = kPanelFloats / (4 * lpr);
+    const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;
+    const int brc = sx::build_panel_plan_device(h->M, h->K, h->m_rp, h->m_ci, h->m_v, lpr, cap, min_reuse, dp, err);
+    if (brc != 0 || dp.nblk != p.plan_nblk || dp.stream_len != p.plan_stream_len) {
+        sx::free_device_plan(dp);
+        if (brc == 2) g_last_error = err;
+        return brc == 2 ? SEXTANS_ERR_HIP : SEXTANS_ERR_STATE;
+    }
+    p.d_lidx = dp.d_idx16; p.d_pval = dp.d_val; p.d_pcol32 = dp.d_col32;
+    dp.d_idx16 = nullptr; dp.d_val = nullptr; dp.d_col32 = nullptr;
+    sx::free_device_plan(dp);
+    p.stream_released = false;
+    return SEXTANS_OK;
+}
+
 int ensure_cluster_plan(sextans_engine *h) {
     if (h->cluster_state != 0) return SEXTANS_OK;
     h->cluster_state = -1;
@@ -437,6 +474,7 @@ int ensure_cluster_plan(sextans_engine *h) {
     PlanTimer timer(h);
     if (h->opt_row_cluster != 2 && cluster_grid(h) == 0) h->cluster_state = 1;
     else if ((h->cluster_decline = cluster_graph(h)) == 0) h->cluster_state = 2;
+    if (h->cluster_state > 0) release_plan_streams(h);
     (void)hipGetLastError();   // a failure in here (out of memory for the sort buffers, ...) only declines the clustered plan
     return SEXTANS_OK;
 }

@@ -85,6 +85,8 @@ struct sextans_engine {
         int plan_dict_stride = 0;       // ints per block in d_dict (dictionaries padded to a common stride)
         bool plan_mixed = false;        // some block with non-zeros has no dictionary (global-gather path needed)
         bool plan_built = false;        // false: only the sampled verdict exists (no packed stream)
+        bool stream_released = false;   // the packed stream (d_lidx / d_pval / d_pcol32: 6 bytes per non-zero) has been handed back while a
+                                        // clustered plan serves the whole-matrix calls; restore_plan_streams() rebuilds it (same bytes)
     };
     PanelState ps;                      // active
     // The same plan over the rows in CLUSTERED order (row_cluster.hip: brick by brick for grid-stencil matrices), 4 lanes per row,
@@ -258,6 +260,7 @@ int read_back_row_ptr(sextans_engine *h, std::vector<int> &rp, int level = 2);
 int read_back_entries(sextans_engine *h, std::vector<int> &ci, std::vector<float> &va, int level = 2);
 int ensure_plan(sextans_engine *h, int lpr, bool force);
 int ensure_cluster_plan(sextans_engine *h);
+int restore_plan_streams(sextans_engine *h);   // the natural-order plan's packed stream, if it was released
 int ensure_colwise(sextans_engine *h);
 int ensure_window(sextans_engine *h, bool force);
 bool window_pays(const sextans_engine *h, int N, int64_t padded);

@@ -182,3 +182,64 @@ def test_bell_shared_tile_kernel_without_sharing_and_auto_dispatch(engine, sx):
         assert np.all(np.abs(got - want64) <= tol)
     finally:
         engine.set_option("bell_shared", -1)
+
+
+@pytest.mark.gpu
+def test_duplicate_or_unsorted_block_columns_never_take_the_shared_kernel(engine, sx):
+    """sextans_set_matrix_bell* does not require distinct, ascending block columns and the per-wavefront kernels sum every slot;
+    spmm_bell_mfma_shared keeps one slot per (block row, union position), so a row that lists a block column twice -- or out of
+    order -- must keep the matrix off it, also when the caller asks for it (bell_shared = 1).  """
+    from sextans_amd import api
+    M, K, N, hw = 32 * 16, 32 * 32, 256, 3
+    W = 2 * hw + 1
+    rs = np.random.RandomState(5)
+    alpha, beta = np.float32(0.85), np.float32(-2.06)
+    B16 = api.gen_uniform_bf16_host(K * N, 6)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    bcol0, bval = api.gen_bell_banded_host(M, K, hw, 9)
+    try:
+        for what in ("duplicate", "unsorted"):
+            bc = bcol0.copy().reshape(M // 32, W)
+            if what == "duplicate":
+                bc[3, 4] = bc[3, 1]; bc[9, W - 1] = bc[9, W - 2]              # the same block column in two slots of a row
+            else:
+                bc[5, [0, 2]] = bc[5, [2, 0]]
+            bcol = bc.reshape(-1)
+            want64, asum = f64_reference(M, K, N, W, bcol, bval, B16, float(alpha), float(beta), C0)
+            tol = 4e-6 * asum + 1e-6 * np.abs(float(beta) * C0) + 1e-30
+            for opt in (-1, 1):
+                engine.set_option("bell_shared", opt)
+                got = _run_bell(engine, M, K, N, W, bcol, bval, B16, alpha, beta, C0)
+                assert engine.last_kernel() == "spmm_bell_mfma", (what, opt)
+                assert np.all(np.abs(got - want64) <= tol), (what, opt, float(np.max(np.abs(got - want64) / tol)))
+    finally:
+        engine.set_option("bell_shared", -1)
+
+
+@pytest.mark.gpu
+def test_measurement_options_are_gated(sx):
+    """bell_debug / cluster_shape / cluster_group / phase_timing are not part of the drop-in surface: without
+    SEXTANS_DEBUG_OPTIONS=1 in the environment a non-default value is refused (the default value itself is accepted)."""
+    import os
+    import ctypes as C
+    from sextans_amd import api
+    L = api.lib()
+    if api.device_count() < 1:
+        pytest.skip("needs a device to create an engine")
+    old = os.environ.pop("SEXTANS_DEBUG_OPTIONS", None)
+    e = api.Engine(0)
+    try:
+        for key, default, other in (("bell_debug", 0, 1), ("cluster_shape", 0, 160202), ("cluster_group", 3, 2), ("phase_timing", 0, 1)):
+            assert L.sextans_set_option(e._h, key.encode(), C.c_int64(default)) == 0
+            assert L.sextans_set_option(e._h, key.encode(), C.c_int64(other)) != 0, key
+            assert e.get_option(key) == default
+        os.environ["SEXTANS_DEBUG_OPTIONS"] = "1"
+        assert L.sextans_set_option(e._h, b"cluster_group", C.c_int64(2)) == 0
+        assert L.sextans_set_option(e._h, b"cluster_shape", C.c_int64(160000)) != 0      # a zero factor is refused even then
+        assert L.sextans_set_option(e._h, b"cluster_group", C.c_int64(3)) == 0
+    finally:
+        e.close()
+        if old is None:
+            os.environ.pop("SEXTANS_DEBUG_OPTIONS", None)
+        else:
+            os.environ["SEXTANS_DEBUG_OPTIONS"] = old

@@ -210,3 +210,30 @@ def test_device_permutation_tool_matches_the_host_one():
         assert np.array_equal(a.view(np.uint32), np.asarray(b).view(np.uint32))
     for q in list(d[:3]) + list(p):
         api.device_free(0, q)
+
+
+@pytest.mark.parametrize("N", [32, 40, 128])
+def test_tile_group_pipelining_is_bit_identical(engine, oracle, N):
+    """Option pipeline_tiles = 1 (off by default: measured slower): the layout passes of the second tile group run on
+    the engine's side stream under the first group's kernel -- natural-order, grid-brick and reordered forms, eager and inside the
+    hipGraph of the repeat loop."""
+    from sextans_amd import meshgen
+    rp, ci, v, M = _fem(16, 15, 14, 3)
+    prp, pci, pv = meshgen.permute_symmetric(rp, ci, v, M, meshgen.node_permutation(M // 3, 3, 3))
+    rs = np.random.RandomState(N)
+    try:
+        for name, (a, b, c), rc in (("natural", (rp, ci, v), 0), ("bricks", (rp, ci, v), 1), ("reordered", (prp, pci, pv), 2)):
+            B, C0 = _operands(rs, M, M, N)
+            want = C0.copy()
+            oracle.spmm(M, N, M, ALPHA, a, b, c, B, BETA, want)
+            _set(engine, row_cluster=rc, fuse_b=0)
+            engine.set_option("pipeline_tiles", 1)
+            engine.set_matrix_csr(M, M, a, b, c)
+            for rp_time in (1, 3):
+                out = C0.copy()
+                engine.spmm(N, ALPHA, B, BETA, out, rp_time=rp_time)
+                assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (name, N, rp_time, engine.last_kernel())
+            assert engine.last_kernel().startswith("spmm_csr_panel_v2")
+    finally:
+        engine.set_option("pipeline_tiles", 0)
+        _set(engine)

@@ -142,3 +142,48 @@ def test_row_ranges_and_long_rows_with_a_clustered_plan(engine, oracle):
         assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
     finally:
         _set(engine)
+
+
+def test_released_plan_stream_is_rebuilt_for_row_ranges(engine, oracle):
+    """A matrix too large for column-major staging (K x 16 floats > 16 MiB): once the clustered plan serves the whole-matrix calls
+    the natural-order plan hands its packed stream back (stat "device_bytes" drops by 6 bytes per non-zero); the first row-range
+    call rebuilds it -- same bytes, same results."""
+    import torch
+    from sextans_amd import api
+    nx = 45
+    M = K = nx * nx * nx * 3
+    rp, ci, v = api.gen_fem3d_host(nx, nx, nx, 3, 7)
+    rs = np.random.RandomState(8)
+    N = 16
+    B = rs.uniform(-1, 1, K * N).astype(np.float32)
+    C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    try:
+        _set(engine, row_cluster=0)
+        engine.set_matrix_csr(M, K, rp, ci, v)
+        out = C0.copy(); engine.spmm(N, ALPHA, B, BETA, out)
+        natural_only = engine.get_stat("device_bytes")
+        _set(engine, row_cluster=-1)
+        engine.set_matrix_csr(M, K, rp, ci, v)
+        out = C0.copy(); engine.spmm(N, ALPHA, B, BETA, out)
+        assert int(engine.get_stat("row_cluster")) == 1
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+        with_cluster = engine.get_stat("device_bytes")
+        assert with_cluster < natural_only + 2.0 * len(ci), (natural_only, with_cluster)     # not two 6-byte streams side by side
+        st = torch.cuda.current_stream().cuda_stream
+        dB = torch.from_numpy(B).cuda(); dCin = torch.from_numpy(C0).cuda()
+        got = torch.full((M * N,), float("nan"), device="cuda")
+        cuts = [0, engine.align_row(N, M // 2), M]
+        for i in range(2):
+            c0, c1 = cuts[i], cuts[i + 1]
+            slab = torch.full(((c1 - c0) * N,), float("nan"), device="cuda")
+            engine.spmm_device_rows(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr() + 4 * c0, M, slab.data_ptr(), c1 - c0, c0, c1,
+                                    reuse_b_panels=i > 0, stream=st)
+            assert engine.last_kernel().startswith("spmm_csr_panel")
+            got.view(N, M)[:, c0:c1] = slab.view(N, c1 - c0)
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        assert engine.get_stat("device_bytes") > with_cluster + 5.0 * len(ci)                 # the stream is back
+    finally:
+        _set(engine)
