@@ -690,6 +690,23 @@ def gen_fem3d_host(nx, ny, nz, dof, seed, r0=0, r1=None):
     return out
 
 
+def upload_csr(device, rp, ci, v):
+    """Host CSR arrays -> device copies (torch allocations would be freed with their tensors; these are hipMalloc'ed through the
+    library and freed with device_free).  Returns device pointers (rp, ci, v)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    out = []
+    for arr, dt in ((rp, np.int32), (ci, np.int32), (v, np.float32)):
+        a = np.ascontiguousarray(arr, dt)
+        ptr = C.c_void_p()
+        if hip.hipSetDevice(device) != 0 or hip.hipMalloc(C.byref(ptr), C.c_size_t(max(a.nbytes, 4))) != 0:
+            raise SextansError("upload_csr: hipMalloc failed")
+        if a.nbytes and hip.hipMemcpy(ptr, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), 1) != 0:
+            raise SextansError("upload_csr: hipMemcpy failed")
+        out.append(ptr.value)
+    return tuple(out)
+
+
 def permute_symmetric_device(device, M, nnz, d_rp, d_ci, d_v, new_of_old):
     """P A P^T on the device (row / column i -> new_of_old[i]); returns new device pointers (rp, ci, v) -- free with device_free."""
     p, i, v = C.c_void_p(), C.c_void_p(), C.c_void_p()

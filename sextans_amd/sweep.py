@@ -78,12 +78,38 @@ SYNTH_HELP = """synthetic classes (generated in HBM by csrc/synth.hip, seeded, s
   synth:fem3d:nx:ny:nz:dof          27-point node stencil with dof unknowns per node (SuiteSparse FEM class)
   synth:powerlaw:M:xmin:tail_x100:maxlen   P(len >= x) = (xmin/x)^(tail/100): hub rows over a mass of short rows
   synth:stencil2d:nx:ny:points:dof  5- or 9-point 2-D grid stencil, dof unknowns per node
-  synth:kkt:n:arrow                 KKT / arrow blocks: n variables (pentadiagonal H), n/2 constraints, `arrow` dense borders"""
+  synth:kkt:n:arrow                 KKT / arrow blocks: n variables (pentadiagonal H), n/2 constraints, `arrow` dense borders
+numberings without a grid (sextans_amd/meshgen.py; the permutation is computed on the host and applied in HBM):
+  synth:femperm:nx:ny:nz:dof:random the fem3d matrix under a seeded random renumbering of its nodes
+  synth:femperm:nx:ny:nz:dof:rcm    the same under reverse Cuthill-McKee of the node graph (scipy)
+  synth:mesh3d:n:dof:sweep|random|rcm   unstructured jittered-point mesh (n^3 points, ~14 neighbours each), built on the host"""
 
 
 def _synth(spec, device):
     f = spec.split(":")
-    kind, a = f[1], [int(x) for x in f[2:] if "." not in x]
+    kind = f[1]
+    if kind == "femperm":
+        from . import meshgen
+        nx, ny, nz, dof = (int(x) for x in f[2:6])
+        M = K = nx * ny * nz * dof
+        p, i, v, nnz = api.gen_fem3d_device(device, nx, ny, nz, dof, 3)
+        if f[6] == "random":
+            perm = meshgen.node_permutation(M // dof, dof, 1)
+        elif f[6] == "rcm":
+            rp1, ci1, _ = api.gen_fem3d_host(nx, ny, nz, 1, 3)
+            perm = meshgen.expand_dof(meshgen.rcm_node_permutation(rp1, ci1, nx * ny * nz, 1), dof)
+        else:
+            raise ValueError("femperm numbering: random | rcm")
+        q = api.permute_symmetric_device(device, M, nnz, p, i, v, perm)
+        for old in (p, i, v):
+            api.device_free(device, old)
+        return (M, K) + q + (nnz,)
+    if kind == "mesh3d":
+        from . import meshgen
+        n, dof = int(f[2]), int(f[3])
+        rp, ci, v, M = meshgen.jittered_mesh3d(n, n, n, 5, numbering=f[4], dof=dof)
+        return (M, M) + api.upload_csr(device, rp, ci, v) + (int(rp[-1]),)
+    a = [int(x) for x in f[2:] if "." not in x]
     if kind == "uniform":
         M, K = a[0], (a[2] if len(a) > 2 else a[0])
         return (M, K) + api.gen_csr_device(device, M, K, float(f[3]), 4)
@@ -139,7 +165,11 @@ def sweep_synthetic(specs, n_values, steps=20, alpha=0.85, beta=-2.06, device=0,
                        "piece_path_rows": int(eng.get_stat("piece_path_rows")),
                        "reassociated_rows": int(eng.get_stat("reassociated_rows")),
                        "dense_tile_fraction": round(eng.get_stat("dense_tile_fraction"), 4),
-                       "plan_build_s": round(eng.get_stat("plan_build_s"), 3)}
+                       "plan_build_s": round(eng.get_stat("plan_build_s"), 3),
+                       # row order of the LDS-panel plan: 1 grid bricks, 2 graph clustering (reordered form), -1 natural
+                       "row_cluster": int(eng.get_stat("row_cluster")),
+                       "panel_rows_natural": int(eng.get_stat("panel_rows_natural")),
+                       "panel_rows_clustered": int(eng.get_stat("panel_rows_clustered"))}
                 records.append(rec)
                 print(json.dumps(rec), file=out, flush=True)
                 del B, Cin, Cout

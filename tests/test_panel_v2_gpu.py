@@ -233,8 +233,8 @@ def test_panel_threshold_depends_on_n(engine, oracle, sx):
     M = K = nx * ny
     rp, ci, v = api.gen_stencil2d_host(nx, ny, 5, 1, 3)
     for k, val in dict(lanes_per_row=0, kernel=0, panel_min_reuse_x100=200, panel_min_reuse_wide_x100=150, fuse_b=0, panel_v2=-1,
-                       cols_per_lane=0, tiles_per_wg=0, split_rows=0, bucket_rows=-1).items():
-        engine.set_option(k, val)
+                       cols_per_lane=0, tiles_per_wg=0, split_rows=0, bucket_rows=-1, colwise_max_len=0).items():
+        engine.set_option(k, val)                                    # (colwise_max_len = 0: not the lane-per-row kernel, test_colwise_gpu.py)
     engine.set_matrix_csr(M, K, rp, ci, v)
     rs = np.random.RandomState(11)
     built = None
@@ -260,4 +260,5 @@ def test_panel_threshold_depends_on_n(engine, oracle, sx):
     finally:
         engine.set_option("panel_min_reuse_wide_x100", 150)
         engine.set_option("row_cluster", -1)
+        engine.set_option("colwise_max_len", 6)
         _set(engine)

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""tools/rank_slabs.py -- what every rank of a row-partitioned SpMM does on its own, measured ONE RANK AT A TIME ON ONE GPU.
+NOT a scaling curve: the pool gives this build single-GPU boxes, so the slabs of world = 2 / 4 / 8 run one after the other on the
+same device; no collective runs, nothing overlaps.  What it does give: the per-rank kernel and repack times that the N-GPU
+compute phase is made of (max over ranks = the compute-only step of that world size), for config 4 and for the 4M-row FEM matrix,
+each rank holding exactly the matrix it would hold (rows [r0, r1) generated in HBM, B replicated, a packed slab of C written) --
+the reference's counterpart is the row % 64 sharding over PEs with B broadcast (sparse_helper.h:370, sextans.cpp:916-927).
+Writes one JSON document to stdout."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from sextans_amd import api, dist as sxd
+
+N = 16
+st = torch.cuda.current_stream().cuda_stream
+ALPHA, BETA = 0.85, -2.06
+
+
+def measure(e, m_loc, K, nnz):
+    B = torch.empty(K * N, device="cuda"); Cin = torch.empty(m_loc * N, device="cuda"); Cout = torch.empty(m_loc * N, device="cuda")
+    api.gen_uniform_device(0, B.data_ptr(), K * N, 41, st); api.gen_uniform_device(0, Cin.data_ptr(), m_loc * N, 42, st)
+    f = lambda: e.spmm_device2(N, ALPHA, B.data_ptr(), K, BETA, Cin.data_ptr(), m_loc, Cout.data_ptr(), m_loc, st)
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10): f()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 10
+    e.set_option("profile", 1); e.profile_reset()
+    for _ in range(10): f()
+    torch.cuda.synchronize()
+    k, n, r = e.profile_read(); p, _ = e.profile_read_post()
+    e.set_option("profile", 0)
+    by = 8 * nnz + 4 * (m_loc + 1) + 4 * K * N + 8 * m_loc * N
+    return {"rows": m_loc, "nnz": nnz, "kernel": e.last_kernel(), "kernel_us": round(k / 1e3, 1), "repack_us": round(r / 1e3, 1), "post_us": round(p / 1e3, 1),
+            "us_per_step": round(wall * 1e6, 1), "alg_bytes": by, "roofline_frac_kernel": round(by / (k * 1e-9) / 8e12, 4)}
+
+
+def run(name, M, K, gen):
+    out = {"matrix": name, "M": M, "K": K, "N": N, "worlds": {}}
+    for world in (1, 2, 4, 8):
+        ranks = []
+        for (r0, r1) in sxd.partition_rows_even(M, world):
+            p, i, v, nnz = gen(r0, r1)
+            e = api.Engine(0)
+            e.set_matrix_csr_device(r1 - r0, K, nnz, p, i, v)
+            ranks.append(dict(rank=len(ranks), row_range=[r0, r1], **measure(e, r1 - r0, K, nnz)))
+            e.close()
+            for q in (p, i, v): api.device_free(0, q)
+            torch.cuda.empty_cache()
+        slow = max(r["us_per_step"] for r in ranks)
+        out["worlds"][str(world)] = {"ranks": ranks, "max_us_per_step": slow, "max_kernel_us": max(r["kernel_us"] for r in ranks),
+                                     "allgather_bytes_received_per_rank": 4 * N * (M - M // world)}
+        print(f"# {name} world {world}: slowest rank {slow:.1f} us/step, kernel {out['worlds'][str(world)]['max_kernel_us']:.1f} us", file=sys.stderr, flush=True)
+    base = out["worlds"]["1"]["max_us_per_step"]
+    for w in out["worlds"].values():
+        w["compute_only_speedup_if_ranks_ran_in_parallel"] = round(base / w["max_us_per_step"], 2)
+    return out
+
+
+doc = {"what": "per-rank slabs of a row-partitioned SpMM run sequentially on ONE MI355X (tools/rank_slabs.py); not a scaling measurement",
+       "matrices": [run("config4: uniform 4M x 4M, Poisson(40)", 4_000_000, 4_000_000, lambda r0, r1: api.gen_csr_device(0, 4_000_000, 4_000_000, 40.0, 4, r0, r1)),
+                    run("fem3d 110x110x110 x 3 dof (natural order)", 3_993_000, 3_993_000, lambda r0, r1: api.gen_fem3d_device(0, 110, 110, 110, 3, 3, r0, r1))]}
+print(json.dumps(doc, indent=1))
