@@ -291,6 +291,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "small_v2")) return &h->opt_small_v2;
     if (!strcmp(key, "row_cluster")) return &h->opt_row_cluster;
     if (!strcmp(key, "pipeline_tiles")) return &h->opt_pipeline_tiles;
+    if (!strcmp(key, "cluster_top")) return &h->opt_cluster_top;
     if (!strcmp(key, "colwise_max_len")) return &h->opt_colwise_max_len;
     if (!strcmp(key, "cluster_shape")) return &h->opt_cluster_shape;
     if (!strcmp(key, "cluster_group")) return &h->opt_cluster_group;
@@ -338,7 +339,7 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
         (void)hipSetDevice(h->device);
         free_window(h);   // the stream is built for one (rows per wavefront, window) pair
     }
-    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
+    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_top || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
         (void)hipSetDevice(h->device);   // the clustered-order plan is (re)considered under the new setting
         free_cluster_plan(h);
     }

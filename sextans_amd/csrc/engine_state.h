@@ -184,6 +184,10 @@ struct sextans_engine {
     std::vector<int> dist_meta;     // {first row, rows} per (chunk, rank) as last uploaded, and where
     const int *dist_meta_at = nullptr;
     // options
+    int64_t opt_cluster_top = 1 << 30;  // graph clustering: the aggregation stops when clusters reach this many rows.  Default: never -- the whole
+                                        // matrix becomes one merge tree, so that each XCD's contiguous chunk of row blocks is one region of the graph and
+                                        // B lines are shared inside its L2 (4M-row FEM, random node order, N = 16, same box: 771 us with 4096-row
+                                        // clusters in arbitrary order, 727 with 65536, 694 with the full tree)
     int64_t opt_colwise_max_len = 6;    // spmm_csr_colwise is considered for matrices whose mean row length is at most this (5- and 7-point
                                         // stencils; measured on 4M-row matrices: 5 entries per row 361 -> 259 us per step at N = 16, 9 entries 368 -> 407)
     int64_t opt_kernel = 0, opt_lpr = 0, opt_stage = 1, opt_xcd = 1, opt_exact = 1, opt_profile = 0;   // opt_lpr 0 = auto

@@ -258,6 +258,8 @@ __global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
             // (unconditional, immediate offsets: all 2 * NB loads are in flight together; lanes whose row ends earlier
             // over-read inside the padded stream and never multiply what they read.  NB is chosen per matrix from its
             // mean row length so that short-row matrices do not multiply their A traffic.)
+            // (non-temporal loads of this read-once stream -- so that it would not push the B lines neighbouring blocks share out of L2 --
+            // were measured on the reordered form, where B is re-fetched 5x: kernel 744 -> 936 us.  Plain loads.)
             av[b] = *reinterpret_cast<const f32x4 *>(pv + loff + b * BATCH);
             aw[b] = *reinterpret_cast<const uint2 *>(pi + loff + b * BATCH);
         }
