@@ -132,8 +132,22 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     if (nblk <= 0 || nsuper <= 0) return SEXTANS_OK;
     if (mode == 0)
         if (int rc = restore_plan_streams(h)) return rc;   // (released while a clustered plan served the whole-matrix calls)
+    // register-resident batches (16 entries each) per row: from the mean row length of the main matrix, so that matrices
+    // with short rows (1-dof stencils: 27 entries) do not fetch six batches per row
+    const int64_t mean_len = h->M > 0 ? h->m_nnz / h->M : 0;
+    int nb = mean_len + 8 <= 32 ? 2 : mean_len + 8 <= 64 ? 4 : 6;
+    {   // ... corrected by the longest row: no more batches than any row has, and one more when that makes EVERY row
+        // register-resident (nasa4704: mean 22, longest 42 -- a quarter of the wavefronts otherwise finish a row from the
+        // stream, one L2 round trip per 16 entries, and their workgroup waits for them)
+        const int nb_max = std::max(1, (P.plan_max_row + 15) / 16);
+        if (nb_max <= nb) nb = nb_max <= 2 ? 2 : nb_max <= 3 ? 3 : nb_max <= 4 ? 4 : 6;
+        else if (nb == 2 && nb_max == 3) nb = 3;
+    }
+    const bool big = H == 1 && bcol_ld > 0 && nb > 2;   // column-major staging + long rows: the 256-register form (2 workgroups per CU)
     int tpw = (int)h->opt_tiles_per_wg;
-    if (tpw <= 0) {   // all of N in one workgroup while that still leaves >= 4 rounds of workgroups (2 per CU)
+    if (tpw <= 0 && big) {   // ... in ONE round of workgroups
+        tpw = std::min<int>(nsuper, std::max<int>(1, (int)(((int64_t)nblk * nsuper + 2 * h->num_cus - 1) / ((int64_t)2 * h->num_cus))));
+    } else if (tpw <= 0) {   // all of N in one workgroup while that still leaves >= 4 rounds of workgroups (2 per CU)
         const int64_t rounds = (int64_t)nblk * nsuper / ((int64_t)8 * h->num_cus);
         tpw = (int)std::max<int64_t>(1, std::min<int64_t>(nsuper, rounds));
     }
@@ -149,17 +163,6 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
                            P.plan_pad_row, blk_begin, row_base, skip, (long long *)h->d_dbg, slot_row);
         return SEXTANS_OK;
     };
-    // register-resident batches (16 entries each) per row: from the mean row length of the main matrix, so that matrices
-    // with short rows (1-dof stencils: 27 entries) do not fetch six batches per row
-    const int64_t mean_len = h->M > 0 ? h->m_nnz / h->M : 0;
-    int nb = mean_len + 8 <= 32 ? 2 : mean_len + 8 <= 64 ? 4 : 6;
-    {   // ... corrected by the longest row: no more batches than any row has, and one more when that makes EVERY row
-        // register-resident (nasa4704: mean 22, longest 42 -- a quarter of the wavefronts otherwise finish a row from the
-        // stream, one L2 round trip per 16 entries, and their workgroup waits for them)
-        const int nb_max = std::max(1, (P.plan_max_row + 15) / 16);
-        if (nb_max <= nb) nb = nb_max <= 2 ? 2 : nb_max <= 3 ? 3 : nb_max <= 4 ? 4 : 6;
-        else if (nb == 2 && nb_max == 3) nb = 3;
-    }
     if constexpr (H > 1) {
         if (bcol_ld > 0) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, true>) : go(sx::spmm_csr_panel_v2<H, 6, false, true>);
         return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, false>) : go(sx::spmm_csr_panel_v2<H, 6, false, false>);
@@ -174,6 +177,10 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
         if (small_dict && h->opt_small_v2 != 0) {
             if (nb == 3) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 3, true, true, false, 5>) : go(sx::spmm_csr_panel_v2<H, 3, false, true, false, 5>);
             return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, true, false, 5>) : go(sx::spmm_csr_panel_v2<H, 2, false, true, false, 5>);
+        }
+        if (big) {
+            if (nb <= 4) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 4, true, true, false, 9, false, true>) : go(sx::spmm_csr_panel_v2<H, 4, false, true, false, 9, false, true>);
+            return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, true, false, 9, false, true>) : go(sx::spmm_csr_panel_v2<H, 6, false, true, false, 9, false, true>);
         }
         if (bcol_ld > 0) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, true>) : go(sx::spmm_csr_panel_v2<H, 2, false, true>);
         if (mode == 2) {   // block-major C staging
@@ -885,7 +892,10 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             // (column-major staging keeps the round-1 kernel unless the rows are short: then the register-resident form fits
             // 128 registers together with a panel in registers)
             const bool short_rows = h->M > 0 && h->m_nnz / h->M + 8 <= 32;
-            if (panel_here && g.width == 16 && !h->ps.plan_mixed && h->opt_panel_v2 != 0 && (!fuse_b || short_rows) && wide_ok) {
+            // (long rows + column-major staging: the 256-register instantiation, for launches that cannot fill the chip -- option
+            // "panel_v2" = 1 asks for it, the automatic setting keeps spmm_csr_panel there: measured)
+            const bool big_ok = fuse_b && !short_rows && h->opt_panel_v2 == 1 && (int64_t)(blk1 - blk0) * g.ntiles <= 8192;
+            if (panel_here && g.width == 16 && !h->ps.plan_mixed && h->opt_panel_v2 != 0 && (!fuse_b || short_rows || big_ok) && wide_ok) {
                 // whole-matrix calls on repacked panels: the plan over the rows in clustered (brick) order when the matrix has one
                 const bool clustered = whole && !fuse_b && h->cluster_state == 1;
                 if (int rc = launch_panel_v2<1>(h, bsrc, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, bld, clustered ? 0 : blk0,

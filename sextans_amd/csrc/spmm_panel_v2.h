@@ -122,8 +122,10 @@ __device__ __forceinline__ void astore4(float *sbase, unsigned voff_bytes, const
 // floats per tile = 16 M): C_in of a tile is ONE 16-byte load per lane and C_out one 16-byte store -- the four lanes of a slot cover
 // the 64 contiguous bytes of row slot_row[slot], whatever row of the matrix that is; blk_dict then holds RELABELLED columns (rows
 // of the permuted B panels).
-template <int H, int NB, bool EXACT, bool BCOL, bool TIMED = false, int DCAP = 9, bool CROW = false>
-__global__ __launch_bounds__(kBlock, (H == 1 ? 4 : 2)) void spmm_csr_panel_v2(
+// BIG: 2 instead of 4 workgroups per CU = up to 256 registers per lane: the column-major staging (BCOL) of a matrix with long rows
+// keeps a panel AND 4 .. 6 batches of row entries in registers (it spills at 128), for launches too small to fill the chip anyway.
+template <int H, int NB, bool EXACT, bool BCOL, bool TIMED = false, int DCAP = 9, bool CROW = false, bool BIG = false>
+__global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_panel_v2(
     const int2 *__restrict__ slot_info, const unsigned short *__restrict__ p_idx16, const float *__restrict__ p_val,
     const int *__restrict__ blk_row, const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
     const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc,

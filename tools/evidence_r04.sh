@@ -12,6 +12,10 @@ bash tools/prof.sh r04
 find /tmp/rp_reo -name "*kernel_stats.csv" -exec cp {} gpurun_out/r04_reordered_n16_kernel_stats.csv \;
 PMC_SETS="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum;TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum;TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum;SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY;SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES;SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU;GRBM_GUI_ACTIVE" \
   bash tools/pmc.sh gpurun_out/pmc_r04_reordered_n16 python $REPO/tools/run_reordered.py 16 4
+PMC_SETS="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum;SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY;SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES;SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU;GRBM_GUI_ACTIVE" \
+  bash tools/pmc.sh gpurun_out/pmc_r04_fem_n128 python $REPO/tools/run_one.py femN128 iters=3
+PMC_SETS="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum;GRBM_GUI_ACTIVE" \
+  bash tools/pmc.sh gpurun_out/pmc_r04_fem_n16 python $REPO/tools/run_one.py fem iters=5
 python tools/rank_slabs.py > gpurun_out/r04_rank_slab_times.json 2> gpurun_out/r04_rank_slab_times.log
 tail -8 gpurun_out/r04_rank_slab_times.log
 cat gpurun_out/pmc_r04_reordered_n16/summary.txt | head -60
