@@ -209,13 +209,15 @@ def main():
     # (tools/prof.sh -> profiles/*_traffic.json); only valid for the default single-GPU workload.
     # It is NOT measured in this run: the value and its provenance are reported side by side.
     traffic = traffic_source = None
-    tpath = os.path.join(ROOT, "profiles", "r03_config4_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r04_config4_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r03_config4_traffic.json")
     if world == 1 and args.rows == 4_000_000 and args.mean_nnz == 40.0 and N == 16 and not args.opt \
             and os.path.exists(tpath):
         tj = json.load(open(tpath))
         if tj.get("kernel") == eng.last_kernel():
             traffic = tj.get("traffic_bytes_per_launch")
-            traffic_source = ("stored, not measured in this run: profiles/r03_config4_traffic.json <- " +
+            traffic_source = ("stored, not measured in this run: profiles/" + os.path.basename(tpath) + " <- " +
                               str(tj.get("source")))
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,

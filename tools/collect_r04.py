@@ -18,6 +18,7 @@ cp("prof_r04/kernel_stats.csv", "r04_bench_config4_kernel_stats.csv")
 cp("r04_reordered_n16_kernel_stats.csv", "r04_reordered_fem_n16_kernel_stats.csv")
 cp("r04_rank_slab_times.json", "r04_rank_slab_times.json")
 cp("r04_sweep.jsonl", "r04_sweep.jsonl")
+cp("r04_renumbered_classes.jsonl", "r04_renumbered_classes.jsonl")
 for tag, what in (("a", "pipelining_fma_brickshapes"), ("b", "colmajor_staging_large_b"), ("c", "colwise_vs_auto")):
     if os.path.exists(G + f"r04_exp_{tag}.txt"):
         txt = "".join(l for l in open(G + f"r04_exp_{tag}.txt") if "amdgpu.ids" not in l)
@@ -60,7 +61,7 @@ def load(d, pat):
 
 
 M, nnz = 3993000, 317587968
-for d, out, pat, N, title in (("pmc_r04_reordered_n16", "r04_reordered_fem_n16_pmc.txt", r"panel_v2<1, 6, true, false, false, 9, true>", 16,
+for d, out, pat, N, title in (("pmc_r04_reordered_n16", "r04_reordered_fem_n16_pmc.txt", r"panel_v2<1, 6, true, false, false, 9, true", 16,
                                "fem3d 110^3 x 3 dof under a RANDOM NODE ORDER: spmm_csr_panel_v2 in its reordered form (graph-clustered plan)"),
                               ("pmc_r04_fem_n128", "r04_fem_n128_pmc.txt", r"panel_v2", 128, "fem3d 110^3 x 3 dof, natural order, grid-brick plan"),
                               ("pmc_r04_fem_n16", "r04_fem_n16_pmc.txt", r"panel_v2", 16, "fem3d 110^3 x 3 dof, natural order, grid-brick plan")):
