@@ -154,7 +154,11 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     tpw = std::min(tpw, nsuper);
     const int ngrp = (nsuper + tpw - 1) / tpw;
     const int64_t pstride = bcol_ld > 0 ? bcol_ld : (int64_t)h->K * 16;
-    const size_t lds = (size_t)H * sx::kWideHalfBytes;
+    // LDS = the panel: plan capacity + the +1.0f row.  A clustered plan of a short-row matrix is packed for a 320-row panel
+    // (engine_plan.hip: small_panel): 20.5 KB instead of 36.9 KB per workgroup, so the CU holds as many workgroups as the registers
+    // allow (5 at <= 96 registers) instead of the 4 the full panel permits -- these launches are latency-bound
+    const bool small_panel = H == 1 && bcol_ld == 0 && P.plan_pad_row == 5 * 64;
+    const size_t lds = small_panel ? (size_t)(5 * 64 + 1) * 64 : (size_t)H * sx::kWideHalfBytes;
     auto go = [&](auto kern) -> int {
         if (int rc = allow_big_lds(h, reinterpret_cast<const void *>(kern), (int)lds)) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)P.d_row_off,
@@ -183,6 +187,14 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
             return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, true, false, 9, false, true>) : go(sx::spmm_csr_panel_v2<H, 6, false, true, false, 9, false, true>);
         }
         if (bcol_ld > 0) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, true>) : go(sx::spmm_csr_panel_v2<H, 2, false, true>);
+        if (small_panel && mode == 2) {
+            if (nb >= 3) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 3, true, false, false, 5, true>) : go(sx::spmm_csr_panel_v2<H, 3, false, false, false, 5, true>);
+            return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false, false, 5, true>) : go(sx::spmm_csr_panel_v2<H, 2, false, false, false, 5, true>);
+        }
+        if (small_panel) {
+            if (nb >= 3) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 3, true, false, false, 5>) : go(sx::spmm_csr_panel_v2<H, 3, false, false, false, 5>);
+            return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false, false, 5>) : go(sx::spmm_csr_panel_v2<H, 2, false, false, false, 5>);
+        }
         if (mode == 2) {   // block-major C staging
             if (nb == 3) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 3, true, false, false, 9, true>) : go(sx::spmm_csr_panel_v2<H, 3, false, false, false, 9, true>);
             if (nb == 2) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false, false, 9, true>) : go(sx::spmm_csr_panel_v2<H, 2, false, false, false, 9, true>);
@@ -299,6 +311,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "row_cluster")) return &h->opt_row_cluster;
     if (!strcmp(key, "pipeline_tiles")) return &h->opt_pipeline_tiles;
     if (!strcmp(key, "cluster_top")) return &h->opt_cluster_top;
+    if (!strcmp(key, "small_panel")) return &h->opt_small_panel;
     if (!strcmp(key, "colwise_max_len")) return &h->opt_colwise_max_len;
     if (!strcmp(key, "cluster_shape")) return &h->opt_cluster_shape;
     if (!strcmp(key, "cluster_group")) return &h->opt_cluster_group;
@@ -346,7 +359,7 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
         (void)hipSetDevice(h->device);
         free_window(h);   // the stream is built for one (rows per wavefront, window) pair
     }
-    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_top || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
+    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_top || slot == &h->opt_small_panel || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
         (void)hipSetDevice(h->device);   // the clustered-order plan is (re)considered under the new setting
         free_cluster_plan(h);
     }

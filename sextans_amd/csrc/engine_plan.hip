@@ -313,6 +313,11 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
 // It is an optimisation: whatever goes wrong in here (allocation failures included) declines it and the SpMM runs on the
 // natural-order forms it already has.
 namespace {
+// Short rows (<= 2 register-resident batches) whose block dictionaries all fit 320 rows: the clustered plan is packed for a 320-row
+// panel, 20.5 KB of LDS per workgroup (spmm_csr_panel_v2<..., DCAP = 5>): a fifth workgroup per CU for launches that are latency-bound.
+bool small_panel_fits(const sextans_engine *h, const sx::DevicePlan &dp) {
+    return h->opt_small_panel != 0 && !dp.mixed && dp.max_dict <= 5 * 64 && h->M > 0 && h->m_nnz / h->M + 8 <= 48;
+}
 int cluster_grid(sextans_engine *h) {   // 0 = in use, 1 = declined
     if (!h->ps.plan_built || h->ps.plan_lpr != 4 || h->ps.plan_mixed) return 1;
     // ---- grid strides from the columns of ~128 rows out of the middle half of the matrix
@@ -353,7 +358,13 @@ int cluster_grid(sextans_engine *h) {   // 0 = in use, 1 = declined
     if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_perm, &prp, &pci, &pv, err)) return drop();
     const int lpr = 4, RB = sx::kBlock / lpr, cap = kPanelFloats / (4 * lpr);
     const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;
-    const int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, min_reuse, dp, err, d_cut);
+    int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, min_reuse, dp, err, d_cut);
+    int cap_used = cap;
+    if (brc == 0 && small_panel_fits(h, dp)) {   // short rows, small dictionaries: packed again for a 320-row panel (same blocks, less LDS)
+        sx::free_device_plan(dp);
+        cap_used = 5 * RB;
+        brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap_used, min_reuse, dp, err, d_cut);
+    }
     (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv); (void)hipFree(d_cut);
     prp = pci = nullptr; pv = nullptr; d_cut = nullptr;
     if (brc != 0) return drop();
@@ -362,7 +373,7 @@ int cluster_grid(sextans_engine *h) {   // 0 = in use, 1 = declined
     if (dp.mixed || dp.dict_stride > 9 * RB || dp.max_dict > sx::kWideMaxDict || (h->opt_row_cluster < 0 && !gain)) return drop();
     if (sx::build_slot_rows_device(dp.nblk, RB, dp.d_blk_row, d_perm, &h->d_slot_row, err)) return drop();
     (void)hipFree(d_perm);
-    adopt_device_plan(h->psc, dp, h, lpr, cap);
+    adopt_device_plan(h->psc, dp, h, lpr, cap_used);
     h->psc.plan_panel_frac = h->ps.plan_panel_frac;
     h->psc.plan_narrow_frac = h->ps.plan_narrow_frac;
     return 0;
@@ -399,7 +410,13 @@ int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reaso
     // Every block that fits gets a dictionary (threshold 0): the tail of the order holds the rows nothing wanted to merge with, and
     // ONE block of such rows without reuse would make the whole plan "mixed".  The reuse test is made on the plan as a whole below.
     const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;
-    const int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, 0.0, dp, err, nullptr);
+    int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, 0.0, dp, err, nullptr);
+    int cap_used = cap;
+    if (brc == 0 && small_panel_fits(h, dp)) {
+        sx::free_device_plan(dp);
+        cap_used = 5 * RB;
+        brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap_used, 0.0, dp, err, nullptr);
+    }
     (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
     prp = pci = nullptr; pv = nullptr;
     if (brc != 0) return drop(9);
@@ -410,8 +427,9 @@ int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reaso
     if (h->opt_row_cluster < 0 && h->ps.plan_built && (double)dp.total_dict > 0.6 * (double)h->plan_total_dict) return drop(12);
     if (sx::build_slot_rows_device(dp.nblk, RB, dp.d_blk_row, d_order, &h->d_slot_row, err)) return drop(9);
     (void)hipFree(d_order);
-    adopt_device_plan(h->psc, dp, h, lpr, cap);
-    h->psc.plan_panel_frac = h->m_nnz ? (double)dp.nnz_in_panel_blocks / (double)h->m_nnz : 0.0;
+    const double covered = h->m_nnz ? (double)dp.nnz_in_panel_blocks / (double)h->m_nnz : 0.0;
+    adopt_device_plan(h->psc, dp, h, lpr, cap_used);
+    h->psc.plan_panel_frac = covered;
     h->psc.plan_narrow_frac = h->psc.plan_panel_frac;
     h->d_colpos = d_colpos;
     return 0;
