@@ -54,3 +54,21 @@ def test_sweep_synthetic_classes(sx):
     assert by[("powerlaw", 8)]["kernel"].endswith("+hub_pieces") and by[("powerlaw", 8)]["reassociated_rows"] > 0
     assert by[("uniform", 8)]["piece_path_rows"] == 0
     assert all(r["ms"] > 0 and 0 < r["roofline_frac"] < 1 for r in recs)
+
+
+def test_sweep_renumbered_classes(sx):
+    """Round 4: the FEM matrix under random / RCM node orders (renumbered in HBM) and the unstructured meshes, with the row-order
+    figures every synthetic record now carries."""
+    from sextans_amd import sweep
+    buf = io.StringIO()
+    recs = sweep.sweep_synthetic(["synth:femperm:16:15:14:3:random", "synth:femperm:16:15:14:3:rcm", "synth:mesh3d:17:3:random",
+                                  "synth:stencil2d:120:100:5:1"], [16, 32], steps=3, out=buf, options={"fuse_b": 0})   # (small B would be staged column-major)
+    assert len(recs) == 8
+    by = {(":".join(r["matrix"].split(":")[1:]), r["N"]): r for r in recs}
+    r = by[("femperm:16:15:14:3:random", 16)]
+    assert r["kernel"] == "spmm_csr_panel_v2_reordered" and r["row_cluster"] == 2
+    assert 0 < r["panel_rows_clustered"] < 0.5 * r["panel_rows_natural"]
+    assert by[("mesh3d:17:3:random", 32)]["kernel"] == "spmm_csr_panel_v2_reordered"
+    assert by[("femperm:16:15:14:3:rcm", 16)]["kernel"].startswith("spmm_csr_panel")
+    assert by[("stencil2d:120:100:5:1", 16)]["kernel"] == "spmm_csr_colwise"
+    assert all(r["ms"] > 0 and 0 < r["roofline_frac"] < 1 for r in recs)
