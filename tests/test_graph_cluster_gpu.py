@@ -237,3 +237,59 @@ def test_tile_group_pipelining_is_bit_identical(engine, oracle, N):
     finally:
         engine.set_option("pipeline_tiles", 0)
         _set(engine)
+
+
+def test_renumbered_fem_at_full_size():
+    """The 4M-row 3-dof FEM matrix (318 M non-zeros) under a random node order, renumbered in HBM: too large for the oracle as a
+    whole, so (1) the reordered form must equal the natural-order forms of the same matrix BIT FOR BIT at N = 16 and N = 40 (the
+    natural-order forms are pinned to cpu_spmm_CSR by every other test), (2) 600 sampled rows are recomputed by the oracle from the
+    host generator + the same renumbering, (3) the plan figures are what the clustering is for."""
+    import torch
+    from oracle.bindings import Oracle
+    from sextans_amd import api, meshgen
+    n, dof = 110, 3
+    M = n * n * n * dof
+    perm = meshgen.node_permutation(M // dof, dof, 1)
+    base = api.gen_fem3d_device(0, n, n, n, dof, 3)
+    nnz = base[3]
+    p = api.permute_symmetric_device(0, M, nnz, *base[:3], perm)
+    for q in base[:3]:
+        api.device_free(0, q)
+    st = torch.cuda.current_stream().cuda_stream
+    try:
+        for N in (16, 40):
+            B = torch.empty(M * N, device="cuda"); Cin = torch.empty(M * N, device="cuda")
+            api.gen_uniform_device(0, B.data_ptr(), M * N, 41, st); api.gen_uniform_device(0, Cin.data_ptr(), M * N, 42, st)
+            outs = {}
+            for rc in (0, -1):
+                with api.Engine(0) as e:
+                    e.set_option("row_cluster", rc)
+                    e.set_matrix_csr_device(M, M, nnz, *p)
+                    out = torch.zeros(M * N, device="cuda")
+                    e.spmm_device(N, float(ALPHA), B.data_ptr(), M, float(BETA), Cin.data_ptr(), out.data_ptr(), M, st)
+                    torch.cuda.synchronize()
+                    outs[rc] = out
+                    if rc == -1:
+                        assert e.last_kernel() == "spmm_csr_panel_v2_reordered" and int(e.get_stat("row_cluster")) == 2
+                        assert e.get_stat("panel_rows_clustered") < 0.35 * e.get_stat("panel_rows_natural")
+                        assert M / e.get_stat("panel_blocks_clustered") > 58
+            assert torch.equal(outs[0].view(torch.int32), outs[-1].view(torch.int32)), N
+            if N == 16:      # sampled rows against the oracle: row r of the renumbered matrix = row old(r) of the generator's matrix
+                o = Oracle()
+                old_of_new = np.empty(M, np.int64); old_of_new[perm] = np.arange(M)
+                Bh = B.cpu().numpy(); Ch = Cin.cpu().numpy(); got = outs[-1].cpu().numpy()
+                rs = np.random.RandomState(0)
+                for r in rs.choice(M, 600, replace=False):
+                    r0 = int(old_of_new[r])
+                    rp, ci, v = api.gen_fem3d_host(n, n, n, dof, 3, r0, r0 + 1)
+                    cols = perm[ci].astype(np.int32)
+                    order = np.argsort(cols, kind="stable")
+                    rp1 = np.array([0, len(cols)], np.int32)
+                    want = np.ascontiguousarray(Ch.reshape(N, M)[:, r]).copy()
+                    o.spmm(1, N, M, ALPHA, rp1, cols[order], v[order], Bh, BETA, want)
+                    assert np.array_equal(want.view(np.uint32), np.ascontiguousarray(got.reshape(N, M)[:, r]).view(np.uint32)), r
+            del B, Cin, outs
+            torch.cuda.empty_cache()
+    finally:
+        for q in p:
+            api.device_free(0, q)
