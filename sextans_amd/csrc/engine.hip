@@ -49,10 +49,12 @@ int check_device(int device) {
 
 template <int W>
 void launch_repack(const float *dB, int64_t ldb, float *dBp, int K, int col_base, int ntiles,
-                   hipStream_t s) {
-    dim3 grid((unsigned)((K + sx::kBlock - 1) / sx::kBlock), (unsigned)ntiles);
+                   hipStream_t s, int k_begin = 0, int k_end = -1) {
+    if (k_end < 0) k_end = K;
+    if (k_end <= k_begin) return;
+    dim3 grid((unsigned)((k_end - k_begin + sx::kBlock - 1) / sx::kBlock), (unsigned)ntiles);
     hipLaunchKernelGGL(sx::repack_b_panels<W>, grid, dim3(sx::kBlock), 0, s, dB, ldb, dBp, K,
-                       col_base);
+                       col_base, k_begin, k_end);
 }
 
 template <int LPR>
@@ -549,6 +551,8 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "row_cluster")) *value = (double)h->cluster_state;          // 1 grid bricks / 2 graph clustering in use, -1 declined, 0 not evaluated yet
     else if (!strcmp(key, "cluster_shared_fraction")) *value = h->cluster_shared;
     else if (!strcmp(key, "cluster_decline")) *value = (double)h->cluster_decline;
+    else if (!strcmp(key, "col_range_lo")) *value = (double)h->col_lo;
+    else if (!strcmp(key, "col_range_hi")) *value = (double)h->col_hi;
     else if (!strcmp(key, "colwise")) *value = (double)h->colwise_state;
     else if (!strcmp(key, "row_coherence")) *value = h->row_coherence;
     else if (!strcmp(key, "panel_blocks_clustered")) *value = (double)h->psc.plan_nblk;
@@ -704,7 +708,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         // B in 8-column panels (the reference's N tile), then one tile-major launch
         if (!(flags & SEXTANS_ROWS_REUSE_B_PANELS) || h->bp_layout != 8) {
             Prof p(h, &h->ev_repack, s);
-            launch_repack<8>(d_B, ldb, h->d_Bp, h->K, 0, N / 8, s);
+            launch_repack<8>(d_B, ldb, h->d_Bp, h->K, 0, N / 8, s, h->col_lo, h->col_hi);
             h->bp_layout = 8;
         }
         {
@@ -779,11 +783,11 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         auto pre = [&](int t0, int t1, hipStream_t st) {
             float *dst = h->d_Bp + (size_t)h->K * (size_t)(g.col0 + 16 * t0);
             if (reordered) {
-                hipLaunchKernelGGL(sx::repack_b_panels_perm, dim3((unsigned)((h->K + sx::kBlock - 1) / sx::kBlock), (unsigned)(t1 - t0)),
-                                   dim3(sx::kBlock), 0, st, d_B, ldb, dst, h->K, g.col0 + 16 * t0, h->d_colpos);
+                hipLaunchKernelGGL(sx::repack_b_panels_perm, dim3((unsigned)((h->col_hi - h->col_lo + sx::kBlock - 1) / sx::kBlock), (unsigned)(t1 - t0)),
+                                   dim3(sx::kBlock), 0, st, d_B, ldb, dst, h->K, g.col0 + 16 * t0, h->d_colpos, h->col_lo, h->col_hi);
                 launch_repack<16>(d_C_in, ldc_in, h->d_Cs + (int64_t)t0 * cs_tile, h->M, g.col0 + 16 * t0, t1 - t0, st);
             } else {
-                launch_repack<16>(d_B, ldb, dst, h->K, g.col0 + 16 * t0, t1 - t0, st);
+                launch_repack<16>(d_B, ldb, dst, h->K, g.col0 + 16 * t0, t1 - t0, st, h->col_lo, h->col_hi);
             }
         };
         auto kern = [&](int t0, int t1) -> int {
@@ -807,7 +811,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             pre(0, t_cut, s);
             for (size_t i = 1; i < plan.size(); ++i) {                  // an 8-column remainder tile keeps the plain panels
                 const Seg &r = plan[i];
-                launch_repack<8>(d_B, ldb, h->d_Bp + (size_t)h->K * (size_t)r.col0, h->K, r.col0, r.ntiles, s);
+                launch_repack<8>(d_B, ldb, h->d_Bp + (size_t)h->K * (size_t)r.col0, h->K, r.col0, r.ntiles, s, h->col_lo, h->col_hi);
             }
         }
         pre(t_cut, g.ntiles, side);
@@ -846,14 +850,14 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             for (const Seg &g : plan) {
                 float *dst = h->d_Bp + (size_t)h->K * (size_t)g.col0;
                 if (reordered && g.width == 16) {
-                    hipLaunchKernelGGL(sx::repack_b_panels_perm, dim3((unsigned)((h->K + sx::kBlock - 1) / sx::kBlock), (unsigned)g.ntiles),
-                                       dim3(sx::kBlock), 0, s, d_B, ldb, dst, h->K, g.col0, h->d_colpos);
+                    hipLaunchKernelGGL(sx::repack_b_panels_perm, dim3((unsigned)((h->col_hi - h->col_lo + sx::kBlock - 1) / sx::kBlock), (unsigned)g.ntiles),
+                                       dim3(sx::kBlock), 0, s, d_B, ldb, dst, h->K, g.col0, h->d_colpos, h->col_lo, h->col_hi);
                     continue;
                 }
                 switch (g.width) {
-                    case 32: launch_repack<32>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s); break;
-                    case 16: launch_repack<16>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s); break;
-                    default: launch_repack<8>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s); break;
+                    case 32: launch_repack<32>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s, h->col_lo, h->col_hi); break;
+                    case 16: launch_repack<16>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s, h->col_lo, h->col_hi); break;
+                    default: launch_repack<8>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s, h->col_lo, h->col_hi); break;
                 }
             }
         }

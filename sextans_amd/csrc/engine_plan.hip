@@ -124,6 +124,7 @@ void free_matrix(sextans_engine *h) {
     h->d_v = nullptr;
     h->owns_matrix = false;
     h->device_matrix_checked = false;
+    h->col_range_known = false;
     h->m_rp = h->m_ci = h->s_rp = h->s_ci = nullptr; h->m_v = h->s_v = nullptr; h->m_nnz = h->s_nnz = 0;
     h->dist_cut_key.clear();   // chunk cuts are aligned to the packed forms of one matrix
     h->bp_layout = 0;          // B panels belong to one (K, B)
@@ -436,6 +437,31 @@ int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reaso
 }
 }  // namespace
 
+// Columns the matrix as set has entries in.  A call repacks only those rows of B: on one GPU that is all of B, but a rank of a
+// row-partitioned SpMM over a banded / mesh matrix touches 1 / world of B plus a halo, and the replicated repack was what capped
+// the compute phase of the FEM class at 4.2 x on 8 ranks (profiles/r04_rank_slab_times.json).  Rounded outwards to 64 rows.
+int ensure_col_range(sextans_engine *h) {
+    if (h->col_range_known) return SEXTANS_OK;
+    h->col_lo = 0; h->col_hi = h->K;
+    h->col_range_known = true;
+    if (h->nnz <= 0 || !h->d_ci) return SEXTANS_OK;
+    if (!h->owns_matrix && !h->device_matrix_checked) {   // a device matrix nobody has validated yet: its indices are not trusted here
+        int bad = 0;
+        std::string verr;
+        if (sx::validate_csr_device(h->M, h->K, h->nnz, h->d_rp, h->d_ci, &bad, verr)) { g_last_error = verr; return SEXTANS_ERR_HIP; }
+        if (bad) return (bad & 1) ? SEXTANS_ERR_INVALID : SEXTANS_ERR_INDEX;
+        h->device_matrix_checked = true;
+    }
+    int lo = 0, hi = -1;
+    std::string err;
+    if (sx::column_range_device(h->nnz, h->d_ci, &lo, &hi, err)) { (void)hipGetLastError(); return SEXTANS_OK; }
+    if (hi >= lo) {
+        h->col_lo = std::max(0, lo / 64 * 64);
+        h->col_hi = std::min(h->K, (hi / 64 + 1) * 64);
+    }
+    return SEXTANS_OK;
+}
+
 // Short rows in a numbering with locality: the lane-per-row kernel on the caller's column-major B (spmm_colwise_kernel.h).
 int ensure_colwise(sextans_engine *h) {
     if (h->colwise_state != 0) return SEXTANS_OK;
@@ -709,6 +735,7 @@ int ensure_split(sextans_engine *h) {
 // N-tile plan, and (for kernel != 1) the packed row-bucketed form of A.  Idempotent; called by
 // sextans_spmm_device2 and, ahead of the timed region, by sextans_spmm_host.
 int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_panel, bool &use_window, bool whole) {
+    if (int rc = ensure_col_range(h)) return rc;
     if (int rc = ensure_dense(h)) return rc;   // first the dense tiles leave (when the caller routes them to MFMA) ...
     if (int rc = ensure_split(h)) return rc;   // ... then the long rows; the packed forms below are built from what remains
     if (h->dense_W > 0 && N % 32 == 0) {

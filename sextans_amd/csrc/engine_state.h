@@ -96,6 +96,8 @@ struct sextans_engine {
     int *d_colpos = nullptr;            // psc, graph clustering: row of the permuted B panels that holds column c (K ints)
     float *d_Cs = nullptr;              //   ... and the row-major C staging buffer of the reordered form: [N / 16][M][16] floats
     size_t Cs_cap = 0;
+    int col_lo = 0, col_hi = 0;         // columns [col_lo, col_hi) the matrix as set has entries in: the only rows of B a call repacks
+    bool col_range_known = false;
     int colwise_state = 0;              // spmm_csr_colwise for this matrix: 0 not evaluated, 1 short rows in a numbering with locality, -1 no
     double row_coherence = 0.0;         // sampled share of consecutive rows' entries with neighbouring columns
     int cluster_decline = 0;            // why the graph clustering was declined (engine_plan.hip: cluster_graph), 0 = it was not
@@ -267,6 +269,7 @@ int ensure_plan(sextans_engine *h, int lpr, bool force);
 int ensure_cluster_plan(sextans_engine *h);
 int restore_plan_streams(sextans_engine *h);   // the natural-order plan's packed stream, if it was released
 int ensure_colwise(sextans_engine *h);
+int ensure_col_range(sextans_engine *h);
 int ensure_window(sextans_engine *h, bool force);
 bool window_pays(const sextans_engine *h, int N, int64_t padded);
 int ensure_split(sextans_engine *h);

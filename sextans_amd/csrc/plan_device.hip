@@ -286,6 +286,34 @@ int validate_csr_device(int M, int K, int64_t nnz, const int *d_rp, const int *d
     return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void col_minmax(const int *__restrict__ ci, long long nnz, int *lo, int *hi) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+    int a = 0x7fffffff, b = -1;
+    for (long long j = t; j < nnz; j += stride) { const int c = ci[j]; a = min(a, c); b = max(b, c); }
+    for (int off = 32; off > 0; off >>= 1) { a = min(a, __shfl_xor(a, off)); b = max(b, __shfl_xor(b, off)); }
+    if ((threadIdx.x & 63) == 0 && b >= 0) { atomicMin(lo, a); atomicMax(hi, b); }
+}
+}  // namespace
+
+// smallest and largest column index of a device CSR matrix (lo > hi when it has no entries)
+int column_range_device(int64_t nnz, const int *d_ci, int *lo, int *hi, std::string &err) {
+    *lo = 0x7fffffff; *hi = -1;
+    if (nnz <= 0) return 0;
+    int *d = nullptr;
+    PD_HIP(hipMalloc((void **)&d, 2 * sizeof(int)));
+    const int init[2] = {0x7fffffff, -1};
+    hipError_t e1 = hipMemcpy(d, init, sizeof init, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(col_minmax, dim3(2048), dim3(256), 0, nullptr, d_ci, (long long)nnz, d, d + 1);
+    int out[2] = {0x7fffffff, -1};
+    hipError_t e2 = hipMemcpy(out, d, sizeof out, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    PD_HIP(e1);
+    PD_HIP(e2);
+    *lo = out[0]; *hi = out[1];
+    return 0;
+}
+
 void free_device_plan(DevicePlan &d) {
     (void)hipFree(d.d_blk_row); (void)hipFree(d.d_dict_cnt); (void)hipFree(d.d_dict); (void)hipFree(d.d_slot_info);
     (void)hipFree(d.d_idx16); (void)hipFree(d.d_col32); (void)hipFree(d.d_val);

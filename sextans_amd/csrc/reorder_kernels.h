@@ -21,13 +21,13 @@ namespace sx {
 
 // Workgroup = 256 consecutive k of one 16-column panel t: Bp[t][colpos[k]][0..15] = B[k][col_base + 16 t + 0..15].
 __global__ __launch_bounds__(kBlock) void repack_b_panels_perm(const float *__restrict__ B, int64_t ldb, float *__restrict__ Bp, int K,
-                                                               int col_base, const int *__restrict__ colpos) {
+                                                               int col_base, const int *__restrict__ colpos, int k_begin, int k_end) {
     __shared__ float s[16][kBlock + 1];
     const int tid = threadIdx.x;
-    const int k0 = blockIdx.x * kBlock;
+    const int k0 = k_begin + blockIdx.x * kBlock;
     const int t = blockIdx.y;
     const float *src = B + (int64_t)(col_base + t * 16) * ldb;
-    if (k0 + tid < K) {
+    if (k0 + tid < k_end) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) s[c][tid] = src[(int64_t)c * ldb + k0 + tid];
     }
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kBlock) void repack_b_panels_perm(const float *__re
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int kk = (tid >> 2) + 64 * i;
-        if (k0 + kk < K) {
+        if (k0 + kk < k_end) {
             const f32x4 v = {s[4 * q][kk], s[4 * q + 1][kk], s[4 * q + 2][kk], s[4 * q + 3][kk]};
             *reinterpret_cast<f32x4 *>(dst + (int64_t)colpos[k0 + kk] * 16 + 4 * q) = v;
         }

@@ -860,20 +860,23 @@ __global__ __launch_bounds__(chain_fused_threads(NT)) void chain_fused(
 template <int W>
 __global__ __launch_bounds__(kBlock) void repack_b_panels(const float *__restrict__ B, int64_t ldb,
                                                           float *__restrict__ Bp, int K,
-                                                          int col_base) {
+                                                          int col_base, int k_begin, int k_end) {
+    // Rows [k_begin, k_end) of B only: the rows the matrix of this engine has columns in (a rank of a row-partitioned SpMM
+    // over a banded matrix touches 1 / world of B plus a halo: engine_plan.hip, ensure_col_range); panels keep their absolute
+    // addressing (row k of tile t at Bp[t K W + k W]).
     __shared__ float s[W][kBlock + 1];
     const int tid = threadIdx.x;
-    const int k0 = blockIdx.x * kBlock;
+    const int k0 = k_begin + blockIdx.x * kBlock;
     const int t = blockIdx.y;
     const int k = k0 + tid;
     const float *src = B + (int64_t)(col_base + t * W) * ldb;
-    if (k < K) {
+    if (k < k_end) {
 #pragma unroll
         for (int c = 0; c < W; ++c) s[c][tid] = src[(int64_t)c * ldb + k];
     }
     __syncthreads();
     float *dst = Bp + (int64_t)t * K * W + (int64_t)k0 * W;
-    const int nk = min(kBlock, K - k0);
+    const int nk = min(kBlock, k_end - k0);
 #pragma unroll
     for (int i = 0; i < W; ++i) {
         const int e = tid + i * kBlock;   // linear element of the 256 x W chunk

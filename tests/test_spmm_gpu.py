@@ -476,3 +476,35 @@ def test_empty_first_range_does_not_leave_stale_b_panels(engine, oracle):
                                 c0, c1, reuse_b_panels=i > 0, stream=st)
     torch.cuda.synchronize()
     assert np.array_equal(dC.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [0, 1, 2, 4])
+def test_only_the_touched_rows_of_b_are_repacked(engine, oracle, kernel):
+    """A matrix whose columns lie in [lo, hi) of K -- a rank's row slab of a banded matrix -- makes the engine repack only those
+    rows of B (stats col_range_lo / col_range_hi, rounded outwards to 64): rows of B outside may hold anything (NaN here) and
+    neither enter the result nor cost bandwidth.  Bit-identical to cpu_spmm_CSR for every kernel."""
+    rs = np.random.RandomState(kernel + 3)
+    M, K, lo, hi = 3000, 20000, 7001, 9500
+    lens = rs.randint(0, 24, M)
+    rp = np.zeros(M + 1, np.int32); rp[1:] = np.cumsum(lens)
+    ci = np.concatenate([np.sort(rs.choice(np.arange(lo, hi), size=n, replace=False)) for n in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    v = rs.uniform(-1, 1, rp[-1]).astype(np.float32)
+    try:
+        for N in (16, 40):
+            B = rs.uniform(-1, 1, K * N).astype(np.float32)
+            Bm = B.reshape(N, K)
+            Bm[:, :7000 // 64 * 64] = np.nan
+            Bm[:, (9499 // 64 + 1) * 64:] = np.nan
+            C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+            want = C0.copy()
+            oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+            assert not np.isnan(want).any()
+            engine.set_option("kernel", kernel)
+            engine.set_matrix_csr(M, K, rp, ci, v)
+            out = C0.copy()
+            engine.spmm(N, ALPHA, B, BETA, out, rp_time=2)
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (kernel, N, engine.last_kernel())
+            assert engine.get_stat("col_range_lo") == ci.min() // 64 * 64 and engine.get_stat("col_range_hi") == (ci.max() // 64 + 1) * 64
+    finally:
+        engine.set_option("kernel", 0)
