@@ -314,6 +314,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "pipeline_tiles")) return &h->opt_pipeline_tiles;
     if (!strcmp(key, "cluster_top")) return &h->opt_cluster_top;
     if (!strcmp(key, "small_panel")) return &h->opt_small_panel;
+    if (!strcmp(key, "relabel_columns")) return &h->opt_relabel_columns;
     if (!strcmp(key, "colwise_max_len")) return &h->opt_colwise_max_len;
     if (!strcmp(key, "cluster_shape")) return &h->opt_cluster_shape;
     if (!strcmp(key, "cluster_group")) return &h->opt_cluster_group;
@@ -361,7 +362,7 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
         (void)hipSetDevice(h->device);
         free_window(h);   // the stream is built for one (rows per wavefront, window) pair
     }
-    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_top || slot == &h->opt_small_panel || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
+    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_top || slot == &h->opt_small_panel || slot == &h->opt_relabel_columns || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
         (void)hipSetDevice(h->device);   // the clustered-order plan is (re)considered under the new setting
         free_cluster_plan(h);
     }
@@ -782,7 +783,10 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         const int b0 = mode ? 0 : blk0, b1 = mode ? h->psc.plan_nblk : blk1;
         auto pre = [&](int t0, int t1, hipStream_t st) {
             float *dst = h->d_Bp + (size_t)h->K * (size_t)(g.col0 + 16 * t0);
-            if (reordered) {
+            if (reordered && !h->d_colpos) {
+                launch_repack<16>(d_B, ldb, dst, h->K, g.col0 + 16 * t0, t1 - t0, st, h->col_lo, h->col_hi);
+                launch_repack<16>(d_C_in, ldc_in, h->d_Cs + (int64_t)t0 * cs_tile, h->M, g.col0 + 16 * t0, t1 - t0, st);
+            } else if (reordered) {
                 hipLaunchKernelGGL(sx::repack_b_panels_perm, dim3((unsigned)((h->col_hi - h->col_lo + sx::kBlock - 1) / sx::kBlock), (unsigned)(t1 - t0)),
                                    dim3(sx::kBlock), 0, st, d_B, ldb, dst, h->K, g.col0 + 16 * t0, h->d_colpos, h->col_lo, h->col_hi);
                 launch_repack<16>(d_C_in, ldc_in, h->d_Cs + (int64_t)t0 * cs_tile, h->M, g.col0 + 16 * t0, t1 - t0, st);
@@ -849,7 +853,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             h->bp_layout = layout;
             for (const Seg &g : plan) {
                 float *dst = h->d_Bp + (size_t)h->K * (size_t)g.col0;
-                if (reordered && g.width == 16) {
+                if (reordered && g.width == 16 && h->d_colpos) {
                     hipLaunchKernelGGL(sx::repack_b_panels_perm, dim3((unsigned)((h->col_hi - h->col_lo + sx::kBlock - 1) / sx::kBlock), (unsigned)g.ntiles),
                                        dim3(sx::kBlock), 0, s, d_B, ldb, dst, h->K, g.col0, h->d_colpos, h->col_lo, h->col_hi);
                     continue;

@@ -405,9 +405,10 @@ int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reaso
     auto drop = [&](int why) { (void)hipFree(d_order); (void)hipFree(d_colpos); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
                                sx::free_device_plan(dp); return why; };
     if (sx::cluster_rows_graph_device(h->M, h->K, h->m_nnz, h->m_rp, h->m_ci, (int)std::min<int64_t>(h->opt_cluster_top, 0x40000000), &d_order, err)) return drop(6);   // 6 .. 9: a builder failed
-    if (sx::column_first_touch_order_device(h->M, h->K, h->m_rp, h->m_ci, d_order, &d_colpos, err)) return drop(7);
+    const bool relabel = h->opt_relabel_columns != 0;
+    if (relabel && sx::column_first_touch_order_device(h->M, h->K, h->m_rp, h->m_ci, d_order, &d_colpos, err)) return drop(7);
     if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_order, &prp, &pci, &pv, err)) return drop(8);
-    if (sx::relabel_columns_device(h->m_nnz, pci, d_colpos, err)) return drop(8);
+    if (relabel && sx::relabel_columns_device(h->m_nnz, pci, d_colpos, err)) return drop(8);
     // Every block that fits gets a dictionary (threshold 0): the tail of the order holds the rows nothing wanted to merge with, and
     // ONE block of such rows without reuse would make the whole plan "mixed".  The reuse test is made on the plan as a whole below.
     const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;

@@ -173,6 +173,16 @@ def test_device_calls_alias_ranges_and_options(engine, oracle):
         engine.spmm(N, ALPHA, B, BETA, out)
         assert engine.last_kernel() == "spmm_csr_panel_v2_reordered"
         assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+        # natural B panels under the graph-clustered plan (option relabel_columns = 0: measured a wash): same bits
+        _set(engine, row_cluster=2)
+        engine.set_option("relabel_columns", 0)
+        engine.set_matrix_csr(M, M, rp, ci, v)
+        out = C0.copy()
+        engine.spmm(N, ALPHA, B, BETA, out)
+        engine.set_option("relabel_columns", 1)
+        assert engine.last_kernel() == "spmm_csr_panel_v2_reordered"
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+        engine.set_matrix_csr(M, M, rp, ci, v)
         # exact = 0 (FMA): the stated tolerance |d| <= 1e-4 (|alpha| sum |a b| + |beta c|)
         _set(engine, row_cluster=2, exact=0)
         out = C0.copy()
