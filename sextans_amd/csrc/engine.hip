@@ -315,6 +315,8 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "cluster_top")) return &h->opt_cluster_top;
     if (!strcmp(key, "small_panel")) return &h->opt_small_panel;
     if (!strcmp(key, "relabel_columns")) return &h->opt_relabel_columns;
+    if (!strcmp(key, "refine_sweeps")) return &h->opt_refine_sweeps;
+    if (!strcmp(key, "refine_rows")) return &h->opt_refine_rows;
     if (!strcmp(key, "colwise_max_len")) return &h->opt_colwise_max_len;
     if (!strcmp(key, "cluster_shape")) return &h->opt_cluster_shape;
     if (!strcmp(key, "cluster_group")) return &h->opt_cluster_group;
@@ -362,7 +364,7 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
         (void)hipSetDevice(h->device);
         free_window(h);   // the stream is built for one (rows per wavefront, window) pair
     }
-    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_top || slot == &h->opt_small_panel || slot == &h->opt_relabel_columns || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
+    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_top || slot == &h->opt_small_panel || slot == &h->opt_relabel_columns || slot == &h->opt_refine_sweeps || slot == &h->opt_refine_rows || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
         (void)hipSetDevice(h->device);   // the clustered-order plan is (re)considered under the new setting
         free_cluster_plan(h);
     }

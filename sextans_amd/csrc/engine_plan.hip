@@ -401,10 +401,13 @@ int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reaso
     }
     int *d_order = nullptr, *d_colpos = nullptr, *prp = nullptr, *pci = nullptr;
     float *pv = nullptr;
+    unsigned char *d_cut = nullptr;
     sx::DevicePlan dp;
-    auto drop = [&](int why) { (void)hipFree(d_order); (void)hipFree(d_colpos); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
+    auto drop = [&](int why) { (void)hipFree(d_order); (void)hipFree(d_colpos); (void)hipFree(d_cut); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
                                sx::free_device_plan(dp); return why; };
     if (sx::cluster_rows_graph_device(h->M, h->K, h->m_nnz, h->m_rp, h->m_ci, (int)std::min<int64_t>(h->opt_cluster_top, 0x40000000), &d_order, err)) return drop(6);   // 6 .. 9: a builder failed
+    if (h->opt_refine_sweeps > 0)   // boundary rows to the block that holds more of their neighbours (blocks of 62 rows, room for 2 more each)
+        if (sx::refine_blocks_device(h->M, h->m_rp, h->m_ci, d_order, (int)std::min<int64_t>(RB, std::max<int64_t>(32, h->opt_refine_rows)), RB, (int)h->opt_refine_sweeps, &d_cut, err) == 2) return drop(6);
     const bool relabel = h->opt_relabel_columns != 0;
     if (relabel && sx::column_first_touch_order_device(h->M, h->K, h->m_rp, h->m_ci, d_order, &d_colpos, err)) return drop(7);
     if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_order, &prp, &pci, &pv, err)) return drop(8);
@@ -412,15 +415,15 @@ int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reaso
     // Every block that fits gets a dictionary (threshold 0): the tail of the order holds the rows nothing wanted to merge with, and
     // ONE block of such rows without reuse would make the whole plan "mixed".  The reuse test is made on the plan as a whole below.
     const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;
-    int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, 0.0, dp, err, nullptr);
+    int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, 0.0, dp, err, d_cut);
     int cap_used = cap;
     if (brc == 0 && small_panel_fits(h, dp)) {
         sx::free_device_plan(dp);
         cap_used = 5 * RB;
-        brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap_used, 0.0, dp, err, nullptr);
+        brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap_used, 0.0, dp, err, d_cut);
     }
-    (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
-    prp = pci = nullptr; pv = nullptr;
+    (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv); (void)hipFree(d_cut);
+    prp = pci = nullptr; pv = nullptr; d_cut = nullptr;
     if (brc != 0) return drop(9);
     h->cluster_total_dict = dp.total_dict;
     // 10: a row wider than the panel / limits of the 32-bit offsets; 11: the reordered plan has no reuse either; 12: not enough gain

@@ -186,6 +186,8 @@ struct sextans_engine {
     std::vector<int> dist_meta;     // {first row, rows} per (chunk, rank) as last uploaded, and where
     const int *dist_meta_at = nullptr;
     // options
+    int64_t opt_refine_rows = 62;       // ... rows per block before the refinement (64 - room for rows that move in)
+    int64_t opt_refine_sweeps = 8;      // graph clustering: sweeps of the block refinement (0 = blocks are runs of 64 rows of the merge-tree order)
     int64_t opt_relabel_columns = 1;    // graph clustering: B rows relabelled in first-touch order (permuted panels); 0 = natural panels
     int64_t opt_small_panel = 1;        // clustered plans of short-row matrices are packed for a 320-row panel when every dictionary fits (more workgroups per CU)
     int64_t opt_cluster_top = 1 << 30;  // graph clustering: the aggregation stops when clusters reach this many rows.  Default: never -- the whole

@@ -28,6 +28,13 @@ int probe_row_coherence_device(int M, const int *d_rp, const int *d_ci, int nsam
 int cluster_rows_graph_device(int M, int K, int64_t nnz, const int *d_rp, const int *d_ci, int max_cluster_rows, int **d_order,
                               std::string &err);
 
+// Block refinement on top of the clustered order: the order is cut into blocks of `per` rows, `sweeps` sweeps of capacity-constrained
+// label propagation move boundary rows to the neighbouring block that holds more of their neighbours (at most `cap` rows per block);
+// d_order is rewritten (blocks in their old sequence, rows inside a block in their old order) and cut[i] = 1 where a block starts
+// (M bytes on the device, caller frees; the plan builder starts a row block there).  Deterministic.
+int refine_blocks_device(int M, const int *d_rp, const int *d_ci, int *d_order, int per, int cap, int sweeps, unsigned char **d_cut,
+                         std::string &err);
+
 // colpos[c] = new position of column c: columns in the order in which the rows of `order` first touch them (untouched columns
 // last), so that the dictionary of a run of consecutive rows is (mostly) a run of consecutive new positions -- whole cache lines
 // of the relabelled B panel.  K ints on the device, caller frees.

@@ -453,6 +453,95 @@ __global__ __launch_bounds__(256) void init_level0(int M, int *ord, int2 *cinfo,
     if (r == M) cstart[r] = M;
 }
 
+// ---- block refinement ----------------------------------------------------------------------------------------------------
+// The merge tree gives an order in which runs of rows are compact; cutting it every 64 rows still leaves blocks whose boundary rows
+// sit on the wrong side.  A few sweeps of capacity-constrained label propagation repair that: the order is cut into blocks of `per`
+// (< 64) rows, every row counts its neighbours per block and asks to move to the block that holds more of them than its own; per
+// target block the requests with the highest gain are granted while the block has room (<= 64 rows).  Deterministic: requests are
+// radix-sorted by (target, gain, row), a request's rank inside its target's segment decides.  Measured on renumbered meshes
+// (prototype and device agree): -13 .. -14 % dictionary rows for 3 % more blocks (3-dof 27-point: 7.3 -> 6.3 per matrix row, hand-made
+// bricks 6.2).
+constexpr int kRefHT = 128;
+
+__global__ __launch_bounds__(256) void refine_init(int M, int per, const int *__restrict__ order, int *__restrict__ blk, int *__restrict__ pos) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < M) { const int r = order[p]; blk[r] = p / per; pos[r] = p; }
+}
+__global__ __launch_bounds__(256) void refine_sizes(int M, const int *__restrict__ blk, int *size) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < M) atomicAdd(&size[blk[r]], 1);
+}
+// one wavefront per row: key = target block << 32 | (0xffffffff - gain) for rows that want to move this sweep, all-ones otherwise
+__global__ __launch_bounds__(256) void refine_requests(int M, const int *__restrict__ rp, const int *__restrict__ ci, const int *__restrict__ blk,
+                                                       int sweep, unsigned long long *__restrict__ key, int *__restrict__ val) {
+    __shared__ int keys[4][kRefHT];
+    __shared__ int cnts[4][kRefHT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= M) return;
+    if (lane == 0) { key[r] = ~0ull; val[r] = r; }
+    if (((mix32((unsigned)r) >> 7) + (unsigned)sweep) & 1u) return;       // half of the rows per sweep: neighbours do not swap past each other
+    int *kk = keys[wave], *cc = cnts[wave];
+    for (int i = lane; i < kRefHT; i += 64) { kk[i] = -1; cc[i] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    const int own = blk[r];
+    const int j0 = rp[r], len = min(rp[r + 1] - j0, 4 * kTriMaxLen);
+    for (int e = lane; e < len; e += 64) {
+        const int c = ci[j0 + e];
+        if ((unsigned)c >= (unsigned)M || c == r) continue;
+        const int b = blk[c];
+        unsigned h = mix32((unsigned)b) & (kRefHT - 1);
+        for (int probe = 0; probe < kRefHT; ++probe) {
+            const int prev = atomicCAS(&kk[h], -1, b);
+            if (prev == -1 || prev == b) { atomicAdd(&cc[h], 1); break; }
+            h = (h + 1) & (kRefHT - 1);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    int own_cnt = 0, best_cnt = 0, best_b = 0x7fffffff;
+    for (int i = lane; i < kRefHT; i += 64) {
+        const int b = kk[i];
+        if (b < 0) continue;
+        if (b == own) own_cnt = cc[i];
+        else if (cc[i] > best_cnt || (cc[i] == best_cnt && b < best_b)) { best_cnt = cc[i]; best_b = b; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        own_cnt = max(own_cnt, __shfl_xor(own_cnt, off));
+        const int oc = __shfl_xor(best_cnt, off), ob = __shfl_xor(best_b, off);
+        if (oc > best_cnt || (oc == best_cnt && ob < best_b)) { best_cnt = oc; best_b = ob; }
+    }
+    if (lane == 0 && best_cnt > own_cnt)
+        key[r] = ((unsigned long long)(unsigned)best_b << 32) | (unsigned long long)(0xffffffffu - (unsigned)(best_cnt - own_cnt));
+}
+__global__ __launch_bounds__(256) void refine_segments(int M, const unsigned long long *__restrict__ skey, int *__restrict__ seg_start) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M || skey[i] == ~0ull) return;
+    const unsigned t = (unsigned)(skey[i] >> 32);
+    if (i == 0 || (unsigned)(skey[i - 1] >> 32) != t) seg_start[t] = i;
+}
+__global__ __launch_bounds__(256) void refine_grant(int M, int cap, const unsigned long long *__restrict__ skey, const int *__restrict__ sval,
+                                                    const int *__restrict__ seg_start, const int *__restrict__ size_old, int *size_new, int *blk,
+                                                    int *moved) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M || skey[i] == ~0ull) return;
+    const int t = (int)(skey[i] >> 32), r = sval[i];
+    if (i - seg_start[t] >= cap - size_old[t]) return;                    // the block is full for this sweep (departures are not counted: safe)
+    const int own = blk[r];
+    if (size_old[own] <= 1) return;
+    blk[r] = t;
+    atomicAdd(&size_new[t], 1);
+    atomicSub(&size_new[own], 1);
+    atomicAdd(moved, 1);
+}
+__global__ __launch_bounds__(256) void refine_final_keys(int M, const int *__restrict__ blk, const int *__restrict__ pos, unsigned long long *key, int *val) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < M) { key[r] = ((unsigned long long)(unsigned)blk[r] << 32) | (unsigned)pos[r]; val[r] = r; }
+}
+__global__ __launch_bounds__(256) void refine_cuts(int M, const unsigned long long *__restrict__ skey, unsigned char *cut) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < M) cut[i] = (i == 0 || (skey[i] >> 32) != (skey[i - 1] >> 32)) ? 1 : 0;
+}
+
 // ---- column order ----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void first_touch(int M, const int *__restrict__ rp, const int *__restrict__ ci, const int *__restrict__ ord,
                                                    int *first) {
@@ -599,6 +688,57 @@ int cluster_rows_graph_device(int M, int K, int64_t nnz, const int *d_rp, const 
     GC_HIP(hipGetLastError());
     tmp.keep(ord[cur]);
     *d_order = ord[cur];
+    return 0;
+}
+
+int refine_blocks_device(int M, const int *d_rp, const int *d_ci, int *d_order, int per, int cap, int sweeps, unsigned char **d_cut,
+                         std::string &err) {
+    *d_cut = nullptr;
+    if (M < 2 || per < 1 || per > cap) return 1;
+    Scratch tmp;
+    const int nb = (M + per - 1) / per;
+    int *blk = nullptr, *pos = nullptr, *size[2] = {nullptr, nullptr}, *seg = nullptr, *val = nullptr, *sval = nullptr, *moved = nullptr;
+    unsigned long long *key = nullptr, *skey = nullptr;
+    unsigned char *cut = nullptr;
+    GC_HIP(tmp.alloc(&blk, (size_t)M));
+    GC_HIP(tmp.alloc(&pos, (size_t)M));
+    GC_HIP(tmp.alloc(&size[0], (size_t)nb));
+    GC_HIP(tmp.alloc(&size[1], (size_t)nb));
+    GC_HIP(tmp.alloc(&seg, (size_t)nb));
+    GC_HIP(tmp.alloc(&val, (size_t)M));
+    GC_HIP(tmp.alloc(&sval, (size_t)M));
+    GC_HIP(tmp.alloc(&key, (size_t)M));
+    GC_HIP(tmp.alloc(&skey, (size_t)M));
+    GC_HIP(tmp.alloc(&moved, 1));
+    GC_HIP(tmp.alloc(&cut, (size_t)M));
+    void *sort_tmp = nullptr;
+    size_t bytes = 0;
+    GC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, key, skey, val, sval, M, 0, 64, nullptr));
+    GC_HIP(tmp.alloc((char **)&sort_tmp, bytes));
+    hipLaunchKernelGGL(refine_init, dim3(blocks_for(M, 256)), dim3(256), 0, nullptr, M, per, d_order, blk, pos);
+    GC_HIP(hipMemsetAsync(size[0], 0, sizeof(int) * (size_t)nb, nullptr));
+    hipLaunchKernelGGL(refine_sizes, dim3(blocks_for(M, 256)), dim3(256), 0, nullptr, M, blk, size[0]);
+    int cur = 0;
+    for (int sweep = 0; sweep < sweeps; ++sweep) {
+        hipLaunchKernelGGL(refine_requests, dim3(blocks_for(M, 4)), dim3(256), 0, nullptr, M, d_rp, d_ci, blk, sweep, key, val);
+        GC_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp, bytes, key, skey, val, sval, M, 0, 64, nullptr));
+        GC_HIP(hipMemcpyAsync(size[cur ^ 1], size[cur], sizeof(int) * (size_t)nb, hipMemcpyDeviceToDevice, nullptr));
+        GC_HIP(hipMemsetAsync(moved, 0, sizeof(int), nullptr));
+        hipLaunchKernelGGL(refine_segments, dim3(blocks_for(M, 256)), dim3(256), 0, nullptr, M, skey, seg);
+        hipLaunchKernelGGL(refine_grant, dim3(blocks_for(M, 256)), dim3(256), 0, nullptr, M, cap, skey, sval, seg, size[cur], size[cur ^ 1], blk, moved);
+        cur ^= 1;
+        int h_moved = 0;
+        GC_HIP(hipMemcpy(&h_moved, moved, sizeof(int), hipMemcpyDeviceToHost));
+        if (getenv("SEXTANS_CLUSTER_TRACE")) fprintf(stderr, "graph clustering: refinement sweep %d moved %d rows\n", sweep, h_moved);
+        if ((long long)h_moved * 2000 < M) break;
+    }
+    hipLaunchKernelGGL(refine_final_keys, dim3(blocks_for(M, 256)), dim3(256), 0, nullptr, M, blk, pos, key, val);
+    GC_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp, bytes, key, skey, val, d_order, M, 0, 64, nullptr));
+    hipLaunchKernelGGL(refine_cuts, dim3(blocks_for(M, 256)), dim3(256), 0, nullptr, M, skey, cut);
+    GC_HIP(hipDeviceSynchronize());
+    GC_HIP(hipGetLastError());
+    tmp.keep(cut);
+    *d_cut = cut;
     return 0;
 }
 
