@@ -103,7 +103,7 @@ int launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_t
         hipLaunchKernelGGL(kern, dim3(nwg), dim3(sx::kBlock), lds, s, (const int2 *)h->ps.d_row_off, h->ps.d_lidx,
                            h->ps.d_pcol32, h->ps.d_pval, h->ps.d_blk_row, h->ps.d_dict_ptr, h->ps.d_dict, h->ps.plan_dict_stride, dBp,
                            pstride, dCin, ldc_in, dCout, ldc, ntiles, nblk, alpha, beta, xcd, panel_floats,
-                           (long long *)h->d_dbg, blk_begin, row_base, (const unsigned char *)h->d_skip);
+                           (long long *)h->d_dbg, blk_begin, row_base, (const unsigned char *)h->d_skip, (const int *)h->ps.d_ioff);
     };
     if (h->ps.plan_mixed) {
         if (h->opt_exact) go(sx::spmm_csr_panel<LPR, true, true>);
@@ -166,7 +166,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)P.d_row_off,
                            P.d_lidx, P.d_pval, P.d_blk_row, P.d_dict_ptr, P.d_dict, P.plan_dict_stride,
                            dBp, pstride, dCin, ldc_in, dCout, ldc, nsuper, tpw, nblk, alpha, beta, (int)h->opt_xcd,
-                           P.plan_pad_row, blk_begin, row_base, skip, (long long *)h->d_dbg, slot_row);
+                           P.plan_pad_row, blk_begin, row_base, skip, (long long *)h->d_dbg, slot_row, (const int *)P.d_ioff);
         return SEXTANS_OK;
     };
     if constexpr (H > 1) {
@@ -316,6 +316,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "small_panel")) return &h->opt_small_panel;
     if (!strcmp(key, "relabel_columns")) return &h->opt_relabel_columns;
     if (!strcmp(key, "refine_sweeps")) return &h->opt_refine_sweeps;
+    if (!strcmp(key, "share_index")) return &h->opt_share_index;
     if (!strcmp(key, "refine_rows")) return &h->opt_refine_rows;
     if (!strcmp(key, "colwise_max_len")) return &h->opt_colwise_max_len;
     if (!strcmp(key, "cluster_shape")) return &h->opt_cluster_shape;
@@ -369,6 +370,7 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
         free_cluster_plan(h);
     }
     if (slot == &h->opt_colwise_max_len && *slot != value) h->colwise_state = 0;
+    if (slot == &h->opt_share_index && *slot != value) { (void)hipSetDevice(h->device); free_plan(h); }   // every packed form is rebuilt
     if (*slot != value) h->dist_cut_key.clear();   // chunk cuts are aligned to the packed forms the options select (all
                                                    // ranks of a partition must change options together: the cut
                                                    // exchange is a collective)
@@ -566,6 +568,8 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "panel_rows_clustered")) *value = (double)h->cluster_total_dict;
     else if (!strcmp(key, "panel_fraction")) *value = h->ps.plan_panel_frac;
     else if (!strcmp(key, "panel_blocks")) *value = (double)h->ps.plan_nblk;
+    else if (!strcmp(key, "index_stream_entries")) *value = (double)(h->cluster_state > 0 ? h->psc.plan_idx_len : h->ps.plan_idx_len);
+    else if (!strcmp(key, "value_stream_entries")) *value = (double)(h->cluster_state > 0 ? h->psc.plan_stream_len : h->ps.plan_stream_len);
     else return SEXTANS_ERR_INVALID;
     return SEXTANS_OK;
 }
@@ -613,7 +617,19 @@ int sextans_export_plan(sextans_handle_t h, int lanes_per_row, sextans_packed *o
     }
     out->dict_ptr[nblk] = (int)w;
     for (int r = 0; r < M; ++r) out->row_off[r + 1] = out->row_off[r] + ((rp[(size_t)r + 1] - rp[(size_t)r] + 3) & ~3);
-    SX_HIP(hipMemcpy(out->idx16, ps.d_lidx, sizeof(uint16_t) * L, hipMemcpyDeviceToHost));
+    if (!ps.d_ioff) {
+        SX_HIP(hipMemcpy(out->idx16, ps.d_lidx, sizeof(uint16_t) * L, hipMemcpyDeviceToHost));
+    } else {   // index lists shared between consecutive rows: the public form carries every row's own list
+        std::vector<uint16_t> comp((size_t)ps.plan_idx_len);
+        std::vector<int> ioff((size_t)nblk * RB), sinfo((size_t)nblk * RB * 2);
+        SX_HIP(hipMemcpy(comp.data(), ps.d_lidx, sizeof(uint16_t) * comp.size(), hipMemcpyDeviceToHost));
+        SX_HIP(hipMemcpy(ioff.data(), ps.d_ioff, sizeof(int) * ioff.size(), hipMemcpyDeviceToHost));
+        SX_HIP(hipMemcpy(sinfo.data(), ps.d_row_off, sizeof(int) * sinfo.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ioff.size(); ++i) {
+            const int o0 = sinfo[2 * i], len = sinfo[2 * i + 1];
+            for (int e = 0; e < len; ++e) out->idx16[(size_t)o0 + e] = comp[(size_t)ioff[i] + e];
+        }
+    }
     SX_HIP(hipMemcpy(out->val, ps.d_pval, sizeof(float) * L, hipMemcpyDeviceToHost));
     if (ps.plan_mixed) SX_HIP(hipMemcpy(out->col32, ps.d_pcol32, sizeof(int) * L, hipMemcpyDeviceToHost));
     // device stream: byte offset of the B row in the panel; public form: dictionary index, 0xFFFF in the padding

@@ -20,7 +20,7 @@ namespace sxe {
 
 void free_panel_state(sextans_engine::PanelState &p) {
     (void)hipFree(p.d_dict_ptr); (void)hipFree(p.d_dict); (void)hipFree(p.d_lidx); (void)hipFree(p.d_blk_row);
-    (void)hipFree(p.d_row_off); (void)hipFree(p.d_pcol32); (void)hipFree(p.d_pval);
+    (void)hipFree(p.d_row_off); (void)hipFree(p.d_pcol32); (void)hipFree(p.d_pval); (void)hipFree(p.d_ioff);
     p = sextans_engine::PanelState();
 }
 
@@ -49,7 +49,8 @@ int64_t device_bytes(const sextans_engine *h) {
         if (!p.plan_built || !p.plan_lpr) return 0;
         const int64_t rb = sx::kBlock / p.plan_lpr;
         return (int64_t)p.plan_nblk * (4 * (2 + p.plan_dict_stride + 2 * rb)) +
-               (p.stream_released ? 0 : p.plan_stream_len * 6 + (p.plan_mixed ? p.plan_stream_len * 4 : 4));
+               (p.stream_released ? 0 : p.plan_stream_len * 4 + p.plan_idx_len * 2 + (p.d_ioff ? (int64_t)p.plan_nblk * rb * 4 : 0) +
+                                            (p.plan_mixed ? p.plan_stream_len * 4 : 4));
     };
     int64_t b = 0;
     const int64_t rows = (int64_t)h->M + 1;
@@ -183,7 +184,8 @@ void adopt_device_plan(sextans_engine::PanelState &c, sx::DevicePlan &dp, const 
     c.plan_dict_stride = dp.dict_stride;
     c.plan_mixed = dp.mixed;
     c.d_blk_row = dp.d_blk_row; c.d_dict_ptr = dp.d_dict_cnt; c.d_dict = dp.d_dict; c.d_row_off = dp.d_slot_info;
-    c.d_lidx = dp.d_idx16; c.d_pcol32 = dp.d_col32; c.d_pval = dp.d_val;
+    c.d_lidx = dp.d_idx16; c.d_pcol32 = dp.d_col32; c.d_pval = dp.d_val; c.d_ioff = dp.d_ioff;
+    c.plan_idx_len = dp.idx_len;
     c.h_blk_row.swap(dp.h_blk_row);
     c.plan_stream_len = dp.stream_len;
     c.plan_nnz_panel = dp.nnz_in_panel_blocks;
@@ -272,7 +274,8 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
     sx::DevicePlan dp;
     std::string err;
     const int cap = kPanelFloats / (4 * lpr);
-    const int brc = sx::build_panel_plan_device(h->M, h->K, h->m_rp, h->m_ci, h->m_v, lpr, cap, min_reuse, dp, err);
+    const int brc = sx::build_panel_plan_device(h->M, h->K, h->m_rp, h->m_ci, h->m_v, lpr, cap, min_reuse, dp, err, nullptr,
+                                                lpr == 4 && h->opt_share_index != 0);
     if (brc == 2) { g_last_error = err; sx::free_device_plan(dp); return SEXTANS_ERR_HIP; }
     h->ps.plan_lpr = lpr;
     h->ps.plan_min_reuse = plan_key(h);
@@ -287,7 +290,8 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
     h->ps.plan_dict_stride = dp.dict_stride;
     h->ps.plan_mixed = dp.mixed;
     h->ps.d_blk_row = dp.d_blk_row; h->ps.d_dict_ptr = dp.d_dict_cnt; h->ps.d_dict = dp.d_dict; h->ps.d_row_off = dp.d_slot_info;
-    h->ps.d_lidx = dp.d_idx16; h->ps.d_pcol32 = dp.d_col32; h->ps.d_pval = dp.d_val;
+    h->ps.d_lidx = dp.d_idx16; h->ps.d_pcol32 = dp.d_col32; h->ps.d_pval = dp.d_val; h->ps.d_ioff = dp.d_ioff;
+    h->ps.plan_idx_len = dp.idx_len;
     h->ps.h_blk_row.swap(dp.h_blk_row);
     h->ps.plan_stream_len = dp.stream_len;
     h->ps.plan_panel_frac = h->m_nnz ? (double)dp.nnz_in_panel_blocks / (double)h->m_nnz : 0.0;
@@ -359,12 +363,12 @@ int cluster_grid(sextans_engine *h) {   // 0 = in use, 1 = declined
     if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_perm, &prp, &pci, &pv, err)) return drop();
     const int lpr = 4, RB = sx::kBlock / lpr, cap = kPanelFloats / (4 * lpr);
     const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;
-    int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, min_reuse, dp, err, d_cut);
+    int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, min_reuse, dp, err, d_cut, h->opt_share_index != 0);
     int cap_used = cap;
     if (brc == 0 && small_panel_fits(h, dp)) {   // short rows, small dictionaries: packed again for a 320-row panel (same blocks, less LDS)
         sx::free_device_plan(dp);
         cap_used = 5 * RB;
-        brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap_used, min_reuse, dp, err, d_cut);
+        brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap_used, min_reuse, dp, err, d_cut, h->opt_share_index != 0);
     }
     (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv); (void)hipFree(d_cut);
     prp = pci = nullptr; pv = nullptr; d_cut = nullptr;
@@ -415,12 +419,12 @@ int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reaso
     // Every block that fits gets a dictionary (threshold 0): the tail of the order holds the rows nothing wanted to merge with, and
     // ONE block of such rows without reuse would make the whole plan "mixed".  The reuse test is made on the plan as a whole below.
     const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;
-    int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, 0.0, dp, err, d_cut);
+    int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, 0.0, dp, err, d_cut, h->opt_share_index != 0);
     int cap_used = cap;
     if (brc == 0 && small_panel_fits(h, dp)) {
         sx::free_device_plan(dp);
         cap_used = 5 * RB;
-        brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap_used, 0.0, dp, err, d_cut);
+        brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap_used, 0.0, dp, err, d_cut, h->opt_share_index != 0);
     }
     (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv); (void)hipFree(d_cut);
     prp = pci = nullptr; pv = nullptr; d_cut = nullptr;
@@ -489,8 +493,8 @@ void release_plan_streams(sextans_engine *h) {
     sextans_engine::PanelState &p = h->ps;
     if (!p.plan_built || p.stream_released || p.plan_lpr != 4) return;
     if ((size_t)h->K * 16 * sizeof(float) <= ((size_t)16 << 20)) return;   // column-major staging may still pick the natural-order plan
-    (void)hipFree(p.d_lidx); (void)hipFree(p.d_pval); (void)hipFree(p.d_pcol32);
-    p.d_lidx = nullptr; p.d_pval = nullptr; p.d_pcol32 = nullptr;
+    (void)hipFree(p.d_lidx); (void)hipFree(p.d_pval); (void)hipFree(p.d_pcol32); (void)hipFree(p.d_ioff);
+    p.d_lidx = nullptr; p.d_pval = nullptr; p.d_pcol32 = nullptr; p.d_ioff = nullptr;
     p.stream_released = true;
 }
 
@@ -502,14 +506,16 @@ int restore_plan_streams(sextans_engine *h) {
     std::string err;
     const int lpr = p.plan_lpr, cap = kPanelFloats / (4 * lpr);
     const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;
-    const int brc = sx::build_panel_plan_device(h->M, h->K, h->m_rp, h->m_ci, h->m_v, lpr, cap, min_reuse, dp, err);
+    const int brc = sx::build_panel_plan_device(h->M, h->K, h->m_rp, h->m_ci, h->m_v, lpr, cap, min_reuse, dp, err, nullptr,
+                                                lpr == 4 && h->opt_share_index != 0);
     if (brc != 0 || dp.nblk != p.plan_nblk || dp.stream_len != p.plan_stream_len) {
         sx::free_device_plan(dp);
         if (brc == 2) g_last_error = err;
         return brc == 2 ? SEXTANS_ERR_HIP : SEXTANS_ERR_STATE;
     }
-    p.d_lidx = dp.d_idx16; p.d_pval = dp.d_val; p.d_pcol32 = dp.d_col32;
-    dp.d_idx16 = nullptr; dp.d_val = nullptr; dp.d_col32 = nullptr;
+    p.d_lidx = dp.d_idx16; p.d_pval = dp.d_val; p.d_pcol32 = dp.d_col32; p.d_ioff = dp.d_ioff;
+    p.plan_idx_len = dp.idx_len;
+    dp.d_idx16 = nullptr; dp.d_val = nullptr; dp.d_col32 = nullptr; dp.d_ioff = nullptr;
     sx::free_device_plan(dp);
     p.stream_released = false;
     return SEXTANS_OK;

@@ -76,6 +76,9 @@ struct sextans_engine {
         int plan_nblk = 0;
         std::vector<int> h_blk_row;     // host copy of the plan's block boundaries (row-range calls, sextans_align_row)
         unsigned short *d_lidx = nullptr;
+        int *d_ioff = nullptr;          // per (block, slot): start of the slot's index list in d_lidx when identical lists of consecutive rows are
+                                        // stored once (plan_device.hip: share_index_lists); null = at the slot's first packed entry
+        int64_t plan_idx_len = 0;       // entries of d_lidx (= plan_stream_len without sharing)
         double plan_panel_frac = 0.0;   // share of non-zeros living in dictionary blocks
         double plan_narrow_frac = 0.0;  // sampled share of non-zeros in row blocks that meet the N <= 16 threshold ("panel_min_reuse_x100")
         int plan_max_dict = 0;          // largest block dictionary (entries)
@@ -186,6 +189,7 @@ struct sextans_engine {
     std::vector<int> dist_meta;     // {first row, rows} per (chunk, rank) as last uploaded, and where
     const int *dist_meta_at = nullptr;
     // options
+    int64_t opt_share_index = 1;        // plans at 4 lanes per row: consecutive rows with identical 16-bit index lists (dof rows of a mesh node) share one copy
     int64_t opt_refine_rows = 62;       // ... rows per block before the refinement (64 - room for rows that move in)
     int64_t opt_refine_sweeps = 8;      // graph clustering: sweeps of the block refinement (0 = blocks are runs of 64 rows of the merge-tree order)
     int64_t opt_relabel_columns = 1;    // graph clustering: B rows relabelled in first-touch order (permuted panels); 0 = natural panels

@@ -19,6 +19,11 @@ struct DevicePlan {                   // device arrays in exactly the form the L
     int dict_stride = 0;
     int *d_slot_info = nullptr;       // nblk x rows_per_block x {first packed entry, entries}
     unsigned short *d_idx16 = nullptr;   // BYTE offset of the entry's B row in the panel (index * 16 * lpr); padding -> pad row
+    int *d_ioff = nullptr;            // nblk x rows_per_block: where a slot's index list starts in d_idx16 when lists are SHARED (null: at the
+                                      // slot's first packed entry, like the values): consecutive rows of a block with identical index lists --
+                                      // the dof rows of one mesh node -- keep one copy (share_index_lists)
+    int64_t idx_len = 0;              // entries of d_idx16 (= stream_len without sharing)
+    int64_t shared_rows = 0;          // rows whose index list is another row's
     int *d_col32 = nullptr;           // stream_len when `mixed`, else 1 element
     float *d_val = nullptr;
     int64_t stream_len = 0;
@@ -36,6 +41,7 @@ int validate_csr_device(int M, int K, int64_t nnz, const int *d_rp, const int *d
 int column_range_device(int64_t nnz, const int *d_ci, int *lo, int *hi, std::string &err);
 void free_device_plan(DevicePlan &d);
 int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, const float *d_v, int lpr, int max_unique,
-                            double min_reuse, DevicePlan &out, std::string &err, const unsigned char *d_cut = nullptr);
+                            double min_reuse, DevicePlan &out, std::string &err, const unsigned char *d_cut = nullptr,
+                            bool share_index_lists = false);
 
 }  // namespace sx

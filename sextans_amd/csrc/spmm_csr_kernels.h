@@ -232,7 +232,8 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
     const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout,
     int64_t ldc, int ntiles, int nblk, float alpha, float beta, int use_xcd_remap, int panel_floats,
-    long long *dbg, int blk_begin, int row_base, const unsigned char *__restrict__ skip) {
+    long long *dbg, int blk_begin, int row_base, const unsigned char *__restrict__ skip, const int *__restrict__ slot_ioff) {
+    // slot_ioff (may be null): start of the slot's index list in p_idx16 when identical lists of consecutive rows are stored once.
     // Blocks [blk_begin, blk_begin + nblk) of the plan are processed (row-range calls of the multi-GPU pipeline
     // cut at block boundaries); the C pointers address row `row_base` as their row 0.
     const long long t0 = dbg ? clock64() : 0;   // dbg: optional phase timing (engine option "phase_timing")
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     const float *bq = Bp + (int64_t)tile * panel_stride + 4 * q;
     const int len = si.y;
     const int64_t off = si.x;
+    const int64_t offi = slot_ioff ? (int64_t)slot_ioff[(int64_t)blk * RB + slot] : off;
 
     // this lane's 4 entries of a batch: indices (unpacked to int) and values
     auto fetch = [&](int pos, int (&oi)[4], float (&ov)[4]) {
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
         ov[0] = v.x; ov[1] = v.y; ov[2] = v.z; ov[3] = v.w;
         if (use_dict) {
             // dictionary entries carry the BYTE offset of their B row in the panel (index * NT * 4 < 64 Ki)
-            const uint2 w = *reinterpret_cast<const uint2 *>(p_idx16 + o);
+            const uint2 w = *reinterpret_cast<const uint2 *>(p_idx16 + offi + pos + 4 * q);
             oi[0] = (int)(w.x & 0xffffu); oi[1] = (int)(w.x >> 16);
             oi[2] = (int)(w.y & 0xffffu); oi[3] = (int)(w.y >> 16);
         } else {
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     auto fetch_raw = [&](int pos, f32x4 &v, uint2 &w) {
         const int64_t o = off + pos + 4 * q;
         v = *reinterpret_cast<const f32x4 *>(p_val + o);
-        w = *reinterpret_cast<const uint2 *>(p_idx16 + o);
+        w = *reinterpret_cast<const uint2 *>(p_idx16 + offi + pos + 4 * q);
     };
     auto unpack_raw = [&](const f32x4 &v, const uint2 &w) {
         vx[0] = v.x; vx[1] = v.y; vx[2] = v.z; vx[3] = v.w;

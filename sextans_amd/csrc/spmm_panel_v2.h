@@ -130,7 +130,9 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
     const int *__restrict__ blk_row, const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
     const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc,
     int nsuper, int tpw, int nblk, float alpha, float beta, int use_xcd_remap, int pad_row, int blk_begin, int row_base,
-    const unsigned char *__restrict__ skip, long long *dbg, const int *__restrict__ slot_row) {
+    const unsigned char *__restrict__ skip, long long *dbg, const int *__restrict__ slot_row, const int *__restrict__ slot_ioff) {
+    // slot_ioff (may be null): where a slot's 16-bit index list starts in p_idx16 when consecutive rows with identical lists share one
+    // copy (plan_device.hip: share_index_lists); null = at the slot's first packed entry, like its values.
     static_assert(!CROW || (H == 1 && !BCOL), "the block-major C staging exists for 16-column tiles on repacked panels");
     long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, w0 = 0;
     if constexpr (TIMED) { t0 = clock64(); w0 = wall_clock64(); }
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
     const int row1 = blk_row[blk + 1];
     const int nu = dict_cnt[blk];
     const int2 si = slot_info[(int64_t)blk * RB + slot];
+    const int io = slot_ioff ? slot_ioff[(int64_t)blk * RB + slot] : si.x;
     unsigned boff[MAXD];                      // float offset of "my" dictionary rows inside a K x 16 panel (+ my 4 columns)
     {
         const int *bd = blk_dict + (int64_t)blk * dict_stride + slot;
@@ -176,9 +179,11 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
     // `global_load saddr + voffset + immediate` without 64-bit vector address arithmetic.  Slots past the block's last
     // row ({0, 0}) fetch from the base (never consumed).  The stream is padded: over-reads stay in bounds.
     const int wbase = __builtin_amdgcn_readfirstlane(si.x);
+    const int wbase_i = __builtin_amdgcn_readfirstlane(io);
     const float *pv = p_val + wbase;
-    const unsigned short *pi = p_idx16 + wbase;
+    const unsigned short *pi = p_idx16 + wbase_i;
     const unsigned loff = (len > 0 ? (unsigned)(si.x - wbase) : 0u) + 4u * (unsigned)q;
+    const unsigned loffi = (len > 0 ? (unsigned)(io - wbase_i) : 0u) + 4u * (unsigned)q;
     // C: this lane's row (clamped for the loads) and whether it is written
     // (slot_row: the plan walks the rows in clustered order -- row_cluster.hip -- and this table, at an address that depends on the
     // block number only, says which row of the matrix a slot is; without it blocks are runs of consecutive rows)
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
             // (non-temporal loads of this read-once stream -- so that it would not push the B lines neighbouring blocks share out of L2 --
             // were measured on the reordered form, where B is re-fetched 5x: kernel 744 -> 936 us.  Plain loads.)
             av[b] = *reinterpret_cast<const f32x4 *>(pv + loff + b * BATCH);
-            aw[b] = *reinterpret_cast<const uint2 *>(pi + loff + b * BATCH);
+            aw[b] = *reinterpret_cast<const uint2 *>(pi + loffi + b * BATCH);
         }
         // All dictionary indices are waited for HERE, in one counted wait behind which the row loads above stay in flight.  Left to
         // itself the compiler waits for boff[1] after the first (conditional) panel request -- and after a control-flow join its
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
 #undef SX_RBATCH
         for (int pos = NB * BATCH; pos < len; pos += BATCH) {   // rows longer than NB batches: the rest from the stream
             const f32x4 v = *reinterpret_cast<const f32x4 *>(pv + loff + pos);
-            const uint2 w = *reinterpret_cast<const uint2 *>(pi + loff + pos);
+            const uint2 w = *reinterpret_cast<const uint2 *>(pi + loffi + pos);
             int ix[4] = {(int)(w.x & 0xffffu), (int)(w.x >> 16), (int)(w.y & 0xffffu), (int)(w.y >> 16)};
             float vx[4] = {v.x, v.y, v.z, v.w};
             const int cnt = len - pos;

@@ -123,3 +123,48 @@ def test_device_matrix_is_validated_on_the_device(sx):
         e.set_matrix_csr_device(3, 4, 6, rp2.data_ptr(), ci2.data_ptr(), v.data_ptr())
         with pytest.raises(api.SextansError):
             e.spmm_device(8, 1.0, B.data_ptr(), 4, 0.0, Cm.data_ptr(), Cm.data_ptr(), 3)
+
+
+def test_shared_index_lists(engine, oracle):
+    """Consecutive rows of a block with identical 16-bit index lists -- the dof rows of a mesh node -- keep ONE copy of the list
+    (plan_device.hip: share_index_lists; 6 -> 4.67 bytes per non-zero for a 3-dof matrix).  The exported plan is byte-identical to the
+    host builder's either way (the public form carries every row's own list), results are bit-identical, and the index stream of a 3-dof
+    matrix shrinks by more than half while a 1-dof matrix keeps its layout."""
+    from sextans_amd import api
+    import numpy as np
+    from util import ALPHA, BETA
+    rs = np.random.RandomState(2)
+    for dims, dof, shrink in (((12, 11, 10), 3, True), ((20, 18, 16), 1, False)):
+        M = K = dims[0] * dims[1] * dims[2] * dof
+        rp, ci, v = api.gen_fem3d_host(*dims, dof, 7)
+        N = 32
+        B = rs.uniform(-1, 1, K * N).astype(np.float32); C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+        want = C0.copy()
+        oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+        plans = {}
+        try:
+            for share in (0, 1):
+                engine.set_option("share_index", share)
+                engine.set_option("kernel", 2); engine.set_option("fuse_b", 0)
+                engine.set_matrix_csr(M, K, rp, ci, v)
+                for rc in (0, -1):                       # natural-order plan (both panel kernels) and the clustered one
+                    engine.set_option("row_cluster", rc)
+                    for pv2 in (0, -1):
+                        engine.set_option("panel_v2", pv2)
+                        out = C0.copy()
+                        engine.spmm(N, ALPHA, B, BETA, out)
+                        assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (dims, share, rc, pv2, engine.last_kernel())
+                engine.set_option("row_cluster", 0)
+                out = C0.copy(); engine.spmm(N, ALPHA, B, BETA, out)
+                plans[share] = (engine.export_plan(4), engine.get_stat("index_stream_entries"), engine.get_stat("value_stream_entries"))
+            p0, p1 = plans[0][0], plans[1][0]
+            for name in ("blk_row", "dict_ptr", "dict", "row_off", "idx16", "val"):
+                assert np.array_equal(p0[name], p1[name]), name
+            assert plans[0][1] == plans[0][2]
+            if shrink:
+                assert plans[1][1] < 0.5 * plans[1][2], plans[1][1:]
+            else:
+                assert plans[1][1] == plans[1][2]
+        finally:
+            for k, val in (("share_index", 1), ("kernel", 0), ("fuse_b", 1), ("row_cluster", -1), ("panel_v2", -1)):
+                engine.set_option(k, val)

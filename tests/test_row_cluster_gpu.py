@@ -146,7 +146,7 @@ def test_row_ranges_and_long_rows_with_a_clustered_plan(engine, oracle):
 
 def test_released_plan_stream_is_rebuilt_for_row_ranges(engine, oracle):
     """A matrix too large for column-major staging (K x 16 floats > 16 MiB): once the clustered plan serves the whole-matrix calls
-    the natural-order plan hands its packed stream back (stat "device_bytes" drops by 6 bytes per non-zero); the first row-range
+    the natural-order plan hands its packed stream back (stat "device_bytes" drops by 4.7 - 6 bytes per non-zero); the first row-range
     call rebuilds it -- same bytes, same results."""
     import torch
     from sextans_amd import api
@@ -184,6 +184,6 @@ def test_released_plan_stream_is_rebuilt_for_row_ranges(engine, oracle):
             got.view(N, M)[:, c0:c1] = slab.view(N, c1 - c0)
         torch.cuda.synchronize()
         assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
-        assert engine.get_stat("device_bytes") > with_cluster + 5.0 * len(ci)                 # the stream is back
+        assert engine.get_stat("device_bytes") > with_cluster + 4.0 * len(ci)                 # the stream is back (4 B values + shared indices)
     finally:
         _set(engine)
