@@ -96,14 +96,15 @@ int launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_t
     const int64_t pstride = bcol_ld > 0 ? bcol_ld : (int64_t)h->K * NT;
     const int xcd = (int)h->opt_xcd;
     // LDS = B panel sized for the largest dictionary of this matrix (rounded to 1 KiB) + C tile.
-    const int panel_floats = (h->ps.plan_pad_row + 1) * NT;   // dictionary capacity + the +1.0f row the padding entries address
+    const int pad_rows = h->ps.d_ioff ? sx::kWidePadRows : 1;   // (shared index lists may be shifted: their padding entries reach further)
+    const int panel_floats = (h->ps.plan_pad_row + pad_rows) * NT;   // dictionary capacity + the +1.0f rows the padding entries address
     const int tile_floats = NT * (RB + 1);   // the C tile reuses the panel bytes
     const size_t lds = (size_t)(panel_floats > tile_floats ? panel_floats : tile_floats) * sizeof(int);
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(nwg), dim3(sx::kBlock), lds, s, (const int2 *)h->ps.d_row_off, h->ps.d_lidx,
                            h->ps.d_pcol32, h->ps.d_pval, h->ps.d_blk_row, h->ps.d_dict_ptr, h->ps.d_dict, h->ps.plan_dict_stride, dBp,
                            pstride, dCin, ldc_in, dCout, ldc, ntiles, nblk, alpha, beta, xcd, panel_floats,
-                           (long long *)h->d_dbg, blk_begin, row_base, (const unsigned char *)h->d_skip, (const int *)h->ps.d_ioff);
+                           (long long *)h->d_dbg, blk_begin, row_base, (const unsigned char *)h->d_skip, (const int2 *)h->ps.d_ioff, pad_rows);
     };
     if (h->ps.plan_mixed) {
         if (h->opt_exact) go(sx::spmm_csr_panel<LPR, true, true>);
@@ -160,13 +161,13 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     // (engine_plan.hip: small_panel): 20.5 KB instead of 36.9 KB per workgroup, so the CU holds as many workgroups as the registers
     // allow (5 at <= 96 registers) instead of the 4 the full panel permits -- these launches are latency-bound
     const bool small_panel = H == 1 && bcol_ld == 0 && P.plan_pad_row == 5 * 64;
-    const size_t lds = small_panel ? (size_t)(5 * 64 + 1) * 64 : (size_t)H * sx::kWideHalfBytes;
+    const size_t lds = small_panel ? (size_t)(5 * 64 + sx::kWidePadRows) * 64 : (size_t)H * sx::kWideHalfBytes;
     auto go = [&](auto kern) -> int {
         if (int rc = allow_big_lds(h, reinterpret_cast<const void *>(kern), (int)lds)) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)P.d_row_off,
                            P.d_lidx, P.d_pval, P.d_blk_row, P.d_dict_ptr, P.d_dict, P.plan_dict_stride,
                            dBp, pstride, dCin, ldc_in, dCout, ldc, nsuper, tpw, nblk, alpha, beta, (int)h->opt_xcd,
-                           P.plan_pad_row, blk_begin, row_base, skip, (long long *)h->d_dbg, slot_row, (const int *)P.d_ioff);
+                           P.plan_pad_row, blk_begin, row_base, skip, (long long *)h->d_dbg, slot_row, (const int2 *)P.d_ioff);
         return SEXTANS_OK;
     };
     if constexpr (H > 1) {
@@ -621,13 +622,17 @@ int sextans_export_plan(sextans_handle_t h, int lanes_per_row, sextans_packed *o
         SX_HIP(hipMemcpy(out->idx16, ps.d_lidx, sizeof(uint16_t) * L, hipMemcpyDeviceToHost));
     } else {   // index lists shared between consecutive rows: the public form carries every row's own list
         std::vector<uint16_t> comp((size_t)ps.plan_idx_len);
-        std::vector<int> ioff((size_t)nblk * RB), sinfo((size_t)nblk * RB * 2);
+        std::vector<int> ioff((size_t)nblk * RB * 2), sinfo((size_t)nblk * RB * 2);
         SX_HIP(hipMemcpy(comp.data(), ps.d_lidx, sizeof(uint16_t) * comp.size(), hipMemcpyDeviceToHost));
         SX_HIP(hipMemcpy(ioff.data(), ps.d_ioff, sizeof(int) * ioff.size(), hipMemcpyDeviceToHost));
         SX_HIP(hipMemcpy(sinfo.data(), ps.d_row_off, sizeof(int) * sinfo.size(), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < ioff.size(); ++i) {
-            const int o0 = sinfo[2 * i], len = sinfo[2 * i + 1];
-            for (int e = 0; e < len; ++e) out->idx16[(size_t)o0 + e] = comp[(size_t)ioff[i] + e];
+        const unsigned pad = (unsigned)ps.plan_pad_row * 16u * (unsigned)lanes_per_row;
+        for (size_t i = 0; i < (size_t)nblk * RB; ++i) {
+            const int o0 = sinfo[2 * i], len = sinfo[2 * i + 1], src = ioff[2 * i], shift = ioff[2 * i + 1];
+            for (int e = 0; e < len; ++e) {
+                const unsigned v = comp[(size_t)src + e];
+                out->idx16[(size_t)o0 + e] = (uint16_t)(v == pad ? v : v + (unsigned)shift);
+            }
         }
     }
     SX_HIP(hipMemcpy(out->val, ps.d_pval, sizeof(float) * L, hipMemcpyDeviceToHost));

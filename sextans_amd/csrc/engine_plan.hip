@@ -18,6 +18,8 @@
 
 namespace sxe {
 
+static_assert(sx::kPlanPadRows == sx::kWidePadRows, "the plan builder and the kernels agree on the +1.0f rows of a panel");
+
 void free_panel_state(sextans_engine::PanelState &p) {
     (void)hipFree(p.d_dict_ptr); (void)hipFree(p.d_dict); (void)hipFree(p.d_lidx); (void)hipFree(p.d_blk_row);
     (void)hipFree(p.d_row_off); (void)hipFree(p.d_pcol32); (void)hipFree(p.d_pval); (void)hipFree(p.d_ioff);
@@ -49,7 +51,7 @@ int64_t device_bytes(const sextans_engine *h) {
         if (!p.plan_built || !p.plan_lpr) return 0;
         const int64_t rb = sx::kBlock / p.plan_lpr;
         return (int64_t)p.plan_nblk * (4 * (2 + p.plan_dict_stride + 2 * rb)) +
-               (p.stream_released ? 0 : p.plan_stream_len * 4 + p.plan_idx_len * 2 + (p.d_ioff ? (int64_t)p.plan_nblk * rb * 4 : 0) +
+               (p.stream_released ? 0 : p.plan_stream_len * 4 + p.plan_idx_len * 2 + (p.d_ioff ? (int64_t)p.plan_nblk * rb * 8 : 0) +
                                             (p.plan_mixed ? p.plan_stream_len * 4 : 4));
     };
     int64_t b = 0;

@@ -8,6 +8,8 @@ namespace sx {
 
 constexpr int kPlanPartBlocks = 64;   // rows are cut into parts of kPlanPartBlocks * rows_per_block rows; every part starts a
                                       // new block (host and device builders alike, so their block lists are identical)
+constexpr int kPlanPadRows = 16;      // +1.0f rows behind the dictionary in the LDS panel when index lists are shared with a shift: a padding entry of
+                                      // a shifted list addresses pad row + shift (at most kPlanPadRows - 1 panel rows)
 constexpr int kPlanTailPad = 256;     // zero entries behind the last row (the kernels fetch up to 6 batches of 16 ahead)
 
 struct DevicePlan {                   // device arrays in exactly the form the LDS-panel kernels read
@@ -19,9 +21,9 @@ struct DevicePlan {                   // device arrays in exactly the form the L
     int dict_stride = 0;
     int *d_slot_info = nullptr;       // nblk x rows_per_block x {first packed entry, entries}
     unsigned short *d_idx16 = nullptr;   // BYTE offset of the entry's B row in the panel (index * 16 * lpr); padding -> pad row
-    int *d_ioff = nullptr;            // nblk x rows_per_block: where a slot's index list starts in d_idx16 when lists are SHARED (null: at the
-                                      // slot's first packed entry, like the values): consecutive rows of a block with identical index lists --
-                                      // the dof rows of one mesh node -- keep one copy (share_index_lists)
+    int *d_ioff = nullptr;            // nblk x rows_per_block x {start of the slot's index list in d_idx16, shift in bytes to add to every
+                                      // offset of the list} when lists are SHARED (null: every row has its own list at its first packed entry):
+                                      // consecutive rows of a block whose lists are equal up to a constant shift keep one copy (share_index_lists)
     int64_t idx_len = 0;              // entries of d_idx16 (= stream_len without sharing)
     int64_t shared_rows = 0;          // rows whose index list is another row's
     int *d_col32 = nullptr;           // stream_len when `mixed`, else 1 element

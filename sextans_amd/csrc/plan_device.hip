@@ -237,42 +237,63 @@ __global__ __launch_bounds__(256) void plan_emit(const int *__restrict__ rp, con
     }
 }
 
-// ---- index-list sharing: consecutive rows of a block whose 16-bit index lists are identical (the dof rows of one mesh node: same
-// columns, hence the same dictionary ranks) keep ONE copy of the list.  The values stay per row; the index stream shrinks from 2 bytes
-// per non-zero to 2 / dof, i.e. the packed form from 6 to 4.67 bytes per non-zero for a 3-dof matrix -- the LDS-panel kernels are within
-// 20-25 % of the achievable HBM bandwidth, the A stream is 60 % of what they move.
-// one wavefront per (block, slot): is this slot's list the previous slot's?
-__global__ __launch_bounds__(256) void share_detect(long long nslots, int RB, const int2 *__restrict__ slot_info, const unsigned short *__restrict__ idx16,
-                                                    int *__restrict__ same, int *__restrict__ own_len) {
+// ---- index-list sharing: consecutive rows of a block whose 16-bit index lists are identical UP TO A CONSTANT SHIFT keep ONE copy of
+// the list.  Shift 0: the dof rows of one mesh node (same columns, hence the same dictionary ranks).  Shift > 0: the next node along a
+// grid line -- every column moves by the same number of dictionary rows, so every 16-bit byte offset moves by the same multiple of
+// the panel's row size; the kernel adds the slot's shift to its LDS base address once, the inner loop is unchanged.  Padding entries
+// (the +1.0f row behind the dictionary) are shifted with the rest, so the panel carries kPlanPadRows such rows and a chain of shared
+// lists never shifts further than that.  The values stay per row; the index stream shrinks from 2 bytes per non-zero to 2 / (rows per
+// list): the packed form from 6 to ~4.2 bytes per non-zero on grid-ordered matrices, 4.67 on renumbered 3-dof ones -- the LDS-panel
+// kernels run within 20-25 % of the achievable HBM bandwidth and the A stream is 60 % of what they move.
+// one wavefront per (block, slot): is this slot's list the previous slot's, shifted by `step` bytes?
+__global__ __launch_bounds__(256) void share_detect(long long nslots, int RB, unsigned pad_off, unsigned row_bytes, const int2 *__restrict__ slot_info,
+                                                    const unsigned short *__restrict__ idx16, int *__restrict__ cand, int *__restrict__ step) {
     const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= nslots) return;
     const int2 me = slot_info[i];
     bool eq = false;
+    int d = 0;
     if ((i % RB) != 0 && me.y > 0) {
         const int2 pr = slot_info[i - 1];
         if (pr.y == me.y) {
+            d = (int)idx16[me.x] - (int)idx16[pr.x];             // (entry 0 is never padding: rows are padded at their end)
             bool diff = false;
-            for (int e = lane; e < me.y; e += 64) diff |= idx16[(long long)me.x + e] != idx16[(long long)pr.x + e];
-            eq = __ballot(diff) == 0ull;
+            for (int e = lane; e < me.y; e += 64) {
+                const unsigned a = idx16[(long long)me.x + e], b = idx16[(long long)pr.x + e];
+                diff |= (a == pad_off || b == pad_off) ? a != b : (int)a - (int)b != d;
+            }
+            eq = __ballot(diff) == 0ull && d >= 0 && (unsigned)d % row_bytes == 0u;
         }
     }
-    if (lane == 0) { same[i] = eq ? 1 : 0; own_len[i] = eq ? 0 : me.y; }
+    if (lane == 0) { cand[i] = eq ? 1 : 0; step[i] = eq ? d : 0; }
 }
-__global__ __launch_bounds__(256) void share_roots(long long nslots, int RB, const int *__restrict__ same, const int *__restrict__ noff,
-                                                   int *__restrict__ ioff) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nslots) return;
-    long long r = i;
-    while (same[r]) --r;                              // (slot 0 of a block is never "same": the walk stays inside the block)
-    ioff[i] = noff[r];
+// one thread per block: chains of shared lists, total shift bounded by the spare +1.0f rows
+__global__ __launch_bounds__(256) void share_chain(int nblk, int RB, int max_shift, const int2 *__restrict__ slot_info, const int *__restrict__ cand,
+                                                   const int *__restrict__ step, int *__restrict__ root, int *__restrict__ shift,
+                                                   int *__restrict__ own_len) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblk) return;
+    long long r = (long long)b * RB;
+    int cum = 0;
+    for (int s = 0; s < RB; ++s) {
+        const long long i = (long long)b * RB + s;
+        if (s > 0 && cand[i] && cum + step[i] <= max_shift) { cum += step[i]; }
+        else { r = i; cum = 0; }
+        root[i] = (int)(r - (long long)b * RB);
+        shift[i] = cum;
+        own_len[i] = r == i ? slot_info[i].y : 0;
+    }
 }
-__global__ __launch_bounds__(256) void share_compact(long long nslots, const int2 *__restrict__ slot_info, const int *__restrict__ same,
-                                                     const int *__restrict__ noff, const unsigned short *__restrict__ idx16,
-                                                     unsigned short *__restrict__ out) {
+__global__ __launch_bounds__(256) void share_compact(long long nslots, int RB, const int2 *__restrict__ slot_info, const int *__restrict__ root,
+                                                     const int *__restrict__ shift, const int *__restrict__ noff,
+                                                     const unsigned short *__restrict__ idx16, unsigned short *__restrict__ out, int2 *__restrict__ ioff) {
     const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (i >= nslots || same[i]) return;
+    if (i >= nslots) return;
+    const long long ri = i / RB * RB + root[i];
+    if (lane == 0) ioff[i] = make_int2(noff[ri], shift[i]);
+    if (ri != i) return;
     const int2 me = slot_info[i];
     for (int e = lane; e < me.y; e += 64) out[(long long)noff[i] + e] = idx16[(long long)me.x + e];
 }
@@ -467,15 +488,20 @@ int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, cons
     PD_HIP(hipGetLastError());
     PD_HIP(hipDeviceSynchronize());
     out.idx_len = out.stream_len;
-    if (share_index_lists && !out.mixed && nblk > 0) {
+    if (share_index_lists && !out.mixed && nblk > 0 && lpr == 4) {
         const long long nslots = (long long)nblk * RB;
-        int *d_same = nullptr, *d_len = nullptr, *d_noff = nullptr;
-        PD_HIP(tmp.alloc(&d_same, (size_t)nslots));
+        int *d_cand = nullptr, *d_step = nullptr, *d_root = nullptr, *d_shift = nullptr, *d_len = nullptr, *d_noff = nullptr;
+        PD_HIP(tmp.alloc(&d_cand, (size_t)nslots));
+        PD_HIP(tmp.alloc(&d_step, (size_t)nslots));
+        PD_HIP(tmp.alloc(&d_root, (size_t)nslots));
+        PD_HIP(tmp.alloc(&d_shift, (size_t)nslots));
         PD_HIP(tmp.alloc(&d_len, (size_t)nslots + 1));
         PD_HIP(tmp.alloc(&d_noff, (size_t)nslots + 1));
         PD_HIP(hipMemsetAsync(d_len + nslots, 0, sizeof(int), nullptr));
-        hipLaunchKernelGGL(share_detect, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, nullptr, nslots, RB, (const int2 *)out.d_slot_info,
-                           out.d_idx16, d_same, d_len);
+        hipLaunchKernelGGL(share_detect, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, nullptr, nslots, RB, pad_off, row_bytes,
+                           (const int2 *)out.d_slot_info, out.d_idx16, d_cand, d_step);
+        hipLaunchKernelGGL(share_chain, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, nullptr, (int)nblk, RB,
+                           (int)((kPlanPadRows - 1) * row_bytes), (const int2 *)out.d_slot_info, d_cand, d_step, d_root, d_shift, d_len);
         void *scan_tmp = nullptr;
         size_t bytes = 0;
         PD_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, d_len, d_noff, (int)(nslots + 1), nullptr));
@@ -486,19 +512,16 @@ int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, cons
         if ((long long)kept * 10 <= (long long)total * 9) {   // at least a tenth of the index stream goes: worth one more table
             unsigned short *nidx = nullptr;
             PD_HIP(hipMalloc((void **)&nidx, sizeof(unsigned short) * ((size_t)kept + kPlanTailPad)));
-            hipError_t e = hipMalloc((void **)&out.d_ioff, sizeof(int) * (size_t)nslots);
+            hipError_t e = hipMalloc((void **)&out.d_ioff, sizeof(int2) * (size_t)nslots);
             if (e != hipSuccess) { (void)hipFree(nidx); PD_HIP(e); }
             PD_HIP(hipMemsetAsync(nidx, 0, sizeof(unsigned short) * ((size_t)kept + kPlanTailPad), nullptr));
-            hipLaunchKernelGGL(share_compact, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, nullptr, nslots, (const int2 *)out.d_slot_info,
-                               d_same, d_noff, out.d_idx16, nidx);
-            hipLaunchKernelGGL(share_roots, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, nullptr, nslots, RB, d_same, d_noff, out.d_ioff);
+            hipLaunchKernelGGL(share_compact, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, nullptr, nslots, RB, (const int2 *)out.d_slot_info,
+                               d_root, d_shift, d_noff, out.d_idx16, nidx, (int2 *)out.d_ioff);
             e = hipDeviceSynchronize();
             if (e != hipSuccess) { (void)hipFree(nidx); PD_HIP(e); }
             (void)hipFree(out.d_idx16);
             out.d_idx16 = nidx;
             out.idx_len = (int64_t)kept + kPlanTailPad;
-            int h_shared = 0;   // rows sharing = slots with same = 1: total padded entries - kept, as a row count it is read back by the engine if needed
-            (void)h_shared;
         }
     }
     return 0;

@@ -232,8 +232,9 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
     const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout,
     int64_t ldc, int ntiles, int nblk, float alpha, float beta, int use_xcd_remap, int panel_floats,
-    long long *dbg, int blk_begin, int row_base, const unsigned char *__restrict__ skip, const int *__restrict__ slot_ioff) {
-    // slot_ioff (may be null): start of the slot's index list in p_idx16 when identical lists of consecutive rows are stored once.
+    long long *dbg, int blk_begin, int row_base, const unsigned char *__restrict__ skip, const int2 *__restrict__ slot_ioff, int pad_rows) {
+    // slot_ioff (may be null): {start of the slot's index list in p_idx16, shift in bytes added to every offset} when lists of consecutive
+    // rows that are equal up to a shift are stored once; pad_rows: +1.0f rows at the end of the panel (1, or kPlanPadRows with shared lists).
     // Blocks [blk_begin, blk_begin + nblk) of the plan are processed (row-range calls of the multi-GPU pipeline
     // cut at block boundaries); the C pointers address row `row_base` as their row 0.
     const long long t0 = dbg ? clock64() : 0;   // dbg: optional phase timing (engine option "phase_timing")
@@ -283,7 +284,8 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
     const float *bq = Bp + (int64_t)tile * panel_stride + 4 * q;
     const int len = si.y;
     const int64_t off = si.x;
-    const int64_t offi = slot_ioff ? (int64_t)slot_ioff[(int64_t)blk * RB + slot] : off;
+    const int2 io2 = slot_ioff ? slot_ioff[(int64_t)blk * RB + slot] : make_int2(si.x, 0);
+    const int64_t offi = io2.x;
 
     // this lane's 4 entries of a batch: indices (unpacked to int) and values
     auto fetch = [&](int pos, int (&oi)[4], float (&ov)[4]) {
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
         for (int u = 0; u < MAXD_; ++u)
             *reinterpret_cast<f32x4 *>(panel + max(min(slot + min(u * RB, dict_stride - RB), nu - 1), 0) * NT + 4 * q) =
                 bv[u];
-        if (tid < NT) panel[panel_floats - NT + tid] = 1.0f;   // the row padding entries (value -0.0f) point at
+        for (int i = tid; i < pad_rows * NT; i += kBlock) panel[panel_floats - pad_rows * NT + i] = 1.0f;   // the rows padding entries (value -0.0f) point at
         __syncthreads();
     } else if (use_dict) {
         // Stage the block's distinct B rows: slot s copies dictionary entries s, s+RB, ... (indices were
@@ -376,13 +378,13 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
                     *reinterpret_cast<f32x4 *>(
                         panel + max(min(slot + min((h0 + u) * RB, dict_stride - RB), nu - 1), 0) * NT + 4 * q) = v[u];
         }
-        if (tid < NT) panel[panel_floats - NT + tid] = 1.0f;   // the row padding entries (value -0.0f) point at
+        for (int i = tid; i < pad_rows * NT; i += kBlock) panel[panel_floats - pad_rows * NT + i] = 1.0f;   // the rows padding entries (value -0.0f) point at
         __syncthreads();
     }
 
     const long long t2 = dbg ? clock64() : 0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float *pq = panel + 4 * q;
+    const float *pq = reinterpret_cast<const float *>(reinterpret_cast<const char *>(panel + 4 * q) + io2.y);
 
 // One sub-batch = 8 consecutive entries starting at entry `base` of the current batch: broadcast the
 // entries held by lane (k/4) of the row group, issue all B-row reads (BROW: LDS panel or global

@@ -23,7 +23,8 @@
 namespace sx {
 
 constexpr int kWideMaxDict = 576;                                // dictionary capacity of the plan at 4 lanes per row (9 * 64)
-constexpr int kWideHalfBytes = (kWideMaxDict + 1) * 64;          // one half panel: 576 B rows of 64 bytes + the +1.0f row
+constexpr int kWidePadRows = 16;                                 // +1.0f rows behind the dictionary (= kPlanPadRows of plan_device.h)
+constexpr int kWideHalfBytes = (kWideMaxDict + kWidePadRows) * 64;   // one half panel: 576 B rows of 64 bytes + the +1.0f rows
 
 template <int G>
 __device__ __forceinline__ int quad_bcast(int x) {               // value of lane G of the 4-lane row group
@@ -130,9 +131,10 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
     const int *__restrict__ blk_row, const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
     const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc,
     int nsuper, int tpw, int nblk, float alpha, float beta, int use_xcd_remap, int pad_row, int blk_begin, int row_base,
-    const unsigned char *__restrict__ skip, long long *dbg, const int *__restrict__ slot_row, const int *__restrict__ slot_ioff) {
-    // slot_ioff (may be null): where a slot's 16-bit index list starts in p_idx16 when consecutive rows with identical lists share one
-    // copy (plan_device.hip: share_index_lists); null = at the slot's first packed entry, like its values.
+    const unsigned char *__restrict__ skip, long long *dbg, const int *__restrict__ slot_row, const int2 *__restrict__ slot_ioff) {
+    // slot_ioff (may be null): {where a slot's 16-bit index list starts in p_idx16, shift in bytes to add to every offset of the list}
+    // when consecutive rows whose lists are equal up to a constant shift share one copy (plan_device.hip: share_index_lists); null =
+    // own list at the slot's first packed entry, like its values.  The shift goes into this lane's LDS base address once.
     static_assert(!CROW || (H == 1 && !BCOL), "the block-major C staging exists for 16-column tiles on repacked panels");
     long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, w0 = 0;
     if constexpr (TIMED) { t0 = clock64(); w0 = wall_clock64(); }
@@ -160,7 +162,8 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
     const int row1 = blk_row[blk + 1];
     const int nu = dict_cnt[blk];
     const int2 si = slot_info[(int64_t)blk * RB + slot];
-    const int io = slot_ioff ? slot_ioff[(int64_t)blk * RB + slot] : si.x;
+    const int2 io2 = slot_ioff ? slot_ioff[(int64_t)blk * RB + slot] : make_int2(si.x, 0);
+    const int io = io2.x;
     unsigned boff[MAXD];                      // float offset of "my" dictionary rows inside a K x 16 panel (+ my 4 columns)
     {
         const int *bd = blk_dict + (int64_t)blk * dict_stride + slot;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
     const int myrow = slot_row ? slot_row[(int64_t)blk * RB + slot] : min(row0 + slot, row1 - 1);
     const unsigned coff = (unsigned)(myrow - row_base);
     const bool cwrite = row0 + slot < row1 && !(skip && skip[myrow]);
-    const char *pq = lds + 16 * q;
+    const char *pq = lds + 16 * q + io2.y;
 
     // B rows of a panel travel through registers: bv (16-byte loads from the repacked panels) or bs (column-major B:
     // four 4-byte loads per row and lane).  `first`: plain loads the compiler tracks (preheader); otherwise the asm
@@ -232,10 +235,9 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
             for (int h = 0; h < H; ++h)
                 if (u * RB + slot < nu)
                     glds16(Bp + (int64_t)(st * H + h) * panel_stride + boff[u], lds + h * kWideHalfBytes + (u * RB + wave * 16) * 64);
-        if (tid < 16 * H) {
-            const int h = tid / 16;
-            *reinterpret_cast<float *>(lds + h * kWideHalfBytes + pad_row * 64 + 4 * (tid % 16)) = 1.0f;
-        }
+        // the +1.0f rows the padding entries (value -0.0f) address: kWidePadRows of them, a shifted shared list points further in
+#pragma unroll
+        for (int h = 0; h < H; ++h) *reinterpret_cast<float *>(lds + h * kWideHalfBytes + pad_row * 64 + 4 * tid) = 1.0f;   // 256 threads = 16 rows
     };
     constexpr bool DMA = (H == 1) && !BCOL;   // (column-major staging, BCOL, goes through registers: small matrices with short rows)
     auto store_panel = [&]() {                // registers -> LDS panel (+ the +1.0f row the padding entries point at)
@@ -245,10 +247,9 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
             for (int h = 0; h < H; ++h)   // entries past the dictionary rewrite its last row
                 *reinterpret_cast<f32x4 *>(lds + h * kWideHalfBytes + max(min(slot + min(u * RB, dict_stride - RB), nu - 1), 0) * 64 +
                                            16 * q) = BCOL ? f32x4{bs[u][h][0], bs[u][h][1], bs[u][h][2], bs[u][h][3]} : bv[u][h];
-        if (tid < 16 * H) {
-            const int h = tid / 16;
-            *reinterpret_cast<float *>(lds + h * kWideHalfBytes + pad_row * 64 + 4 * (tid % 16)) = 1.0f;
-        }
+        // the +1.0f rows the padding entries (value -0.0f) address: kWidePadRows of them, a shifted shared list points further in
+#pragma unroll
+        for (int h = 0; h < H; ++h) *reinterpret_cast<float *>(lds + h * kWideHalfBytes + pad_row * 64 + 4 * tid) = 1.0f;   // 256 threads = 16 rows
     };
 
     // ---- the row's entries: the first NB batches (96 entries) are loaded ONCE per block and stay in registers for every
