@@ -179,7 +179,8 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
         if (h->opt_phase_timing && h->d_dbg && h->opt_exact) {   // diagnostic instantiations: the forms the dispatcher uses most
             if (small_dict && nb == 3 && h->opt_small_v2 != 0) return go(sx::spmm_csr_panel_v2<H, 3, true, true, true, 5>);
             if (bcol_ld > 0) return go(sx::spmm_csr_panel_v2<H, 2, true, true, true>);
-            if (nb == 6) return go(sx::spmm_csr_panel_v2<H, 6, true, false, true>);
+            if (nb == 6 && mode != 2 && !small_panel) return go(sx::spmm_csr_panel_v2<H, 6, true, false, true>);
+            if (nb == 2 && mode != 2 && small_panel) return go(sx::spmm_csr_panel_v2<H, 2, true, false, true, 5>);
         }
         if (small_dict && h->opt_small_v2 != 0) {
             if (nb == 3) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 3, true, true, false, 5>) : go(sx::spmm_csr_panel_v2<H, 3, false, true, false, 5>);

@@ -15,7 +15,10 @@ if sys.argv[1] == "--child":
         dims = [int(x) for x in sys.argv[3].split("x")]
         M = K = dims[0] * dims[1] * dims[2] * dims[3]
         p = api.gen_fem3d_device(0, *dims, 3)
-    e = api.Engine(0); e.set_matrix_csr_device(M, K, p[3], *p[:3])
+    e = api.Engine(0)
+    for kv in [x for x in os.environ.get('SX_AB_OPTS', '').split(',') if x]:
+        e.set_option(kv.split('=')[0], int(kv.split('=')[1]))
+    e.set_matrix_csr_device(M, K, p[3], *p[:3])
     st = torch.cuda.current_stream().cuda_stream
     res = []
     for N in Ns:
