@@ -176,7 +176,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     } else {
         // small matrices staged from column-major B: dictionary capacity from the plan (5 x 64 covers nasa4704's 300)
         const bool small_dict = bcol_ld > 0 && P.plan_max_dict <= 5 * 64;
-        if (h->opt_phase_timing && h->d_dbg && h->opt_exact) {   // diagnostic instantiations: the forms the dispatcher uses most
+        if (h->opt_phase_timing && h->d_dbg && h->opt_exact && P.plan_sets == 1) {   // diagnostic instantiations: the forms the dispatcher uses most
             if (small_dict && nb == 3 && h->opt_small_v2 != 0) return go(sx::spmm_csr_panel_v2<H, 3, true, true, true, 5>);
             if (bcol_ld > 0) return go(sx::spmm_csr_panel_v2<H, 2, true, true, true>);
             if (nb == 6 && mode != 2 && !small_panel) return go(sx::spmm_csr_panel_v2<H, 6, true, false, true>);
@@ -191,6 +191,10 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
             return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, true, false, 9, false, true>) : go(sx::spmm_csr_panel_v2<H, 6, false, true, false, 9, false, true>);
         }
         if (bcol_ld > 0) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, true>) : go(sx::spmm_csr_panel_v2<H, 2, false, true>);
+        if (P.plan_sets == 2) {   // two row sets per block (short-row clustered plans: every row has <= 32 entries = 2 register-resident batches)
+            if (mode == 2) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false, false, 9, true, false, 2>) : go(sx::spmm_csr_panel_v2<H, 2, false, false, false, 9, true, false, 2>);
+            return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false, false, 9, false, false, 2>) : go(sx::spmm_csr_panel_v2<H, 2, false, false, false, 9, false, false, 2>);
+        }
         if (small_panel && mode == 2) {
             if (nb >= 3) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 3, true, false, false, 5, true>) : go(sx::spmm_csr_panel_v2<H, 3, false, false, false, 5, true>);
             return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false, false, 5, true>) : go(sx::spmm_csr_panel_v2<H, 2, false, false, false, 5, true>);
@@ -316,6 +320,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "pipeline_tiles")) return &h->opt_pipeline_tiles;
     if (!strcmp(key, "cluster_top")) return &h->opt_cluster_top;
     if (!strcmp(key, "small_panel")) return &h->opt_small_panel;
+    if (!strcmp(key, "row_sets")) return &h->opt_row_sets;
     if (!strcmp(key, "relabel_columns")) return &h->opt_relabel_columns;
     if (!strcmp(key, "refine_sweeps")) return &h->opt_refine_sweeps;
     if (!strcmp(key, "share_index")) return &h->opt_share_index;
@@ -367,7 +372,7 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
         (void)hipSetDevice(h->device);
         free_window(h);   // the stream is built for one (rows per wavefront, window) pair
     }
-    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_top || slot == &h->opt_small_panel || slot == &h->opt_relabel_columns || slot == &h->opt_refine_sweeps || slot == &h->opt_refine_rows || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
+    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_top || slot == &h->opt_small_panel || slot == &h->opt_row_sets || slot == &h->opt_relabel_columns || slot == &h->opt_refine_sweeps || slot == &h->opt_refine_rows || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
         (void)hipSetDevice(h->device);   // the clustered-order plan is (re)considered under the new setting
         free_cluster_plan(h);
     }
@@ -561,6 +566,7 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "col_range_lo")) *value = (double)h->col_lo;
     else if (!strcmp(key, "col_range_hi")) *value = (double)h->col_hi;
     else if (!strcmp(key, "colwise")) *value = (double)h->colwise_state;
+    else if (!strcmp(key, "row_sets")) *value = (double)(h->cluster_state > 0 ? h->psc.plan_sets : h->ps.plan_sets);
     else if (!strcmp(key, "row_coherence")) *value = h->row_coherence;
     else if (!strcmp(key, "panel_blocks_clustered")) *value = (double)h->psc.plan_nblk;
     else if (!strcmp(key, "device_bytes")) *value = (double)device_bytes(h);

@@ -49,7 +49,7 @@ void free_plan(sextans_engine *h) {   // every packed form of the current main m
 int64_t device_bytes(const sextans_engine *h) {
     auto plan_bytes = [](const sextans_engine::PanelState &p) -> int64_t {
         if (!p.plan_built || !p.plan_lpr) return 0;
-        const int64_t rb = sx::kBlock / p.plan_lpr;
+        const int64_t rb = (int64_t)(sx::kBlock / p.plan_lpr) * p.plan_sets;
         return (int64_t)p.plan_nblk * (4 * (2 + p.plan_dict_stride + 2 * rb)) +
                (p.stream_released ? 0 : p.plan_stream_len * 4 + p.plan_idx_len * 2 + (p.d_ioff ? (int64_t)p.plan_nblk * rb * 8 : 0) +
                                             (p.plan_mixed ? p.plan_stream_len * 4 : 4));
@@ -62,7 +62,7 @@ int64_t device_bytes(const sextans_engine *h) {
     b += ((int64_t)h->split_nv * 8 + (int64_t)h->nhub * 8) * 2 + (int64_t)h->nchain * 24;
     b += plan_bytes(h->ps) + plan_bytes(h->psc);
     for (const auto &p : h->plan_stash) b += plan_bytes(p);
-    if (h->d_slot_row) b += (int64_t)h->psc.plan_nblk * 64 * 4;
+    if (h->d_slot_row) b += (int64_t)h->psc.plan_nblk * 64 * h->psc.plan_sets * 4;
     if (h->d_colpos) b += (int64_t)h->K * 4;
     if (h->d_wstream) b += h->win_padded * 8 + (int64_t)h->win_nwaves * 4;
     if (h->d_dense_Af) b += (int64_t)h->dense_mb * h->dense_W * (2048 + 4);
@@ -181,6 +181,7 @@ int64_t plan_key(const sextans_engine *h) { return h->opt_min_reuse_x100 * 10000
 // DevicePlan -> PanelState (the arrays change owner)
 void adopt_device_plan(sextans_engine::PanelState &c, sx::DevicePlan &dp, const sextans_engine *h, int lpr, int cap) {
     c.plan_lpr = lpr;
+    c.plan_sets = dp.sets;
     c.plan_min_reuse = plan_key(h);
     c.plan_nblk = dp.nblk;
     c.plan_dict_stride = dp.dict_stride;
@@ -351,6 +352,12 @@ int cluster_grid(sextans_engine *h) {   // 0 = in use, 1 = declined
     // natural order (12-row runs gave away half of the gain at N = 128, where C is half of the traffic); the plan builder starts a
     // block at every brick (`cut`), so blocks and bricks coincide.
     int run_rows = 16, b2 = gs.s3 > 0 ? 2 : 4, b3 = gs.s3 > 0 ? 2 : 1;
+    // Short rows (every row <= 32 entries = 2 register-resident batches; 3 batches x 2 sets spill at 128 registers): bricks of 128 rows -- 16 x 4 x 2 (3-D), 16 x 8 (2-D) -- as blocks of TWO 64-slot row
+    // sets on one dictionary (spmm_panel_v2.h: SETS): 3.4 instead of 4.5 dictionary rows per matrix row on a 27-point mesh, and block
+    // meta, prologue round trips and panel are paid once per 128 rows.  Falls back to 64-row bricks when a dictionary outgrows the panel.
+    // (measured same-box, tools/exp_r04i.sh: 27-point 1-dof -3.5 % at N = 16, -4 % at N = 128; 2-D 9-point -2 .. -7 % at N = 16 but +3 .. +8 %
+    // at N >= 32, where the tile loop re-reads both sets' panels: automatic for 3-D grids only, row_sets = 3 forces it for 2-D grids too)
+    int sets = (h->opt_cluster_shape == 0 && h->M > 0 && h->ps.plan_max_row <= 32 && (h->opt_row_sets >= 3 || (h->opt_row_sets == 2 && gs.s3 > 0))) ? 2 : 1;
     if (h->opt_cluster_shape > 0) {   // measurement switch (SEXTANS_DEBUG_OPTIONS): run_rows * 10000 + b2 * 100 + b3, validated by set_option
         run_rows = (int)(h->opt_cluster_shape / 10000); b2 = (int)(h->opt_cluster_shape / 100 % 100); b3 = (int)(h->opt_cluster_shape % 100);
         if (run_rows < 1 || b2 < 1 || b3 < 1) return 1;
@@ -361,24 +368,34 @@ int cluster_grid(sextans_engine *h) {   // 0 = in use, 1 = declined
     float *pv = nullptr;
     sx::DevicePlan dp;
     auto drop = [&]() { (void)hipFree(d_perm); (void)hipFree(d_cut); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv); sx::free_device_plan(dp); return 1; };
-    if (sx::build_brick_order_device(h->M, gs, run_rows, b2, b3, (int)h->opt_cluster_group, &d_perm, &d_cut, err)) return drop();
-    if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_perm, &prp, &pci, &pv, err)) return drop();
     const int lpr = 4, RB = sx::kBlock / lpr, cap = kPanelFloats / (4 * lpr);
     const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;
-    int brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, min_reuse, dp, err, d_cut, h->opt_share_index != 0);
-    int cap_used = cap;
-    if (brc == 0 && small_panel_fits(h, dp)) {   // short rows, small dictionaries: packed again for a 320-row panel (same blocks, less LDS)
+    int brc = 1, cap_used = cap;
+    for (; sets >= 1; --sets) {
+        (void)hipFree(d_perm); (void)hipFree(d_cut); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
+        d_perm = prp = pci = nullptr; d_cut = nullptr; pv = nullptr;
         sx::free_device_plan(dp);
-        cap_used = 5 * RB;
-        brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap_used, min_reuse, dp, err, d_cut, h->opt_share_index != 0);
+        const int l2 = sets == 2 ? (gs.s3 > 0 ? 4 : 8) : b2, l3 = sets == 2 ? (gs.s3 > 0 ? 2 : 1) : b3;
+        if (sx::build_brick_order_device(h->M, gs, run_rows, l2, l3, (int)h->opt_cluster_group, &d_perm, &d_cut, err)) return drop();
+        if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_perm, &prp, &pci, &pv, err)) return drop();
+        cap_used = cap;
+        brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, min_reuse, dp, err, d_cut, h->opt_share_index != 0, sets);
+        if (sets == 2 && (brc != 0 || dp.mixed || dp.max_dict > sx::kWideMaxDict || dp.dict_stride > 9 * RB)) continue;   // 128-row bricks do not fit the panel
+        if (brc == 0 && sets == 1 && small_panel_fits(h, dp)) {   // short rows, small dictionaries: packed again for a 320-row panel (same blocks, less LDS)
+            sx::free_device_plan(dp);
+            cap_used = 5 * RB;
+            brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap_used, min_reuse, dp, err, d_cut, h->opt_share_index != 0);
+        }
+        break;
     }
+    if (sets < 1) sets = 1;
     (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv); (void)hipFree(d_cut);
     prp = pci = nullptr; pv = nullptr; d_cut = nullptr;
     if (brc != 0) return drop();
     h->cluster_total_dict = dp.total_dict;
     const bool gain = (double)dp.total_dict <= 0.85 * (double)h->plan_total_dict;
     if (dp.mixed || dp.dict_stride > 9 * RB || dp.max_dict > sx::kWideMaxDict || (h->opt_row_cluster < 0 && !gain)) return drop();
-    if (sx::build_slot_rows_device(dp.nblk, RB, dp.d_blk_row, d_perm, &h->d_slot_row, err)) return drop();
+    if (sx::build_slot_rows_device(dp.nblk, RB * dp.sets, dp.d_blk_row, d_perm, &h->d_slot_row, err)) return drop();
     (void)hipFree(d_perm);
     adopt_device_plan(h->psc, dp, h, lpr, cap_used);
     h->psc.plan_panel_frac = h->ps.plan_panel_frac;

@@ -67,6 +67,7 @@ struct sextans_engine {
     // callers that alternate between N classes (N = 8 -> 2 lanes, N >= 16 -> 4) do not rebuild on every switch.
     struct PanelState {
         int plan_lpr = 0;               // 0 = no plan
+        int plan_sets = 1;              // row slots per block = plan_sets * (256 / plan_lpr): 2 for the short-row clustered plan (spmm_panel_v2.h: SETS)
         int64_t plan_min_reuse = -1;
         // d_dict_ptr: entries per block dictionary; d_dict: dictionaries at stride plan_dict_stride;
         // d_row_off: {first packed entry, entries} per (block, slot)
@@ -208,6 +209,7 @@ struct sextans_engine {
     int64_t opt_cluster_group = 3;      // bricks are laid out in groups of g x g brick columns (A/B on the 4M-row FEM matrix: g = 3)
     int64_t opt_row_cluster = -1;       // clustered-order plan for spmm_csr_panel_v2 (ensure_cluster_plan): -1 auto, 0 never, 1 whenever one
                                         // can be built, 2 = graph clustering (reordered form) also where the grid bricks would apply
+    int64_t opt_row_sets = 2;           // clustered grid plan of a short-row matrix (rows <= 32 entries): 128-row bricks = two 64-slot row sets per block and panel; 2 = 3-D grids, 3 = 2-D grids too, 1 = never
     int64_t opt_pipeline_tiles = 0;     // N >= 32 on spmm_csr_panel_v2: 1 = the 16-column tiles run as two groups and the layout passes of the second
                                         // group go to the side stream under the first group's kernel.  Built and measured: the second
                                         // pass over the packed A stream costs more than the hidden repack saves (FEM 4M, N = 128: 3.94 -> 4.09 ms

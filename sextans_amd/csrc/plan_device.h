@@ -13,7 +13,7 @@ constexpr int kPlanPadRows = 16;      // +1.0f rows behind the dictionary in the
 constexpr int kPlanTailPad = 256;     // zero entries behind the last row (the kernels fetch up to 6 batches of 16 ahead)
 
 struct DevicePlan {                   // device arrays in exactly the form the LDS-panel kernels read
-    int lpr = 0, rows_per_block = 0;
+    int lpr = 0, rows_per_block = 0, sets = 1;   // rows_per_block = sets * (256 / lpr) row slots
     int nblk = 0;
     int *d_blk_row = nullptr;         // nblk + 1
     int *d_dict_cnt = nullptr;        // nblk: dictionary entries (0 = direct block)
@@ -44,6 +44,6 @@ int column_range_device(int64_t nnz, const int *d_ci, int *lo, int *hi, std::str
 void free_device_plan(DevicePlan &d);
 int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, const float *d_v, int lpr, int max_unique,
                             double min_reuse, DevicePlan &out, std::string &err, const unsigned char *d_cut = nullptr,
-                            bool share_index_lists = false);
+                            bool share_index_lists = false, int sets = 1);
 
 }  // namespace sx

@@ -170,30 +170,33 @@ __global__ __launch_bounds__(256) void plan_emit(const int *__restrict__ rp, con
                                                  const int *__restrict__ row_off, const int *__restrict__ blk_row,
                                                  const int *__restrict__ dict_cnt, int RB, int dstride, unsigned row_bytes,
                                                  unsigned pad_off, int *__restrict__ bdict, int *__restrict__ slot_info,
-                                                 unsigned short *__restrict__ idx16, int *__restrict__ col32, float *__restrict__ pval) {
+                                                 unsigned short *__restrict__ idx16, int *__restrict__ col32, float *__restrict__ pval, int sets) {
+    // sets: a block has sets * RB row slots (one dictionary; the kernel walks them RB at a time)
     __shared__ int keys[kHT], rankv[kHT];
     __shared__ int sorted[P];
     __shared__ int s_n;
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int r0 = blk_row[b], r1 = blk_row[b + 1], nu = dict_cnt[b];
-    const int lpr = 256 / RB, slot = tid / lpr, q = tid % lpr;
+    const int lpr = 256 / RB, q = tid % lpr;
     // per-slot row extents {first packed entry, entries}: dictionary rows are consumed in whole groups of 4 entries
     // (exact-safe padding), direct rows keep their true length; slots past the block's last row stay {0, 0}
-    if (q == 0) {
-        int2 si = make_int2(0, 0);
-        if (r0 + slot < r1) {
-            const int len = rp[r0 + slot + 1] - rp[r0 + slot];
-            si = make_int2(row_off[r0 + slot], nu > 0 ? (len + 3) & ~3 : len);
+    if (q == 0)
+        for (int slot = tid / lpr; slot < RB * sets; slot += RB) {
+            int2 si = make_int2(0, 0);
+            if (r0 + slot < r1) {
+                const int len = rp[r0 + slot + 1] - rp[r0 + slot];
+                si = make_int2(row_off[r0 + slot], nu > 0 ? (len + 3) & ~3 : len);
+            }
+            reinterpret_cast<int2 *>(slot_info)[(long long)b * RB * sets + slot] = si;
         }
-        reinterpret_cast<int2 *>(slot_info)[(long long)b * RB + slot] = si;
-    }
     if (nu == 0) {   // direct block: 32-bit columns, B rows gathered from global memory by the kernel
         for (int i = tid; i < dstride; i += 256) bdict[(long long)b * dstride + i] = 0;
-        if (r0 + slot < r1) {
-            const int row = r0 + slot, j0 = rp[row], len = rp[row + 1] - j0, o0 = row_off[row];
-            for (int e = q; e < len; e += lpr) { pval[o0 + e] = va[j0 + e]; col32[o0 + e] = ci[j0 + e]; }
-        }
+        for (int slot = tid / lpr; slot < RB * sets; slot += RB)
+            if (r0 + slot < r1) {
+                const int row = r0 + slot, j0 = rp[row], len = rp[row + 1] - j0, o0 = row_off[row];
+                for (int e = q; e < len; e += lpr) { pval[o0 + e] = va[j0 + e]; col32[o0 + e] = ci[j0 + e]; }
+            }
         return;
     }
     for (int i = tid; i < kHT; i += 256) keys[i] = kEmpty;
@@ -223,7 +226,8 @@ __global__ __launch_bounds__(256) void plan_emit(const int *__restrict__ rp, con
     for (int i = tid; i < dstride; i += 256) bdict[(long long)b * dstride + i] = sorted[min(i, nu - 1)];
     for (int i = tid; i < nu; i += 256) rankv[hs_find(keys, sorted[i])] = i;
     __syncthreads();
-    if (r0 + slot < r1) {
+    for (int slot = tid / lpr; slot < RB * sets; slot += RB) {
+        if (r0 + slot >= r1) break;
         const int row = r0 + slot, j0 = rp[row], len = rp[row + 1] - j0, o0 = row_off[row], plen = (len + 3) & ~3;
         for (int e = q; e < plen; e += lpr) {
             if (e < len) {
@@ -385,13 +389,16 @@ void free_device_plan(DevicePlan &d) {
 // 0 = built; 1 = not representable (padded stream exceeds 32-bit entry offsets): caller keeps the row-group kernel;
 // 2 = HIP error (err set)
 int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, const float *d_v, int lpr, int max_unique,
-                            double min_reuse, DevicePlan &out, std::string &err, const unsigned char *d_cut, bool share_index_lists) {
+                            double min_reuse, DevicePlan &out, std::string &err, const unsigned char *d_cut, bool share_index_lists, int sets) {
     (void)K;
     free_device_plan(out);
-    const int RB = 256 / lpr;
-    const int PR = kPlanPartBlocks * RB;
+    if (sets < 1 || (sets > 1 && lpr != 4)) { err = "row sets per block: 4 lanes per row only"; return 2; }
+    const int RB = 256 / lpr;           // row slots per set (= per workgroup pass)
+    const int RBS = RB * sets;          // row slots per block
+    const int PR = kPlanPartBlocks * RBS;
     const int nparts = M > 0 ? (M + PR - 1) / PR : 0;
-    out.rows_per_block = RB;
+    out.rows_per_block = RBS;
+    out.sets = sets;
     out.lpr = lpr;
     const unsigned row_bytes = 16u * (unsigned)lpr;
     const unsigned pad_off = (unsigned)max_unique * row_bytes;   // the +1.0f row sits right behind a full dictionary
@@ -434,7 +441,7 @@ int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, cons
     PD_HIP(tmp.alloc(&d_pb_cnt, (size_t)nparts * (size_t)PR));
     PD_HIP(tmp.alloc(&d_part_nblk, (size_t)nparts));
     PD_HIP(tmp.alloc(&d_part_blk_base, (size_t)nparts));
-    hipLaunchKernelGGL(plan_blocks, dim3((unsigned)nparts), dim3(256), 0, nullptr, d_rp, d_ci, M, PR, RB, max_unique, min_reuse,
+    hipLaunchKernelGGL(plan_blocks, dim3((unsigned)nparts), dim3(256), 0, nullptr, d_rp, d_ci, M, PR, RBS, max_unique, min_reuse,
                        d_pb_row, d_pb_cnt, d_part_nblk, d_cut);
     std::vector<int> h_nblk((size_t)nparts), h_bbase((size_t)nparts);
     PD_HIP(hipMemcpy(h_nblk.data(), d_part_nblk, sizeof(int) * (size_t)nparts, hipMemcpyDeviceToHost));
@@ -470,7 +477,7 @@ int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, cons
     const size_t stream = (size_t)total + kPlanTailPad;
     out.stream_len = (int64_t)stream;
     PD_HIP(hipMalloc((void **)&out.d_dict, sizeof(int) * (size_t)nblk * (size_t)dstride));
-    PD_HIP(hipMalloc((void **)&out.d_slot_info, sizeof(int) * (size_t)nblk * (size_t)RB * 2));
+    PD_HIP(hipMalloc((void **)&out.d_slot_info, sizeof(int) * (size_t)nblk * (size_t)RBS * 2));
     PD_HIP(hipMalloc((void **)&out.d_idx16, sizeof(unsigned short) * stream));
     PD_HIP(hipMalloc((void **)&out.d_val, sizeof(float) * stream));
     PD_HIP(hipMalloc((void **)&out.d_col32, sizeof(int) * (out.mixed ? stream : 1)));   // only direct blocks read it
@@ -480,7 +487,7 @@ int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, cons
     auto emit = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), 0, nullptr, d_rp, d_ci, d_v, d_row_off, out.d_blk_row,
                            out.d_dict_cnt, RB, dstride, row_bytes, pad_off, out.d_dict, out.d_slot_info, out.d_idx16,
-                           out.d_col32, out.d_val);
+                           out.d_col32, out.d_val, sets);
     };
     if (max_unique <= 512) emit(plan_emit<512>);
     else if (max_unique <= 1024) emit(plan_emit<1024>);
@@ -489,7 +496,7 @@ int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, cons
     PD_HIP(hipDeviceSynchronize());
     out.idx_len = out.stream_len;
     if (share_index_lists && !out.mixed && nblk > 0 && lpr == 4) {
-        const long long nslots = (long long)nblk * RB;
+        const long long nslots = (long long)nblk * RBS;
         int *d_cand = nullptr, *d_step = nullptr, *d_root = nullptr, *d_shift = nullptr, *d_len = nullptr, *d_noff = nullptr;
         PD_HIP(tmp.alloc(&d_cand, (size_t)nslots));
         PD_HIP(tmp.alloc(&d_step, (size_t)nslots));
@@ -498,9 +505,9 @@ int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, cons
         PD_HIP(tmp.alloc(&d_len, (size_t)nslots + 1));
         PD_HIP(tmp.alloc(&d_noff, (size_t)nslots + 1));
         PD_HIP(hipMemsetAsync(d_len + nslots, 0, sizeof(int), nullptr));
-        hipLaunchKernelGGL(share_detect, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, nullptr, nslots, RB, pad_off, row_bytes,
+        hipLaunchKernelGGL(share_detect, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, nullptr, nslots, RBS, pad_off, row_bytes,
                            (const int2 *)out.d_slot_info, out.d_idx16, d_cand, d_step);
-        hipLaunchKernelGGL(share_chain, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, nullptr, (int)nblk, RB,
+        hipLaunchKernelGGL(share_chain, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, nullptr, (int)nblk, RBS,
                            (int)((kPlanPadRows - 1) * row_bytes), (const int2 *)out.d_slot_info, d_cand, d_step, d_root, d_shift, d_len);
         void *scan_tmp = nullptr;
         size_t bytes = 0;
@@ -515,7 +522,7 @@ int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, cons
             hipError_t e = hipMalloc((void **)&out.d_ioff, sizeof(int2) * (size_t)nslots);
             if (e != hipSuccess) { (void)hipFree(nidx); PD_HIP(e); }
             PD_HIP(hipMemsetAsync(nidx, 0, sizeof(unsigned short) * ((size_t)kept + kPlanTailPad), nullptr));
-            hipLaunchKernelGGL(share_compact, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, nullptr, nslots, RB, (const int2 *)out.d_slot_info,
+            hipLaunchKernelGGL(share_compact, dim3((unsigned)((nslots + 3) / 4)), dim3(256), 0, nullptr, nslots, RBS, (const int2 *)out.d_slot_info,
                                d_root, d_shift, d_noff, out.d_idx16, nidx, (int2 *)out.d_ioff);
             e = hipDeviceSynchronize();
             if (e != hipSuccess) { (void)hipFree(nidx); PD_HIP(e); }

@@ -125,7 +125,11 @@ __device__ __forceinline__ void astore4(float *sbase, unsigned voff_bytes, const
 // of the permuted B panels).
 // BIG: 2 instead of 4 workgroups per CU = up to 256 registers per lane: the column-major staging (BCOL) of a matrix with long rows
 // keeps a panel AND 4 .. 6 batches of row entries in registers (it spills at 128), for launches too small to fill the chip anyway.
-template <int H, int NB, bool EXACT, bool BCOL, bool TIMED = false, int DCAP = 9, bool CROW = false, bool BIG = false>
+// SETS (round 4, short rows): a block has SETS * 64 row slots that share ONE dictionary / panel; the workgroup fetches the entries of
+// all its sets in the prologue and multiplies them set after set.  Block meta, the two dependent round trips of the prologue and the
+// panel are paid once per 128 rows, and a 16 x 4 x 2 brick of a 27-point mesh needs 3.4 dictionary rows per matrix row where a
+// 16 x 2 x 2 brick needs 4.5 (the panel copy is more than half of the bytes a short-row block moves through the L1).
+template <int H, int NB, bool EXACT, bool BCOL, bool TIMED = false, int DCAP = 9, bool CROW = false, bool BIG = false, int SETS = 1>
 __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_panel_v2(
     const int2 *__restrict__ slot_info, const unsigned short *__restrict__ p_idx16, const float *__restrict__ p_val,
     const int *__restrict__ blk_row, const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
@@ -136,10 +140,12 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
     // when consecutive rows whose lists are equal up to a constant shift share one copy (plan_device.hip: share_index_lists); null =
     // own list at the slot's first packed entry, like its values.  The shift goes into this lane's LDS base address once.
     static_assert(!CROW || (H == 1 && !BCOL), "the block-major C staging exists for 16-column tiles on repacked panels");
+    static_assert(SETS == 1 || (H == 1 && !BCOL && !TIMED && !BIG && NB <= 2), "several row sets per block: 16-column tiles on repacked panels, short rows");
     long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, w0 = 0;
     if constexpr (TIMED) { t0 = clock64(); w0 = wall_clock64(); }
     constexpr int LPR = 4;
-    constexpr int RB = kBlock / LPR;          // 64 rows per workgroup
+    constexpr int RB = kBlock / LPR;          // 64 row slots per set
+    constexpr int RBS = RB * SETS;            // row slots per block
     constexpr int NTT = 16 * H;               // columns per super tile
     constexpr int BATCH = 16;
     constexpr int MAXD = DCAP;                // dictionary capacity of this launch = MAXD * RB (<= 9 * RB, the plan's limit)
@@ -161,9 +167,12 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
     const int row0 = blk_row[blk];
     const int row1 = blk_row[blk + 1];
     const int nu = dict_cnt[blk];
-    const int2 si = slot_info[(int64_t)blk * RB + slot];
-    const int2 io2 = slot_ioff ? slot_ioff[(int64_t)blk * RB + slot] : make_int2(si.x, 0);
-    const int io = io2.x;
+    int2 si[SETS], io2[SETS];
+#pragma unroll
+    for (int t = 0; t < SETS; ++t) {
+        si[t] = slot_info[(int64_t)blk * RBS + t * RB + slot];
+        io2[t] = slot_ioff ? slot_ioff[(int64_t)blk * RBS + t * RB + slot] : make_int2(si[t].x, 0);
+    }
     unsigned boff[MAXD];                      // float offset of "my" dictionary rows inside a K x 16 panel (+ my 4 columns)
     {
         const int *bd = blk_dict + (int64_t)blk * dict_stride + slot;
@@ -173,7 +182,9 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
             boff[u] = BCOL ? (unsigned)col : (unsigned)col * 16u + 4u * (unsigned)q;
         }
     }
-    const int len = si.y;
+    int len[SETS];
+#pragma unroll
+    for (int t = 0; t < SETS; ++t) len[t] = si[t].y;
     if constexpr (TIMED) {   // first round trip done: block meta, row extents, dictionary indices
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(boff[0]), "+v"(boff[MAXD - 1]) : : "memory");
         t1 = clock64();
@@ -181,19 +192,28 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
     // Row stream: wave-uniform base (first entry of the wave's first row) + a 32-bit lane offset, so every fetch is one
     // `global_load saddr + voffset + immediate` without 64-bit vector address arithmetic.  Slots past the block's last
     // row ({0, 0}) fetch from the base (never consumed).  The stream is padded: over-reads stay in bounds.
-    const int wbase = __builtin_amdgcn_readfirstlane(si.x);
-    const int wbase_i = __builtin_amdgcn_readfirstlane(io);
+    // (several sets: one base -- the rows of a later set follow those of the first in the stream, and so do their index lists)
+    const int wbase = __builtin_amdgcn_readfirstlane(si[0].x);
+    const int wbase_i = __builtin_amdgcn_readfirstlane(io2[0].x);
     const float *pv = p_val + wbase;
     const unsigned short *pi = p_idx16 + wbase_i;
-    const unsigned loff = (len > 0 ? (unsigned)(si.x - wbase) : 0u) + 4u * (unsigned)q;
-    const unsigned loffi = (len > 0 ? (unsigned)(io - wbase_i) : 0u) + 4u * (unsigned)q;
+    unsigned loff[SETS], loffi[SETS];
     // C: this lane's row (clamped for the loads) and whether it is written
     // (slot_row: the plan walks the rows in clustered order -- row_cluster.hip -- and this table, at an address that depends on the
     // block number only, says which row of the matrix a slot is; without it blocks are runs of consecutive rows)
-    const int myrow = slot_row ? slot_row[(int64_t)blk * RB + slot] : min(row0 + slot, row1 - 1);
-    const unsigned coff = (unsigned)(myrow - row_base);
-    const bool cwrite = row0 + slot < row1 && !(skip && skip[myrow]);
-    const char *pq = lds + 16 * q + io2.y;
+    int myrow[SETS];
+    unsigned coff[SETS];
+    bool cwrite[SETS];
+    const char *pq[SETS];
+#pragma unroll
+    for (int t = 0; t < SETS; ++t) {
+        loff[t] = (len[t] > 0 ? (unsigned)(si[t].x - wbase) : 0u) + 4u * (unsigned)q;
+        loffi[t] = (len[t] > 0 ? (unsigned)(io2[t].x - wbase_i) : 0u) + 4u * (unsigned)q;
+        myrow[t] = slot_row ? slot_row[(int64_t)blk * RBS + t * RB + slot] : min(row0 + t * RB + slot, row1 - 1);
+        coff[t] = (unsigned)(myrow[t] - row_base);
+        cwrite[t] = row0 + t * RB + slot < row1 && !(skip && skip[myrow[t]]);
+        pq[t] = lds + 16 * q + io2[t].y;
+    }
 
     // B rows of a panel travel through registers: bv (16-byte loads from the repacked panels) or bs (column-major B:
     // four 4-byte loads per row and lane).  `first`: plain loads the compiler tracks (preheader); otherwise the asm
@@ -257,20 +277,22 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
     // that ARE in flight during it (C_in, next panel) are only waited for after it.  Longer rows continue from the
     // stream (L2) with plain loads.
     static_assert(NB >= 1 && NB <= 6, "register-resident batches");
-    f32x4 av[NB];
-    int ai[NB][4];
+    f32x4 av[SETS][NB];
+    int ai[SETS][NB][4];
     {
-        uint2 aw[NB];
+        uint2 aw[SETS][NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            // (unconditional, immediate offsets: all 2 * NB loads are in flight together; lanes whose row ends earlier
-            // over-read inside the padded stream and never multiply what they read.  NB is chosen per matrix from its
-            // mean row length so that short-row matrices do not multiply their A traffic.)
-            // (non-temporal loads of this read-once stream -- so that it would not push the B lines neighbouring blocks share out of L2 --
-            // were measured on the reordered form, where B is re-fetched 5x: kernel 744 -> 936 us.  Plain loads.)
-            av[b] = *reinterpret_cast<const f32x4 *>(pv + loff + b * BATCH);
-            aw[b] = *reinterpret_cast<const uint2 *>(pi + loffi + b * BATCH);
-        }
+        for (int t = 0; t < SETS; ++t)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                // (unconditional, immediate offsets: all 2 * NB loads are in flight together; lanes whose row ends earlier
+                // over-read inside the padded stream and never multiply what they read.  NB is chosen per matrix from its
+                // mean row length so that short-row matrices do not multiply their A traffic.)
+                // (non-temporal loads of this read-once stream -- so that it would not push the B lines neighbouring blocks share out of L2 --
+                // were measured on the reordered form, where B is re-fetched 5x: kernel 744 -> 936 us.  Plain loads.)
+                av[t][b] = *reinterpret_cast<const f32x4 *>(pv + loff[t] + b * BATCH);
+                aw[t][b] = *reinterpret_cast<const uint2 *>(pi + loffi[t] + b * BATCH);
+            }
         // All dictionary indices are waited for HERE, in one counted wait behind which the row loads above stay in flight.  Left to
         // itself the compiler waits for boff[1] after the first (conditional) panel request -- and after a control-flow join its
         // wait-count bookkeeping can only say vmcnt(0): the row entries and the first piece had to land before pieces 2..9 were even
@@ -284,32 +306,44 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
             asm volatile("" : "+v"(boff[0]), "+v"(boff[1]), "+v"(boff[2]), "+v"(boff[3]), "+v"(boff[4]));
         if constexpr (DMA) dma_panel(st_begin); else load_panel(st_begin, true);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            ai[b][0] = (int)(aw[b].x & 0xffffu); ai[b][1] = (int)(aw[b].x >> 16);
-            ai[b][2] = (int)(aw[b].y & 0xffffu); ai[b][3] = (int)(aw[b].y >> 16);
-        }
+        for (int t = 0; t < SETS; ++t)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                ai[t][b][0] = (int)(aw[t][b].x & 0xffffu); ai[t][b][1] = (int)(aw[t][b].x >> 16);
+                ai[t][b][2] = (int)(aw[t][b].y & 0xffffu); ai[t][b][3] = (int)(aw[t][b].y >> 16);
+            }
     }
     // C: column (col0 + 16h + 4q + j) of this lane = uniform column base (col0 + 16h + j) + a per-lane byte offset
-    const unsigned cvoff_in = (4u * (unsigned)q * (unsigned)ldc_in + coff) * 4u;
-    const unsigned cvoff_out = (4u * (unsigned)q * (unsigned)ldc + coff) * 4u;
-    const unsigned cvoff_row = ((unsigned)myrow * 16u + 4u * (unsigned)q) * 4u;   // CROW: my 16 bytes of the tile (row-major staging)
+    unsigned cvoff_in[SETS], cvoff_out[SETS], cvoff_row[SETS];
+#pragma unroll
+    for (int t = 0; t < SETS; ++t) {
+        cvoff_in[t] = (4u * (unsigned)q * (unsigned)ldc_in + coff[t]) * 4u;
+        cvoff_out[t] = (4u * (unsigned)q * (unsigned)ldc + coff[t]) * 4u;
+        cvoff_row[t] = ((unsigned)myrow[t] * 16u + 4u * (unsigned)q) * 4u;   // CROW: my 16 bytes of the tile (row-major staging)
+    }
     // C_in of the FIRST super tile is requested here, in the same round trip as the panel and the row entries (for a
     // matrix of a few thousand rows the whole kernel is three round trips: one more is 15 % of its time)
-    float cin[H][4];
-    f32x4 cinv = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (CROW) {
-        aload4(cinv, Cin + (int64_t)st_begin * ldc_in, cvoff_row);
-    } else {
+    float cin[SETS][H][4];
+    f32x4 cinv[SETS];
 #pragma unroll
-        for (int h = 0; h < H; ++h)
+    for (int t = 0; t < SETS; ++t) {
+        cinv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (CROW) {
+            aload4(cinv[t], Cin + (int64_t)st_begin * ldc_in, cvoff_row[t]);
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) aload1(cin[h][j], Cin + ((int64_t)st_begin * NTT + h * 16 + j) * ldc_in, cvoff_in);
+            for (int h = 0; h < H; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) aload1(cin[t][h][j], Cin + ((int64_t)st_begin * NTT + h * 16 + j) * ldc_in, cvoff_in[t]);
+        }
     }
     if constexpr (!DMA) store_panel();
     // (a use of the row registers HERE makes the compiler wait for their loads before the loop; otherwise its wait
     // bookkeeping carries them into the loop as "possibly pending" and every batch waits for younger loads)
 #pragma unroll
-    for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(av[b]));
+    for (int t = 0; t < SETS; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(av[t][b]));
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing the compiler tracks is outstanding from here on
     if constexpr (TIMED) t2 = clock64();                // second round trip done: row entries, first panel (and C_in)
@@ -328,66 +362,80 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
             }
         }
         if (st != st_begin) {
-            if constexpr (CROW) {
-                aload4(cinv, Cin + (int64_t)st * ldc_in, cvoff_row);
-            } else {
 #pragma unroll
-                for (int h = 0; h < H; ++h)
+            for (int t = 0; t < SETS; ++t) {
+                if constexpr (CROW) {
+                    aload4(cinv[t], Cin + (int64_t)st * ldc_in, cvoff_row[t]);
+                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) aload1(cin[h][j], Cin + (col0 + h * 16 + j) * ldc_in, cvoff_in);
+                    for (int h = 0; h < H; ++h)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) aload1(cin[t][h][j], Cin + (col0 + h * 16 + j) * ldc_in, cvoff_in[t]);
+                }
             }
         }
         if constexpr (!DMA) {
             if (st + 1 < st_end) load_panel(st + 1, false);
         }
-        f32x4 acc[H];
+        f32x4 acc[SETS][H];
 #pragma unroll
-        for (int h = 0; h < H; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < SETS; ++t) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) acc[t][h] = f32x4{0.f, 0.f, 0.f, 0.f};
         // a batch whose 16 entries are live for every lane of the wavefront runs without predicates
 #define SX_RBATCH(b)                                                                                  \
         if constexpr ((b) < NB) {                                                                      \
-        if (__builtin_amdgcn_ballot_w64(len >= ((b) + 1) * BATCH) == __builtin_amdgcn_ballot_w64(true)) { \
-            float vb[4] = {av[b].x, av[b].y, av[b].z, av[b].w};                                        \
-            wide_batch<H, EXACT>(ai[b], vb, pq, acc);                                                  \
-        } else if (len > (b) * BATCH) {                                                               \
-            float vb[4] = {av[b].x, av[b].y, av[b].z, av[b].w};                                        \
-            const int cnt = len - (b) * BATCH;                                                         \
-            wide_quad<0, H, EXACT>(ai[b], vb, pq, acc); pin<H>(acc);                                   \
-            if (cnt > 4) { wide_quad<1, H, EXACT>(ai[b], vb, pq, acc); pin<H>(acc); }                  \
-            if (cnt > 8) { wide_quad<2, H, EXACT>(ai[b], vb, pq, acc); pin<H>(acc); }                  \
-            if (cnt > 12) { wide_quad<3, H, EXACT>(ai[b], vb, pq, acc); pin<H>(acc); }                 \
+        if (__builtin_amdgcn_ballot_w64(len[t] >= ((b) + 1) * BATCH) == __builtin_amdgcn_ballot_w64(true)) { \
+            float vb[4] = {av[t][b].x, av[t][b].y, av[t][b].z, av[t][b].w};                            \
+            wide_batch<H, EXACT>(ai[t][b], vb, pq[t], acc[t]);                                         \
+        } else if (len[t] > (b) * BATCH) {                                                            \
+            float vb[4] = {av[t][b].x, av[t][b].y, av[t][b].z, av[t][b].w};                            \
+            const int cnt = len[t] - (b) * BATCH;                                                      \
+            wide_quad<0, H, EXACT>(ai[t][b], vb, pq[t], acc[t]); pin<H>(acc[t]);                       \
+            if (cnt > 4) { wide_quad<1, H, EXACT>(ai[t][b], vb, pq[t], acc[t]); pin<H>(acc[t]); }      \
+            if (cnt > 8) { wide_quad<2, H, EXACT>(ai[t][b], vb, pq[t], acc[t]); pin<H>(acc[t]); }      \
+            if (cnt > 12) { wide_quad<3, H, EXACT>(ai[t][b], vb, pq[t], acc[t]); pin<H>(acc[t]); }     \
         }                                                                                              \
         }
         SX_RBATCH(0) SX_RBATCH(1) SX_RBATCH(2) SX_RBATCH(3) SX_RBATCH(4) SX_RBATCH(5)
 #undef SX_RBATCH
-        for (int pos = NB * BATCH; pos < len; pos += BATCH) {   // rows longer than NB batches: the rest from the stream
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(pv + loff + pos);
-            const uint2 w = *reinterpret_cast<const uint2 *>(pi + loffi + pos);
+        for (int pos = NB * BATCH; pos < len[t]; pos += BATCH) {   // rows longer than NB batches: the rest from the stream
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(pv + loff[t] + pos);
+            const uint2 w = *reinterpret_cast<const uint2 *>(pi + loffi[t] + pos);
             int ix[4] = {(int)(w.x & 0xffffu), (int)(w.x >> 16), (int)(w.y & 0xffffu), (int)(w.y >> 16)};
             float vx[4] = {v.x, v.y, v.z, v.w};
-            const int cnt = len - pos;
-            wide_quad<0, H, EXACT>(ix, vx, pq, acc); pin<H>(acc);
-            if (cnt > 4) { wide_quad<1, H, EXACT>(ix, vx, pq, acc); pin<H>(acc); }
-            if (cnt > 8) { wide_quad<2, H, EXACT>(ix, vx, pq, acc); pin<H>(acc); }
-            if (cnt > 12) { wide_quad<3, H, EXACT>(ix, vx, pq, acc); pin<H>(acc); }
+            const int cnt = len[t] - pos;
+            wide_quad<0, H, EXACT>(ix, vx, pq[t], acc[t]); pin<H>(acc[t]);
+            if (cnt > 4) { wide_quad<1, H, EXACT>(ix, vx, pq[t], acc[t]); pin<H>(acc[t]); }
+            if (cnt > 8) { wide_quad<2, H, EXACT>(ix, vx, pq[t], acc[t]); pin<H>(acc[t]); }
+            if (cnt > 12) { wide_quad<3, H, EXACT>(ix, vx, pq[t], acc[t]); pin<H>(acc[t]); }
+        }
         }
 
         if constexpr (TIMED) {
-            asm volatile("" : "+v"(acc[0]) : : "memory");
+            asm volatile("" : "+v"(acc[0][0]) : : "memory");
             t_rows += clock64() - (st == st_begin ? t2 : t3);
         }
         // ---- drain: C_in and the next panel have landed (and the previous super tile's stores are acknowledged)
         if constexpr (H == 2) {
             asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(cin[0][0]), "+v"(cin[0][1]), "+v"(cin[0][2]), "+v"(cin[0][3]), "+v"(cin[1][0]), "+v"(cin[1][1]),
-                           "+v"(cin[1][2]), "+v"(cin[1][3])
+                         : "+v"(cin[0][0][0]), "+v"(cin[0][0][1]), "+v"(cin[0][0][2]), "+v"(cin[0][0][3]), "+v"(cin[0][1][0]), "+v"(cin[0][1][1]),
+                           "+v"(cin[0][1][2]), "+v"(cin[0][1][3])
                          :
                          : "memory");
+        } else if constexpr (CROW && SETS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cinv[0]), "+v"(cinv[SETS - 1]) : : "memory");
         } else if constexpr (CROW) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cinv) : : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cinv[0]) : : "memory");
+        } else if constexpr (SETS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(cin[0][0][0]), "+v"(cin[0][0][1]), "+v"(cin[0][0][2]), "+v"(cin[0][0][3]), "+v"(cin[SETS - 1][0][0]),
+                           "+v"(cin[SETS - 1][0][1]), "+v"(cin[SETS - 1][0][2]), "+v"(cin[SETS - 1][0][3])
+                         :
+                         : "memory");
         } else {
-            static_assert(H == 1 || H == 2, "the drain names the C_in registers explicitly");
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cin[0][0]), "+v"(cin[0][1]), "+v"(cin[0][2]), "+v"(cin[0][3]) : : "memory");
+            static_assert((H == 1 || H == 2) && SETS <= 2, "the drain names the C_in registers explicitly");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(cin[0][0][0]), "+v"(cin[0][0][1]), "+v"(cin[0][0][2]), "+v"(cin[0][0][3]) : : "memory");
         }
         // The same wait also covers the NEXT panel's B rows (load_panel(st + 1, false) wrote bv / bs behind the compiler's back): name
         // every one of those registers in a volatile asm right behind the wait (volatile asms keep their order), so that no use of
@@ -402,19 +450,22 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
                 }
         }
         // ---- C straight from the accumulators
-        if constexpr (CROW) {
-            if (cwrite) {
-                const f32x4 o = {epilogue<EXACT>(alpha, acc[0].x, beta, cinv.x), epilogue<EXACT>(alpha, acc[0].y, beta, cinv.y),
-                                 epilogue<EXACT>(alpha, acc[0].z, beta, cinv.z), epilogue<EXACT>(alpha, acc[0].w, beta, cinv.w)};
-                astore4(Cout + (int64_t)st * ldc, cvoff_row, o);
-            }
-        } else if (cwrite) {
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const float a4[4] = {acc[h].x, acc[h].y, acc[h].z, acc[h].w};
+        for (int t = 0; t < SETS; ++t) {
+            if constexpr (CROW) {
+                if (cwrite[t]) {
+                    const f32x4 o = {epilogue<EXACT>(alpha, acc[t][0].x, beta, cinv[t].x), epilogue<EXACT>(alpha, acc[t][0].y, beta, cinv[t].y),
+                                     epilogue<EXACT>(alpha, acc[t][0].z, beta, cinv[t].z), epilogue<EXACT>(alpha, acc[t][0].w, beta, cinv[t].w)};
+                    astore4(Cout + (int64_t)st * ldc, cvoff_row[t], o);
+                }
+            } else if (cwrite[t]) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    astore1(Cout + (col0 + h * 16 + j) * ldc, cvoff_out, epilogue<EXACT>(alpha, a4[j], beta, cin[h][j]));
+                for (int h = 0; h < H; ++h) {
+                    const float a4[4] = {acc[t][h].x, acc[t][h].y, acc[t][h].z, acc[t][h].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        astore1(Cout + (col0 + h * 16 + j) * ldc, cvoff_out[t], epilogue<EXACT>(alpha, a4[j], beta, cin[t][h][j]));
+                }
             }
         }
         if constexpr (!DMA) {

@@ -10,7 +10,7 @@ from util import ALPHA, BETA, random_csr
 pytestmark = pytest.mark.gpu
 
 OPTS = dict(lanes_per_row=0, kernel=0, fuse_b=0, panel_v2=-1, cols_per_lane=0, tiles_per_wg=0, split_rows=0, bucket_rows=-1,
-            panel_min_reuse_x100=200, panel_min_reuse_wide_x100=150, row_cluster=-1, cluster_group=3, cluster_shape=0)
+            panel_min_reuse_x100=200, panel_min_reuse_wide_x100=150, row_cluster=-1, cluster_group=3, cluster_shape=0, row_sets=2)
 
 
 def _set(engine, **kw):
@@ -187,3 +187,47 @@ def test_released_plan_stream_is_rebuilt_for_row_ranges(engine, oracle):
         assert engine.get_stat("device_bytes") > with_cluster + 4.0 * len(ci)                 # the stream is back (4 B values + shared indices)
     finally:
         _set(engine)
+
+
+@pytest.mark.parametrize("N", [16, 48, 128])
+def test_two_row_sets_per_block(engine, oracle, N):
+    """Short-row grid matrices (every row <= 32 entries): the clustered plan uses 128-row bricks as blocks of TWO 64-slot row sets on one
+    dictionary / panel (spmm_panel_v2.h: SETS; option row_sets: 2 = 3-D grids, 3 = 2-D grids too, 1 = never).  Bit-identical to
+    cpu_spmm_CSR whatever the setting, fewer panel rows than 64-row bricks, partial bricks at the grid edges (30 x 28 x 26 is no
+    multiple of 16 x 4 x 2) and rows of 0 entries included; longer rows (3 dof: 81 entries) keep 64-row blocks."""
+    from sextans_amd import api
+    cases = [("27-point 1 dof", api.gen_fem3d_host(30, 28, 26, 1, 7), 30 * 28 * 26, True),
+             ("2-D 9-point 2 dof", api.gen_stencil2d_host(120, 110, 9, 2, 3), 120 * 110 * 2, False),
+             ("27-point 3 dof", api.gen_fem3d_host(16, 15, 14, 3, 7), 16 * 15 * 14 * 3, None)]
+    rs = np.random.RandomState(N)
+    for name, (rp, ci, v), M, auto in cases:
+        rp, ci, v = np.array(rp), np.array(ci), np.array(v)
+        if auto is not None:                       # a few empty rows: slots of 0 entries inside a set
+            keep = np.ones(len(ci), bool)
+            for r in (5, 77, M - 3):
+                keep[rp[r]:rp[r + 1]] = False
+            lens = np.diff(rp); lens[[5, 77, M - 3]] = 0
+            ci, v = ci[keep], v[keep]
+            rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        K = M
+        B = rs.uniform(-1, 1, K * N).astype(np.float32)
+        C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+        want = C0.copy()
+        oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+        try:
+            rows = {}
+            for sets in (1, 2, 3):
+                _set(engine, row_cluster=1, row_sets=sets)
+                engine.set_matrix_csr(M, K, rp, ci, v)
+                for rp_time in (1, 3):
+                    out = C0.copy()
+                    engine.spmm(N, ALPHA, B, BETA, out, rp_time=rp_time)
+                    assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (name, N, sets, rp_time, engine.last_kernel())
+                assert engine.last_kernel() == "spmm_csr_panel_v2" and int(engine.get_stat("row_cluster")) == 1, (name, sets)
+                used = int(engine.get_stat("row_sets"))
+                assert used == (1 if auto is None or sets == 1 else 2 if (sets == 3 or auto) else 1), (name, sets, used)
+                rows[sets] = engine.get_stat("panel_rows_clustered")
+            if auto is not None:
+                assert rows[3] < 0.9 * rows[1], (name, rows)
+        finally:
+            _set(engine)
