@@ -266,6 +266,15 @@ int sextans_destroy(sextans_handle_t h);
  *   SpMM with N >= 16), "panel_rows_natural", "panel_rows_clustered" (B rows copied into LDS per 16-column tile), "panel_blocks",
  *   "panel_blocks_clustered", "cluster_shared_fraction" (sampled pre-test of form 2).  The same reason the reference schedules its
  *   non-zeros: keeping the on-chip B window hot (sparse_helper.h:345-403).
+ *   Tunables of the two forms (defaults are the measured best; every setting is bit-identical): "small_panel" (1: clustered plans
+ *   of short-row matrices are packed for a 320-row panel when every dictionary fits), "row_sets" (2: short-row 3-D grid matrices --
+ *   every row <= 32 entries -- use 128-row bricks as two 64-slot row sets on one panel; 3 = 2-D grids too; 1 = never; stat
+ *   "row_sets"), "refine_sweeps" (8) / "refine_rows" (62): block refinement of the graph-clustered order, "relabel_columns" (1),
+ *   "cluster_top" (depth of the merge tree).
+ * "share_index" (default 1): consecutive rows of a block whose 16-bit index lists are equal up to a constant shift keep one copy
+ *   of the list (stats "index_stream_entries", "value_stream_entries"); the exported plan carries every row's own list.
+ * "colwise_max_len" (default 6; "kernel" = 4 forces it): rows of at most this mean length in a numbering with locality (stat
+ *   "row_coherence" >= 0.7) run on the lane-per-row kernel over the caller's column-major operands (no B repack; stat "colwise").
  * "cluster_group" (default 3), "cluster_shape" (0 = default bricks): layout tunables of form (1); measurement switches (below).
  * "small_v2" (default 1: small matrices staged from column-major B size the launch's dictionary capacity and register-resident
  * batches from the plan; 0 = the full-capacity form, for measurements),
@@ -302,7 +311,11 @@ int sextans_export_plan(sextans_handle_t h, int lanes_per_row, struct sextans_pa
  * "window_state" (0 not evaluated, 1 built, -1 rejected), "panel_fraction", "panel_blocks", "piece_path_rows",
  * "reassociated_rows", "bucket_threshold", "split_threshold", "dense_tiles", "dense_tile_fraction",
  * "dense_tiles_on_mfma", "row_cluster" and the other clustering figures listed with that option, "device_bytes" (bytes of
- * device memory the engine holds right now: matrix copies, packed plans, workspaces). */
+ * device memory the engine holds right now: matrix copies, packed plans, workspaces), "col_range_lo" / "col_range_hi" (the rows
+ * of B the matrix has columns in: only those are repacked -- a rank of a row-partitioned SpMM over a banded matrix touches
+ * 1 / world of B plus a halo), "cluster_decline" (why the graph clustering was not used: 1 not square, 2 long-row paths,
+ * 3 offsets, 4 natural blocks full, 5 no shared neighbourhoods, 6..9 a builder failed, 10..12 plan unusable / no gain,
+ * 13 short rows in a local numbering). */
 int sextans_get_stat(sextans_handle_t h, const char *key, double *value);
 
 /* Upload a CSR matrix (host pointers) once; later spmm calls reuse the device copy.  This is
