@@ -16,13 +16,14 @@
 // It pays only for SHORT rows (the per-entry cost is 1 + 16 vector-memory instructions per lane; the LDS-panel kernel needs
 // 1 LDS read per 4 columns) in numberings WITH locality (else every one of those loads touches 64 lines): the dispatcher uses it
 // when the mean row length is <= 6 and sampled consecutive rows have neighbouring columns (engine_plan.hip: ensure_colwise).
-// Measured (4M rows, same-box A/B, us per step): 5-point stencil N = 16 361 -> 259, N = 32 592 -> 484, N = 128 2011 -> 1859; 9-point
+// Measured (4M rows, same-box A/B, us per step, first version): 5-point stencil N = 16 361 -> 259, N = 32 592 -> 484, N = 128 2011 -> 1859; 9-point
 // (9 per row) 368 -> 407: already a loss; 27-point 450 -> 2489; banded random columns 530 -> 1836 (no coherence between rows).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "spmm_csr_kernels.h"
+
 
 namespace sx {
 
@@ -50,6 +51,41 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_colwise(const int *__restrict
     float cin[NC];
 #pragma unroll
     for (int n = 0; n < NC; ++n) cin[n] = Cin[lr + (int64_t)(col0 + n) * ldc_in];
+    // The first PRE entries of the row: columns and values first (one round trip), then the B values of entry e + 1 are requested
+    // before the products of entry e are formed (two register sets): a 5-entry row costs ~3 dependent round trips instead of 6.
+    // Same-box, 5-point stencil 4M rows: N = 16 250 -> 230 us, N = 32 475 -> 430, N = 128 1 840 -> 1 610 (9 entries per row, forced: 397 -> 351,
+    // still behind the panel kernel's 320 per step).  The order of the multiply-adds is unchanged.
+    constexpr int PRE = 8;
+    {
+        int cc[PRE];
+        float aa[PRE];
+        const int len = min(j1 - j, PRE);
+#pragma unroll
+        for (int e = 0; e < PRE; ++e) {
+            cc[e] = 0; aa[e] = 0.f;
+            if (e < len) { cc[e] = ci[j + e]; aa[e] = va[j + e]; }
+        }
+        constexpr int DEPTH = 1;   // entries whose B values are in flight ahead of the one being multiplied (2 / 3: 118 / 132 registers, measured equal / slower)
+        float bv[DEPTH + 1][NC];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (d < len) {
+#pragma unroll
+                for (int n = 0; n < NC; ++n) bv[d][n] = b[cc[d] + (int64_t)n * ldb];
+            }
+#pragma unroll
+        for (int e = 0; e < PRE; ++e) {
+            if (e < len) {
+                if (e + DEPTH < PRE && e + DEPTH < len) {
+#pragma unroll
+                    for (int n = 0; n < NC; ++n) bv[(e + DEPTH) % (DEPTH + 1)][n] = b[cc[(e + DEPTH) % PRE] + (int64_t)n * ldb];
+                }
+#pragma unroll
+                for (int n = 0; n < NC; ++n) acc[n] = mac<EXACT>(acc[n], aa[e], bv[e % (DEPTH + 1)][n]);
+            }
+        }
+        j += len;
+    }
     if (j < j1) {
         int c = ci[j];
         float a = va[j];
