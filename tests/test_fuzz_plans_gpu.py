@@ -1,0 +1,107 @@
+"""Randomised parity of the round-4 plan forms: grid / mesh matrices of odd sizes, with rows removed or emptied, in natural, random and
+partially shuffled numberings, at N that are and are not multiples of 16, under random settings of the options that select a plan form
+(row_cluster, share_index, row_sets, small_panel, relabel_columns, refine_sweeps, kernel, lanes_per_row).  Every result is compared
+bit for bit with cpu_spmm_CSR (oracle/), whole-matrix calls and rp_time replays alike.  The point is the corners no hand-written case
+names: partial bricks, blocks cut by the dictionary capacity, chains of shared index lists that end at a block boundary, empty slots
+inside a row set, rows longer than the register-resident batches next to rows of one entry."""
+import os
+
+import numpy as np
+import pytest
+
+from util import ALPHA, BETA
+
+pytestmark = pytest.mark.gpu
+
+DEFAULTS = dict(row_cluster=-1, share_index=1, row_sets=2, small_panel=1, relabel_columns=1, refine_sweeps=8, kernel=0, lanes_per_row=0,
+                panel_min_reuse_x100=200, panel_min_reuse_wide_x100=150, fuse_b=0)
+
+
+def _matrix(rs):
+    from sextans_amd import api, meshgen
+    kind = rs.randint(0, 5)
+    if kind == 0:
+        dims = [int(rs.randint(3, 22)) for _ in range(3)]
+        dof = int(rs.choice([1, 1, 2, 3, 4]))
+        rp, ci, v = api.gen_fem3d_host(*dims, dof, int(rs.randint(1, 99)))
+        M, name = dims[0] * dims[1] * dims[2] * dof, f"fem {dims} x {dof}"
+    elif kind == 1:
+        nx, ny = int(rs.randint(5, 150)), int(rs.randint(5, 120))
+        pts, dof = int(rs.choice([5, 9])), int(rs.choice([1, 2, 3]))
+        rp, ci, v = api.gen_stencil2d_host(nx, ny, pts, dof, int(rs.randint(1, 99)))
+        M, name = nx * ny * dof, f"stencil {nx}x{ny} {pts}-pt x {dof}"
+    elif kind == 2:
+        n = int(rs.randint(4, 16))
+        dof = int(rs.choice([1, 3]))
+        rp, ci, v, M = meshgen.jittered_mesh3d(n, n + 1, n + 2, int(rs.randint(1, 99)), numbering=str(rs.choice(["sweep", "random", "grid"])), dof=dof)
+        name = f"mesh {n} x {dof}"
+    elif kind == 3:   # a grid matrix under a random node renumbering
+        dims = [int(rs.randint(4, 18)) for _ in range(3)]
+        dof = int(rs.choice([1, 3]))
+        rp, ci, v = api.gen_fem3d_host(*dims, dof, 5)
+        M = dims[0] * dims[1] * dims[2] * dof
+        rp, ci, v = meshgen.permute_symmetric(rp, ci, v, M, meshgen.node_permutation(M // dof, dof, int(rs.randint(1, 99))))
+        name = f"fem {dims} x {dof} random order"
+    else:             # a grid matrix with a shuffled slab in the middle
+        dims = [int(rs.randint(6, 20)) for _ in range(3)]
+        rp, ci, v = api.gen_fem3d_host(*dims, 1, 5)
+        M = dims[0] * dims[1] * dims[2]
+        perm = np.arange(M)
+        a, b = sorted(rs.randint(0, M, 2))
+        perm[a:b] = perm[a:b][rs.permutation(b - a)]
+        rp, ci, v = meshgen.permute_symmetric(rp, ci, v, M, perm)
+        name = f"fem {dims} shuffled [{a},{b})"
+    rp, ci, v = np.array(rp, np.int32), np.array(ci, np.int32), np.array(v, np.float32)
+    lens = np.diff(rp)
+    keep = np.ones(len(ci), bool)
+    mode = rs.randint(0, 4)
+    if mode == 1:     # a few rows emptied
+        for r in rs.randint(0, M, max(1, M // 50)):
+            keep[rp[r]:rp[r + 1]] = False
+    elif mode == 2:   # random entries dropped (rows of a node stop sharing their index lists)
+        keep &= rs.rand(len(ci)) > 0.1
+    elif mode == 3:   # one row made long (dense-ish) -- columns stay sorted and distinct
+        r = int(rs.randint(0, M))
+        extra = np.setdiff1d(rs.choice(M, min(M, 200), replace=False), ci[rp[r]:rp[r + 1]]).astype(np.int32)
+        row_c = np.concatenate([ci[rp[r]:rp[r + 1]], extra]); order = np.argsort(row_c, kind="stable")
+        row_v = np.concatenate([v[rp[r]:rp[r + 1]], rs.uniform(-1, 1, len(extra)).astype(np.float32)])[order]
+        ci = np.concatenate([ci[:rp[r]], row_c[order], ci[rp[r + 1]:]]); v = np.concatenate([v[:rp[r]], row_v, v[rp[r + 1]:]])
+        lens[r] += len(extra)
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        keep = np.ones(len(ci), bool)
+    if not keep.all():
+        rows = np.repeat(np.arange(M), lens)
+        lens = np.bincount(rows[keep], minlength=M)
+        ci, v = ci[keep], v[keep]
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    return name + f" mode {mode}", M, rp, ci.astype(np.int32), v.astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_random_plan_forms_are_bit_identical(engine, oracle, seed):
+    rs = np.random.RandomState(1000 + seed)
+    name, M, rp, ci, v = _matrix(rs)
+    K = M
+    try:
+        for trial in range(4):
+            N = int(rs.choice([8, 16, 16, 24, 32, 40, 64, 136]))
+            opts = dict(DEFAULTS, row_cluster=int(rs.choice([-1, 0, 1, 1, 2, 2])), share_index=int(rs.choice([0, 1, 1])), row_sets=int(rs.choice([1, 2, 3])),
+                        small_panel=int(rs.choice([0, 1])), relabel_columns=int(rs.choice([0, 1, 1])), refine_sweeps=int(rs.choice([0, 8])),
+                        kernel=int(rs.choice([0, 0, 0, 2, 4])), lanes_per_row=int(rs.choice([0, 0, 4])))
+            for k, val in opts.items():
+                engine.set_option(k, val)
+            engine.set_matrix_csr(M, K, rp, ci, v)
+            B = rs.uniform(-1, 1, K * N).astype(np.float32)
+            C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+            want = C0.copy()
+            oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+            for rp_time in (1, 3):
+                out = C0.copy()
+                engine.spmm(N, ALPHA, B, BETA, out, rp_time=rp_time)
+                assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (name, N, opts, rp_time, engine.last_kernel())
+            if os.environ.get("SEXTANS_FUZZ_VERBOSE"):
+                print(f"[fuzz] {name} N={N} rc={opts['row_cluster']}: {engine.last_kernel()} state={int(engine.get_stat('row_cluster'))} "
+                      f"sets={int(engine.get_stat('row_sets'))} idx/val={engine.get_stat('index_stream_entries') / max(engine.get_stat('value_stream_entries'), 1):.2f}")
+    finally:
+        for k, val in DEFAULTS.items():
+            engine.set_option(k, val)
