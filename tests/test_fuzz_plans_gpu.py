@@ -105,3 +105,53 @@ def test_random_plan_forms_are_bit_identical(engine, oracle, seed):
     finally:
         for k, val in DEFAULTS.items():
             engine.set_option(k, val)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_large_matrices_default_options(engine, oracle, seed):
+    """The same at sizes where B no longer fits the L2s (10^5 .. 10^6 rows): the automatic choices of the dispatcher -- grid bricks, graph
+    clustering + reordered form, natural plan, lane-per-row kernel -- under DEFAULT options, whole-matrix calls and one row-range call."""
+    from sextans_amd import api, meshgen
+    rs = np.random.RandomState(7000 + seed)
+    kind = seed % 4
+    if kind == 0:
+        dims, dof = [int(rs.randint(35, 60)) for _ in range(3)], int(rs.choice([1, 3]))
+        rp, ci, v = api.gen_fem3d_host(*dims, dof, 3)
+        M = dims[0] * dims[1] * dims[2] * dof
+    elif kind == 1:
+        dims, dof = [int(rs.randint(30, 50)) for _ in range(3)], int(rs.choice([1, 3]))
+        rp, ci, v = api.gen_fem3d_host(*dims, dof, 3)
+        M = dims[0] * dims[1] * dims[2] * dof
+        rp, ci, v = meshgen.permute_symmetric(rp, ci, v, M, meshgen.node_permutation(M // dof, dof, seed))
+    elif kind == 2:
+        n = int(rs.randint(40, 60))
+        rp, ci, v, M = meshgen.jittered_mesh3d(n, n, n, seed, numbering=str(rs.choice(["sweep", "random"])), dof=int(rs.choice([1, 3])))
+    else:
+        nx, ny, pts = int(rs.randint(300, 700)), int(rs.randint(300, 600)), int(rs.choice([5, 9]))
+        rp, ci, v = api.gen_stencil2d_host(nx, ny, pts, 1, 3)
+        M = nx * ny
+    rp, ci, v = np.array(rp, np.int32), np.array(ci, np.int32), np.array(v, np.float32)
+    K = M
+    for k, val in DEFAULTS.items():
+        engine.set_option(k, val)
+    engine.set_matrix_csr(M, K, rp, ci, v)
+    for N in (16, int(rs.choice([24, 32, 48]))):
+        B = rs.uniform(-1, 1, K * N).astype(np.float32)
+        C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+        want = C0.copy()
+        oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+        out = C0.copy()
+        engine.spmm(N, ALPHA, B, BETA, out)
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (kind, M, N, engine.last_kernel(), engine.get_stat("row_cluster"))
+        # one row-range call (what a rank of the row-partitioned SpMM issues): its rows into a packed slab, the natural-order plan
+        import torch
+        st = torch.cuda.current_stream().cuda_stream
+        c0, c1 = sorted(int(x) for x in rs.randint(0, M, 2))
+        if c1 > c0:
+            dB = torch.from_numpy(B).cuda(); dCin = torch.from_numpy(C0).cuda()
+            slab = torch.full(((c1 - c0) * N,), float("nan"), device="cuda")
+            engine.spmm_device_rows(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr() + 4 * c0, M, slab.data_ptr(), c1 - c0, c0, c1, stream=st)
+            torch.cuda.synchronize()
+            got = slab.cpu().numpy().reshape(N, c1 - c0)
+            assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want.reshape(N, M)[:, c0:c1]).view(np.uint32)), (kind, M, N, c0, c1, engine.last_kernel())
+            del dB, dCin, slab
