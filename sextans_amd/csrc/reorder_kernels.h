@@ -49,23 +49,38 @@ __global__ __launch_bounds__(kBlock) void repack_b_panels_perm(const float *__re
 // back.  Workgroup = 256 consecutive rows of one tile.
 __global__ __launch_bounds__(kBlock) void tiles_to_colmajor(const float *__restrict__ Cs, float *__restrict__ C, int64_t ldc, int M,
                                                             int col_base) {
-    __shared__ float s[16][kBlock + 1];
+    // 16-byte accesses on both sides: a lane reads 4 consecutive floats of the staging chunk and writes 4 consecutive ROWS of one
+    // column (rows of the LDS tile are 260 floats apart: 16-byte aligned, conflict-free for both access patterns).
+    constexpr int LD = kBlock + 4;
+    __shared__ __attribute__((aligned(16))) float s[16 * LD];
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * kBlock;
     const int t = blockIdx.y;
     const float *src = Cs + (int64_t)t * M * 16 + (int64_t)r0 * 16;
     const int nr = min(kBlock, M - r0);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int e = tid + i * kBlock;   // linear element of the 256 x 16 chunk
-        const int rr = e / 16, c = e % 16;
-        if (rr < nr) s[c][rr] = src[e];
+    for (int i = 0; i < 4; ++i) {
+        const int e4 = tid + i * kBlock;          // float4 number e4 of the 256 x 16 chunk: row e4 / 4, columns 4 (e4 % 4) ..
+        const int rr = e4 >> 2, c4 = (e4 & 3) * 4;
+        if (rr < nr) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (int64_t)e4 * 4);
+            s[(c4 + 0) * LD + rr] = v.x; s[(c4 + 1) * LD + rr] = v.y; s[(c4 + 2) * LD + rr] = v.z; s[(c4 + 3) * LD + rr] = v.w;
+        }
     }
     __syncthreads();
-    float *dst = C + (int64_t)(col_base + t * 16) * ldc;
-    if (tid < nr) {
+    float *dst = C + (int64_t)(col_base + t * 16) * ldc + r0;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) dst[(int64_t)c * ldc + r0 + tid] = s[c][tid];
+    for (int i = 0; i < 4; ++i) {
+        const int g = tid + i * kBlock;           // group g: column g / 64, rows 4 (g % 64) .. + 3
+        const int c = g >> 6, rr = (g & 63) * 4;
+        float *d = dst + (int64_t)c * ldc + rr;
+        if (rr + 3 < nr) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(&s[c * LD + rr]);
+            if ((reinterpret_cast<uintptr_t>(d) & 15) == 0) *reinterpret_cast<f32x4 *>(d) = v;
+            else { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+        } else {
+            for (int k = 0; rr + k < nr; ++k) d[k] = s[c * LD + rr + k];
+        }
     }
 }
 
