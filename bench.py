@@ -283,7 +283,9 @@ def main():
                          lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 40, numbering="random")),
                         ("fem_4M_rcm_node_order_N16",
                          lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 40, numbering="rcm")),
+                        ("fem27pt_1dof_4M_N16", lambda: fem_secondary(api, torch, dev, stream, (160, 160, 160, 1), 16, 50)),
                         ("stencil2d_5pt_4M_N16", lambda: stencil_secondary(api, torch, dev, stream, 2000, 2000, 5, 16, 50)),
+                        ("stencil2d_9pt_4M_N16", lambda: stencil_secondary(api, torch, dev, stream, 2000, 2000, 9, 16, 50)),
                         ("config5_blocked_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream)),
                         ("blockbanded_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream, banded_half_width=127)),
                         ("powerlaw_1M_rows_N16", lambda: powerlaw_secondary(api, torch, dev, stream)),
