@@ -261,7 +261,7 @@ int sextans_destroy(sextans_handle_t h);
  *   "grid_stride_plane"); (2) matrices whose numbering has no locality but whose graph has (meshes in an arbitrary node order) are
  *   aggregated over the matrix graph on the device (csrc/graph_cluster.hip), their columns relabelled in first-touch order, and the
  *   SpMM runs in its REORDERED form: B repacked into permuted panels, C staged block-major (two extra passes over C inside the call;
- *   sextans_last_kernel = "spmm_csr_panel_v2_reordered").  Needs M == K and no rows on the long-row path.  Stats: "row_cluster"
+ *   sextans_last_kernel = "spmm_csr_panel_v2_reordered").  Needs M == K; rows on the long-row paths (pieces, exact chains) are fine.  Stats: "row_cluster"
  *   (1 grid bricks / 2 graph clustering in use, -1 declined, 0 not evaluated yet -- it is evaluated by the first whole-matrix
  *   SpMM with N >= 16), "panel_rows_natural", "panel_rows_clustered" (B rows copied into LDS per 16-column tile), "panel_blocks",
  *   "panel_blocks_clustered", "cluster_shared_fraction" (sampled pre-test of form 2).  The same reason the reference schedules its

@@ -130,7 +130,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     // ldc_in == ldc == floats per tile; the same slot -> row table addresses the staging rows.
     const sextans_engine::PanelState &P = mode ? h->psc : h->ps;
     const int *slot_row = mode ? h->d_slot_row : nullptr;
-    const unsigned char *skip = mode == 2 ? nullptr : (const unsigned char *)h->d_skip;
+    const unsigned char *skip = (const unsigned char *)h->d_skip;   // rows on the piece path: never written by this kernel (mode 2: their staging rows keep C_in)
     const int nblk = blk_end - blk_begin;
     if (nblk <= 0 || nsuper <= 0) return SEXTANS_OK;
     if (mode == 0)
@@ -503,7 +503,9 @@ const char *kernel_name(int main, bool hubs, bool dense) {   // static strings f
 // Exact chains of the chain rows [c0, c1) (chain_fused, spmm_csr_kernels.h): products from the repacked B panels (segment by
 // segment, like the piece kernel) and the serial sum of every (row, column) in one workgroup, epilogue included.
 void launch_chains(sextans_engine *h, const std::vector<Seg> &plan, const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc,
-                   int N, int c0, int c1, int row_base, float alpha, float beta, hipStream_t s) {
+                   int N, int c0, int c1, int row_base, float alpha, float beta, hipStream_t s, bool permuted_panels = false) {
+    // permuted_panels (the reordered form): the 16-column panels hold B row k at row colpos[k]; the chain rows' entries come from
+    // their compact relabelled copy (ensure_cluster_plan); 8-column remainder tiles keep the natural panels and the source arrays
     // one workgroup per (chain row, 16- or 8-column tile): chain_fused
     {
         for (const Seg &g : plan) {
@@ -512,8 +514,10 @@ void launch_chains(sextans_engine *h, const std::vector<Seg> &plan, const float 
             const int ntiles = g.ntiles * (g.width / NT);
             auto go = [&](auto kern, int lds, int threads) {
                 (void)allow_big_lds(h, reinterpret_cast<const void *>(kern), lds);
+                const bool perm = permuted_panels && g.width == 16;
                 hipLaunchKernelGGL(kern, dim3((unsigned)(c1 - c0) * (unsigned)ntiles), dim3((unsigned)threads), (size_t)lds, s, h->d_chain_row,
-                                   h->d_chain_beg, h->d_chain_off, (c0 == 0 && c1 == h->nchain) ? h->d_chain_perm : (const int *)nullptr, h->s_ci, h->s_v, bp, (int64_t)h->K * g.width, g.width, dCin, ldc_in, dCout,
+                                   perm ? h->d_chain_beg_c : h->d_chain_beg, h->d_chain_off, (c0 == 0 && c1 == h->nchain) ? h->d_chain_perm : (const int *)nullptr,
+                                   perm ? (const int *)h->d_chain_ci_perm : h->s_ci, perm ? (const float *)h->d_chain_v_c : h->s_v, bp, (int64_t)h->K * g.width, g.width, dCin, ldc_in, dCout,
                                    ldc, g.col0, ntiles, c0, row_base, alpha, beta);
             };
 #define SX_FUSED(W) if (h->opt_exact) go(sx::chain_fused<W, true>, sx::chain_fused_lds_bytes(W), sx::chain_fused_threads(W)); \
@@ -526,14 +530,14 @@ void launch_chains(sextans_engine *h, const std::vector<Seg> &plan, const float 
 
 template <int LPR>
 void launch_hub_pieces(sextans_engine *h, const sextans_engine::PieceTable &t, const float *dBp, int ntiles, int col0,
-                       int v0, int v1, hipStream_t s) {
+                       int v0, int v1, hipStream_t s, const int *colpos = nullptr) {
     constexpr int RB = sx::kBlock / LPR;
     const int nblk = (v1 - v0 + RB - 1) / RB;
     if (nblk <= 0) return;
     float *P = h->d_P + (int64_t)col0 * h->split_nv;
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ntiles), dim3(sx::kBlock), 0, s, t.d_vrp, t.d_vend, h->s_ci,
-                           h->s_v, dBp, (int64_t)h->K * 4 * LPR, P, (int64_t)h->split_nv, v0, v1, ntiles);
+                           h->s_v, dBp, (int64_t)h->K * 4 * LPR, P, (int64_t)h->split_nv, v0, v1, ntiles, colpos);
     };
     if (h->opt_exact) go(sx::spmm_csr_pieces<LPR, true>); else go(sx::spmm_csr_pieces<LPR, false>);
 }
@@ -788,8 +792,8 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     // The reordered form (graph-clustered plan, ensure_cluster_plan): whole-matrix calls, 16-column tiles.  Its B panels hold the
     // rows of B in the plan's column order and C goes through the block-major staging buffer (reorder_kernels.h); an 8-column
     // remainder tile keeps the natural-order kernels and panels.  (Layout tag -W: such panels are never reused by a row-range call.)
-    const bool reordered = whole && h->cluster_state == 2 && h->opt_kernel != 1 && h->opt_kernel != 3 && W == 16 && !fuse_b && !hubs &&
-                           !chains && h->dense_W == 0 && h->d_Cs && N >= 16;
+    const bool reordered = whole && h->cluster_state == 2 && h->opt_kernel != 1 && h->opt_kernel != 3 && W == 16 && !fuse_b &&
+                           (!chains || h->d_chain_ci_perm) && h->dense_W == 0 && h->d_Cs && N >= 16;
     const int64_t cs_tile = reordered ? (int64_t)h->M * 16 : 0;   // floats per 16-column tile of the staging buffer
     const int layout = reordered ? -W : W;
     const bool skip_repack = fuse_b || ((flags & SEXTANS_ROWS_REUSE_B_PANELS) != 0 && h->bp_layout == layout);
@@ -903,7 +907,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     {
         Prof p(h, &h->ev_kernel, s);
         bool v2_used = false;
-        if (chains) {
+        if (chains && !reordered) {
             // the chains need one or two wavefronts for about a millisecond: on their own stream, beside the main kernel
             // (fork after the B panels are in place, join before the call's work on `s` is considered complete)
             SX_HIP(hipEventRecord(h->ev_fork, s));
@@ -919,6 +923,9 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
                 if (int rc = launch_panel_v2<1>(h, bp, h->d_Cs, cs_tile, h->d_Cs, cs_tile, g.ntiles, alpha, beta, s, 0, 0, h->psc.plan_nblk, 0, 2))
                     return rc;
                 v2_used = true;
+                // rows on the piece path: their partial sums from the PERMUTED panels (column c sits at row colpos[c]); folded into C
+                // behind the staging -> C pass below, which leaves C_in in their rows
+                if (hubs) launch_hub_pieces<4>(h, pt, bp, g.ntiles, g.col0, v0, v1, s, h->d_colpos);
                 continue;
             }
             const bool panel_here = use_panel && g.width == W;   // the plan is built for width W
@@ -971,8 +978,8 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             }
 #undef SX_SEG
         }
-        if (hubs) fold();
-        if (chains) SX_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+        if (hubs && !reordered) fold();
+        if (chains && !reordered) SX_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
         h->last_kernel = reordered ? "spmm_csr_panel_v2_reordered" : kernel_name(v2_used ? 3 : use_panel ? 1 : 0, hubs || chains, h->dense_W > 0);
     }
     if (reordered) {
@@ -981,6 +988,9 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             if (g.width == 16)
                 hipLaunchKernelGGL(sx::tiles_to_colmajor, dim3((unsigned)((h->M + sx::kBlock - 1) / sx::kBlock), (unsigned)g.ntiles),
                                    dim3(sx::kBlock), 0, s, h->d_Cs, d_C_out, ldc, h->M, g.col0);
+        if (hubs) fold();
+        // chain rows write C themselves: behind the staging -> C pass (which left C_in in their rows), from the permuted panels
+        if (chains) launch_chains(h, plan, d_C_in, ldc_in, d_C_out, ldc, N, ch0, ch1, row_begin, alpha, beta, s, true);
     }
     SX_HIP(hipGetLastError());
     return SEXTANS_OK;

@@ -30,6 +30,8 @@ void free_cluster_plan(sextans_engine *h) {   // the clustered-order plan and it
     free_panel_state(h->psc);
     (void)hipFree(h->d_slot_row); (void)hipFree(h->d_colpos);
     h->d_slot_row = h->d_colpos = nullptr;
+    (void)hipFree(h->d_chain_ci_perm); (void)hipFree(h->d_chain_beg_c); (void)hipFree(h->d_chain_v_c);
+    h->d_chain_ci_perm = h->d_chain_beg_c = nullptr; h->d_chain_v_c = nullptr;
     h->cluster_state = 0;
     h->colwise_state = 0;
     h->row_coherence = 0.0;
@@ -405,7 +407,7 @@ int cluster_grid(sextans_engine *h) {   // 0 = in use, 1 = declined
 
 int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reason (stat "cluster_decline")
     if (h->M != h->K || h->m_nnz <= 0) return 1;                                        // 1: not square
-    if (h->d_skip || h->nhub > 0 || h->nchain > 0 || h->dense_W > 0) return 2;           // 2: rows on the long-row / dense-tile paths
+    if (h->dense_W > 0) return 2;                                                       // 2: dense tiles on the MFMA path (rows on the piece / chain paths are fine: they are empty here)
     if ((int64_t)h->K * 64 >= ((int64_t)1 << 32)) return 3;   // 3: 32-bit byte offsets into a K x 16 panel
     const int lpr = 4, RB = sx::kBlock / lpr, cap = kPanelFloats / (4 * lpr);
     std::string err;
@@ -540,6 +542,15 @@ int restore_plan_streams(sextans_engine *h) {
     return SEXTANS_OK;
 }
 
+__global__ __launch_bounds__(256) void compact_chain_entries(const int *__restrict__ cbeg, const long long *__restrict__ coff, const int *__restrict__ ci,
+                                                             const float *__restrict__ va, const int *__restrict__ colpos, int *__restrict__ out_ci,
+                                                             float *__restrict__ out_v) {
+    const int i = blockIdx.x;
+    const long long o = coff[i], len = coff[i + 1] - o;
+    const int b = cbeg[i];
+    for (long long e = threadIdx.x; e < len; e += 256) { out_ci[o + e] = colpos[ci[b + e]]; out_v[o + e] = va[b + e]; }
+}
+
 int ensure_cluster_plan(sextans_engine *h) {
     if (h->cluster_state != 0) return SEXTANS_OK;
     h->cluster_state = -1;
@@ -547,6 +558,25 @@ int ensure_cluster_plan(sextans_engine *h) {
     PlanTimer timer(h);
     if (h->opt_row_cluster != 2 && cluster_grid(h) == 0) h->cluster_state = 1;
     else if ((h->cluster_decline = cluster_graph(h)) == 0) h->cluster_state = 2;
+    if (h->cluster_state == 2 && h->nchain > 0 && h->d_colpos) {
+        // the exact-chain kernels read B rows by column index: for the permuted panels of the reordered form they get the chain rows'
+        // entries once more, compact, with relabelled columns (a few thousand entries)
+        const long long total = h->h_chain_off.empty() ? 0 : h->h_chain_off.back();
+        std::vector<int> beg((size_t)h->nchain);
+        for (int i = 0; i < h->nchain; ++i) beg[(size_t)i] = (int)h->h_chain_off[(size_t)i];
+        bool ok = total > 0 && total < 0x7fffffffLL && hipMalloc((void **)&h->d_chain_ci_perm, sizeof(int) * (size_t)total) == hipSuccess &&
+                  hipMalloc((void **)&h->d_chain_v_c, sizeof(float) * (size_t)total) == hipSuccess && upload(&h->d_chain_beg_c, beg) == SEXTANS_OK;
+        if (ok) {
+            hipLaunchKernelGGL(compact_chain_entries, dim3((unsigned)h->nchain), dim3(256), 0, nullptr, h->d_chain_beg, h->d_chain_off, h->s_ci, h->s_v,
+                               h->d_colpos, h->d_chain_ci_perm, h->d_chain_v_c);
+            ok = hipDeviceSynchronize() == hipSuccess;
+        }
+        if (!ok) {   // (declined like every other failure in here)
+            free_cluster_plan(h);
+            h->cluster_state = -1;
+            h->cluster_decline = 9;
+        }
+    }
     if (h->cluster_state > 0) release_plan_streams(h);
     (void)hipGetLastError();   // a failure in here (out of memory for the sort buffers, ...) only declines the clustered plan
     return SEXTANS_OK;
@@ -659,6 +689,7 @@ int ensure_split(sextans_engine *h) {
     PlanTimer timer(h);
     std::vector<int> rp;
     if (int rc = read_back_row_ptr(h, rp, 1)) return rc;
+    bool rare_long = false;
     std::vector<int> rows;                     // ascending
     for (int r = 0; r < h->M; ++r)
         if ((int64_t)rp[(size_t)r + 1] - rp[(size_t)r] > L0) rows.push_back(r);
@@ -671,11 +702,29 @@ int ensure_split(sextans_engine *h) {
             long_nnz += len;
             longest = std::max(longest, len);
         }
-        if (longest <= std::min(T, Tc) && h->opt_bucket_rows < 0 && long_nnz * 50 < h->s_nnz) return SEXTANS_OK;
+        if (longest <= std::min(T, Tc) && h->opt_bucket_rows < 0 && long_nnz * 50 < h->s_nnz) {
+            // ... unless a row cannot fit an LDS panel at all (more entries than the dictionary holds): ONE such row in a mesh matrix
+            // makes its block a direct block, the plan "mixed", takes every clustered plan and the register-resident kernel away from the
+            // other 4 M rows, and its workgroup runs thousands of entries alone (1.5M-row 3-dof FEM, N = 16: 267 us per step; with three
+            // 1000-entry rows 408, with one 5000-entry row 547; renumbered 357 -> 680).  Those rows alone leave for the piece path (one
+            // piece each: same order, same rounding).
+            constexpr int64_t kPanelRowLimit = 512;
+            if (longest <= kPanelRowLimit) return SEXTANS_OK;
+            L0 = kPanelRowLimit;
+            std::vector<int> keep;
+            for (int r : rows)
+                if ((int64_t)rp[(size_t)r + 1] - rp[(size_t)r] > L0) keep.push_back(r);
+            rows.swap(keep);
+            rare_long = true;
+        }
     }
+    // ... as exact chains where the strict order allows them (the default): a single piece of 5000 entries is one lane group's serial
+    // gather loop (~60 ns per entry: 300 us, the tail of the whole SpMM), a chain forms the products in parallel and adds them at
+    // ~1.2 ns each
+    const int64_t Tc_rows = (rare_long && Tc != INT64_MAX) ? std::min<int64_t>(Tc, L0) : Tc;
     // chain rows leave the piece tables
     std::vector<int> chain_rows, piece_rows;
-    for (int r : rows) ((int64_t)rp[(size_t)r + 1] - rp[(size_t)r] > Tc ? chain_rows : piece_rows).push_back(r);
+    for (int r : rows) ((int64_t)rp[(size_t)r + 1] - rp[(size_t)r] > Tc_rows ? chain_rows : piece_rows).push_back(r);
     if (!chain_rows.empty()) {
         std::vector<int> beg;
         std::vector<long long> off(1, 0);
@@ -696,7 +745,7 @@ int ensure_split(sextans_engine *h) {
         h->h_chain_row = chain_rows;
         h->h_chain_off = off;
         h->nchain = (int)chain_rows.size();
-        h->chain_T = Tc;
+        h->chain_T = Tc_rows;
     }
     std::vector<int> ci;
     std::vector<float> va;

@@ -166,6 +166,9 @@ struct sextans_engine {
     int nchain = 0;
     int *d_chain_row = nullptr, *d_chain_beg = nullptr, *d_chain_perm = nullptr;   // perm: chain rows by length, longest first
     long long *d_chain_off = nullptr;                   // prefix of the lengths
+    // the chain rows' entries once more, compact, columns relabelled for the permuted B panels of the reordered form (ensure_cluster_plan)
+    int *d_chain_ci_perm = nullptr, *d_chain_beg_c = nullptr;
+    float *d_chain_v_c = nullptr;
     std::vector<int> h_chain_row;
     std::vector<long long> h_chain_off;
     int64_t chain_T = 0;

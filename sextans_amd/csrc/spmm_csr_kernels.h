@@ -530,7 +530,8 @@ template <int LPR, bool EXACT>
 __global__ __launch_bounds__(kBlock) void spmm_csr_pieces(const int *__restrict__ vbeg, const int *__restrict__ vend,
                                                           const int *__restrict__ col_idx, const float *__restrict__ val,
                                                           const float *__restrict__ Bp, int64_t panel_stride, float *P,
-                                                          int64_t ldp, int v_begin, int v_end, int ntiles) {
+                                                          int64_t ldp, int v_begin, int v_end, int ntiles, const int *__restrict__ colpos) {
+    // colpos (may be null): the panels hold row colpos[k] of B at row k -- the permuted panels of the reordered form (reorder_kernels.h)
     constexpr int NT = 4 * LPR;
     constexpr int RB = kBlock / LPR;
     constexpr int E = LPR >= 8 ? 1 : 8 / LPR;   // entries per lane and batch: 8 gathers per batch whatever the tile width
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_pieces(const int *__restrict_
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int i = max(min(p + E * q + e, jend - 1), 0);
-            x.c[e] = col_idx[i];
+            x.c[e] = colpos ? colpos[col_idx[i]] : col_idx[i];
             x.a[e] = val[i];
         }
     };

@@ -303,3 +303,58 @@ def test_renumbered_fem_at_full_size():
     finally:
         for q in p:
             api.device_free(0, q)
+
+
+def _with_long_rows(rp, ci, v, M, rows, L, seed=1):
+    """rows `rows` get ~L more distinct random columns (sorted, values U(-1, 1))"""
+    rs = np.random.RandomState(seed)
+    rp, ci, v = np.asarray(rp), np.asarray(ci), np.asarray(v)
+    lens = np.diff(rp).copy()
+    pc, pv, prev = [], [], 0
+    for r in sorted(rows):
+        pc.append(ci[rp[prev]:rp[r]]); pv.append(v[rp[prev]:rp[r]])
+        c = np.union1d(ci[rp[r]:rp[r + 1]], rs.choice(M, L, replace=False)).astype(np.int32)
+        pc.append(c); pv.append(rs.uniform(-1, 1, len(c)).astype(np.float32))
+        lens[r] = len(c); prev = r + 1
+    pc.append(ci[rp[prev]:]); pv.append(v[rp[prev]:])
+    return np.concatenate([[0], np.cumsum(lens)]).astype(np.int32), np.concatenate(pc).astype(np.int32), np.concatenate(pv).astype(np.float32)
+
+
+@pytest.mark.parametrize("N", [16, 40])
+def test_a_few_long_rows_do_not_take_the_clustered_plans_away(engine, oracle, N):
+    """A mesh matrix with a handful of rows that cannot fit an LDS panel (constraint rows: 600 .. 5000 entries).  Such a row used to
+    stay in the main matrix (its share of the non-zeros is far below the bucketing rule's 2 %), made its block a direct block and the
+    plan "mixed": every clustered plan declined, the register-resident kernel gone, one workgroup running thousands of entries alone
+    (1.5M-row FEM: 267 -> 547 us per step).  Now rows longer than 512 entries always leave for the piece path (one piece each: same
+    order), the grid-brick plan serves the rest, and so does the graph-clustered plan with the REORDERED form: the piece kernel reads
+    the permuted panels through the column relabelling and its rows are folded into C behind the staging -> C pass.  Bit-identical."""
+    from sextans_amd import meshgen
+    rp, ci, v, M = _fem(20, 18, 16, 3)
+    long_rows = [7, M // 2 + 1, M - 2]
+    grid = _with_long_rows(rp, ci, v, M, long_rows, 700)
+    perm = meshgen.node_permutation(M // 3, 3, 4)
+    rnd = meshgen.permute_symmetric(*_with_long_rows(rp, ci, v, M, long_rows[:1], 3000), M, perm)
+    rs = np.random.RandomState(N)
+    try:
+        for name, (rp2, ci2, v2), state in (("grid order", grid, 1), ("random order", rnd, 2)):
+            B, C0 = _operands(rs, M, M, N)
+            want = C0.copy()
+            oracle.spmm(M, N, M, ALPHA, rp2, ci2, v2, B, BETA, want)
+            for rc in (1 if state == 1 else 2, -1, 0):
+                _set(engine, row_cluster=rc, fuse_b=0)
+                engine.set_matrix_csr(M, M, rp2, ci2, v2)
+                for rp_time in (1, 3):
+                    out = C0.copy()
+                    engine.spmm(N, ALPHA, B, BETA, out, rp_time=rp_time)
+                    assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (name, N, rc, rp_time, engine.last_kernel())
+                    inplace = C0.copy()                              # C_in == C_out on the device path is the default of spmm(); rows of the piece path
+                    engine.spmm(N, ALPHA, B, BETA, inplace, rp_time=1)  # read their C_in AFTER the staging pass wrote the rest
+                    assert np.array_equal(inplace.view(np.uint32), want.view(np.uint32))
+                assert int(engine.get_stat("piece_path_rows")) == (3 if state == 1 else 1), (name, engine.get_stat("piece_path_rows"))
+                assert int(engine.get_stat("reassociated_rows")) == 0
+                if rc != 0:
+                    assert int(engine.get_stat("row_cluster")) == state, (name, rc, engine.get_stat("row_cluster"), engine.get_stat("cluster_decline"))
+                    if state == 2 and N % 16 == 0:
+                        assert engine.last_kernel() == "spmm_csr_panel_v2_reordered"
+    finally:
+        _set(engine)
