@@ -454,7 +454,11 @@ int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reaso
     // 10: a row wider than the panel / limits of the 32-bit offsets; 11: the reordered plan has no reuse either; 12: not enough gain
     if (dp.mixed || dp.dict_stride > 9 * RB || dp.max_dict > sx::kWideMaxDict || (int64_t)h->M * 64 >= ((int64_t)1 << 32)) return drop(10);
     if ((double)h->m_nnz < min_reuse * (double)dp.total_dict) return drop(11);
-    if (h->opt_row_cluster < 0 && h->ps.plan_built && (double)dp.total_dict > 0.6 * (double)h->plan_total_dict) return drop(12);
+    {   // automatic: worth the two extra passes over C only if it copies >= 40 % fewer B rows than what would run otherwise -- the
+        // natural-order plan, or the grid-brick plan when the grid path built one first (ensure_cluster_plan)
+        const int64_t ref = h->cluster_ref_dict > 0 ? h->cluster_ref_dict : (h->ps.plan_built ? h->plan_total_dict : 0);
+        if (h->opt_row_cluster < 0 && ref > 0 && (double)dp.total_dict > 0.6 * (double)ref) return drop(12);
+    }
     if (sx::build_slot_rows_device(dp.nblk, RB, dp.d_blk_row, d_order, &h->d_slot_row, err)) return drop(9);
     (void)hipFree(d_order);
     const double covered = h->m_nnz ? (double)dp.nnz_in_panel_blocks / (double)h->m_nnz : 0.0;
@@ -556,8 +560,40 @@ int ensure_cluster_plan(sextans_engine *h) {
     h->cluster_state = -1;
     if (h->opt_row_cluster == 0 || h->M < 4096) return SEXTANS_OK;
     PlanTimer timer(h);
-    if (h->opt_row_cluster != 2 && cluster_grid(h) == 0) h->cluster_state = 1;
-    else if ((h->cluster_decline = cluster_graph(h)) == 0) h->cluster_state = 2;
+    h->cluster_ref_dict = 0;
+    if (h->opt_row_cluster != 2 && cluster_grid(h) == 0) {
+        h->cluster_state = 1;
+        // A grid whose rows reach into several far-apart column ranges (DOF-MAJOR numbering: all x unknowns, then y, then z -- a row of
+        // the 3-dof FEM matrix has its 81 columns in three blocks of the matrix) gets bricks of one unknown each, whose dictionaries are
+        // three times the node-major ones: blocks of ~28 rows, 20 dictionary rows per matrix row.  The graph clustering puts the rows of
+        // a node back together whatever the numbering: measured on the 3M-row matrix 860 us per step with the bricks, 720 reordered
+        // (node-major order: 530).  So when the brick plan's blocks are cut short by the dictionary, the graph plan is built as well and
+        // kept if it copies >= 40 % fewer B rows than the bricks.
+        const double rows_per_block = (double)h->M / std::max(1, h->psc.plan_nblk);
+        if (h->opt_row_cluster < 0 && rows_per_block < 40.0 * h->psc.plan_sets) {
+            sextans_engine::PanelState grid = std::move(h->psc);
+            int *grid_slot_row = h->d_slot_row;
+            const int64_t grid_dict = h->cluster_total_dict;
+            h->psc = sextans_engine::PanelState();
+            h->d_slot_row = nullptr;
+            h->cluster_ref_dict = grid_dict;
+            const int why = cluster_graph(h);
+            (void)hipGetLastError();
+            if (why == 0) {
+                free_panel_state(grid);
+                (void)hipFree(grid_slot_row);
+                h->cluster_state = 2;
+            } else {   // keep the bricks
+                free_panel_state(h->psc);
+                (void)hipFree(h->d_slot_row); (void)hipFree(h->d_colpos);
+                h->d_colpos = nullptr;
+                h->psc = std::move(grid);
+                h->d_slot_row = grid_slot_row;
+                h->cluster_total_dict = grid_dict;
+                h->cluster_decline = why;
+            }
+        }
+    } else if ((h->cluster_decline = cluster_graph(h)) == 0) h->cluster_state = 2;
     if (h->cluster_state == 2 && h->nchain > 0 && h->d_colpos) {
         // the exact-chain kernels read B rows by column index: for the permuted panels of the reordered form they get the chain rows'
         // entries once more, compact, with relabelled columns (a few thousand entries)

@@ -96,6 +96,7 @@ struct sextans_engine {
     // The same plan over the rows in CLUSTERED order (row_cluster.hip: brick by brick for grid-stencil matrices), 4 lanes per row,
     // used by spmm_csr_panel_v2 for whole-matrix calls; row-range calls and every other kernel keep the natural-order plan above.
     PanelState psc;
+    int64_t cluster_ref_dict = 0;       // panel rows of the grid-brick plan while the graph plan is weighed against it (ensure_cluster_plan)
     int *d_slot_row = nullptr;          // psc: row of the main matrix per (block, slot)
     int *d_colpos = nullptr;            // psc, graph clustering: row of the permuted B panels that holds column c (K ints)
     float *d_Cs = nullptr;              //   ... and the row-major C staging buffer of the reordered form: [N / 16][M][16] floats
