@@ -49,12 +49,13 @@ int check_device(int device) {
 
 template <int W>
 void launch_repack(const float *dB, int64_t ldb, float *dBp, int K, int col_base, int ntiles,
-                   hipStream_t s, int k_begin = 0, int k_end = -1) {
+                   hipStream_t s, int k_begin = 0, int k_end = -1, int ncols = -1) {
     if (k_end < 0) k_end = K;
     if (k_end <= k_begin) return;
+    if (ncols < 0) ncols = ntiles * W;   // (fewer: the last panel is zero-filled past them)
     dim3 grid((unsigned)((k_end - k_begin + sx::kBlock - 1) / sx::kBlock), (unsigned)ntiles);
     hipLaunchKernelGGL(sx::repack_b_panels<W>, grid, dim3(sx::kBlock), 0, s, dB, ldb, dBp, K,
-                       col_base, k_begin, k_end);
+                       col_base, k_begin, k_end, ncols);
 }
 
 template <int LPR>
@@ -124,7 +125,7 @@ int launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_t
 template <int H>
 int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc,
                       int nsuper, float alpha, float beta, hipStream_t s, int64_t bcol_ld, int blk_begin, int blk_end,
-                      int row_base, int mode = 0) {
+                      int row_base, int mode = 0, int last_cols = 16) {
     // mode 1 (grid bricks): the plan over the rows in brick order, whole-matrix calls only; its slot -> row table addresses C.
     // mode 2 (graph clustering, the reordered form): dBp = permuted panels, dCin == dCout == the row-major staging buffer,
     // ldc_in == ldc == floats per tile; the same slot -> row table addresses the staging rows.
@@ -167,7 +168,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)P.d_row_off,
                            P.d_lidx, P.d_pval, P.d_blk_row, P.d_dict_ptr, P.d_dict, P.plan_dict_stride,
                            dBp, pstride, dCin, ldc_in, dCout, ldc, nsuper, tpw, nblk, alpha, beta, (int)h->opt_xcd,
-                           P.plan_pad_row, blk_begin, row_base, skip, (long long *)h->d_dbg, slot_row, (const int2 *)P.d_ioff);
+                           P.plan_pad_row, blk_begin, row_base, skip, (long long *)h->d_dbg, slot_row, (const int2 *)P.d_ioff, last_cols);
         return SEXTANS_OK;
     };
     if constexpr (H > 1) {
@@ -795,7 +796,24 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     const bool reordered = whole && h->cluster_state == 2 && h->opt_kernel != 1 && h->opt_kernel != 3 && W == 16 && !fuse_b &&
                            (!chains || h->d_chain_ci_perm) && h->dense_W == 0 && h->d_Cs && N >= 16;
     const int64_t cs_tile = reordered ? (int64_t)h->M * 16 : 0;   // floats per 16-column tile of the staging buffer
-    const int layout = reordered ? -W : W;
+    // N = 16 t + 8 on the register-resident panel kernel: the 8-column tail used to go to the gather kernel (the plan is built for
+    // 16-column tiles) -- 4M-row FEM matrix: N = 24 2 152 us per step against 1 099 at N = 32.  It now runs as one more 16-column tile:
+    // its B panel is zero in the 8 columns that do not exist, the kernel neither loads nor stores C there (`last_cols`), the passes of
+    // the reordered form skip them.  Not with rows on the piece / chain paths (their buffers are sized by N) or column-major staging.
+    auto seg_cols = [](const Seg &g) { return g.last_cols ? (g.ntiles - 1) * g.width + g.last_cols : g.ntiles * g.width; };
+    {
+        const bool wide0 = h->ps.plan_max_dict <= sx::kWideMaxDict && (int64_t)h->K * 64 < ((int64_t)1 << 32) && std::max(ldc, ldc_in) * 64 < ((int64_t)1 << 32);
+        const bool v2_here = reordered || (use_panel && !h->ps.plan_mixed && h->opt_panel_v2 != 0 && !fuse_b && wide0 && h->opt_cols_per_lane != 8);
+        if (v2_here && W == 16 && plan.size() == 2 && plan[0].width == 16 && plan[1].width == 8 && plan[1].ntiles == 1 && h->nhub == 0 &&
+            h->nchain == 0 && h->dense_W == 0 && h->opt_pipeline_tiles == 0 && h->Bp_cap >= (size_t)h->K * (size_t)(N + 8) &&
+            (!reordered || h->Cs_cap >= (size_t)(N / 16 + 1) * (size_t)h->M * 16)) {
+            plan[0].ntiles += 1;
+            plan[0].last_cols = 8;
+            plan.pop_back();
+        }
+    }
+    const bool merged_tail = plan[0].last_cols != 0;
+    const int layout = reordered ? -W : merged_tail ? W + 100 : W;
     const bool skip_repack = fuse_b || ((flags & SEXTANS_ROWS_REUSE_B_PANELS) != 0 && h->bp_layout == layout);
 
     // Tile-group pipelining (N >= 32 on the register-resident panel kernel, no long rows): the 16-column tiles are cut into two
@@ -822,7 +840,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
                 launch_repack<16>(d_C_in, ldc_in, h->d_Cs + (int64_t)t0 * cs_tile, h->M, g.col0 + 16 * t0, t1 - t0, st);
             } else if (reordered) {
                 hipLaunchKernelGGL(sx::repack_b_panels_perm, dim3((unsigned)((h->col_hi - h->col_lo + sx::kBlock - 1) / sx::kBlock), (unsigned)(t1 - t0)),
-                                   dim3(sx::kBlock), 0, st, d_B, ldb, dst, h->K, g.col0 + 16 * t0, h->d_colpos, h->col_lo, h->col_hi);
+                                   dim3(sx::kBlock), 0, st, d_B, ldb, dst, h->K, g.col0 + 16 * t0, h->d_colpos, h->col_lo, h->col_hi, 16 * (t1 - t0));
                 launch_repack<16>(d_C_in, ldc_in, h->d_Cs + (int64_t)t0 * cs_tile, h->M, g.col0 + 16 * t0, t1 - t0, st);
             } else {
                 launch_repack<16>(d_B, ldb, dst, h->K, g.col0 + 16 * t0, t1 - t0, st, h->col_lo, h->col_hi);
@@ -838,7 +856,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         };
         auto post = [&](int t0, int t1, hipStream_t st) {
             hipLaunchKernelGGL(sx::tiles_to_colmajor, dim3((unsigned)((h->M + sx::kBlock - 1) / sx::kBlock), (unsigned)(t1 - t0)), dim3(sx::kBlock),
-                               0, st, h->d_Cs + (int64_t)t0 * cs_tile, d_C_out, ldc, h->M, g.col0 + 16 * t0);
+                               0, st, h->d_Cs + (int64_t)t0 * cs_tile, d_C_out, ldc, h->M, g.col0 + 16 * t0, 16 * (t1 - t0));
         };
         hipStream_t side = h->aux_stream;
         h->bp_layout = layout;
@@ -889,12 +907,12 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
                 float *dst = h->d_Bp + (size_t)h->K * (size_t)g.col0;
                 if (reordered && g.width == 16 && h->d_colpos) {
                     hipLaunchKernelGGL(sx::repack_b_panels_perm, dim3((unsigned)((h->col_hi - h->col_lo + sx::kBlock - 1) / sx::kBlock), (unsigned)g.ntiles),
-                                       dim3(sx::kBlock), 0, s, d_B, ldb, dst, h->K, g.col0, h->d_colpos, h->col_lo, h->col_hi);
+                                       dim3(sx::kBlock), 0, s, d_B, ldb, dst, h->K, g.col0, h->d_colpos, h->col_lo, h->col_hi, seg_cols(g));
                     continue;
                 }
                 switch (g.width) {
                     case 32: launch_repack<32>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s, h->col_lo, h->col_hi); break;
-                    case 16: launch_repack<16>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s, h->col_lo, h->col_hi); break;
+                    case 16: launch_repack<16>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s, h->col_lo, h->col_hi, seg_cols(g)); break;
                     default: launch_repack<8>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s, h->col_lo, h->col_hi); break;
                 }
             }
@@ -902,7 +920,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         if (reordered)
             for (const Seg &g : plan)
                 if (g.width == 16)
-                    launch_repack<16>(d_C_in, ldc_in, h->d_Cs, h->M, g.col0, g.ntiles, s);   // C_in -> row-major tiles
+                    launch_repack<16>(d_C_in, ldc_in, h->d_Cs, h->M, g.col0, g.ntiles, s, 0, -1, seg_cols(g));   // C_in -> row-major tiles
     }
     {
         Prof p(h, &h->ev_kernel, s);
@@ -921,7 +939,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             float *cout = d_C_out + (int64_t)g.col0 * ldc;
             if (reordered && g.width == 16) {
                 if (int rc = launch_panel_v2<1>(h, bp, h->d_Cs, cs_tile, h->d_Cs, cs_tile, g.ntiles, alpha, beta, s, 0, 0, h->psc.plan_nblk, 0, 2))
-                    return rc;
+                    return rc;   // (a merged tail tile needs no mask here: its staging columns exist, the pass below writes back the valid ones)
                 v2_used = true;
                 // rows on the piece path: their partial sums from the PERMUTED panels (column c sits at row colpos[c]); folded into C
                 // behind the staging -> C pass below, which leaves C_in in their rows
@@ -960,7 +978,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
                 // whole-matrix calls on repacked panels: the plan over the rows in clustered (brick) order when the matrix has one
                 const bool clustered = whole && !fuse_b && h->cluster_state == 1;
                 if (int rc = launch_panel_v2<1>(h, bsrc, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, bld, clustered ? 0 : blk0,
-                                                clustered ? h->psc.plan_nblk : blk1, row_begin, clustered ? 1 : 0))
+                                                clustered ? h->psc.plan_nblk : blk1, row_begin, clustered ? 1 : 0, g.last_cols ? g.last_cols : 16))
                     return rc;
                 v2_used = true;
                 if (hubs) launch_hub_pieces<4>(h, pt, bp, g.ntiles, g.col0, v0, v1, s);
@@ -987,7 +1005,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         for (const Seg &g : plan)
             if (g.width == 16)
                 hipLaunchKernelGGL(sx::tiles_to_colmajor, dim3((unsigned)((h->M + sx::kBlock - 1) / sx::kBlock), (unsigned)g.ntiles),
-                                   dim3(sx::kBlock), 0, s, h->d_Cs, d_C_out, ldc, h->M, g.col0);
+                                   dim3(sx::kBlock), 0, s, h->d_Cs, d_C_out, ldc, h->M, g.col0, seg_cols(g));
         if (hubs) fold();
         // chain rows write C themselves: behind the staging -> C pass (which left C_in in their rows), from the permuted panels
         if (chains) launch_chains(h, plan, d_C_in, ldc_in, d_C_out, ldc, N, ch0, ch1, row_begin, alpha, beta, s, true);

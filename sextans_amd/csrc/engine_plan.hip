@@ -872,8 +872,9 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
             SX_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         }
     }
-    if (h->Bp_cap < (size_t)h->K * (size_t)N || !h->d_Bp) h->bp_layout = 0;   // new workspace: nothing to reuse
-    if (int rc = ensure(&h->d_Bp, &h->Bp_cap, (size_t)h->K * (size_t)N)) return rc;
+    const size_t n16 = (size_t)((N + 15) / 16) * 16;   // (N = 16 t + 8: room for the tail as a zero-padded 16-column tile)
+    if (h->Bp_cap < (size_t)h->K * n16 || !h->d_Bp) h->bp_layout = 0;   // new workspace: nothing to reuse
+    if (int rc = ensure(&h->d_Bp, &h->Bp_cap, (size_t)h->K * n16)) return rc;
     // main tile width: 4*lanes_per_row, but never wider than N itself (N = 8 -> 2 lanes per row); then
     // 16- and 8-wide tiles for the remainder (N is a multiple of 8, the reference's N-tile
     // granularity: sextans.cpp:57-60).
@@ -908,7 +909,7 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
         if (lpr == 4 && whole && h->opt_kernel != 3) {
             if (int rc = ensure_cluster_plan(h)) return rc;
             if (h->cluster_state == 2 && N >= 16)   // row-major C staging of the reordered form: N / 16 tiles of M x 16
-                if (int rc = ensure(&h->d_Cs, &h->Cs_cap, (size_t)(N / 16) * (size_t)h->M * 16)) return rc;
+                if (int rc = ensure(&h->d_Cs, &h->Cs_cap, (n16 / 16) * (size_t)h->M * 16)) return rc;
         }
         use_panel = h->ps.plan_built && ((h->opt_kernel == 2) || (h->ps.plan_panel_frac >= 0.5 && (N >= 32 || h->ps.plan_narrow_frac >= 0.5)));
     }

@@ -38,7 +38,8 @@ namespace sxe {
 struct EventPair { hipEvent_t a, b; };
 constexpr int kRowsNoFuseB = 0x100;   // internal flag of sextans_spmm_device_rows: always stage from the repacked panel
 constexpr int kPanelFloats = 9216;    // at most 36 KiB of LDS for the B panel (576 rows at N-tile 16)
-struct Seg { int width, col0, ntiles; };   // N is covered by segments of equally wide tiles
+struct Seg { int width, col0, ntiles; int last_cols = 0; };   // N is covered by segments of equally wide tiles; last_cols != 0: valid columns of the
+                                                               // segment's LAST tile (8: the tail of N = 16 t + 8 merged into the 16-column segment)
 }  // namespace sxe
 
 struct sextans_engine {

@@ -21,7 +21,7 @@ namespace sx {
 
 // Workgroup = 256 consecutive k of one 16-column panel t: Bp[t][colpos[k]][0..15] = B[k][col_base + 16 t + 0..15].
 __global__ __launch_bounds__(kBlock) void repack_b_panels_perm(const float *__restrict__ B, int64_t ldb, float *__restrict__ Bp, int K,
-                                                               int col_base, const int *__restrict__ colpos, int k_begin, int k_end) {
+                                                               int col_base, const int *__restrict__ colpos, int k_begin, int k_end, int ncols) {
     __shared__ float s[16][kBlock + 1];
     const int tid = threadIdx.x;
     const int k0 = k_begin + blockIdx.x * kBlock;
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(kBlock) void repack_b_panels_perm(const float *__re
     const float *src = B + (int64_t)(col_base + t * 16) * ldb;
     if (k0 + tid < k_end) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) s[c][tid] = src[(int64_t)c * ldb + k0 + tid];
+        for (int c = 0; c < 16; ++c) s[c][tid] = t * 16 + c < ncols ? src[(int64_t)c * ldb + k0 + tid] : 0.f;   // (ncols: see repack_b_panels)
     }
     __syncthreads();
     float *dst = Bp + (int64_t)t * K * 16;
@@ -48,7 +48,8 @@ __global__ __launch_bounds__(kBlock) void repack_b_panels_perm(const float *__re
 // kernel scatters / gathers 64-byte rows itself, where the latency hides behind everything else it has in flight); this is the way
 // back.  Workgroup = 256 consecutive rows of one tile.
 __global__ __launch_bounds__(kBlock) void tiles_to_colmajor(const float *__restrict__ Cs, float *__restrict__ C, int64_t ldc, int M,
-                                                            int col_base) {
+                                                            int col_base, int ncols) {
+    // ncols: columns of C from col_base on (the last tile of N = 16 t + 8 has 8: its other staging columns are not written back)
     // 16-byte accesses on both sides: a lane reads 4 consecutive floats of the staging chunk and writes 4 consecutive ROWS of one
     // column (rows of the LDS tile are 260 floats apart: 16-byte aligned, conflict-free for both access patterns).
     constexpr int LD = kBlock + 4;
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(kBlock) void tiles_to_colmajor(const float *__restr
     for (int i = 0; i < 4; ++i) {
         const int g = tid + i * kBlock;           // group g: column g / 64, rows 4 (g % 64) .. + 3
         const int c = g >> 6, rr = (g & 63) * 4;
+        if (t * 16 + c >= ncols) continue;
         float *d = dst + (int64_t)c * ldc + rr;
         if (rr + 3 < nr) {
             const f32x4 v = *reinterpret_cast<const f32x4 *>(&s[c * LD + rr]);

@@ -865,7 +865,9 @@ __global__ __launch_bounds__(chain_fused_threads(NT)) void chain_fused(
 template <int W>
 __global__ __launch_bounds__(kBlock) void repack_b_panels(const float *__restrict__ B, int64_t ldb,
                                                           float *__restrict__ Bp, int K,
-                                                          int col_base, int k_begin, int k_end) {
+                                                          int col_base, int k_begin, int k_end, int ncols) {
+    // ncols: columns of B from col_base on; a last panel that reaches past them is filled with zeros there (N = 16 t + 8 run as t + 1
+    // 16-column tiles: the padded columns multiply zeros and are never stored, spmm_panel_v2.h `last_cols`)
     // Rows [k_begin, k_end) of B only: the rows the matrix of this engine has columns in (a rank of a row-partitioned SpMM
     // over a banded matrix touches 1 / world of B plus a halo: engine_plan.hip, ensure_col_range); panels keep their absolute
     // addressing (row k of tile t at Bp[t K W + k W]).
@@ -877,7 +879,7 @@ __global__ __launch_bounds__(kBlock) void repack_b_panels(const float *__restric
     const float *src = B + (int64_t)(col_base + t * W) * ldb;
     if (k < k_end) {
 #pragma unroll
-        for (int c = 0; c < W; ++c) s[c][tid] = src[(int64_t)c * ldb + k];
+        for (int c = 0; c < W; ++c) s[c][tid] = t * W + c < ncols ? src[(int64_t)c * ldb + k] : 0.f;
     }
     __syncthreads();
     float *dst = Bp + (int64_t)t * K * W + (int64_t)k0 * W;

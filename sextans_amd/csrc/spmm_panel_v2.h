@@ -135,7 +135,9 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
     const int *__restrict__ blk_row, const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
     const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc,
     int nsuper, int tpw, int nblk, float alpha, float beta, int use_xcd_remap, int pad_row, int blk_begin, int row_base,
-    const unsigned char *__restrict__ skip, long long *dbg, const int *__restrict__ slot_row, const int2 *__restrict__ slot_ioff) {
+    const unsigned char *__restrict__ skip, long long *dbg, const int *__restrict__ slot_row, const int2 *__restrict__ slot_ioff, int last_cols) {
+    // last_cols (16-column tiles, column-major C): valid columns of the LAST super tile of the launch -- 8 when N = 16 t + 8 runs as
+    // t + 1 tiles (its B panel is zero there): lanes whose 4 columns lie beyond neither load C_in nor store C for that tile
     // slot_ioff (may be null): {where a slot's 16-bit index list starts in p_idx16, shift in bytes to add to every offset of the list}
     // when consecutive rows whose lists are equal up to a constant shift share one copy (plan_device.hip: share_index_lists); null =
     // own list at the slot's first packed entry, like its values.  The shift goes into this lane's LDS base address once.
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
     }
     // C_in of the FIRST super tile is requested here, in the same round trip as the panel and the row entries (for a
     // matrix of a few thousand rows the whole kernel is three round trips: one more is 15 % of its time)
+    const bool cvalid = H != 1 || 4 * q < last_cols;   // my 4 columns exist in the last tile too
     float cin[SETS][H][4];
     f32x4 cinv[SETS];
 #pragma unroll
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
         cinv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (CROW) {
             aload4(cinv[t], Cin + (int64_t)st_begin * ldc_in, cvoff_row[t]);
-        } else {
+        } else if (cvalid || st_begin + 1 < nsuper) {
 #pragma unroll
             for (int h = 0; h < H; ++h)
 #pragma unroll
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
             for (int t = 0; t < SETS; ++t) {
                 if constexpr (CROW) {
                     aload4(cinv[t], Cin + (int64_t)st * ldc_in, cvoff_row[t]);
-                } else {
+                } else if (cvalid || st + 1 < nsuper) {
 #pragma unroll
                     for (int h = 0; h < H; ++h)
 #pragma unroll
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
                                      epilogue<EXACT>(alpha, acc[t][0].z, beta, cinv[t].z), epilogue<EXACT>(alpha, acc[t][0].w, beta, cinv[t].w)};
                     astore4(Cout + (int64_t)st * ldc, cvoff_row[t], o);
                 }
-            } else if (cwrite[t]) {
+            } else if (cwrite[t] && (cvalid || st + 1 < nsuper)) {
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
                     const float a4[4] = {acc[t][h].x, acc[t][h].y, acc[t][h].z, acc[t][h].w};
