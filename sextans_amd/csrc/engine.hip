@@ -794,7 +794,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     // rows of B in the plan's column order and C goes through the block-major staging buffer (reorder_kernels.h); an 8-column
     // remainder tile keeps the natural-order kernels and panels.  (Layout tag -W: such panels are never reused by a row-range call.)
     const bool reordered = whole && h->cluster_state == 2 && h->opt_kernel != 1 && h->opt_kernel != 3 && W == 16 && !fuse_b &&
-                           (!chains || h->d_chain_ci_perm) && h->dense_W == 0 && h->d_Cs && N >= 16;
+                           (!chains || h->d_chain_ci_perm) && h->dense_W == 0 && h->d_Cs && (N >= 16 || (N == 8 && !hubs && !chains));
     const int64_t cs_tile = reordered ? (int64_t)h->M * 16 : 0;   // floats per 16-column tile of the staging buffer
     // N = 16 t + 8 on the register-resident panel kernel: the 8-column tail used to go to the gather kernel (the plan is built for
     // 16-column tiles) -- 4M-row FEM matrix: N = 24 2 152 us per step against 1 099 at N = 32.  It now runs as one more 16-column tile:
@@ -810,6 +810,9 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             plan[0].ntiles += 1;
             plan[0].last_cols = 8;
             plan.pop_back();
+        } else if (v2_here && W == 16 && plan.size() == 1 && plan[0].width == 8 && plan[0].ntiles == 1 && h->nhub == 0 && h->nchain == 0 &&
+                   h->dense_W == 0 && h->Bp_cap >= (size_t)h->K * 16 && (!reordered || h->Cs_cap >= (size_t)h->M * 16)) {
+            plan[0] = Seg{16, 0, 1, 8};   // N = 8 on the 16-column plan (engine_plan.hip: prepare, n8_wide)
         }
     }
     const bool merged_tail = plan[0].last_cols != 0;

@@ -883,8 +883,13 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
     // once N >= 32: a 128-byte B row is one fabric request where two 64-byte tiles are two (uniform 4M matrix,
     // N = 32/64/128: 3.15/6.9/15.2 ms with 8 lanes against 6.1/12.6/27.7 ms with 4).
     int lpr = h->opt_lpr ? (int)h->opt_lpr : 4;
+    // N = 8 (the reference's own N tile) on a large matrix without long rows: the 16-column plan and the register-resident kernel
+    // with a half-empty tile (spmm_panel_v2.h: last_cols) beat the 8-column panel kernel (4M-row FEM: 733 -> ~620 us per step) and
+    // save the second packed plan; small B (column-major staging) and matrices with rows on the piece / chain paths keep 2 lanes per row
+    bool n8_wide = N == 8 && !h->opt_lpr && h->opt_kernel == 0 && h->opt_panel_v2 != 0 && h->opt_cols_per_lane != 8 && h->nhub == 0 && h->nchain == 0 &&
+                   h->dense_W == 0 && (size_t)h->K * 8 * sizeof(float) > ((size_t)16 << 20) && (int64_t)h->K * 64 < ((int64_t)1 << 32);
     auto tiles = [&]() {
-        while (lpr > 2 && 4 * lpr > N) lpr /= 2;
+        while (lpr > 2 && 4 * lpr > N && !(n8_wide && lpr == 4)) lpr /= 2;
         W = 4 * lpr;
         plan.clear();
         int col = 0;
@@ -908,10 +913,17 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
         // use the clustered plan and do not pay for it.)
         if (lpr == 4 && whole && h->opt_kernel != 3) {
             if (int rc = ensure_cluster_plan(h)) return rc;
-            if (h->cluster_state == 2 && N >= 16)   // row-major C staging of the reordered form: N / 16 tiles of M x 16
+            if (h->cluster_state == 2 && (N >= 16 || n8_wide))   // row-major C staging of the reordered form: ceil(N / 16) tiles of M x 16
                 if (int rc = ensure(&h->d_Cs, &h->Cs_cap, (n16 / 16) * (size_t)h->M * 16)) return rc;
         }
         use_panel = h->ps.plan_built && ((h->opt_kernel == 2) || (h->ps.plan_panel_frac >= 0.5 && (N >= 32 || h->ps.plan_narrow_frac >= 0.5)));
+        if (n8_wide && !(use_panel && !h->ps.plan_mixed && h->ps.plan_max_dict <= sx::kWideMaxDict)) {   // not a case for the wide kernel after all
+            n8_wide = false;
+            lpr = 4;
+            tiles();
+            if (int rc = ensure_plan(h, lpr, h->opt_kernel == 2)) return rc;
+            use_panel = h->ps.plan_built && ((h->opt_kernel == 2) || (h->ps.plan_panel_frac >= 0.5 && h->ps.plan_narrow_frac >= 0.5));
+        }
     }
     // (the reordered form of a graph-clustered matrix runs 16-column tiles whether or not a natural-order plan exists)
     const bool reorder = whole && h->cluster_state == 2 && h->opt_kernel != 1 && h->opt_kernel != 3 && lpr == 4;
