@@ -27,9 +27,12 @@ __global__ __launch_bounds__(kBlock) void repack_b_panels_perm(const float *__re
     const int k0 = k_begin + blockIdx.x * kBlock;
     const int t = blockIdx.y;
     const float *src = B + (int64_t)(col_base + t * 16) * ldb;
-    if (k0 + tid < k_end) {
+    if ((t + 1) * 16 > ncols) {   // (ncols: see repack_b_panels -- uniform test, the zero-padded last panel only)
+        if (k0 + tid < k_end)
+            for (int c = 0; c < 16; ++c) s[c][tid] = t * 16 + c < ncols ? src[(int64_t)c * ldb + k0 + tid] : 0.f;
+    } else if (k0 + tid < k_end) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) s[c][tid] = t * 16 + c < ncols ? src[(int64_t)c * ldb + k0 + tid] : 0.f;   // (ncols: see repack_b_panels)
+        for (int c = 0; c < 16; ++c) s[c][tid] = src[(int64_t)c * ldb + k0 + tid];
     }
     __syncthreads();
     float *dst = Bp + (int64_t)t * K * 16;

@@ -877,9 +877,12 @@ __global__ __launch_bounds__(kBlock) void repack_b_panels(const float *__restric
     const int t = blockIdx.y;
     const int k = k0 + tid;
     const float *src = B + (int64_t)(col_base + t * W) * ldb;
-    if (k < k_end) {
+    if ((t + 1) * W > ncols) {   // (uniform: the zero-padded last panel only -- a per-element test in the loop below cost 35 % of the pass)
+        if (k < k_end)
+            for (int c = 0; c < W; ++c) s[c][tid] = t * W + c < ncols ? src[(int64_t)c * ldb + k] : 0.f;
+    } else if (k < k_end) {
 #pragma unroll
-        for (int c = 0; c < W; ++c) s[c][tid] = t * W + c < ncols ? src[(int64_t)c * ldb + k] : 0.f;
+        for (int c = 0; c < W; ++c) s[c][tid] = src[(int64_t)c * ldb + k];
     }
     __syncthreads();
     float *dst = Bp + (int64_t)t * K * W + (int64_t)k0 * W;
