@@ -887,7 +887,8 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
     // with a half-empty tile (spmm_panel_v2.h: last_cols) beat the 8-column panel kernel (4M-row FEM: 733 -> ~620 us per step) and
     // save the second packed plan; small B (column-major staging) and matrices with rows on the piece / chain paths keep 2 lanes per row
     bool n8_wide = N == 8 && !h->opt_lpr && h->opt_kernel == 0 && h->opt_panel_v2 != 0 && h->opt_cols_per_lane != 8 && h->nhub == 0 && h->nchain == 0 &&
-                   h->dense_W == 0 && (size_t)h->K * 8 * sizeof(float) > ((size_t)16 << 20) && (int64_t)h->K * 64 < ((int64_t)1 << 32);
+                   h->dense_W == 0 && (size_t)h->K * 8 * sizeof(float) > ((size_t)16 << 20) && (int64_t)h->K * 64 < ((int64_t)1 << 32) &&
+                   h->M > 0 && h->m_nnz / h->M >= 48;   // (shorter rows: measured a loss -- 2-D 9-point x 2 dof 0.48 -> 0.37 of the roofline per step, 43-entry mesh rows 0.38 -> 0.33)
     auto tiles = [&]() {
         while (lpr > 2 && 4 * lpr > N && !(n8_wide && lpr == 4)) lpr /= 2;
         W = 4 * lpr;
