@@ -15,13 +15,21 @@ cases["diagonal"] = csr(sp.diags([rs.uniform(-1, 1, M)], [0], format="csr", dtyp
 cases["tridiagonal"] = csr(sp.diags([rs.uniform(-1, 1, M - 1), rs.uniform(-1, 1, M), rs.uniform(-1, 1, M - 1)], [-1, 0, 1], format="csr", dtype=np.float32))
 rp, ci, v = api.gen_stencil2d_host(1414, 1414, 5, 1, 3); M5 = 1414 * 1414
 cases["5-point stencil, random order"] = meshgen.permute_symmetric(rp, ci, v, M5, rs.permutation(M5))
-rp, ci, v = api.gen_fem3d_host(88, 88, 88, 3, 3); Mf = 88 ** 3 * 3
+rp, ci, v = api.gen_fem3d_host(64, 64, 64, 3, 3); Mf = 64 ** 3 * 3
 A = sp.csr_matrix((np.asarray(v), np.asarray(ci), np.asarray(rp)), shape=(Mf, Mf))
 D = sp.diags([(rs.rand(Mf) < 0.5).astype(np.float32)], [0], format="csr")
 cases["FEM 3 dof, half of the rows emptied"] = csr(D @ A)
 nb = 40000; bs = 48
 blk = sp.block_diag([sp.csr_matrix(rs.uniform(-1, 1, (bs, bs)).astype(np.float32))] * 1, format="csr")
 cases["block diagonal, 48 x 48 dense blocks"] = csr(sp.kron(sp.identity(nb, format="csr", dtype=np.float32), blk, format="csr"))
+L = sp.tril(A, format="csr")
+cases["FEM 3 dof, lower triangle only"] = csr(L)
+far = sp.csr_matrix((rs.uniform(-1, 1, 4 * Mf).astype(np.float32), (np.repeat(np.arange(Mf), 4), rs.randint(0, Mf, 4 * Mf))), shape=(Mf, Mf))
+far.sum_duplicates()
+cases["FEM 3 dof + 4 random far entries per row"] = csr(A + far)
+cases["FEM 3 dof, random order, lower triangle"] = meshgen.permute_symmetric(*csr(A), Mf, meshgen.node_permutation(Mf // 3, 3, 2))
+t = cases["FEM 3 dof, random order, lower triangle"]
+cases["FEM 3 dof, random order, lower triangle"] = csr(sp.tril(sp.csr_matrix((t[2], t[1], t[0]), shape=(Mf, Mf)), format="csr"))
 N = 16
 for name, (rp, ci, v) in cases.items():
     M = len(rp) - 1; nnz = int(rp[-1])
