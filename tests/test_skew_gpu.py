@@ -275,3 +275,43 @@ def test_power_law_1m_rows_strict_order_default(engine, sx):
     finally:
         for q in pl[:3]:
             api.device_free(0, q)
+
+
+def test_emptied_rows_do_not_make_the_others_long(engine, oracle):
+    """A mesh matrix with half of its rows emptied (eliminated unknowns): the automatic bucketing threshold is twice the mean length of
+    the NON-EMPTY rows -- with the mean over all rows every remaining row counted as long and went to the piece kernel (2M-row FEM:
+    913 us per step instead of 351).  And rows above the threshold that are a quarter of the matrix are no outliers: a bimodal matrix
+    (27- and 270-entry rows) is not bucketed either.  Bit-identical, piece_path_rows == 0."""
+    from sextans_amd import api
+    rs = np.random.RandomState(5)
+    rp, ci, v = api.gen_fem3d_host(14, 13, 12, 3, 7)
+    rp, ci, v = np.array(rp), np.array(ci), np.array(v)
+    M = K = 14 * 13 * 12 * 3
+    lens = np.diff(rp)
+    keep_row = rs.rand(M) < 0.5
+    keep = np.repeat(keep_row, lens)
+    lens2 = np.where(keep_row, lens, 0)
+    half = (np.concatenate([[0], np.cumsum(lens2)]).astype(np.int32), ci[keep], v[keep])
+    # bimodal: 40 % of the rows get 10 x their entries (extra random columns)
+    import scipy.sparse as sp
+    A = sp.csr_matrix((v, ci, rp), shape=(M, K))
+    extra_rows = np.flatnonzero(rs.rand(M) < 0.4)
+    E = sp.csr_matrix((rs.uniform(-1, 1, len(extra_rows) * 200).astype(np.float32), (np.repeat(extra_rows, 200), rs.randint(0, K, len(extra_rows) * 200))), shape=(M, K))
+    E.sum_duplicates()
+    Bm = (A + E).tocsr(); Bm.sort_indices()
+    bimodal = (Bm.indptr.astype(np.int32), Bm.indices.astype(np.int32), Bm.data.astype(np.float32))
+    N = 16
+    try:
+        for name, (rp2, ci2, v2) in (("half emptied", half), ("bimodal", bimodal)):
+            _defaults(engine)
+            engine.set_matrix_csr(M, K, rp2, ci2, v2)
+            assert int(engine.get_stat("piece_path_rows")) == 0, (name, engine.get_stat("piece_path_rows"), engine.get_stat("bucket_threshold"))
+            B = rs.uniform(-1, 1, K * N).astype(np.float32)
+            C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+            want = C0.copy()
+            oracle.spmm(M, N, K, ALPHA, rp2, ci2, v2, B, BETA, want)
+            out = C0.copy()
+            engine.spmm(N, ALPHA, B, BETA, out)
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (name, engine.last_kernel())
+    finally:
+        _defaults(engine)
