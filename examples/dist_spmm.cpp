@@ -71,7 +71,7 @@ int main(int argc, char **argv) {
             HIP(hipMemcpy(result[(size_t)g].data(), dCout, Cin.size() * 4, hipMemcpyDeviceToHost));
             sextans_destroy(h);
             sextans_dist_comm_destroy(comm);
-            hipFree(dB); hipFree(dCin); hipFree(dCout); hipStreamDestroy(st);
+            (void)hipFree(dB); (void)hipFree(dCin); (void)hipFree(dCout); (void)hipStreamDestroy(st);
         });
     for (auto &t : ranks) t.join();
     // single-GPU result of the same product
