@@ -359,7 +359,7 @@ int cluster_grid(sextans_engine *h) {   // 0 = in use, 1 = declined
     // meta, prologue round trips and panel are paid once per 128 rows.  Falls back to 64-row bricks when a dictionary outgrows the panel.
     // (measured same-box, tools/exp_r04i.sh: 27-point 1-dof -3.5 % at N = 16, -4 % at N = 128; 2-D 9-point -2 .. -7 % at N = 16 but +3 .. +8 %
     // at N >= 32, where the tile loop re-reads both sets' panels: automatic for 3-D grids only, row_sets = 3 forces it for 2-D grids too)
-    int sets = (h->opt_cluster_shape == 0 && h->M > 0 && h->ps.plan_max_row <= 32 && (h->opt_row_sets >= 3 || (h->opt_row_sets == 2 && gs.s3 > 0))) ? 2 : 1;
+    int sets = (h->M > 0 && h->ps.plan_max_row <= 32 && (h->opt_row_sets >= 3 || (h->opt_row_sets == 2 && gs.s3 > 0 && h->opt_cluster_shape == 0))) ? 2 : 1;
     if (h->opt_cluster_shape > 0) {   // measurement switch (SEXTANS_DEBUG_OPTIONS): run_rows * 10000 + b2 * 100 + b3, validated by set_option
         run_rows = (int)(h->opt_cluster_shape / 10000); b2 = (int)(h->opt_cluster_shape / 100 % 100); b3 = (int)(h->opt_cluster_shape % 100);
         if (run_rows < 1 || b2 < 1 || b3 < 1) return 1;
@@ -377,7 +377,7 @@ int cluster_grid(sextans_engine *h) {   // 0 = in use, 1 = declined
         (void)hipFree(d_perm); (void)hipFree(d_cut); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
         d_perm = prp = pci = nullptr; d_cut = nullptr; pv = nullptr;
         sx::free_device_plan(dp);
-        const int l2 = sets == 2 ? (gs.s3 > 0 ? 4 : 8) : b2, l3 = sets == 2 ? (gs.s3 > 0 ? 2 : 1) : b3;
+        const int l2 = sets == 2 && h->opt_cluster_shape == 0 ? (gs.s3 > 0 ? 4 : 8) : b2, l3 = sets == 2 && h->opt_cluster_shape == 0 ? (gs.s3 > 0 ? 2 : 1) : b3;   // (a measurement shape + row_sets = 3: that shape as two row sets)
         if (sx::build_brick_order_device(h->M, gs, run_rows, l2, l3, (int)h->opt_cluster_group, &d_perm, &d_cut, err)) return drop();
         if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_perm, &prp, &pci, &pv, err)) return drop();
         cap_used = cap;
