@@ -389,3 +389,28 @@ def test_dof_major_numbering_gets_the_graph_plan(engine, oracle):
         assert rows[-1] < 0.6 * rows[1], rows
     finally:
         _set(engine)
+
+
+@pytest.mark.parametrize("dims", [(17, 17, 17), (18, 17, 15), (19, 15, 15)])
+def test_reordered_form_row_counts_not_a_multiple_of_four(engine, oracle, dims):
+    """M % 4 = 1, 2, 3: the staging -> C pass writes 4 consecutive rows of a column per lane where the address is 16-byte aligned and
+    falls back to scalar stores elsewhere (and for the last rows of a column); N = 8, 16, 24, 40 cover the half-empty tail tile."""
+    from sextans_amd import meshgen
+    rp, ci, v, M = _fem(*dims, 1)
+    assert M % 4 != 0 and M >= 4096
+    rp, ci, v = meshgen.permute_symmetric(rp, ci, v, M, meshgen.node_permutation(M, 1, 9))
+    rs = np.random.RandomState(M)
+    try:
+        _set(engine, row_cluster=2, fuse_b=0)
+        engine.set_matrix_csr(M, M, rp, ci, v)
+        for N in (16, 24, 40, 8):
+            B, C0 = _operands(rs, M, M, N)
+            want = C0.copy()
+            oracle.spmm(M, N, M, ALPHA, rp, ci, v, B, BETA, want)
+            out = C0.copy()
+            engine.spmm(N, ALPHA, B, BETA, out)
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (dims, N, engine.last_kernel())
+            if N >= 16:
+                assert engine.last_kernel() == "spmm_csr_panel_v2_reordered" and int(engine.get_stat("row_cluster")) == 2
+    finally:
+        _set(engine)
