@@ -77,7 +77,7 @@ def _matrix(rs):
     return name + f" mode {mode}", M, rp, ci.astype(np.int32), v.astype(np.float32)
 
 
-@pytest.mark.parametrize("seed", range(96))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SEXTANS_FUZZ_SEEDS", "96"))))   # (a soak run: SEXTANS_FUZZ_SEEDS=3000)
 def test_random_plan_forms_are_bit_identical(engine, oracle, seed):
     rs = np.random.RandomState(1000 + seed)
     name, M, rp, ci, v = _matrix(rs)
@@ -107,7 +107,7 @@ def test_random_plan_forms_are_bit_identical(engine, oracle, seed):
             engine.set_option(k, val)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SEXTANS_FUZZ_LARGE_SEEDS", "8"))))
 def test_random_large_matrices_default_options(engine, oracle, seed):
     """The same at sizes where B no longer fits the L2s (10^5 .. 10^6 rows): the automatic choices of the dispatcher -- grid bricks, graph
     clustering + reordered form, natural plan, lane-per-row kernel -- under DEFAULT options, whole-matrix calls and one row-range call."""
