@@ -509,10 +509,19 @@ void launch_chains(sextans_engine *h, const std::vector<Seg> &plan, const float 
     // their compact relabelled copy (ensure_cluster_plan); 8-column remainder tiles keep the natural panels and the source arrays
     // one workgroup per (chain row, 16- or 8-column tile): chain_fused
     {
+        std::vector<Seg> segs;   // a segment whose last tile is half empty (N = 16 t + 8): its full tiles, then the 8 valid columns of the tail
         for (const Seg &g : plan) {
+            if (g.last_cols == 8 && g.width == 16) {
+                if (g.ntiles > 1) segs.push_back(Seg{16, g.col0, g.ntiles - 1, 0});
+                segs.push_back(Seg{16, g.col0 + 16 * (g.ntiles - 1), 1, 8});
+            } else {
+                segs.push_back(g);
+            }
+        }
+        for (const Seg &g : segs) {
             const float *bp = h->d_Bp + (size_t)h->K * (size_t)g.col0;
-            const int NT = g.width >= 16 ? 16 : 8;
-            const int ntiles = g.ntiles * (g.width / NT);
+            const int NT = (g.width >= 16 && g.last_cols != 8) ? 16 : 8;   // (the tail: the first 8-column half of its 16-column panel)
+            const int ntiles = g.last_cols == 8 ? 1 : g.ntiles * (g.width / NT);
             auto go = [&](auto kern, int lds, int threads) {
                 (void)allow_big_lds(h, reinterpret_cast<const void *>(kern), lds);
                 const bool perm = permuted_panels && g.width == 16;
@@ -799,13 +808,18 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     // N = 16 t + 8 on the register-resident panel kernel: the 8-column tail used to go to the gather kernel (the plan is built for
     // 16-column tiles) -- 4M-row FEM matrix: N = 24 2 152 us per step against 1 099 at N = 32.  It now runs as one more 16-column tile:
     // its B panel is zero in the 8 columns that do not exist, the kernel neither loads nor stores C there (`last_cols`), the passes of
-    // the reordered form skip them.  Not with rows on the piece / chain paths (their buffers are sized by N) or column-major staging.
+    // the reordered form skip them; rows on the piece path sum 16 columns into their (wider) partial-sum buffer and fold N, the exact
+    // chains take the tail as one 8-column tile of the 16-column panel.  Not with dense tiles on the MFMA path or column-major staging.
     auto seg_cols = [](const Seg &g) { return g.last_cols ? (g.ntiles - 1) * g.width + g.last_cols : g.ntiles * g.width; };
     {
         const bool wide0 = h->ps.plan_max_dict <= sx::kWideMaxDict && (int64_t)h->K * 64 < ((int64_t)1 << 32) && std::max(ldc, ldc_in) * 64 < ((int64_t)1 << 32);
         const bool v2_here = reordered || (use_panel && !h->ps.plan_mixed && h->opt_panel_v2 != 0 && !fuse_b && wide0 && h->opt_cols_per_lane != 8);
-        if (v2_here && W == 16 && plan.size() == 2 && plan[0].width == 16 && plan[1].width == 8 && plan[1].ntiles == 1 && h->nhub == 0 &&
-            h->nchain == 0 && h->dense_W == 0 && h->opt_pipeline_tiles == 0 && h->Bp_cap >= (size_t)h->K * (size_t)(N + 8) &&
+        if (v2_here && W == 16 && plan.size() == 2 && plan[0].width == 16 && plan[1].width == 8 && plan[1].ntiles == 1 &&
+            (h->nhub == 0 || h->P_cap >= (size_t)h->split_nv * (size_t)(N + 8)) &&
+            // (with rows on the piece / chain paths only where the main rows are long enough to matter: on the KKT class -- 6 entries per
+            // row, arrow borders as chains -- the wider piece / chain work cost more than the gather tail: 1 510 -> 1 687 us at N = 24)
+            ((h->nhub == 0 && h->nchain == 0) || (h->M > 0 && h->m_nnz / h->M >= 16)) &&
+            h->dense_W == 0 && h->opt_pipeline_tiles == 0 && h->Bp_cap >= (size_t)h->K * (size_t)(N + 8) &&
             (!reordered || h->Cs_cap >= (size_t)(N / 16 + 1) * (size_t)h->M * 16)) {
             plan[0].ntiles += 1;
             plan[0].last_cols = 8;

@@ -871,8 +871,8 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
             h->bell_Bf_cap = need;
         }
     }
-    if (h->nhub > 0)
-        if (int rc = ensure(&h->d_P, &h->P_cap, (size_t)h->split_nv * (size_t)N)) return rc;
+    if (h->nhub > 0)   // (16-column granularity: N = 16 t + 8 may run its tail as a half-empty 16-column tile)
+        if (int rc = ensure(&h->d_P, &h->P_cap, (size_t)h->split_nv * (size_t)((N + 15) / 16 * 16))) return rc;
     if (h->nchain > 0 || (N >= 32 && h->opt_pipeline_tiles != 0)) {
         if (!h->ev_pipe[0])
             for (hipEvent_t &e : h->ev_pipe) SX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
