@@ -271,6 +271,8 @@ int sextans_destroy(sextans_handle_t h);
  *   every row <= 32 entries -- use 128-row bricks as two 64-slot row sets on one panel; 3 = 2-D grids too; 1 = never; stat
  *   "row_sets"), "refine_sweeps" (8) / "refine_rows" (62): block refinement of the graph-clustered order, "relabel_columns" (1),
  *   "cluster_top" (depth of the merge tree).
+ * "row_offset" (default -1): the matrix of this engine is the row slab [row_offset, row_offset + M) of a K x K matrix (what a rank of
+ *   sextans_dist_spmm holds, which sets it): the graph clustering of "row_cluster" then runs on the slab's own square pattern.
  * "share_index" (default 1): consecutive rows of a block whose 16-bit index lists are equal up to a constant shift keep one copy
  *   of the list (stats "index_stream_entries", "value_stream_entries"); the exported plan carries every row's own list.
  * "colwise_max_len" (default 6; "kernel" = 4 forces it): rows of at most this mean length in a numbering with locality (stat
@@ -485,6 +487,10 @@ int sextans_gen_stencil2d_device(int device, int nx, int ny, int points, int dof
  * New device arrays (sextans_device_free).  Rows of up to 4096 entries. */
 int sextans_csr_permute_symmetric_device(int device, int M, int64_t nnz, const int *d_row_ptr, const int *d_col_idx, const float *d_val,
                                          const int *new_of_old, int **o_row_ptr, int **o_col_idx, float **o_val);
+/* Rows [r0, r1) of a device-resident CSR matrix as a matrix of their own (what a rank of the row-partitioned SpMM holds; measurement
+ * infrastructure): a new row_ptr of r1 - r0 + 1 entries starting at 0 (sextans_device_free), *first_entry = where the slab's
+ * col_idx / val begin inside the original arrays (use d_col_idx + *first_entry, d_val + *first_entry), *nnz = its non-zeros. */
+int sextans_csr_slice_rows_device(int device, int r0, int r1, const int *d_row_ptr, int **o_row_ptr, int64_t *first_entry, int64_t *nnz);
 int sextans_gen_kkt_host(int n, int arrow, uint64_t seed, int r0, int r1, int **row_ptr, int **col_idx, float **val, int64_t *nnz);
 int sextans_gen_kkt_device(int device, int n, int arrow, uint64_t seed, int r0, int r1, int **d_row_ptr, int **d_col_idx,
                            float **d_val, int64_t *nnz);

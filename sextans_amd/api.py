@@ -719,6 +719,15 @@ def permute_symmetric_device(device, M, nnz, d_rp, d_ci, d_v, new_of_old):
     return p.value, i.value, v.value
 
 
+def slice_rows_device(device, r0, r1, d_rp, d_ci, d_v):
+    """Rows [r0, r1) of a device CSR matrix as (rp, ci, v, nnz): rp is a new device array (device_free), ci / v point INTO the originals."""
+    p, first, nnz = C.c_void_p(), C.c_int64(), C.c_int64()
+    L = lib()
+    L.sextans_csr_slice_rows_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    _check(L.sextans_csr_slice_rows_device(device, r0, r1, d_rp, C.byref(p), C.byref(first), C.byref(nnz)), "csr_slice_rows_device")
+    return p.value, d_ci + 4 * first.value, d_v + 4 * first.value, nnz.value
+
+
 def gen_fem3d_device(device, nx, ny, nz, dof, seed, r0=0, r1=None):
     r1 = nx * ny * nz * dof if r1 is None else r1
     p, i, v = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -322,6 +322,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "cluster_top")) return &h->opt_cluster_top;
     if (!strcmp(key, "small_panel")) return &h->opt_small_panel;
     if (!strcmp(key, "row_sets")) return &h->opt_row_sets;
+    if (!strcmp(key, "row_offset")) return &h->opt_row_offset;
     if (!strcmp(key, "relabel_columns")) return &h->opt_relabel_columns;
     if (!strcmp(key, "refine_sweeps")) return &h->opt_refine_sweeps;
     if (!strcmp(key, "share_index")) return &h->opt_share_index;
@@ -373,7 +374,7 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
         (void)hipSetDevice(h->device);
         free_window(h);   // the stream is built for one (rows per wavefront, window) pair
     }
-    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_top || slot == &h->opt_small_panel || slot == &h->opt_row_sets || slot == &h->opt_relabel_columns || slot == &h->opt_refine_sweeps || slot == &h->opt_refine_rows || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
+    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_top || slot == &h->opt_small_panel || slot == &h->opt_row_sets || slot == &h->opt_row_offset || slot == &h->opt_relabel_columns || slot == &h->opt_refine_sweeps || slot == &h->opt_refine_rows || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
         (void)hipSetDevice(h->device);   // the clustered-order plan is (re)considered under the new setting
         free_cluster_plan(h);
     }

@@ -116,6 +116,8 @@ int sextans_dist_spmm(sextans_handle_t h, void *comm, int world, int rank, const
     if (m_loc != h->M || ldc < M_total || ldc_in < M_total || ldb < h->K) return SEXTANS_ERR_INVALID;
     SX_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
+    // (where this rank's rows sit in the matrix: lets the graph clustering run on the slab -- used by whole-slab calls, nchunks = 1)
+    if (h->opt_row_offset != row0) (void)sextans_set_option(h, "row_offset", row0);
     if (nchunks < 1) nchunks = 1;
     if (nchunks > 16) nchunks = 16;
     // Chunk c of rank g = local rows [cuts[g][c], cuts[g][c+1]).  Every rank snaps its OWN interior cuts to the

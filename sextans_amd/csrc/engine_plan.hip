@@ -406,17 +406,28 @@ int cluster_grid(sextans_engine *h) {   // 0 = in use, 1 = declined
 }
 
 int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reason (stat "cluster_decline")
-    if (h->M != h->K || h->m_nnz <= 0) return 1;                                        // 1: not square
+    // square, or a row slab of a square matrix whose position is known (option row_offset, set by sextans_dist_spmm): then the
+    // clustering runs on the slab's own square pattern, everything behind it on the rectangular matrix
+    const bool slab = h->M != h->K && h->opt_row_offset >= 0 && h->opt_row_offset + h->M <= h->K;
+    if ((h->M != h->K && !slab) || h->m_nnz <= 0) return 1;                             // 1: not square
     if (h->dense_W > 0) return 2;                                                       // 2: dense tiles on the MFMA path (rows on the piece / chain paths are fine: they are empty here)
     if ((int64_t)h->K * 64 >= ((int64_t)1 << 32)) return 3;   // 3: 32-bit byte offsets into a K x 16 panel
     const int lpr = 4, RB = sx::kBlock / lpr, cap = kPanelFloats / (4 * lpr);
     std::string err;
+    int *g_rp_own = nullptr, *g_ci_own = nullptr;      // the graph the rows are clustered over
+    const int *g_rp = h->m_rp, *g_ci = h->m_ci;
+    int64_t g_nnz = h->m_nnz;
+    if (slab) {
+        if (sx::local_square_pattern_device(h->M, h->m_rp, h->m_ci, (int)h->opt_row_offset, &g_rp_own, &g_ci_own, &g_nnz, err)) return 6;
+        g_rp = g_rp_own; g_ci = g_ci_own;
+    }
+    struct FreeGraph { int *a, *b; ~FreeGraph() { (void)hipFree(a); (void)hipFree(b); } } free_graph{g_rp_own, g_ci_own};
     if (h->opt_row_cluster < 0) {
         // worth trying?  Not when the natural-order plan already fills its blocks (numberings with locality: the grid path or
         // nothing), and not when neighbouring rows do not share neighbourhoods (random columns: there is nothing to find)
         if (h->ps.plan_built && !h->ps.plan_mixed && h->ps.plan_nblk > 0 && (double)h->M / h->ps.plan_nblk >= 50.0) return 4;   // 4: natural blocks are full
         double shared = 0.0, near = 0.0;
-        if (sx::probe_shared_neighbourhood_device(h->M, h->m_rp, h->m_ci, 256, &shared, &near, err)) return 5;
+        if (sx::probe_shared_neighbourhood_device(h->M, g_rp, g_ci, 256, &shared, &near, err)) return 5;
         h->cluster_shared = shared;
         if (shared < 0.2) return 5;                                                                                               // 5: no shared neighbourhoods
         // 13: short rows in a numbering that has locality -- per row the two extra passes over C move more bytes than the row's
@@ -430,9 +441,9 @@ int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reaso
     sx::DevicePlan dp;
     auto drop = [&](int why) { (void)hipFree(d_order); (void)hipFree(d_colpos); (void)hipFree(d_cut); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
                                sx::free_device_plan(dp); return why; };
-    if (sx::cluster_rows_graph_device(h->M, h->K, h->m_nnz, h->m_rp, h->m_ci, (int)std::min<int64_t>(h->opt_cluster_top, 0x40000000), &d_order, err)) return drop(6);   // 6 .. 9: a builder failed
+    if (sx::cluster_rows_graph_device(h->M, h->M, g_nnz, g_rp, g_ci, (int)std::min<int64_t>(h->opt_cluster_top, 0x40000000), &d_order, err)) return drop(6);   // 6 .. 9: a builder failed
     if (h->opt_refine_sweeps > 0)   // boundary rows to the block that holds more of their neighbours (blocks of 62 rows, room for 2 more each)
-        if (sx::refine_blocks_device(h->M, h->m_rp, h->m_ci, d_order, (int)std::min<int64_t>(RB, std::max<int64_t>(32, h->opt_refine_rows)), RB, (int)h->opt_refine_sweeps, &d_cut, err) == 2) return drop(6);
+        if (sx::refine_blocks_device(h->M, g_rp, g_ci, d_order, (int)std::min<int64_t>(RB, std::max<int64_t>(32, h->opt_refine_rows)), RB, (int)h->opt_refine_sweeps, &d_cut, err) == 2) return drop(6);
     const bool relabel = h->opt_relabel_columns != 0;
     if (relabel && sx::column_first_touch_order_device(h->M, h->K, h->m_rp, h->m_ci, d_order, &d_colpos, err)) return drop(7);
     if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_order, &prp, &pci, &pv, err)) return drop(8);

@@ -214,6 +214,8 @@ struct sextans_engine {
     int64_t opt_cluster_group = 3;      // bricks are laid out in groups of g x g brick columns (A/B on the 4M-row FEM matrix: g = 3)
     int64_t opt_row_cluster = -1;       // clustered-order plan for spmm_csr_panel_v2 (ensure_cluster_plan): -1 auto, 0 never, 1 whenever one
                                         // can be built, 2 = graph clustering (reordered form) also where the grid bricks would apply
+    int64_t opt_row_offset = -1;        // this engine's matrix is the row slab [row_offset, row_offset + M) of a K x K matrix (set by sextans_dist_spmm): lets the
+                                        // graph clustering run on a rank's slab (edges to other ranks' rows ignored); -1 = unknown (only square matrices cluster)
     int64_t opt_row_sets = 2;           // clustered grid plan of a short-row matrix (rows <= 32 entries): 128-row bricks = two 64-slot row sets per block and panel; 2 = 3-D grids, 3 = 2-D grids too, 1 = never
     int64_t opt_pipeline_tiles = 0;     // N >= 32 on spmm_csr_panel_v2: 1 = the 16-column tiles run as two groups and the layout passes of the second
                                         // group go to the side stream under the first group's kernel.  Built and measured: the second

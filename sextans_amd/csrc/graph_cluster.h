@@ -40,6 +40,12 @@ int refine_blocks_device(int M, const int *d_rp, const int *d_ci, int *d_order, 
 // of the relabelled B panel.  K ints on the device, caller frees.
 int column_first_touch_order_device(int M, int K, const int *d_rp, const int *d_ci, const int *d_order, int **d_colpos, std::string &err);
 
+// Row SLAB of a square matrix (rows [row_offset, row_offset + M) of a K x K matrix: what a rank of the row-partitioned SpMM holds): the
+// square pattern of the slab's own rows -- entries whose column c lies in [row_offset, row_offset + M), as c - row_offset; edges to
+// rows the slab does not hold are dropped.  out_rp (M + 1) / out_ci on the device, caller frees.  The clustering above runs on it.
+int local_square_pattern_device(int M, const int *d_rp, const int *d_ci, int row_offset, int **out_rp, int **out_ci, int64_t *out_nnz,
+                                std::string &err);
+
 // in place: ci[j] = colpos[ci[j]]
 int relabel_columns_device(int64_t nnz, int *d_ci, const int *d_colpos, std::string &err);
 

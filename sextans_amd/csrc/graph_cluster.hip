@@ -773,4 +773,50 @@ int relabel_columns_device(int64_t nnz, int *d_ci, const int *d_colpos, std::str
     return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void slab_count(int M, const int *__restrict__ rp, const int *__restrict__ ci, int off, int *__restrict__ cnt) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= M) return;
+    int n = 0;
+    for (int j = rp[r]; j < rp[r + 1]; ++j) n += (unsigned)(ci[j] - off) < (unsigned)M;
+    cnt[r] = n;
+}
+__global__ __launch_bounds__(256) void slab_fill(int M, const int *__restrict__ rp, const int *__restrict__ ci, int off, const int *__restrict__ orp,
+                                                 int *__restrict__ oci) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= M) return;
+    int o = orp[r];
+    for (int j = rp[r]; j < rp[r + 1]; ++j) {
+        const int c = ci[j] - off;
+        if ((unsigned)c < (unsigned)M) oci[o++] = c;
+    }
+}
+}  // namespace
+
+int local_square_pattern_device(int M, const int *d_rp, const int *d_ci, int row_offset, int **out_rp, int **out_ci, int64_t *out_nnz,
+                                std::string &err) {
+    *out_rp = *out_ci = nullptr;
+    *out_nnz = 0;
+    if (M <= 0) return 1;
+    Scratch tmp;
+    int *cnt = nullptr, *orp = nullptr, *oci = nullptr;
+    GC_HIP(tmp.alloc(&cnt, (size_t)M + 1));
+    GC_HIP(tmp.alloc(&orp, (size_t)M + 1));
+    GC_HIP(hipMemsetAsync(cnt + M, 0, sizeof(int), nullptr));
+    hipLaunchKernelGGL(slab_count, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, nullptr, M, d_rp, d_ci, row_offset, cnt);
+    void *scan_tmp = nullptr;
+    size_t bytes = 0;
+    GC_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, cnt, orp, M + 1, nullptr));
+    GC_HIP(tmp.alloc((char **)&scan_tmp, bytes));
+    GC_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, bytes, cnt, orp, M + 1, nullptr));
+    int total = 0;
+    GC_HIP(hipMemcpy(&total, orp + M, sizeof(int), hipMemcpyDeviceToHost));
+    GC_HIP(tmp.alloc(&oci, (size_t)std::max(total, 1)));
+    hipLaunchKernelGGL(slab_fill, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, nullptr, M, d_rp, d_ci, row_offset, orp, oci);
+    GC_HIP(hipDeviceSynchronize());
+    tmp.keep(orp); tmp.keep(oci);
+    *out_rp = orp; *out_ci = oci; *out_nnz = total;
+    return 0;
+}
+
 }  // namespace sx

@@ -652,6 +652,27 @@ int sextans_gen_uniform_device(int device, float *d_dst, int64_t n, uint64_t see
     return SEXTANS_OK;
 }
 
+__global__ __launch_bounds__(256) void slice_row_ptr(int n, const int *__restrict__ rp, int *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i <= n) out[i] = rp[i] - rp[0];
+}
+
+int sextans_csr_slice_rows_device(int device, int r0, int r1, const int *d_row_ptr, int **o_row_ptr, int64_t *first_entry, int64_t *nnz) {
+    if (r0 < 0 || r1 < r0 || !d_row_ptr || !o_row_ptr || !first_entry || !nnz) return SEXTANS_ERR_INVALID;
+    SY_HIP(hipSetDevice(device));
+    int ends[2] = {0, 0};
+    SY_HIP(hipMemcpy(&ends[0], d_row_ptr + r0, sizeof(int), hipMemcpyDeviceToHost));
+    SY_HIP(hipMemcpy(&ends[1], d_row_ptr + r1, sizeof(int), hipMemcpyDeviceToHost));
+    int *out = nullptr;
+    SY_HIP(hipMalloc((void **)&out, sizeof(int) * ((size_t)(r1 - r0) + 1)));
+    hipLaunchKernelGGL(slice_row_ptr, dim3((unsigned)((r1 - r0 + 256) / 256)), dim3(256), 0, nullptr, r1 - r0, d_row_ptr + r0, out);
+    if (hipDeviceSynchronize() != hipSuccess) { (void)hipFree(out); return SEXTANS_ERR_HIP; }
+    *o_row_ptr = out;
+    *first_entry = ends[0];
+    *nnz = (int64_t)ends[1] - ends[0];
+    return SEXTANS_OK;
+}
+
 int sextans_csr_permute_symmetric_device(int device, int M, int64_t nnz, const int *d_row_ptr, const int *d_col_idx, const float *d_val,
                                          const int *new_of_old, int **o_row_ptr, int **o_col_idx, float **o_val) {
     if (M < 0 || nnz < 0 || !d_row_ptr || !new_of_old || !o_row_ptr || !o_col_idx || !o_val) return SEXTANS_ERR_INVALID;

@@ -414,3 +414,37 @@ def test_reordered_form_row_counts_not_a_multiple_of_four(engine, oracle, dims):
                 assert engine.last_kernel() == "spmm_csr_panel_v2_reordered" and int(engine.get_stat("row_cluster")) == 2
     finally:
         _set(engine)
+
+
+def test_row_slab_of_a_renumbered_matrix_clusters_with_its_row_offset(engine, oracle):
+    """What a rank of the row-partitioned SpMM holds: rows [r0, r1) of a square matrix, all K columns.  Told where its rows sit (option
+    row_offset -- sextans_dist_spmm sets it), the engine clusters the slab over its own square pattern (edges to rows of other ranks
+    dropped) and runs the reordered form on the rectangular matrix; without the offset a non-square matrix keeps the natural-order forms.
+    Bit-identical to the same rows of cpu_spmm_CSR either way."""
+    from sextans_amd import meshgen
+    from sextans_amd import dist as sxd
+    rp, ci, v, M = _fem(26, 24, 22, 3)
+    rp, ci, v = meshgen.permute_symmetric(rp, ci, v, M, meshgen.node_permutation(M // 3, 3, 13))
+    N = 16
+    rs = np.random.RandomState(17)
+    B, C0 = _operands(rs, M, M, N)
+    want = C0.copy()
+    oracle.spmm(M, N, M, ALPHA, rp, ci, v, B, BETA, want)
+    try:
+        for r0, r1 in ((0, M // 2), (M // 2, M - 4097), (M - 4097, M)):   # (the last slab holds a tenth of the rows: too few of its neighbours are its own)
+            lrp, lci, lv = sxd.slice_csr(rp, ci, v, r0, r1)
+            m = r1 - r0
+            Cl = np.ascontiguousarray(C0.reshape(N, M)[:, r0:r1]).reshape(-1)
+            wl = np.ascontiguousarray(want.reshape(N, M)[:, r0:r1]).reshape(-1)
+            for off, state in ((r0, 2), (-1, -1)):
+                _set(engine, row_cluster=-1, fuse_b=0)
+                engine.set_option("row_offset", off)
+                engine.set_matrix_csr(m, M, lrp, lci, lv)
+                out = Cl.copy()
+                engine.spmm(N, ALPHA, B, BETA, out)
+                assert np.array_equal(out.view(np.uint32), wl.view(np.uint32)), (r0, r1, off, engine.last_kernel())
+                if r1 - r0 > M // 3 or off < 0:
+                    assert int(engine.get_stat("row_cluster")) == state, (r0, r1, off, engine.get_stat("row_cluster"), engine.get_stat("cluster_decline"))
+    finally:
+        engine.set_option("row_offset", -1)
+        _set(engine)

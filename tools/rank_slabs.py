@@ -37,17 +37,22 @@ def measure(e, m_loc, K, nnz):
             "us_per_step": round(wall * 1e6, 1), "alg_bytes": by, "roofline_frac_kernel": round(by / (k * 1e-9) / 8e12, 4)}
 
 
-def run(name, M, K, gen):
+def run(name, M, K, gen, slab_offset=False, owned=3):
+    # slab_offset: the engine is told where its rows sit (option row_offset; sextans_dist_spmm does that): the graph clustering then
+    # also runs on a rank's slab.  owned: how many of the arrays gen() returns are this call's to free.
     out = {"matrix": name, "M": M, "K": K, "N": N, "worlds": {}}
     for world in (1, 2, 4, 8):
         ranks = []
         for (r0, r1) in sxd.partition_rows_even(M, world):
             p, i, v, nnz = gen(r0, r1)
             e = api.Engine(0)
+            if slab_offset: e.set_option("row_offset", r0)
             e.set_matrix_csr_device(r1 - r0, K, nnz, p, i, v)
-            ranks.append(dict(rank=len(ranks), row_range=[r0, r1], **measure(e, r1 - r0, K, nnz)))
+            m = measure(e, r1 - r0, K, nnz)
+            m["row_cluster"] = int(e.get_stat("row_cluster")); m["cluster_decline"] = int(e.get_stat("cluster_decline"))
+            ranks.append(dict(rank=len(ranks), row_range=[r0, r1], **m))
             e.close()
-            for q in (p, i, v): api.device_free(0, q)
+            for q in (p, i, v)[:owned]: api.device_free(0, q)
             torch.cuda.empty_cache()
         slow = max(r["us_per_step"] for r in ranks)
         out["worlds"][str(world)] = {"ranks": ranks, "max_us_per_step": slow, "max_kernel_us": max(r["kernel_us"] for r in ranks),
@@ -59,7 +64,14 @@ def run(name, M, K, gen):
     return out
 
 
+from sextans_amd import meshgen
+_base = api.gen_fem3d_device(0, 110, 110, 110, 3, 3)
+_perm = api.permute_symmetric_device(0, 3_993_000, _base[3], *_base[:3], meshgen.node_permutation(3_993_000 // 3, 3, 1))
+for q in _base[:3]: api.device_free(0, q)
+_slab = lambda r0, r1: api.slice_rows_device(0, r0, r1, *_perm)
 doc = {"what": "per-rank slabs of a row-partitioned SpMM run sequentially on ONE MI355X (tools/rank_slabs.py); not a scaling measurement",
        "matrices": [run("config4: uniform 4M x 4M, Poisson(40)", 4_000_000, 4_000_000, lambda r0, r1: api.gen_csr_device(0, 4_000_000, 4_000_000, 40.0, 4, r0, r1)),
-                    run("fem3d 110x110x110 x 3 dof (natural order)", 3_993_000, 3_993_000, lambda r0, r1: api.gen_fem3d_device(0, 110, 110, 110, 3, 3, r0, r1))]}
+                    run("fem3d 110x110x110 x 3 dof (natural order)", 3_993_000, 3_993_000, lambda r0, r1: api.gen_fem3d_device(0, 110, 110, 110, 3, 3, r0, r1)),
+                    run("fem3d 110x110x110 x 3 dof, random node order, slabs without their position (natural-order forms)", 3_993_000, 3_993_000, _slab, False, 1),
+                    run("fem3d 110x110x110 x 3 dof, random node order, slabs that know their row offset (graph clustering per slab)", 3_993_000, 3_993_000, _slab, True, 1)]}
 print(json.dumps(doc, indent=1))
