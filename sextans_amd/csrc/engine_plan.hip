@@ -66,6 +66,7 @@ int64_t device_bytes(const sextans_engine *h) {
     for (const auto &p : h->plan_stash) b += plan_bytes(p);
     if (h->d_slot_row) b += (int64_t)h->psc.plan_nblk * 64 * h->psc.plan_sets * 4;
     if (h->d_colpos) b += (int64_t)h->K * 4;
+    if (h->d_chain_ci_perm && !h->h_chain_off.empty()) b += (int64_t)h->h_chain_off.back() * 8 + (int64_t)h->nchain * 4;
     if (h->d_wstream) b += h->win_padded * 8 + (int64_t)h->win_nwaves * 4;
     if (h->d_dense_Af) b += (int64_t)h->dense_mb * h->dense_W * (2048 + 4);
     if (h->d_bell_Af) b += (int64_t)(h->bell_M / 32) * h->bell_W * (2048 + (h->d_bell_col_owned ? 4 : 0));
