@@ -794,7 +794,10 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
                         (size_t)h->K * (size_t)N * sizeof(float) <= ((size_t)16 << 20) &&
                         // (a graph-clustered plan beats the natural-order blocks of a renumbered matrix also while B fits the L2s, once the
                         // matrix is large enough for three more launches not to matter: 332 K rows 123 -> 85 us per step)
-                        !(whole && h->cluster_state == 2 && h->M >= 65536);
+                        // (... and below that size once the call is large enough: a 13 965-row matrix in a random node order, N = 128,
+                        // 112 us staged from column-major B on its natural-order plan against 34 us reordered; N = 16: 13.3 against 15.0.
+                        // Crossover measured at ~24 M non-zero x column products: tools/small_renumbered.py)
+                        !(whole && h->cluster_state == 2 && (h->M >= 65536 || h->m_nnz * (int64_t)N >= ((int64_t)24 << 20)));
     // (Staging from column-major B for LARGE matrices -- no repack launch at all -- was measured in round 4 and loses everywhere: 4M-row
     // 3-dof FEM N = 16 kernel 660 -> 872 us against 83 us of repack saved; 1-dof 27-point 379 -> 577; 2-D 9-point 296 -> 427;
     // 5-point 270 -> 412: 36 four-byte loads per lane and panel through registers instead of nine LDS-DMA requests.)
