@@ -5,13 +5,19 @@ sys.path.insert(0, ROOT)
 import torch
 from sextans_amd import api
 st = torch.cuda.current_stream().cuda_stream
+order = sys.argv[1] if len(sys.argv) > 1 else "grid"
+from sextans_amd import meshgen
 for n in (12, 16, 20, 25, 32, 40, 44, 50, 64, 80, 110):
     dof = 3
     M = n * n * n * dof
     p = api.gen_fem3d_device(0, n, n, n, dof, 3)
     nnz = p[3]
+    if order == "random":
+        q = api.permute_symmetric_device(0, M, nnz, *p[:3], meshgen.node_permutation(M // dof, dof, 1))
+        for x in p[:3]: api.device_free(0, x)
+        p = q + (nnz,)
     e = api.Engine(0); e.set_matrix_csr_device(M, M, nnz, *p[:3])
-    line = f"fem {n}^3 x 3: M={M:8d} nnz={nnz:10d}"
+    line = f"fem {n}^3 x 3 {order}: M={M:8d} nnz={nnz:10d}"
     for N in (16, 64):
         B = torch.empty(M * N, device="cuda"); Cin = torch.empty(M * N, device="cuda"); Cout = torch.empty(M * N, device="cuda")
         api.gen_uniform_device(0, B.data_ptr(), M * N, 41, st); api.gen_uniform_device(0, Cin.data_ptr(), M * N, 42, st)
