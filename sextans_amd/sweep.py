@@ -154,6 +154,12 @@ def sweep_synthetic(specs, n_values, steps=20, alpha=0.85, beta=-2.06, device=0,
                     f()
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
+                f()
+                torch.cuda.synchronize(dev)
+                for _ in range(min(300, int(0.06 / max(time.perf_counter() - t0, 1e-6)))):   # ~60 ms of warm-up: the first launches after an idle phase run slower
+                    f()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
                 for _ in range(steps):
                     f()
                 torch.cuda.synchronize(dev)
