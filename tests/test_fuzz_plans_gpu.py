@@ -135,7 +135,7 @@ def test_random_large_matrices_default_options(engine, oracle, seed):
     for k, val in DEFAULTS.items():
         engine.set_option(k, val)
     engine.set_matrix_csr(M, K, rp, ci, v)
-    for N in (16, int(rs.choice([24, 32, 48]))):
+    for N in (16, int(rs.choice([8, 24, 32, 48]))):
         B = rs.uniform(-1, 1, K * N).astype(np.float32)
         C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
         want = C0.copy()
