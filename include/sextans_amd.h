@@ -277,7 +277,7 @@ int sextans_destroy(sextans_handle_t h);
  *   of the list (stats "index_stream_entries", "value_stream_entries"); the exported plan carries every row's own list.
  * "colwise_max_len" (default 6; "kernel" = 4 forces it): rows of at most this mean length in a numbering with locality (stat
  *   "row_coherence" >= 0.7) run on the lane-per-row kernel over the caller's column-major operands (no B repack; stat "colwise").
- * "cluster_group" (default 3), "cluster_shape" (0 = default bricks): layout tunables of form (1); measurement switches (below).
+ * "cluster_group" (default 6), "cluster_shape" (0 = default bricks): layout tunables of form (1); measurement switches (below).
  * "small_v2" (default 1: small matrices staged from column-major B size the launch's dictionary capacity and register-resident
  * batches from the plan; 0 = the full-capacity form, for measurements),
  * "cols_per_lane" (0/4 = 16-column tiles at 4 workgroups per CU, the default; 8 = 32-column super tiles at 2 per CU),

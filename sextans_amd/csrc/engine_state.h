@@ -211,7 +211,7 @@ struct sextans_engine {
                                         // 8 = register-blocked 32-column super tiles (spmm_csr_panel_v2<2>: 2 workgroups per
                                         // CU -- measured slower than 4 columns per lane at 4 workgroups per CU)
     int64_t opt_cluster_shape = 0;      // measurement switch: brick shape run_rows * 10000 + lines * 100 + planes (0 = 16 x 2 x 2 / 16 x 4)
-    int64_t opt_cluster_group = 3;      // bricks are laid out in groups of g x g brick columns (A/B on the 4M-row FEM matrix: g = 3)
+    int64_t opt_cluster_group = 6;      // bricks are laid out in groups of g x g brick columns (same-box A/B, g = 3 -> 6: FEM 3-dof -1 .. -2 %, 27-point 1-dof -5 %, 2-D 9-point -4 .. -5 %)
     int64_t opt_row_cluster = -1;       // clustered-order plan for spmm_csr_panel_v2 (ensure_cluster_plan): -1 auto, 0 never, 1 whenever one
                                         // can be built, 2 = graph clustering (reordered form) also where the grid bricks would apply
     int64_t opt_row_offset = -1;        // this engine's matrix is the row slab [row_offset, row_offset + M) of a K x K matrix (set by sextans_dist_spmm): lets the

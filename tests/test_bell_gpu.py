@@ -229,14 +229,14 @@ def test_measurement_options_are_gated(sx):
     old = os.environ.pop("SEXTANS_DEBUG_OPTIONS", None)
     e = api.Engine(0)
     try:
-        for key, default, other in (("bell_debug", 0, 1), ("cluster_shape", 0, 160202), ("cluster_group", 3, 2), ("phase_timing", 0, 1)):
+        for key, default, other in (("bell_debug", 0, 1), ("cluster_shape", 0, 160202), ("cluster_group", 6, 2), ("phase_timing", 0, 1)):
             assert L.sextans_set_option(e._h, key.encode(), C.c_int64(default)) == 0
             assert L.sextans_set_option(e._h, key.encode(), C.c_int64(other)) != 0, key
             assert e.get_option(key) == default
         os.environ["SEXTANS_DEBUG_OPTIONS"] = "1"
         assert L.sextans_set_option(e._h, b"cluster_group", C.c_int64(2)) == 0
         assert L.sextans_set_option(e._h, b"cluster_shape", C.c_int64(160000)) != 0      # a zero factor is refused even then
-        assert L.sextans_set_option(e._h, b"cluster_group", C.c_int64(3)) == 0
+        assert L.sextans_set_option(e._h, b"cluster_group", C.c_int64(6)) == 0
     finally:
         e.close()
         if old is None:

@@ -10,7 +10,7 @@ from util import ALPHA, BETA, random_csr
 pytestmark = pytest.mark.gpu
 
 OPTS = dict(lanes_per_row=0, kernel=0, fuse_b=0, panel_v2=-1, cols_per_lane=0, tiles_per_wg=0, split_rows=0, bucket_rows=-1,
-            panel_min_reuse_x100=200, panel_min_reuse_wide_x100=150, row_cluster=-1, cluster_group=3, cluster_shape=0, row_sets=2)
+            panel_min_reuse_x100=200, panel_min_reuse_wide_x100=150, row_cluster=-1, cluster_group=6, cluster_shape=0, row_sets=2)
 
 
 def _set(engine, **kw):
