@@ -163,11 +163,14 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     // allow (5 at <= 96 registers) instead of the 4 the full panel permits -- these launches are latency-bound
     const bool small_panel = H == 1 && bcol_ld == 0 && P.plan_pad_row == 5 * 64;
     const size_t lds = small_panel ? (size_t)(5 * 64 + sx::kWidePadRows) * 64 : (size_t)H * sx::kWideHalfBytes;
+    // contiguous chunks of row blocks per XCD -- except the reordered form at N <= 32, where handing the blocks of the merge-tree order to
+    // the XCDs round-robin measured 1.3 .. 4.5 % faster (renumbered FEM 607 -> 582 us, unstructured mesh 444 -> 424; N = 128: +1.4 % the other way)
+    const int xcd = (mode == 2 && nsuper <= 2) ? 0 : (int)h->opt_xcd;
     auto go = [&](auto kern) -> int {
         if (int rc = allow_big_lds(h, reinterpret_cast<const void *>(kern), (int)lds)) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)P.d_row_off,
                            P.d_lidx, P.d_pval, P.d_blk_row, P.d_dict_ptr, P.d_dict, P.plan_dict_stride,
-                           dBp, pstride, dCin, ldc_in, dCout, ldc, nsuper, tpw, nblk, alpha, beta, (int)h->opt_xcd,
+                           dBp, pstride, dCin, ldc_in, dCout, ldc, nsuper, tpw, nblk, alpha, beta, xcd,
                            P.plan_pad_row, blk_begin, row_base, skip, (long long *)h->d_dbg, slot_row, (const int2 *)P.d_ioff, last_cols);
         return SEXTANS_OK;
     };
