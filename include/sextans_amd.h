@@ -77,6 +77,9 @@ int sextans_matrix_load(const char *path, int *format, int *M, int *K, int *nnz,
 int sextans_mtx_read_cached(const char *path, const char *cache_path, int format, int *M, int *K, int *nnz,
                             int **ptr, int **idx, float **val, int *cache_hit);
 
+/* Matrix-Market `real general` writer (tools: holdout matrices written to disk for the CLI); %.9g keeps every fp32 value. */
+int sextans_mtx_write(const char *path, int M, int K, const int *row_ptr, const int *col_idx, const float *val);
+
 /* Replaces CSC_2_CSR (sparse_helper.h:475-509).  Caller provides row_ptr[M+1], col_idx[nnz],
  * csr_val[nnz].  Per-row column order = CSC traversal order (ascending columns). */
 int sextans_csc_to_csr(int M, int K, int nnz, const int *col_ptr, const int *row_idx,
@@ -491,6 +494,16 @@ int sextans_csr_permute_symmetric_device(int device, int M, int64_t nnz, const i
  * infrastructure): a new row_ptr of r1 - r0 + 1 entries starting at 0 (sextans_device_free), *first_entry = where the slab's
  * col_idx / val begin inside the original arrays (use d_col_idx + *first_entry, d_val + *first_entry), *nnz = its non-zeros. */
 int sextans_csr_slice_rows_device(int device, int r0, int r1, const int *d_row_ptr, int **o_row_ptr, int64_t *first_entry, int64_t *nnz);
+/* HOLDOUT class (round 5): kron(T_n, P) -- n copies of a caller-given pm x pk sparsity pattern P (the tests and the bench pass the
+ * pattern of a real SuiteSparse matrix, nasa4704) on the block diagonal, each coupled to its neighbours through the same pattern
+ * (T_n tridiagonal): M = n * pm rows, row i * pm + p holds the columns j * pk + P[p][*] for j = i - 1, i, i + 1; values U(-1,1) from the
+ * counter RNG (halved in the off-diagonal blocks).  `variant` bits: 1 = rectangular (every third column dropped, the rest renumbered:
+ * K = 2/3 of n * pk), 2 = unsymmetric pattern (30 % of the strictly lower entries dropped).  *K_out = columns of the result.  The
+ * pattern arrays are HOST pointers in both forms.  Same bits on host and device; any row range [r0, r1). */
+int sextans_gen_kron_host(int n, int pm, int pk, const int *p_row_ptr, const int *p_col_idx, int variant, uint64_t seed, int r0, int r1,
+                          int **row_ptr, int **col_idx, float **val, int64_t *nnz, int *K_out);
+int sextans_gen_kron_device(int device, int n, int pm, int pk, const int *p_row_ptr, const int *p_col_idx, int variant, uint64_t seed,
+                            int r0, int r1, int **d_row_ptr, int **d_col_idx, float **d_val, int64_t *nnz, int *K_out);
 int sextans_gen_kkt_host(int n, int arrow, uint64_t seed, int r0, int r1, int **row_ptr, int **col_idx, float **val, int64_t *nnz);
 int sextans_gen_kkt_device(int device, int n, int arrow, uint64_t seed, int r0, int r1, int **d_row_ptr, int **d_col_idx,
                            float **d_val, int64_t *nnz);

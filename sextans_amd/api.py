@@ -781,6 +781,41 @@ def gen_kkt_device(device, n, arrow, seed, r0=0, r1=None):
     return _gen_device(lib().sextans_gen_kkt_device, (device, n, arrow, seed, r0, r1))
 
 
+def gen_kron_host(n, p_rp, p_ci, pk, variant, seed, r0=0, r1=None):
+    """kron(T_n, P) holdout class (include/sextans_amd.h) -> (row_ptr, col_idx, val, K)."""
+    L = lib()
+    p_rp = np.ascontiguousarray(p_rp, np.int32); p_ci = np.ascontiguousarray(p_ci, np.int32)
+    pm = len(p_rp) - 1
+    r1 = n * pm if r1 is None else r1
+    L.sextans_gen_kron_host.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                                        C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.POINTER(C.c_float)),
+                                        C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+    p, i, v = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()
+    nnz, K = C.c_int64(), C.c_int()
+    _check(L.sextans_gen_kron_host(n, pm, pk, p_rp, p_ci, variant, seed, r0, r1, C.byref(p), C.byref(i), C.byref(v), C.byref(nnz),
+                                   C.byref(K)), "gen_kron_host")
+    out = (_take(p, r1 - r0 + 1, np.int32), _take(i, nnz.value, np.int32), _take(v, nnz.value, np.float32), K.value)
+    for q in (p, i, v):
+        L.sextans_host_free(q)
+    return out
+
+
+def gen_kron_device(device, n, p_rp, p_ci, pk, variant, seed, r0=0, r1=None):
+    """Device form -> (d_row_ptr, d_col_idx, d_val, nnz, K); free the arrays with device_free."""
+    L = lib()
+    p_rp = np.ascontiguousarray(p_rp, np.int32); p_ci = np.ascontiguousarray(p_ci, np.int32)
+    pm = len(p_rp) - 1
+    r1 = n * pm if r1 is None else r1
+    L.sextans_gen_kron_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int)]
+    p, i, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    nnz, K = C.c_int64(), C.c_int()
+    _check(L.sextans_gen_kron_device(device, n, pm, pk, p_rp, p_ci, variant, seed, r0, r1, C.byref(p), C.byref(i), C.byref(v),
+                                     C.byref(nnz), C.byref(K)), "gen_kron_device")
+    return p.value, i.value, v.value, nnz.value, K.value
+
+
 def gen_powerlaw_host(M, K, xmin, tail_x100, max_len, seed, r0=0, r1=None):
     """Power-law row lengths, P(len >= x) = (xmin/x)^(tail_x100/100) on [xmin, max_len] -> (row_ptr, col_idx, val)."""
     L = lib()

@@ -25,8 +25,19 @@ int probe_row_coherence_device(int M, const int *d_rp, const int *d_ci, int nsam
 // neighbouring cluster it shares the most neighbourhood with; a merged pair's rows become contiguous, so the final order is the
 // leaf order of the merge tree: any run of consecutive rows is a graph-compact set.  M == K required (a column index is read as
 // the row of the neighbour).  Returns 0 = built, 1 = declined (not square, empty), 2 = HIP error (err set).
+// d_weights (optional): one byte per entry of the pattern, the weight of that edge, instead of the shared-neighbourhood count
+// computed here (the row-similarity graph below brings its own).
 int cluster_rows_graph_device(int M, int K, int64_t nnz, const int *d_rp, const int *d_ci, int max_cluster_rows, int **d_order,
-                              std::string &err);
+                              std::string &err, const unsigned char *d_weights = nullptr);
+
+// Row-similarity graph of a RECTANGULAR matrix (the reference schedules any M x K matrix: sparse_helper.h:345-403): row r joined to
+// the 16 rows that share the most columns with it (found through the transposed pattern), weight = shared columns.  A square
+// M x M pattern with exactly 16 slots per row (-1 = empty; all consumers skip indices outside [0, M)), g_w one byte per slot; the
+// caller frees the three arrays.  *shared_fraction = best overlap / row length over a sample of rows (the pre-test of
+// probe_shared_neighbourhood_device for matrices without "row c"), *near_fraction = share of entries near the scaled diagonal.
+// Returns 0 = built, 1 = declined, 2 = HIP error.
+int row_similarity_graph_device(int M, int K, int64_t nnz, const int *d_rp, const int *d_ci, int **g_rp, int **g_ci, unsigned char **g_w,
+                                int64_t *g_nnz, double *shared_fraction, double *near_fraction, std::string &err);
 
 // Block refinement on top of the clustered order: the order is cut into blocks of `per` rows, `sweeps` sweeps of capacity-constrained
 // label propagation move boundary rows to the neighbouring block that holds more of their neighbours (at most `cap` rows per block);

@@ -597,7 +597,7 @@ int probe_row_coherence_device(int M, const int *d_rp, const int *d_ci, int nsam
 }
 
 int cluster_rows_graph_device(int M, int K, int64_t nnz, const int *d_rp, const int *d_ci, int max_cluster_rows, int **d_order,
-                              std::string &err) {
+                              std::string &err, const unsigned char *d_weights) {
     *d_order = nullptr;
     if (M != K || M < 2 || nnz <= 0) return 1;
     Scratch tmp;
@@ -630,7 +630,8 @@ int cluster_rows_graph_device(int M, int K, int64_t nnz, const int *d_rp, const 
     GC_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, is_leader, new_idx, M + 1, nullptr));
     GC_HIP(tmp.alloc((char **)&scan_tmp, scan_bytes));
 
-    hipLaunchKernelGGL(tri_weights, dim3(blocks_for(M, 4)), dim3(256), 0, nullptr, M, d_rp, d_ci, t);
+    if (d_weights) GC_HIP(hipMemcpyAsync(t, d_weights, (size_t)nnz, hipMemcpyDeviceToDevice, nullptr));
+    else hipLaunchKernelGGL(tri_weights, dim3(blocks_for(M, 4)), dim3(256), 0, nullptr, M, d_rp, d_ci, t);
     hipLaunchKernelGGL(init_level0, dim3(blocks_for((long long)M + 1, 256)), dim3(256), 0, nullptr, M, ord[0], cinfo[0], cstart[0]);
     int nc = M, cur = 0, level = 0;
     const bool trace = getenv("SEXTANS_CLUSTER_TRACE") != nullptr;
@@ -816,6 +817,179 @@ int local_square_pattern_device(int M, const int *d_rp, const int *d_ci, int row
     GC_HIP(hipDeviceSynchronize());
     tmp.keep(orp); tmp.keep(oci);
     *out_rp = orp; *out_ci = oci; *out_nnz = total;
+    return 0;
+}
+
+// ---- row-similarity graph of a RECTANGULAR matrix ----------------------------------------------------------------------------
+// cluster_rows_graph_device reads a column index as the row of a neighbour: M == K.  The reference schedules ANY M x K matrix for
+// its on-chip window (sparse_helper.h:345-403, K and M independent); the LP / least-squares / rectangular matrices of SuiteSparse
+// have no "row c".  What two rows of any matrix can share is COLUMNS: the rows are clustered over the graph in which row r is joined
+// to the kRowSimDeg rows that share the most columns with it.
+//   transpose  the pattern sorted by column (hipcub radix sort of (column, row) pairs, stable: rows ascending inside a column);
+//   candidates one wavefront per row r: kRowSimCols of its columns spread over the row; from each column's row list a window of up to
+//              64 rows centred on r itself (binary search: in a numbering with locality the nearby rows are the similar ones, in a
+//              random numbering any window is as good as another) is counted into an LDS hash table -- a row that shares many
+//              columns with r turns up in many of the lists;
+//   weights    the kRowSimDeg most frequent candidates get their exact overlap |cols(r) & cols(r')| (the same measure tri_weights
+//              uses for square matrices), 1 .. 255;
+//   output     a square M x M pattern with exactly kRowSimDeg slots per row (-1 = empty slot; every consumer skips indices outside
+//              [0, M)) + one weight byte per slot: cluster_rows_graph_device(..., d_weights) and refine_blocks_device run on it.
+namespace {
+constexpr int kRowSimDeg = 16, kRowSimCols = 16, kRowSimHT = 1024;
+
+__global__ __launch_bounds__(256) void expand_row_ids(int M, const int *__restrict__ rp, int *__restrict__ rows) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= M) return;
+    for (int j = rp[r] + lane; j < rp[r + 1]; j += 64) rows[j] = r;
+}
+__global__ __launch_bounds__(256) void column_starts(int K, long long nnz, const int *__restrict__ sorted_cols, int *__restrict__ cp) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c > K) return;
+    long long lo = 0, hi = nnz;                     // first position whose column is >= c
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (sorted_cols[mid] < c) lo = mid + 1; else hi = mid; }
+    cp[c] = (int)lo;
+}
+__global__ __launch_bounds__(256) void row_similarity(int M, int K, const int *__restrict__ rp, const int *__restrict__ ci, const int *__restrict__ cp,
+                                                      const int *__restrict__ crow, int *__restrict__ g_ci, unsigned char *__restrict__ g_w,
+                                                      unsigned long long *__restrict__ acc /* [0] best overlap, [1] row length, [2] near, [3] entries */) {
+    __shared__ int keys[4][kRowSimHT];
+    __shared__ int cnts[4][kRowSimHT];
+    __shared__ int tabs[4][kTriHT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= M) return;
+    int *kk = keys[wave], *cc = cnts[wave], *tab = tabs[wave];
+    const int j0 = rp[r], len = rp[r + 1] - j0;
+    if (len == 0) {
+        if (lane < kRowSimDeg) { g_ci[(long long)r * kRowSimDeg + lane] = -1; g_w[(long long)r * kRowSimDeg + lane] = 0; }
+        return;
+    }
+    for (int i = lane; i < kRowSimHT; i += 64) { kk[i] = -1; cc[i] = 0; }
+    for (int i = lane; i < kTriHT; i += 64) tab[i] = -1;
+    __builtin_amdgcn_wave_barrier();
+    const bool small = len <= kTriMaxLen;
+    if (small) for (int e = lane; e < len; e += 64) set_insert(tab, ci[j0 + e]);
+    const int S = min(len, kRowSimCols);
+    for (int s = 0; s < S; ++s) {
+        const int c = ci[j0 + (int)((long long)s * len / S)];
+        const int l0 = cp[c], L = cp[c + 1] - l0;
+        int start = 0, n = L;
+        if (L > 64) {                               // window of 64 rows around r's own position in the column's (ascending) row list
+            int lo = 0, hi = L;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (crow[l0 + mid] < r) lo = mid + 1; else hi = mid; }
+            start = min(max(lo - 32, 0), L - 64);
+            n = 64;
+        }
+        if (lane < n) {
+            const int q = crow[l0 + start + lane];
+            if (q != r) {
+                unsigned h = mix32((unsigned)q) & (kRowSimHT - 1);
+                for (int probe = 0; probe < kRowSimHT; ++probe) {
+                    const int prev = atomicCAS(&kk[h], -1, q);
+                    if (prev == -1 || prev == q) { atomicAdd(&cc[h], 1); break; }
+                    h = (h + 1) & (kRowSimHT - 1);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int PER = kRowSimHT / 64;
+    unsigned long long sc[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int slot = lane + 64 * i, q = kk[slot];
+        sc[i] = 0ull;
+        if (q >= 0) {
+            const unsigned lo = (unsigned)min(r, q), hi = (unsigned)max(r, q);
+            sc[i] = ((unsigned long long)(unsigned)cc[slot] << 44) | ((unsigned long long)(mix32(lo * 0x9E3779B1u + mix32(hi)) & 0xfffu) << 32) | (unsigned)q;
+        }
+    }
+    unsigned best_overlap = 0;
+    for (int k = 0; k < kRowSimDeg; ++k) {
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) best = sc[i] > best ? sc[i] : best;
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned olo = __shfl_xor((unsigned)(best & 0xffffffffull), off), ohi = __shfl_xor((unsigned)(best >> 32), off);
+            const unsigned long long other = ((unsigned long long)ohi << 32) | olo;
+            best = other > best ? other : best;
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) if (sc[i] == best) sc[i] = 0ull;
+        int q = -1;
+        unsigned w = 0;
+        if (best) {
+            q = (int)(unsigned)(best & 0xffffffffull);
+            const int k0 = rp[q], lq = rp[q + 1] - k0;
+            if (small && lq <= kTriMaxLen) {
+                for (int e = 0; e < lq; e += 64) {
+                    const bool hit = (e + lane < lq) && set_has(tab, ci[k0 + e + lane]);
+                    w += (unsigned)__popcll(__ballot(hit));
+                }
+            } else w = (unsigned)(best >> 44);          // long rows: the sampled count
+            best_overlap = max(best_overlap, w);
+            w = min(255u, max(1u, w));
+        }
+        if (lane == 0) { g_ci[(long long)r * kRowSimDeg + k] = q; g_w[(long long)r * kRowSimDeg + k] = (unsigned char)w; }
+    }
+    if ((r & 63) == 0) {                                // statistics from every 64th row
+        unsigned near = 0;
+        const long long diag = (long long)r * K / M;
+        for (int e = lane; e < len; e += 64) {
+            const long long d = (long long)ci[j0 + e] - diag;
+            near += (d < 0 ? -d : d) < (long long)K / 64 + 1 ? 1u : 0u;
+        }
+        for (int off = 32; off > 0; off >>= 1) near += __shfl_xor(near, off);
+        if (lane == 0) {
+            atomicAdd(&acc[0], (unsigned long long)min(best_overlap, (unsigned)len)); atomicAdd(&acc[1], (unsigned long long)len);
+            atomicAdd(&acc[2], (unsigned long long)near); atomicAdd(&acc[3], (unsigned long long)len);
+        }
+    }
+}
+}  // namespace
+
+int row_similarity_graph_device(int M, int K, int64_t nnz, const int *d_rp, const int *d_ci, int **g_rp, int **g_ci, unsigned char **g_w,
+                                int64_t *g_nnz, double *shared_fraction, double *near_fraction, std::string &err) {
+    *g_rp = *g_ci = nullptr; *g_w = nullptr; *g_nnz = 0;
+    *shared_fraction = *near_fraction = 0.0;
+    if (M < 2 || K < 1 || nnz <= 0 || nnz > 0x7fffffffLL || (int64_t)M * kRowSimDeg > 0x7fffffffLL) return 1;
+    Scratch tmp;
+    int *rows = nullptr, *cols = nullptr, *srows = nullptr, *scols = nullptr, *cp = nullptr, *orp = nullptr, *oci = nullptr;
+    unsigned char *ow = nullptr;
+    unsigned long long *d_acc = nullptr, h_acc[4] = {0, 0, 0, 0};
+    GC_HIP(tmp.alloc(&rows, (size_t)nnz));
+    GC_HIP(tmp.alloc(&cols, (size_t)nnz));
+    GC_HIP(tmp.alloc(&srows, (size_t)nnz));
+    GC_HIP(tmp.alloc(&scols, (size_t)nnz));
+    GC_HIP(tmp.alloc(&cp, (size_t)K + 1));
+    GC_HIP(tmp.alloc(&orp, (size_t)M + 1));
+    GC_HIP(tmp.alloc(&oci, (size_t)M * kRowSimDeg));
+    GC_HIP(tmp.alloc(&ow, (size_t)M * kRowSimDeg));
+    GC_HIP(tmp.alloc(&d_acc, 4));
+    GC_HIP(hipMemsetAsync(d_acc, 0, sizeof h_acc, nullptr));
+    hipLaunchKernelGGL(expand_row_ids, dim3(blocks_for(M, 4)), dim3(256), 0, nullptr, M, d_rp, rows);
+    GC_HIP(hipMemcpyAsync(cols, d_ci, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToDevice, nullptr));
+    int bits = 1;
+    while (bits < 32 && (1LL << bits) < (long long)K) ++bits;
+    void *sort_tmp = nullptr;
+    size_t bytes = 0;
+    GC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, cols, scols, rows, srows, (int)nnz, 0, bits, nullptr));
+    GC_HIP(tmp.alloc((char **)&sort_tmp, bytes));
+    GC_HIP(hipcub::DeviceRadixSort::SortPairs(sort_tmp, bytes, cols, scols, rows, srows, (int)nnz, 0, bits, nullptr));   // stable: rows ascending per column
+    hipLaunchKernelGGL(column_starts, dim3(blocks_for((long long)K + 1, 256)), dim3(256), 0, nullptr, K, (long long)nnz, scols, cp);
+    hipLaunchKernelGGL(iota_fill, dim3(blocks_for((long long)M + 1, 256)), dim3(256), 0, nullptr, M + 1, orp, (int *)nullptr, 0);
+    hipLaunchKernelGGL(row_similarity, dim3(blocks_for(M, 4)), dim3(256), 0, nullptr, M, K, d_rp, d_ci, cp, srows, oci, ow, d_acc);
+    // orp[r] = r * kRowSimDeg
+    struct Scale { __device__ int operator()(int x) const { return x * kRowSimDeg; } };
+    GC_HIP(hipcub::DeviceTransform::Transform(orp, orp, M + 1, Scale(), nullptr));
+    GC_HIP(hipMemcpy(h_acc, d_acc, sizeof h_acc, hipMemcpyDeviceToHost));
+    GC_HIP(hipDeviceSynchronize());
+    GC_HIP(hipGetLastError());
+    if (h_acc[1]) *shared_fraction = (double)h_acc[0] / (double)h_acc[1];
+    if (h_acc[3]) *near_fraction = (double)h_acc[2] / (double)h_acc[3];
+    tmp.keep(orp); tmp.keep(oci); tmp.keep(ow);
+    *g_rp = orp; *g_ci = oci; *g_w = ow; *g_nnz = (int64_t)M * kRowSimDeg;
     return 0;
 }
 

@@ -556,6 +556,37 @@ int sextans_matrix_load(const char *path, int *format, int *M, int *K, int *nnz,
     return load_cache(path, format, M, K, nnz, ptr, idx, val, nullptr, nullptr);
 }
 
+// Matrix-Market writer for the tools (holdout matrices written to disk and run through the CLI): `real general`, one entry per
+// line in CSR order, %.9g (every fp32 value round-trips).  Row ranges are formatted by all cores into per-thread buffers and
+// written in order.  The reference's mmio.h writers (mm_write_mtx_crd) are never called by its host (out of scope).
+int sextans_mtx_write(const char *path, int M, int K, const int *row_ptr, const int *col_idx, const float *val) {
+    if (!path || M < 0 || K < 0 || !row_ptr || (row_ptr[M] > 0 && (!col_idx || !val))) return SEXTANS_ERR_INVALID;
+    FILE *f = fopen(path, "w");
+    if (!f) return SEXTANS_ERR_OPEN;
+    fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n", M, K, row_ptr[M]);
+    const int T = (int)std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
+    const int chunk_rows = 65536;
+    bool ok = true;
+    for (int base = 0; base < M && ok; base += chunk_rows * T) {
+        std::vector<std::string> out((size_t)T);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t]() {
+                const int r0 = std::min(M, base + t * chunk_rows), r1 = std::min(M, r0 + chunk_rows);
+                std::string &o = out[(size_t)t];
+                o.reserve((size_t)(row_ptr[r1] - row_ptr[r0]) * 28);
+                char line[64];
+                for (int r = r0; r < r1; ++r)
+                    for (int j = row_ptr[r]; j < row_ptr[r + 1]; ++j)
+                        o.append(line, (size_t)snprintf(line, sizeof line, "%d %d %.9g\n", r + 1, col_idx[j] + 1, (double)val[j]));
+            });
+        for (auto &x : th) x.join();
+        for (int t = 0; t < T && ok; ++t) ok = out[(size_t)t].empty() || fwrite(out[(size_t)t].data(), 1, out[(size_t)t].size(), f) == out[(size_t)t].size();
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? SEXTANS_OK : SEXTANS_ERR_OPEN;
+}
+
 int sextans_mtx_read_cached(const char *path, const char *cache_path, int format, int *M, int *K, int *nnz,
                             int **ptr, int **idx, float **val, int *cache_hit) {
     if (!path || (format != SEXTANS_FMT_CSR && format != SEXTANS_FMT_CSC)) return SEXTANS_ERR_INVALID;

@@ -62,6 +62,7 @@ SX_HD float u01m1(uint64_t bits) {
 struct Spec {
     int kind, K, bw, nx, ny, nz, dof;
     uint64_t seed;
+    const int *p_rp = nullptr, *p_ci = nullptr;   // kind 5: the pattern P (host pointers for the host generator, device pointers on the device)
 };
 
 SX_HD uint16_t f32_to_bf16_rne(float f) {
@@ -127,7 +128,40 @@ SX_HD int kkt_row(const Spec &sp, int row, int *c) {
     return k;
 }
 
+// kind 5: kron(T_n, P) -- n = sp.nx copies of a given pm x pk pattern P (sp.ny x sp.nz; the holdout class uses the pattern of a real
+// SuiteSparse matrix, nasa4704) on the block diagonal, each coupled to its two neighbours through the same pattern (T_n tridiagonal):
+// row i * pm + p holds, for j = i - 1, i, i + 1 inside [0, n), the columns j * pk + P[p][*] -- ascending.  Values U(-1, 1) keyed by
+// (row, column of the UNMODIFIED product), halved in the off-diagonal blocks ("the same pattern scaled").  Variants (sp.bw, bit set):
+//   1  rectangular: every third column (c % 3 == 2) is dropped with its entries, the rest renumbered c' = 2 * (c / 3) + c % 3;
+//   2  unsymmetric pattern: 30 % of the strictly lower entries (c < row; hash of (row, c)) are dropped.
+constexpr uint64_t kKronDropSalt = 0x64726f70ULL;   // "drop"
+SX_HD bool kron_keep(const Spec &sp, int row, int64_t c) {
+    if ((sp.bw & 1) && c % 3 == 2) return false;
+    if ((sp.bw & 2) && c < (int64_t)row && mulhi64(rnd(sp.seed ^ kKronDropSalt, (uint64_t)row, (uint64_t)c), 10) < 3) return false;
+    return true;
+}
+SX_HD int kron_row(const Spec &sp, int row, int *c, float *v) {
+    const int pm = sp.ny, pk = sp.nz, i = row / pm, p = row % pm;
+    const int q0 = sp.p_rp[p], q1 = sp.p_rp[p + 1];
+    int k = 0;
+    for (int j = i - 1; j <= i + 1; ++j) {
+        if (j < 0 || j >= sp.nx) continue;
+        for (int q = q0; q < q1; ++q) {
+            const int64_t col = (int64_t)j * pk + sp.p_ci[q];
+            if (!kron_keep(sp, row, col)) continue;
+            if (c) {
+                c[k] = (int)((sp.bw & 1) ? 2 * (col / 3) + col % 3 : col);
+                const float x = u01m1(rnd(sp.seed ^ kValSalt, (uint64_t)row, (uint64_t)col));
+                v[k] = j == i ? x : 0.5f * x;
+            }
+            ++k;
+        }
+    }
+    return k;
+}
+
 SX_HD int row_len(const Spec &sp, const uint64_t *table, int row) {
+    if (sp.kind == 5) return kron_row(sp, row, nullptr, nullptr);
     if (sp.kind == 1) return fem_neighbors(sp, row / sp.dof, nullptr) * sp.dof;
     if (sp.kind == 3) return stencil2d_neighbors(sp, row / sp.dof, nullptr) * sp.dof;
     if (sp.kind == 4) return kkt_row(sp, row, nullptr);
@@ -154,6 +188,7 @@ SX_HD int row_len(const Spec &sp, const uint64_t *table, int row) {
 }
 
 SX_HD void fill_row(const Spec &sp, int row, int len, int *c, float *v) {
+    if (sp.kind == 5) { kron_row(sp, row, c, v); return; }
     if (sp.kind == 1) {
         int nb[27];
         const int n = fem_neighbors(sp, row / sp.dof, nb);   // ascending node order by construction
@@ -511,6 +546,55 @@ int sextans_gen_kkt_device(int device, int n, int arrow, uint64_t seed, int r0, 
     if (r0 < 0 || r1 < r0 || r1 > M) return SEXTANS_ERR_INVALID;
     const Spec sp{4, M, 0, n, arrow, 1, 1, seed};
     return gen_device(device, sp, 1.0, r0, r1, d_row_ptr, d_col_idx, d_val, nnz);
+}
+
+// kron(T_n, P): see kron_row above.  The pattern is validated here (monotone row_ptr, ascending in-range columns).
+static int kron_spec(int n, int pm, int pk, const int *p_row_ptr, const int *p_col_idx, int variant, uint64_t seed, int r0, int r1, Spec *sp) {
+    if (n < 1 || pm < 1 || pk < 1 || !p_row_ptr || !p_col_idx || variant < 0 || variant > 3 || (int64_t)n * pm > 0x7fffffffLL ||
+        (int64_t)n * pk > 0x7fffffffLL || r0 < 0 || r1 < r0 || (int64_t)r1 > (int64_t)n * pm || p_row_ptr[0] != 0)
+        return SEXTANS_ERR_INVALID;
+    for (int p = 0; p < pm; ++p) {
+        if (p_row_ptr[p + 1] < p_row_ptr[p]) return SEXTANS_ERR_INVALID;
+        for (int q = p_row_ptr[p]; q < p_row_ptr[p + 1]; ++q)
+            if (p_col_idx[q] < 0 || p_col_idx[q] >= pk || (q > p_row_ptr[p] && p_col_idx[q] <= p_col_idx[q - 1])) return SEXTANS_ERR_INDEX;
+    }
+    const int64_t K0 = (int64_t)n * pk;
+    const int K = (int)((variant & 1) ? 2 * (K0 / 3) + (K0 % 3 < 2 ? K0 % 3 : 2) : K0);
+    *sp = Spec{5, K, variant, n, pm, pk, 1, seed};
+    return SEXTANS_OK;
+}
+
+int sextans_gen_kron_host(int n, int pm, int pk, const int *p_row_ptr, const int *p_col_idx, int variant, uint64_t seed, int r0, int r1,
+                          int **row_ptr, int **col_idx, float **val, int64_t *nnz, int *K_out) {
+    if (!row_ptr || !col_idx || !val || !nnz) return SEXTANS_ERR_INVALID;
+    Spec sp;
+    if (int rc = kron_spec(n, pm, pk, p_row_ptr, p_col_idx, variant, seed, r0, r1, &sp)) return rc;
+    sp.p_rp = p_row_ptr; sp.p_ci = p_col_idx;
+    if (K_out) *K_out = sp.K;
+    return gen_host(sp, 1.0, r0, r1, row_ptr, col_idx, val, nnz);
+}
+
+int sextans_gen_kron_device(int device, int n, int pm, int pk, const int *p_row_ptr, const int *p_col_idx, int variant, uint64_t seed,
+                            int r0, int r1, int **d_row_ptr, int **d_col_idx, float **d_val, int64_t *nnz, int *K_out) {
+    if (!d_row_ptr || !d_col_idx || !d_val || !nnz) return SEXTANS_ERR_INVALID;
+    Spec sp;
+    if (int rc = kron_spec(n, pm, pk, p_row_ptr, p_col_idx, variant, seed, r0, r1, &sp)) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return SEXTANS_ERR_NO_DEVICE;
+    SY_HIP(hipSetDevice(device));
+    int *d_prp = nullptr, *d_pci = nullptr;
+    const size_t pn = (size_t)p_row_ptr[pm];
+    if (hipMalloc((void **)&d_prp, sizeof(int) * ((size_t)pm + 1)) != hipSuccess || hipMalloc((void **)&d_pci, sizeof(int) * (pn ? pn : 1)) != hipSuccess ||
+        hipMemcpy(d_prp, p_row_ptr, sizeof(int) * ((size_t)pm + 1), hipMemcpyHostToDevice) != hipSuccess ||
+        (pn && hipMemcpy(d_pci, p_col_idx, sizeof(int) * pn, hipMemcpyHostToDevice) != hipSuccess)) {
+        (void)hipFree(d_prp); (void)hipFree(d_pci);
+        return SEXTANS_ERR_HIP;
+    }
+    sp.p_rp = d_prp; sp.p_ci = d_pci;
+    if (K_out) *K_out = sp.K;
+    const int rc = gen_device(device, sp, 1.0, r0, r1, d_row_ptr, d_col_idx, d_val, nnz);
+    (void)hipFree(d_prp); (void)hipFree(d_pci);
+    return rc;
 }
 
 int sextans_gen_bell_host(int M, int K, int ell_width, uint64_t seed, int **block_col, uint16_t **block_val) {

@@ -82,7 +82,11 @@ SYNTH_HELP = """synthetic classes (generated in HBM by csrc/synth.hip, seeded, s
 numberings without a grid (sextans_amd/meshgen.py; the permutation is computed on the host and applied in HBM):
   synth:femperm:nx:ny:nz:dof:random the fem3d matrix under a seeded random renumbering of its nodes
   synth:femperm:nx:ny:nz:dof:rcm    the same under reverse Cuthill-McKee of the node graph (scipy)
-  synth:mesh3d:n:dof:sweep|random|rcm   unstructured jittered-point mesh (n^3 points, ~14 neighbours each), built on the host"""
+  synth:mesh3d:n:dof:sweep|random|rcm   unstructured jittered-point mesh (n^3 points, ~14 neighbours each), built on the host
+holdout class with the local structure of a real SuiteSparse matrix (sextans_amd/holdout.py; round 5):
+  synth:kron:n[:sym|rect|unsym[:natural|random|rcm]]   kron(T_n, nasa4704): n copies of the nasa4704 pattern coupled tridiagonally
+                                                       (n = 850: 4.0 M rows, 267 M non-zeros); rect = every third column dropped,
+                                                       unsym = 30 % of the strictly lower entries dropped"""
 
 
 def _synth(spec, device):
@@ -104,6 +108,9 @@ def _synth(spec, device):
         for old in (p, i, v):
             api.device_free(device, old)
         return (M, K) + q + (nnz,)
+    if kind == "kron":
+        from . import holdout
+        return holdout.kron_device(device, int(f[2]), f[3] if len(f) > 3 else "", f[4] if len(f) > 4 else "natural")
     if kind == "mesh3d":
         from . import meshgen
         n, dof = int(f[2]), int(f[3])
@@ -175,7 +182,8 @@ def sweep_synthetic(specs, n_values, steps=20, alpha=0.85, beta=-2.06, device=0,
                        # row order of the LDS-panel plan: 1 grid bricks, 2 graph clustering (reordered form), -1 natural
                        "row_cluster": int(eng.get_stat("row_cluster")),
                        "panel_rows_natural": int(eng.get_stat("panel_rows_natural")),
-                       "panel_rows_clustered": int(eng.get_stat("panel_rows_clustered"))}
+                       "panel_rows_clustered": int(eng.get_stat("panel_rows_clustered")),
+                       "cluster_decline": int(eng.get_stat("cluster_decline"))}
                 records.append(rec)
                 print(json.dumps(rec), file=out, flush=True)
                 del B, Cin, Cout
