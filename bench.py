@@ -281,9 +281,17 @@ def main():
                          lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 128, 10, options={"exact": 0})),
                         ("fem_4M_random_node_order_N16",
                          lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 40, numbering="random")),
+                        ("rowmajor_fem_4M_N16",
+                         lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 100, layout="rm", torch_op=True)),
+                        ("rowmajor_fem_4M_N128", lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 128, 10, layout="rm")),
+                        ("rowmajor_fem_random_N16",
+                         lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 40, numbering="random", layout="rm", torch_op=True)),
                         ("fem_4M_rcm_node_order_N16",
                          lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 40, numbering="rcm")),
                         ("holdout_kron_nasa4704_4M_N16", lambda: holdout_secondary(api, torch, dev, stream, 16, 40)),
+                        ("rowmajor_holdout_kron_nasa4704_4M_N16", lambda: holdout_secondary(api, torch, dev, stream, 16, 40, layout="rm")),
+                        ("rowmajor_holdout_kron_nasa4704_4M_random_order_N16",
+                         lambda: holdout_secondary(api, torch, dev, stream, 16, 40, numbering="random", layout="rm")),
                         ("holdout_kron_nasa4704_4M_random_order_N16",
                          lambda: holdout_secondary(api, torch, dev, stream, 16, 40, numbering="random")),
                         ("holdout_kron_nasa4704_4M_rect_N16", lambda: holdout_secondary(api, torch, dev, stream, 16, 40, variant="rect")),
@@ -379,14 +387,17 @@ def cpu_baseline(api, M, K, N, args, Cout, flops_per_row, all_cores=True):
     return out
 
 
-def _measure(api, torch, e, M, K, N, nnz, dev, stream, iters):
-    """Steady-state step time (wall, synchronised) and HIP-event time of the dominant kernel."""
+def _measure(api, torch, e, M, K, N, nnz, dev, stream, iters, layout="cm"):
+    """Steady-state step time (wall, synchronised) and HIP-event time of the dominant kernel.
+    layout "rm": the same operands read as ROW-major K x N / M x N through sextans_spmm_device_rm (no layout passes)."""
     B = torch.empty(K * N, dtype=torch.float32, device=dev)
     Cin = torch.empty(M * N, dtype=torch.float32, device=dev)
     Cout = torch.empty(M * N, dtype=torch.float32, device=dev)
     api.gen_uniform_device(dev.index, B.data_ptr(), K * N, 41, stream)
     api.gen_uniform_device(dev.index, Cin.data_ptr(), M * N, 42, stream)
     f = lambda: e.spmm_device(N, ALPHA, B.data_ptr(), K, BETA, Cin.data_ptr(), Cout.data_ptr(), M, stream)
+    if layout == "rm":
+        f = lambda: e.spmm_device_rm(N, ALPHA, B.data_ptr(), N, BETA, Cin.data_ptr(), N, Cout.data_ptr(), N, stream)
     # warm-up until the device has run this workload for ~60 ms: the first ~30 launches after an idle phase run 5-8 % slower (clock
     # ramp; tools/placement.py, tools/thermal.py: 593 us for the first 30 kernels of the FEM matrix, 549 afterwards, flat for 8 s)
     for _ in range(3):
@@ -419,6 +430,8 @@ def _measure(api, torch, e, M, K, N, nnz, dev, stream, iters):
            "alg_gbs_kernel": round(by / (k_ns * 1e-9) / 1e9, 1),
            "roofline_frac_kernel": round(by / (k_ns * 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
            "roofline_frac_step": round(by / per / 1e9 / HBM_PEAK_GBS, 4)}
+    if layout == "rm":
+        out["layout"] = "row-major B and C (sextans_spmm_device_rm)"
     if post_ns:      # the reordered form: "repack_us" = B into permuted panels + C_in into the staging buffer, this = staging -> C_out
         out["post_us"] = round(post_ns / 1e3, 2)
     state = int(e.get_stat("row_cluster"))
@@ -555,7 +568,7 @@ def uniform_secondary(api, torch, dev, stream, args, N):
     return out
 
 
-def fem_secondary(api, torch, dev, stream, dims, N, iters, numbering="grid", options=None):
+def fem_secondary(api, torch, dev, stream, dims, N, iters, numbering="grid", options=None, layout="cm", torch_op=False):
     """SuiteSparse-like FEM input (27-point node stencil, `dof` unknowns per node): the class of
     matrices with B-row reuse, where the LDS-panel kernel applies.  dims = (nx, ny, nz, dof).
     numbering: "grid" (natural order), "random" (a seeded random renumbering of the NODES, applied in HBM: what an arbitrary
@@ -578,11 +591,33 @@ def fem_secondary(api, torch, dev, stream, dims, N, iters, numbering="grid", opt
     for k, val in (options or {}).items():
         e.set_option(k, val)
     e.set_matrix_csr_device(M, K, nnz, p, i, v)
-    out = _measure(api, torch, e, M, K, N, nnz, dev, stream, iters)
+    out = _measure(api, torch, e, M, K, N, nnz, dev, stream, iters, layout)
     out["matrix"] = f"fem3d {nx}x{ny}x{nz}, {dof} dof/node" + ("" if numbering == "grid" else f", {numbering} node order")
     if options:
         out["options"] = options
     e.close()
+    if torch_op:     # the operator front end on the same matrix: wall time per call of torch_op.spmm on row-major tensors, in place
+        from sextans_amd import torch_op as top
+        rp_t = torch.empty(M + 1, dtype=torch.int32, device=dev); ci_t = torch.empty(nnz, dtype=torch.int32, device=dev); v_t = torch.empty(nnz, device=dev)
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        for dst, src, n in ((rp_t, p, M + 1), (ci_t, i, nnz), (v_t, v, nnz)):
+            assert hip.hipMemcpy(dst.data_ptr(), src, 4 * n, 3) == 0
+        A = torch.sparse_csr_tensor(rp_t, ci_t, v_t, size=(M, K))
+        Bt = torch.empty((K, N), device=dev); Ct = torch.empty((M, N), device=dev); Ot = torch.empty((M, N), device=dev)
+        api.gen_uniform_device(dev.index, Bt.data_ptr(), K * N, 41, stream); api.gen_uniform_device(dev.index, Ct.data_ptr(), M * N, 42, stream)
+        g = lambda: top.spmm(A, Bt, ALPHA, BETA, Ct, out=Ot)
+        for _ in range(100):
+            g()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            g()
+        torch.cuda.synchronize()
+        out["torch_op_us_per_call"] = round((time.perf_counter() - t0) / iters * 1e6, 2)
+        top.clear_cache()
+        del A, rp_t, ci_t, v_t, Bt, Ct, Ot
     if numbering == "random":        # the same matrix on the natural-order forms (what round 3 would have run)
         e = api.Engine(dev.index)
         e.set_option("row_cluster", 0)
@@ -595,7 +630,7 @@ def fem_secondary(api, torch, dev, stream, dims, N, iters, numbering="grid", opt
     return out
 
 
-def holdout_secondary(api, torch, dev, stream, N, iters, n=850, variant="", numbering="natural"):
+def holdout_secondary(api, torch, dev, stream, N, iters, n=850, variant="", numbering="natural", layout="cm"):
     """HOLDOUT class (round 5): kron(T_n, nasa4704) -- the local structure of the one real SuiteSparse matrix in this mount carried
     to 4 M rows (sextans_amd/holdout.py); the generators of the other `also` entries were written next to the dispatcher's
     heuristics, this one was not.  variant: "" | "rect" (every third column dropped) | "unsym" (30 % of the lower entries dropped)."""
@@ -603,7 +638,7 @@ def holdout_secondary(api, torch, dev, stream, N, iters, n=850, variant="", numb
     M, K, p, i, v, nnz = holdout.kron_device(dev.index, n, variant, numbering)
     e = api.Engine(dev.index)
     e.set_matrix_csr_device(M, K, nnz, p, i, v)
-    out = _measure(api, torch, e, M, K, N, nnz, dev, stream, iters)
+    out = _measure(api, torch, e, M, K, N, nnz, dev, stream, iters, layout)
     out["matrix"] = f"kron(T_{n}, nasa4704)" + (f", {variant}" if variant else "") + f", {numbering} numbering"
     out["cluster_decline"] = int(e.get_stat("cluster_decline"))
     e.close()

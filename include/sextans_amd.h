@@ -264,7 +264,7 @@ int sextans_destroy(sextans_handle_t h);
  *   "grid_stride_plane"); (2) matrices whose numbering has no locality but whose graph has (meshes in an arbitrary node order) are
  *   aggregated over the matrix graph on the device (csrc/graph_cluster.hip), their columns relabelled in first-touch order, and the
  *   SpMM runs in its REORDERED form: B repacked into permuted panels, C staged block-major (two extra passes over C inside the call;
- *   sextans_last_kernel = "spmm_csr_panel_v2_reordered").  Needs M == K; rows on the long-row paths (pieces, exact chains) are fine.  Stats: "row_cluster"
+ *   sextans_last_kernel = "spmm_csr_panel_v2_reordered").  Any M x K since round 5 ("row_similarity"); rows on the long-row paths (pieces, exact chains) are fine.  Stats: "row_cluster"
  *   (1 grid bricks / 2 graph clustering in use, -1 declined, 0 not evaluated yet -- it is evaluated by the first whole-matrix
  *   SpMM with N >= 16), "panel_rows_natural", "panel_rows_clustered" (B rows copied into LDS per 16-column tile), "panel_blocks",
  *   "panel_blocks_clustered", "cluster_shared_fraction" (sampled pre-test of form 2).  The same reason the reference schedules its
@@ -274,6 +274,12 @@ int sextans_destroy(sextans_handle_t h);
  *   every row <= 32 entries -- use 128-row bricks as two 64-slot row sets on one panel; 3 = 2-D grids too; 1 = never; stat
  *   "row_sets"), "refine_sweeps" (8) / "refine_rows" (62): block refinement of the graph-clustered order, "relabel_columns" (1),
  *   "cluster_top" (depth of the merge tree).
+ * "row_similarity" (-1 auto / 0 never / 1 always): which graph form (2) clusters the rows over.  A square matrix with a symmetric
+ *   pattern is its own graph (column c = row c).  RECTANGULAR matrices have no such reading: their rows are joined to the 16 rows that share the most columns with them
+ *   (found through the transposed pattern, csrc/graph_cluster.hip: row_similarity_graph_device) -- the reference schedules any
+ *   M x K matrix for its on-chip window too (sparse_helper.h:345-403).  A square matrix with an unsymmetric pattern (sampled: stat
+ *   "pattern_symmetry" < 0.98) is clustered over A + A^T -- the pairwise matching needs symmetric weights.  Stat
+ *   "cluster_graph_kind": 0 the matrix itself, 1 a row slab's own square pattern ("row_offset"), 2 row similarity, 3 A + A^T.
  * "row_offset" (default -1): the matrix of this engine is the row slab [row_offset, row_offset + M) of a K x K matrix (what a rank of
  *   sextans_dist_spmm holds, which sets it): the graph clustering of "row_cluster" then runs on the slab's own square pattern.
  * "share_index" (default 1): consecutive rows of a block whose 16-bit index lists are equal up to a constant shift keep one copy
@@ -318,7 +324,7 @@ int sextans_export_plan(sextans_handle_t h, int lanes_per_row, struct sextans_pa
  * "dense_tiles_on_mfma", "row_cluster" and the other clustering figures listed with that option, "device_bytes" (bytes of
  * device memory the engine holds right now: matrix copies, packed plans, workspaces), "col_range_lo" / "col_range_hi" (the rows
  * of B the matrix has columns in: only those are repacked -- a rank of a row-partitioned SpMM over a banded matrix touches
- * 1 / world of B plus a halo), "cluster_decline" (why the graph clustering was not used: 1 not square, 2 long-row paths,
+ * 1 / world of B plus a halo), "cluster_decline" (why the graph clustering was not used: 1 not square and "row_similarity" = 0, 2 long-row paths,
  * 3 offsets, 4 natural blocks full, 5 no shared neighbourhoods, 6..9 a builder failed, 10..12 plan unusable / no gain,
  * 13 short rows in a local numbering). */
 int sextans_get_stat(sextans_handle_t h, const char *key, double *value);
@@ -354,6 +360,18 @@ int sextans_spmm_device(sextans_handle_t h, int N, float alpha, const float *d_B
 int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
                          float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out,
                          int64_t ldc_out, void *stream);
+
+/* ROW-MAJOR operands (round 5): B is K x N with B[k * ldb + n], C_in / C_out are M x N with C[m * ldc + n] (ld >= N; C_in and C_out may
+ * alias).  The reference lays B and C out for its kernel on the host, outside the timed call (sextans-host.cpp:150-195, 264-270); the
+ * column-major entry points above pay for that inside the call (B repack; two more passes over C in the reordered form).  Here the
+ * caller's B IS the kernel's panel (N = 16: exactly; N > 16: tile t = columns 16 t .. at row stride ldb) and C is read and written in
+ * the caller's rows, 16 bytes per lane: no layout pass on the LDS-panel paths (natural-order, grid-brick and graph-clustered plans;
+ * sextans_last_kernel = "spmm_csr_panel_v2_rowmajor[_clustered]"), and a graph-clustered plan is used from 25 % fewer panel rows on
+ * instead of 40 %.  Needs 16-byte aligned pointers, ld % 4 == 0, K * ldb < 2^32 and M * ldc < 2^30; everything else (gather /
+ * lane-per-row kernels, rows on the long-row paths, dense tiles on MFMA, unaligned operands) goes through column-major copies in the
+ * engine's workspaces.  Same arithmetic, same order: bit-identical to cpu_spmm_CSR. */
+int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb, float beta, const float *d_C_in,
+                           int64_t ldc_in, float *d_C_out, int64_t ldc, void *stream);
 
 /* Row-range form: computes rows [row_begin, row_end) only.  d_C_in / d_C_out address row_begin as
  * their row 0 (ldc_in, ldc_out >= row_end - row_begin).  Used to pipeline a rank's slab in chunks so the

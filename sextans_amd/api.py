@@ -153,6 +153,8 @@ def lib():
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.sextans_spmm_device2.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    L.sextans_spmm_device_rm.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
+                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     L.sextans_spmm_device_rows.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p]
@@ -613,6 +615,11 @@ class Engine:
     def spmm_device2(self, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out, ldc_out, stream=None):
         _check(lib().sextans_spmm_device2(self._h, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out,
                                           ldc_out, stream), "spmm_device2")
+
+    def spmm_device_rm(self, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out, ldc_out, stream=None):
+        """ROW-major operands (B[k * ldb + n], C[m * ldc + n]): no layout pass on the LDS-panel paths (include/sextans_amd.h)."""
+        _check(lib().sextans_spmm_device_rm(self._h, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out, ldc_out, stream),
+               "spmm_device_rm")
 
     def spmm_device_rows(self, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out, ldc_out, row_begin, row_end,
                          reuse_b_panels=False, stream=None):

@@ -125,7 +125,10 @@ int launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_t
 template <int H>
 int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc,
                       int nsuper, float alpha, float beta, hipStream_t s, int64_t bcol_ld, int blk_begin, int blk_end,
-                      int row_base, int mode = 0, int last_cols = 16) {
+                      int row_base, int mode = 0, int last_cols = 16, int64_t rm_ldb = 0) {
+    // rm_ldb > 0 (sextans_spmm_device_rm): dBp is the caller's ROW-major B with that leading dimension, dCin / dCout its row-major C
+    // (ldc_in / ldc = row strides); mode 2 then reads B through the plan's dictionaries translated back to the caller's column
+    // numbers (h->d_dict_nat) instead of permuted panels.
     // mode 1 (grid bricks): the plan over the rows in brick order, whole-matrix calls only; its slot -> row table addresses C.
     // mode 2 (graph clustering, the reordered form): dBp = permuted panels, dCin == dCout == the row-major staging buffer,
     // ldc_in == ldc == floats per tile; the same slot -> row table addresses the staging rows.
@@ -157,7 +160,9 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     }
     tpw = std::min(tpw, nsuper);
     const int ngrp = (nsuper + tpw - 1) / tpw;
-    const int64_t pstride = bcol_ld > 0 ? bcol_ld : (int64_t)h->K * 16;
+    const bool rm = rm_ldb > 0;
+    const int64_t pstride = rm ? rm_ldb : bcol_ld > 0 ? bcol_ld : (int64_t)h->K * 16;
+    const int *dict = (rm && mode == 2 && h->d_dict_nat) ? h->d_dict_nat : P.d_dict;
     // LDS = the panel: plan capacity + the +1.0f row.  A clustered plan of a short-row matrix is packed for a 320-row panel
     // (engine_plan.hip: small_panel): 20.5 KB instead of 36.9 KB per workgroup, so the CU holds as many workgroups as the registers
     // allow (5 at <= 96 registers) instead of the 4 the full panel permits -- these launches are latency-bound
@@ -169,7 +174,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     auto go = [&](auto kern) -> int {
         if (int rc = allow_big_lds(h, reinterpret_cast<const void *>(kern), (int)lds)) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)P.d_row_off,
-                           P.d_lidx, P.d_pval, P.d_blk_row, P.d_dict_ptr, P.d_dict, P.plan_dict_stride,
+                           P.d_lidx, P.d_pval, P.d_blk_row, P.d_dict_ptr, dict, P.plan_dict_stride,
                            dBp, pstride, dCin, ldc_in, dCout, ldc, nsuper, tpw, nblk, alpha, beta, xcd,
                            P.plan_pad_row, blk_begin, row_base, skip, (long long *)h->d_dbg, slot_row, (const int2 *)P.d_ioff, last_cols);
         return SEXTANS_OK;
@@ -195,6 +200,17 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
             return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 6, true, true, false, 9, false, true>) : go(sx::spmm_csr_panel_v2<H, 6, false, true, false, 9, false, true>);
         }
         if (bcol_ld > 0) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, true>) : go(sx::spmm_csr_panel_v2<H, 2, false, true>);
+        if (rm) {   // the caller's row-major operands: the 16-byte C accesses of the staging form on the caller's own rows, B without a repack
+#define SX_RM(NBV, DC, ST) (h->opt_exact ? go(sx::spmm_csr_panel_v2<H, NBV, true, false, false, DC, true, false, ST, true>) \
+                                          : go(sx::spmm_csr_panel_v2<H, NBV, false, false, false, DC, true, false, ST, true>))
+            if (P.plan_sets == 2) return SX_RM(2, 9, 2);
+            if (small_panel) return nb >= 3 ? SX_RM(3, 5, 1) : SX_RM(2, 5, 1);
+            if (nb == 3) return SX_RM(3, 9, 1);
+            if (nb == 2) return SX_RM(2, 9, 1);
+            if (nb == 4) return SX_RM(4, 9, 1);
+            return SX_RM(6, 9, 1);
+#undef SX_RM
+        }
         if (P.plan_sets == 2) {   // two row sets per block (short-row clustered plans: every row has <= 32 entries = 2 register-resident batches)
             if (mode == 2) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false, false, 9, true, false, 2>) : go(sx::spmm_csr_panel_v2<H, 2, false, false, false, 9, true, false, 2>);
             return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false, false, 9, false, false, 2>) : go(sx::spmm_csr_panel_v2<H, 2, false, false, false, 9, false, false, 2>);
@@ -327,6 +343,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "row_sets")) return &h->opt_row_sets;
     if (!strcmp(key, "row_offset")) return &h->opt_row_offset;
     if (!strcmp(key, "relabel_columns")) return &h->opt_relabel_columns;
+    if (!strcmp(key, "row_similarity")) return &h->opt_row_similarity;
     if (!strcmp(key, "refine_sweeps")) return &h->opt_refine_sweeps;
     if (!strcmp(key, "share_index")) return &h->opt_share_index;
     if (!strcmp(key, "refine_rows")) return &h->opt_refine_rows;
@@ -367,6 +384,7 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
     if (slot == &h->opt_cluster_group && (value < 1 || value > 64)) return SEXTANS_ERR_INVALID;
     if (slot == &h->opt_panel_v2 && (value < -1 || value > 1)) return SEXTANS_ERR_INVALID;
     if (slot == &h->opt_row_cluster && (value < -1 || value > 2)) return SEXTANS_ERR_INVALID;
+    if (slot == &h->opt_row_similarity && (value < -1 || value > 1)) return SEXTANS_ERR_INVALID;
     if (slot == &h->opt_lpr && value != 0 && value != 2 && value != 4 && value != 8) return SEXTANS_ERR_INVALID;
     if (slot == &h->opt_win_rows && (value < 1 || value > sx::kWinMaxRowsPerWave)) return SEXTANS_ERR_INVALID;
     if (slot == &h->opt_win_cols && (value < 1 || value > 0x7fffffff)) return SEXTANS_ERR_INVALID;
@@ -377,9 +395,10 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
         (void)hipSetDevice(h->device);
         free_window(h);   // the stream is built for one (rows per wavefront, window) pair
     }
-    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_top || slot == &h->opt_small_panel || slot == &h->opt_row_sets || slot == &h->opt_row_offset || slot == &h->opt_relabel_columns || slot == &h->opt_refine_sweeps || slot == &h->opt_refine_rows || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
+    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_top || slot == &h->opt_small_panel || slot == &h->opt_row_sets || slot == &h->opt_row_offset || slot == &h->opt_relabel_columns || slot == &h->opt_row_similarity || slot == &h->opt_refine_sweeps || slot == &h->opt_refine_rows || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
         (void)hipSetDevice(h->device);   // the clustered-order plan is (re)considered under the new setting
         free_cluster_plan(h);
+        h->cluster_rm_tried = false;
     }
     if (slot == &h->opt_colwise_max_len && *slot != value) h->colwise_state = 0;
     if (slot == &h->opt_share_index && *slot != value) { (void)hipSetDevice(h->device); free_plan(h); }   // every packed form is rebuilt
@@ -581,6 +600,8 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "row_cluster")) *value = (double)h->cluster_state;          // 1 grid bricks / 2 graph clustering in use, -1 declined, 0 not evaluated yet
     else if (!strcmp(key, "cluster_shared_fraction")) *value = h->cluster_shared;
     else if (!strcmp(key, "cluster_decline")) *value = (double)h->cluster_decline;
+    else if (!strcmp(key, "cluster_graph_kind")) *value = (double)h->cluster_graph_kind;
+    else if (!strcmp(key, "pattern_symmetry")) *value = h->pattern_symmetry;
     else if (!strcmp(key, "col_range_lo")) *value = (double)h->col_lo;
     else if (!strcmp(key, "col_range_hi")) *value = (double)h->col_hi;
     else if (!strcmp(key, "colwise")) *value = (double)h->colwise_state;
@@ -800,7 +821,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
                         // (... and below that size once the call is large enough: a 13 965-row matrix in a random node order, N = 128,
                         // 112 us staged from column-major B on its natural-order plan against 34 us reordered; N = 16: 13.3 against 15.0.
                         // Crossover measured at ~24 M non-zero x column products: tools/small_renumbered.py)
-                        !(whole && h->cluster_state == 2 && (h->M >= 65536 || h->m_nnz * (int64_t)N >= ((int64_t)24 << 20)));
+                        !(whole && h->cluster_state == 2 && h->cluster_cm_pays && (h->M >= 65536 || h->m_nnz * (int64_t)N >= ((int64_t)24 << 20)));
     // (Staging from column-major B for LARGE matrices -- no repack launch at all -- was measured in round 4 and loses everywhere: 4M-row
     // 3-dof FEM N = 16 kernel 660 -> 872 us against 83 us of repack saved; 1-dof 27-point 379 -> 577; 2-D 9-point 296 -> 427;
     // 5-point 270 -> 412: 36 four-byte loads per lane and panel through registers instead of nine LDS-DMA requests.)
@@ -809,8 +830,11 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     // The reordered form (graph-clustered plan, ensure_cluster_plan): whole-matrix calls, 16-column tiles.  Its B panels hold the
     // rows of B in the plan's column order and C goes through the block-major staging buffer (reorder_kernels.h); an 8-column
     // remainder tile keeps the natural-order kernels and panels.  (Layout tag -W: such panels are never reused by a row-range call.)
-    const bool reordered = whole && h->cluster_state == 2 && h->opt_kernel != 1 && h->opt_kernel != 3 && W == 16 && !fuse_b &&
-                           (!chains || h->d_chain_ci_perm) && h->dense_W == 0 && h->d_Cs && (N >= 16 || (N == 8 && !hubs && !chains));
+    const bool reordered = whole && h->cluster_state == 2 && h->cluster_cm_pays && h->opt_kernel != 1 && h->opt_kernel != 3 && W == 16 && !fuse_b &&
+                           (!chains || h->d_chain_ci_perm) && h->dense_W == 0 && h->d_Cs &&
+                           // (the staging buffer is sized by prepare() for the N it saw: a plan that survived a set_option("kernel") and a
+                           // larger N since then must not run past its end -- ADVICE r04)
+                           h->Cs_cap >= (size_t)((N + 15) / 16) * (size_t)h->M * 16 && (N >= 16 || (N == 8 && !hubs && !chains));
     const int64_t cs_tile = reordered ? (int64_t)h->M * 16 : 0;   // floats per 16-column tile of the staging buffer
     // N = 16 t + 8 on the register-resident panel kernel: the 8-column tail used to go to the gather kernel (the plan is built for
     // 16-column tiles) -- 4M-row FEM matrix: N = 24 2 152 us per step against 1 099 at N = 32.  It now runs as one more 16-column tile:
@@ -1033,6 +1057,115 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         if (hubs) fold();
         // chain rows write C themselves: behind the staging -> C pass (which left C_in in their rows), from the permuted panels
         if (chains) launch_chains(h, plan, d_C_in, ldc_in, d_C_out, ldc, N, ch0, ch1, row_begin, alpha, beta, s, true);
+    }
+    SX_HIP(hipGetLastError());
+    return SEXTANS_OK;
+}
+
+}  // extern "C"
+namespace {
+// 32 x 32 tiles through LDS: dst[c * ld_dst + r] = src[r * ld_src + c] for r < rows, c < cols (row-major -> column-major and back)
+__global__ __launch_bounds__(256) void transpose_tiles(const float *__restrict__ src, int64_t ld_src, float *__restrict__ dst, int64_t ld_dst, int rows, int cols) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) t[i][tx] = src[(int64_t)(r0 + i) * ld_src + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) dst[(int64_t)(c0 + i) * ld_dst + r0 + tx] = t[tx][i];
+}
+void launch_transpose(const float *src, int64_t ld_src, float *dst, int64_t ld_dst, int rows, int cols, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return;
+    hipLaunchKernelGGL(transpose_tiles, dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32)), dim3(256), 0, s, src, ld_src, dst, ld_dst, rows, cols);
+}
+__global__ __launch_bounds__(256) void invert_positions(int K, const int *__restrict__ colpos, int *__restrict__ colinv) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < K) colinv[colpos[k]] = k;
+}
+__global__ __launch_bounds__(256) void translate_dict(long long n, int K, const int *__restrict__ dict, const int *__restrict__ colinv, int *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const int c = dict[i]; out[i] = (unsigned)c < (unsigned)K ? colinv[c] : 0; }   // (slots past a block's dictionary are never used)
+}
+}  // namespace
+extern "C" {
+
+// Row-major operands.  The reference lays B and C out for its kernel on the host, OUTSIDE the timed call (sextans-host.cpp:150-195,
+// 264-270); a caller whose operands are row-major (torch tensors; the natural layout of a "K x N feature matrix") gets the same here:
+// no layout pass at all on the LDS-panel paths.
+int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb, float beta, const float *d_C_in,
+                           int64_t ldc_in, float *d_C_out, int64_t ldc, void *stream) {
+    if (!h || N <= 0 || (N % 8) != 0 || !d_B || !d_C_in || !d_C_out || ldb < N || ldc_in < N || ldc < N) return SEXTANS_ERR_INVALID;
+    if (!h->d_rp) return SEXTANS_ERR_STATE;
+    SX_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (h->M == 0) return SEXTANS_OK;
+    std::vector<Seg> plan;
+    int W = 0;
+    bool use_panel = false, use_window = false;
+    // (N = 8 runs as one half-empty 16-column tile of the 16-column plan: without a repack to pay for there is no reason for a second
+    // packed plan at 2 lanes per row)
+    const int Nplan = N == 8 ? 16 : N;
+    if (int rc = prepare(h, Nplan, plan, W, use_panel, use_window, true)) return rc;
+    // A clustered plan that was declined only because the column-major form has to pay two passes over C for it (decline 12) is
+    // reconsidered for this layout, where it costs nothing: built once, used by row-major calls only unless it pays for both.
+    if (h->cluster_state == -1 && h->cluster_decline == 12 && !h->cluster_rm_tried && W == 16 && h->opt_row_cluster < 0) {
+        h->cluster_rm_tried = true;
+        free_cluster_plan(h);
+        h->cluster_for_rm = true;
+        const int rc = prepare(h, Nplan, plan, W, use_panel, use_window, true);
+        h->cluster_for_rm = false;
+        if (rc) return rc;
+    }
+    const bool colwise = h->opt_kernel == 4 || (h->opt_kernel == 0 && h->colwise_state == 1);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(d_B) | reinterpret_cast<uintptr_t>(d_C_in) | reinterpret_cast<uintptr_t>(d_C_out)) & 15) == 0 &&
+                         ldb % 4 == 0 && ldc_in % 4 == 0 && ldc % 4 == 0;
+    // 32-bit offsets inside the kernel: floats into B, bytes into C
+    const bool fits = (int64_t)h->K * ldb < ((int64_t)1 << 32) && (int64_t)h->M * std::max(ldc, ldc_in) * 4 < ((int64_t)1 << 32);
+    int mode = -1;
+    if (W == 16 && (h->opt_kernel == 0 || h->opt_kernel == 2) && h->opt_panel_v2 != 0 && h->opt_cols_per_lane != 8 && h->nhub == 0 && h->nchain == 0 &&
+        h->dense_W == 0 && !colwise && aligned && fits && h->m_nnz > 0) {
+        if (h->cluster_state == 2) mode = 2;
+        else if (h->cluster_state == 1) mode = 1;
+        else if (use_panel && !h->ps.plan_mixed && h->ps.plan_max_dict <= sx::kWideMaxDict) mode = 0;
+    }
+    if (mode == 2 && h->d_colpos && !h->d_dict_nat) {   // the plan's dictionaries hold relabelled columns: translate them back once
+        const long long n = (long long)h->psc.plan_nblk * h->psc.plan_dict_stride;
+        int *colinv = nullptr;
+        if (hipMalloc((void **)&colinv, sizeof(int) * (size_t)std::max(h->K, 1)) != hipSuccess || hipMalloc((void **)&h->d_dict_nat, sizeof(int) * (size_t)std::max<long long>(n, 1)) != hipSuccess) {
+            (void)hipFree(colinv); (void)hipFree(h->d_dict_nat); h->d_dict_nat = nullptr; (void)hipGetLastError();
+            mode = -1;
+        } else {
+            hipLaunchKernelGGL(invert_positions, dim3((unsigned)((h->K + 255) / 256)), dim3(256), 0, s, h->K, h->d_colpos, colinv);
+            hipLaunchKernelGGL(translate_dict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, h->K, h->psc.d_dict, colinv, h->d_dict_nat);
+            SX_HIP(hipStreamSynchronize(s));
+            (void)hipFree(colinv);
+        }
+    }
+    if (mode >= 0) {
+        Prof p(h, &h->ev_kernel, s);
+        const int ntiles = (N + 15) / 16, last_cols = N % 16 ? 8 : 16;
+        const sextans_engine::PanelState &P = mode ? h->psc : h->ps;
+        if (int rc = launch_panel_v2<1>(h, d_B, d_C_in, ldc_in, d_C_out, ldc, ntiles, alpha, beta, s, 0, 0, P.plan_nblk, 0, mode, last_cols, ldb)) return rc;
+        h->last_kernel = mode == 2 ? "spmm_csr_panel_v2_rowmajor_clustered" : "spmm_csr_panel_v2_rowmajor";
+        SX_HIP(hipGetLastError());
+        return SEXTANS_OK;
+    }
+    // Everything else (gather / lane-per-row / window kernels, rows on the piece and chain paths, dense tiles, unaligned operands):
+    // through column-major copies in the engine's workspaces -- two transposes in front, one behind.
+    const size_t nB = (size_t)h->K * (size_t)N, nC = (size_t)h->M * (size_t)N;
+    if (int rc = ensure(&h->d_B, &h->B_cap, nB)) return rc;
+    size_t ccap = h->C_cap;
+    if (int rc = ensure(&h->d_Cin, &ccap, nC)) return rc;
+    if (int rc = ensure(&h->d_Cout, &h->C_cap, nC)) return rc;
+    {
+        Prof p(h, &h->ev_repack, s);
+        launch_transpose(d_B, ldb, h->d_B, h->K, h->K, N, s);
+        launch_transpose(d_C_in, ldc_in, h->d_Cin, h->M, h->M, N, s);
+    }
+    if (int rc = sextans_spmm_device_rows(h, N, alpha, h->d_B, h->K, beta, h->d_Cin, h->M, h->d_Cout, h->M, 0, h->M, 0, stream)) return rc;
+    {
+        Prof p(h, &h->ev_post, s);
+        launch_transpose(h->d_Cout, h->M, d_C_out, ldc, N, h->M, s);
     }
     SX_HIP(hipGetLastError());
     return SEXTANS_OK;

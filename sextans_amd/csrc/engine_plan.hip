@@ -28,8 +28,9 @@ void free_panel_state(sextans_engine::PanelState &p) {
 
 void free_cluster_plan(sextans_engine *h) {   // the clustered-order plan and its tables; it is reconsidered at the next whole-matrix call
     free_panel_state(h->psc);
-    (void)hipFree(h->d_slot_row); (void)hipFree(h->d_colpos);
-    h->d_slot_row = h->d_colpos = nullptr;
+    (void)hipFree(h->d_slot_row); (void)hipFree(h->d_colpos); (void)hipFree(h->d_dict_nat);
+    h->d_slot_row = h->d_colpos = h->d_dict_nat = nullptr;
+    h->cluster_cm_pays = true;
     (void)hipFree(h->d_chain_ci_perm); (void)hipFree(h->d_chain_beg_c); (void)hipFree(h->d_chain_v_c);
     h->d_chain_ci_perm = h->d_chain_beg_c = nullptr; h->d_chain_v_c = nullptr;
     h->cluster_state = 0;
@@ -38,9 +39,12 @@ void free_cluster_plan(sextans_engine *h) {   // the clustered-order plan and it
     h->cluster_decline = 0;
     h->cluster_total_dict = 0;
     h->cluster_shared = 0.0;
+    h->cluster_graph_kind = 0;
+    h->pattern_symmetry = 1.0;
 }
 
 void free_plan(sextans_engine *h) {   // every packed form of the current main matrix
+    h->cluster_rm_tried = false;
     free_panel_state(h->ps);
     for (auto &p : h->plan_stash) free_panel_state(p);
     free_cluster_plan(h);
@@ -407,29 +411,61 @@ int cluster_grid(sextans_engine *h) {   // 0 = in use, 1 = declined
 }
 
 int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reason (stat "cluster_decline")
-    // square, or a row slab of a square matrix whose position is known (option row_offset, set by sextans_dist_spmm): then the
-    // clustering runs on the slab's own square pattern, everything behind it on the rectangular matrix
+    // Which graph are the rows clustered over?
+    //   (a) square matrix with a (nearly) symmetric pattern: the matrix itself, a column index read as the row of the neighbour;
+    //   (b) a row slab of a square matrix whose position is known (option row_offset, set by sextans_dist_spmm): the slab's own
+    //       square pattern, everything behind it on the rectangular matrix;
+    //   (c) anything else -- rectangular (LP / least-squares matrices; the reference schedules any M x K matrix, sparse_helper.h:
+    //       345-403) or square with an unsymmetric pattern (row c says little about row r there: measured on the holdout class with
+    //       30 % of its lower entries dropped, graph (a) gave 2 x the panel rows of the symmetric pattern, 4 x under a random
+    //       numbering) -- the ROW-SIMILARITY graph: r joined to the rows that share the most columns with it (graph_cluster.hip).
+    // Option "row_similarity": -1 automatic, 0 never (rectangular matrices are declined as before round 5), 1 always.
     const bool slab = h->M != h->K && h->opt_row_offset >= 0 && h->opt_row_offset + h->M <= h->K;
-    if ((h->M != h->K && !slab) || h->m_nnz <= 0) return 1;                             // 1: not square
+    const bool rect = h->M != h->K && !slab;
+    if (h->m_nnz <= 0 || (rect && h->opt_row_similarity == 0)) return 1;                 // 1: not square (and the row-similarity graph switched off)
     if (h->dense_W > 0) return 2;                                                       // 2: dense tiles on the MFMA path (rows on the piece / chain paths are fine: they are empty here)
     if ((int64_t)h->K * 64 >= ((int64_t)1 << 32)) return 3;   // 3: 32-bit byte offsets into a K x 16 panel
     const int lpr = 4, RB = sx::kBlock / lpr, cap = kPanelFloats / (4 * lpr);
     std::string err;
     int *g_rp_own = nullptr, *g_ci_own = nullptr;      // the graph the rows are clustered over
+    unsigned char *g_w_own = nullptr;                  // ... and its weights, when it brings its own
     const int *g_rp = h->m_rp, *g_ci = h->m_ci;
     int64_t g_nnz = h->m_nnz;
+    struct FreeGraph { int *&a, *&b; unsigned char *&c; ~FreeGraph() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); } } free_graph{g_rp_own, g_ci_own, g_w_own};
+    // worth trying?  Not when the natural-order plan already fills its blocks (numberings with locality: the grid path or nothing)
+    if (h->opt_row_cluster < 0 && h->ps.plan_built && !h->ps.plan_mixed && h->ps.plan_nblk > 0 && (double)h->M / h->ps.plan_nblk >= 50.0) return 4;   // 4: natural blocks are full
     if (slab) {
         if (sx::local_square_pattern_device(h->M, h->m_rp, h->m_ci, (int)h->opt_row_offset, &g_rp_own, &g_ci_own, &g_nnz, err)) return 6;
         g_rp = g_rp_own; g_ci = g_ci_own;
     }
-    struct FreeGraph { int *a, *b; ~FreeGraph() { (void)hipFree(a); (void)hipFree(b); } } free_graph{g_rp_own, g_ci_own};
+    double shared = 0.0, near = 0.0, sym = 1.0;
+    bool rowsim = rect || h->opt_row_similarity > 0;
+    if (!rowsim) {
+        if (sx::probe_shared_neighbourhood_device(h->M, g_rp, g_ci, 256, &shared, &near, err, &sym)) return 5;
+        h->pattern_symmetry = sym;
+    }
+    auto adopt = [&](int *rp, int *ci, unsigned char *w, int64_t n) {   // replaces the graph owned so far
+        (void)hipFree(g_rp_own); (void)hipFree(g_ci_own); (void)hipFree(g_w_own);
+        g_rp_own = rp; g_ci_own = ci; g_w_own = w; g_rp = rp; g_ci = ci; g_nnz = n;
+    };
+    if (rowsim) {
+        int *rp = nullptr, *ci = nullptr;
+        unsigned char *w = nullptr;
+        int64_t n = 0;
+        if (sx::row_similarity_graph_device(h->M, h->K, h->m_nnz, h->m_rp, h->m_ci, &rp, &ci, &w, &n, &shared, &near, err)) return 6;
+        adopt(rp, ci, w, n);
+    }
+    if (rowsim || sym < 0.98) {   // the matching needs symmetric weights: G + G^T (the kNN lists of the row-similarity graph are not mutual either)
+        int *rp = nullptr, *ci = nullptr;
+        unsigned char *w = nullptr;
+        int64_t n = 0;
+        if (sx::symmetrize_graph_device(h->M, g_nnz, g_rp, g_ci, g_w_own, &rp, &ci, g_w_own ? &w : nullptr, &n, err)) return 6;
+        adopt(rp, ci, w, n);
+    }
+    h->cluster_graph_kind = rowsim ? 2 : sym < 0.98 ? 3 : slab ? 1 : 0;
+    h->cluster_shared = shared;
     if (h->opt_row_cluster < 0) {
-        // worth trying?  Not when the natural-order plan already fills its blocks (numberings with locality: the grid path or
-        // nothing), and not when neighbouring rows do not share neighbourhoods (random columns: there is nothing to find)
-        if (h->ps.plan_built && !h->ps.plan_mixed && h->ps.plan_nblk > 0 && (double)h->M / h->ps.plan_nblk >= 50.0) return 4;   // 4: natural blocks are full
-        double shared = 0.0, near = 0.0;
-        if (sx::probe_shared_neighbourhood_device(h->M, g_rp, g_ci, 256, &shared, &near, err)) return 5;
-        h->cluster_shared = shared;
+        // ... and not when neighbouring rows do not share neighbourhoods (random columns: there is nothing to find)
         if (shared < 0.2) return 5;                                                                                               // 5: no shared neighbourhoods
         // 13: short rows in a numbering that has locality -- per row the two extra passes over C move more bytes than the row's
         // non-zeros, and the gather kernel finds its B rows in L2 (2-D 5-point stencils, 1-dof meshes in sweep order: measured equal
@@ -442,7 +478,7 @@ int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reaso
     sx::DevicePlan dp;
     auto drop = [&](int why) { (void)hipFree(d_order); (void)hipFree(d_colpos); (void)hipFree(d_cut); (void)hipFree(prp); (void)hipFree(pci); (void)hipFree(pv);
                                sx::free_device_plan(dp); return why; };
-    if (sx::cluster_rows_graph_device(h->M, h->M, g_nnz, g_rp, g_ci, (int)std::min<int64_t>(h->opt_cluster_top, 0x40000000), &d_order, err)) return drop(6);   // 6 .. 9: a builder failed
+    if (sx::cluster_rows_graph_device(h->M, h->M, g_nnz, g_rp, g_ci, (int)std::min<int64_t>(h->opt_cluster_top, 0x40000000), &d_order, err, g_w_own)) return drop(6);   // 6 .. 9: a builder failed
     if (h->opt_refine_sweeps > 0)   // boundary rows to the block that holds more of their neighbours (blocks of 62 rows, room for 2 more each)
         if (sx::refine_blocks_device(h->M, g_rp, g_ci, d_order, (int)std::min<int64_t>(RB, std::max<int64_t>(32, h->opt_refine_rows)), RB, (int)h->opt_refine_sweeps, &d_cut, err) == 2) return drop(6);
     const bool relabel = h->opt_relabel_columns != 0;
@@ -468,8 +504,12 @@ int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reaso
     if ((double)h->m_nnz < min_reuse * (double)dp.total_dict) return drop(11);
     {   // automatic: worth the two extra passes over C only if it copies >= 40 % fewer B rows than what would run otherwise -- the
         // natural-order plan, or the grid-brick plan when the grid path built one first (ensure_cluster_plan)
+        // Row-major calls (sextans_spmm_device_rm) pay no pass for it: there a plan that copies >= 25 % fewer B rows is kept (measured on
+        // the holdout class: 36 % fewer panel rows = kernel 686 -> 593 us), for those calls only ("cluster_cm_pays").
         const int64_t ref = h->cluster_ref_dict > 0 ? h->cluster_ref_dict : (h->ps.plan_built ? h->plan_total_dict : 0);
-        if (h->opt_row_cluster < 0 && ref > 0 && (double)dp.total_dict > 0.6 * (double)ref) return drop(12);
+        const bool auto_ref = h->opt_row_cluster < 0 && ref > 0;
+        if (auto_ref && (double)dp.total_dict > (h->cluster_for_rm ? 0.75 : 0.6) * (double)ref) return drop(12);
+        h->cluster_cm_pays = !(auto_ref && (double)dp.total_dict > 0.6 * (double)ref);
     }
     if (sx::build_slot_rows_device(dp.nblk, RB, dp.d_blk_row, d_order, &h->d_slot_row, err)) return drop(9);
     (void)hipFree(d_order);
@@ -625,7 +665,7 @@ int ensure_cluster_plan(sextans_engine *h) {
             h->cluster_decline = 9;
         }
     }
-    if (h->cluster_state > 0) release_plan_streams(h);
+    if (h->cluster_state == 1 || (h->cluster_state == 2 && h->cluster_cm_pays)) release_plan_streams(h);
     (void)hipGetLastError();   // a failure in here (out of memory for the sort buffers, ...) only declines the clustered plan
     return SEXTANS_OK;
 }
@@ -936,7 +976,7 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
         // use the clustered plan and do not pay for it.)
         if (lpr == 4 && whole && h->opt_kernel != 3) {
             if (int rc = ensure_cluster_plan(h)) return rc;
-            if (h->cluster_state == 2 && (N >= 16 || n8_wide))   // row-major C staging of the reordered form: ceil(N / 16) tiles of M x 16
+            if (h->cluster_state == 2 && h->cluster_cm_pays && (N >= 16 || n8_wide))   // row-major C staging of the reordered form: ceil(N / 16) tiles of M x 16
                 if (int rc = ensure(&h->d_Cs, &h->Cs_cap, (n16 / 16) * (size_t)h->M * 16)) return rc;
         }
         use_panel = h->ps.plan_built && ((h->opt_kernel == 2) || (h->ps.plan_panel_frac >= 0.5 && (N >= 32 || h->ps.plan_narrow_frac >= 0.5)));
@@ -949,7 +989,7 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
         }
     }
     // (the reordered form of a graph-clustered matrix runs 16-column tiles whether or not a natural-order plan exists)
-    const bool reorder = whole && h->cluster_state == 2 && h->opt_kernel != 1 && h->opt_kernel != 3 && lpr == 4;
+    const bool reorder = whole && h->cluster_state == 2 && h->cluster_cm_pays && h->opt_kernel != 1 && h->opt_kernel != 3 && lpr == 4;
     if (!h->opt_lpr && !use_panel && !reorder && N >= 32 && lpr != 8) { lpr = 8; tiles(); }
     // "kernel" 3 = K-windowed accumulator-resident kernel; auto picks it for matrices without B-row reuse
     // whose B does not fit the L2s when the traffic model says the sweep moves fewer bytes than the gather.

@@ -99,6 +99,10 @@ struct sextans_engine {
     PanelState psc;
     int64_t cluster_ref_dict = 0;       // panel rows of the grid-brick plan while the graph plan is weighed against it (ensure_cluster_plan)
     int *d_slot_row = nullptr;          // psc: row of the main matrix per (block, slot)
+    int *d_dict_nat = nullptr;          // psc, graph clustering: the block dictionaries in the CALLER's column numbers (row-major calls read B where it lies)
+    bool cluster_for_rm = false;        // the plan is being (re)considered for row-major calls: no passes over C to pay for
+    bool cluster_rm_tried = false;      //   ... once per matrix
+    bool cluster_cm_pays = true;        // the graph-clustered plan also serves column-major calls (>= 40 % fewer panel rows: it pays two passes over C)
     int *d_colpos = nullptr;            // psc, graph clustering: row of the permuted B panels that holds column c (K ints)
     float *d_Cs = nullptr;              //   ... and the row-major C staging buffer of the reordered form: [N / 16][M][16] floats
     size_t Cs_cap = 0;
@@ -108,6 +112,8 @@ struct sextans_engine {
     double row_coherence = 0.0;         // sampled share of consecutive rows' entries with neighbouring columns
     int cluster_decline = 0;            // why the graph clustering was declined (engine_plan.hip: cluster_graph), 0 = it was not
     double cluster_shared = 0.0;        // sampled share of a neighbour row's columns a row has too (graph clustering pre-test)
+    int cluster_graph_kind = 0;         // graph the rows were clustered over: 0 the matrix itself, 1 a slab's own square pattern, 2 row similarity
+    double pattern_symmetry = 1.0;      // sampled share of entries (r, c) of a square matrix whose mirror (c, r) exists
     int cluster_state = 0;              // 0 not evaluated, 1 grid bricks in use, 2 graph clustering (reordered form) in use, -1 declined
     int64_t cluster_s2 = 0, cluster_s3 = 0;
     int64_t plan_total_dict = 0, cluster_total_dict = 0;   // sum of the block dictionaries: natural order / clustered order
@@ -198,6 +204,7 @@ struct sextans_engine {
     int64_t opt_share_index = 1;        // plans at 4 lanes per row: consecutive rows with identical 16-bit index lists (dof rows of a mesh node) share one copy
     int64_t opt_refine_rows = 62;       // ... rows per block before the refinement (64 - room for rows that move in)
     int64_t opt_refine_sweeps = 8;      // graph clustering: sweeps of the block refinement (0 = blocks are runs of 64 rows of the merge-tree order)
+    int64_t opt_row_similarity = -1;    // graph clustering over the row-similarity graph: -1 when the matrix is rectangular or its pattern unsymmetric, 0 never, 1 always
     int64_t opt_relabel_columns = 1;    // graph clustering: B rows relabelled in first-touch order (permuted panels); 0 = natural panels
     int64_t opt_small_panel = 1;        // clustered plans of short-row matrices are packed for a 320-row panel when every dictionary fits (more workgroups per CU)
     int64_t opt_cluster_top = 1 << 30;  // graph clustering: the aggregation stops when clusters reach this many rows.  Default: never -- the whole

@@ -13,8 +13,9 @@ namespace sx {
 // over `nsample` rows spread over the matrix: ~0 for matrices with random columns, 0.3 .. 0.7 for mesh / stencil matrices in
 // ANY numbering.  *near_fraction = share of the sampled rows' entries within M / 64 of the diagonal (does the numbering have
 // locality?).  Needs M == K.  Returns non-zero on a HIP error.
+// *symmetric_fraction (optional) = share of the sampled entries (r, c) whose mirror (c, r) exists (1.0 = symmetric pattern).
 int probe_shared_neighbourhood_device(int M, const int *d_rp, const int *d_ci, int nsample, double *shared_fraction, double *near_fraction,
-                                      std::string &err);
+                                      std::string &err, double *symmetric_fraction = nullptr);
 
 // Share of the j-th entries of sampled consecutive rows (r, r + 1) whose columns differ by at most 32: ~1 for stencil / banded /
 // generator-ordered mesh matrices, ~0 for random columns or random numberings (dispatcher test of spmm_csr_colwise).
@@ -56,6 +57,13 @@ int column_first_touch_order_device(int M, int K, const int *d_rp, const int *d_
 // rows the slab does not hold are dropped.  out_rp (M + 1) / out_ci on the device, caller frees.  The clustering above runs on it.
 int local_square_pattern_device(int M, const int *d_rp, const int *d_ci, int row_offset, int **out_rp, int **out_ci, int64_t *out_nnz,
                                 std::string &err);
+
+// G + G^T of a square pattern (entries outside [0, M) are dropped): every row keeps its own entries and gets, behind them, the rows
+// that point at it and that it does not hold itself; d_w (optional) = one weight byte per entry, mirrored with its entry.  The
+// handshake matching of the clustering needs symmetric weights (graph_cluster.hip).  s_rp (M + 1) / s_ci / s_w on the device, caller
+// frees.  Returns 0 = built, 1 = declined (empty / too large), 2 = HIP error.
+int symmetrize_graph_device(int M, int64_t nnz, const int *d_rp, const int *d_ci, const unsigned char *d_w, int **s_rp, int **s_ci,
+                            unsigned char **s_w, int64_t *s_nnz, std::string &err);
 
 // in place: ci[j] = colpos[ci[j]]
 int relabel_columns_device(int64_t nnz, int *d_ci, const int *d_colpos, std::string &err);

@@ -129,7 +129,13 @@ __device__ __forceinline__ void astore4(float *sbase, unsigned voff_bytes, const
 // all its sets in the prologue and multiplies them set after set.  Block meta, the two dependent round trips of the prologue and the
 // panel are paid once per 128 rows, and a 16 x 4 x 2 brick of a 27-point mesh needs 3.4 dictionary rows per matrix row where a
 // 16 x 2 x 2 brick needs 4.5 (the panel copy is more than half of the bytes a short-row block moves through the L1).
-template <int H, int NB, bool EXACT, bool BCOL, bool TIMED = false, int DCAP = 9, bool CROW = false, bool BIG = false, int SETS = 1>
+// RM (round 5, the row-major entry point sextans_spmm_device_rm): the caller's operands ARE the layouts this kernel wants -- B row-major
+// K x N (Bp = B, panel_stride = its leading dimension: dictionary row `col` of tile st is the 64 bytes at B + col * ldb + 16 st; at N = 16
+// the caller's B IS panel 0) and C row-major M x N (ldc_in / ldc = row strides: the 16-byte accesses of CROW go straight to the caller's
+// rows, C_in + row * ldc_in + 16 st).  No repack launch, no staging passes: the reference lays its operands out for its kernel outside
+// the timed call too (sextans-host.cpp:150-195).  The lanes whose 4 columns lie beyond N in the last tile (last_cols = 8) neither copy B
+// nor touch C there (a lane only ever reads its own 16-byte column slice of the LDS panel, so what those slices hold does not matter).
+template <int H, int NB, bool EXACT, bool BCOL, bool TIMED = false, int DCAP = 9, bool CROW = false, bool BIG = false, int SETS = 1, bool RM = false>
 __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_panel_v2(
     const int2 *__restrict__ slot_info, const unsigned short *__restrict__ p_idx16, const float *__restrict__ p_val,
     const int *__restrict__ blk_row, const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
@@ -142,6 +148,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
     // when consecutive rows whose lists are equal up to a constant shift share one copy (plan_device.hip: share_index_lists); null =
     // own list at the slot's first packed entry, like its values.  The shift goes into this lane's LDS base address once.
     static_assert(!CROW || (H == 1 && !BCOL), "the block-major C staging exists for 16-column tiles on repacked panels");
+    static_assert(!RM || (CROW && !TIMED && !BIG), "row-major operands use the 16-byte C accesses of the staging form");
     static_assert(SETS == 1 || (H == 1 && !BCOL && !TIMED && !BIG && NB <= 2), "several row sets per block: 16-column tiles on repacked panels, short rows");
     long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, w0 = 0;
     if constexpr (TIMED) { t0 = clock64(); w0 = wall_clock64(); }
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
 #pragma unroll
         for (int u = 0; u < MAXD; ++u) {
             const int col = bd[min(u * RB, dict_stride - RB)];
-            boff[u] = BCOL ? (unsigned)col : (unsigned)col * 16u + 4u * (unsigned)q;
+            boff[u] = BCOL ? (unsigned)col : RM ? (unsigned)col * (unsigned)panel_stride + 4u * (unsigned)q : (unsigned)col * 16u + 4u * (unsigned)q;
         }
     }
     int len[SETS];
@@ -250,13 +257,14 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
     // copied by the 4 lanes of `slot`, a wave's 64 lanes write 1 KiB of consecutive LDS; rows past the dictionary stay
     // unwritten and are never read).
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool cvalid = H != 1 || 4 * q < last_cols;   // my 4 columns exist in the last tile too
     auto dma_panel = [&](int st) {
 #pragma unroll
         for (int u = 0; u < MAXD; ++u)
 #pragma unroll
             for (int h = 0; h < H; ++h)
-                if (u * RB + slot < nu)
-                    glds16(Bp + (int64_t)(st * H + h) * panel_stride + boff[u], lds + h * kWideHalfBytes + (u * RB + wave * 16) * 64);
+                if (u * RB + slot < nu && (!RM || cvalid || st + 1 < nsuper))
+                    glds16(Bp + (RM ? (int64_t)st * 16 : (int64_t)(st * H + h) * panel_stride) + boff[u], lds + h * kWideHalfBytes + (u * RB + wave * 16) * 64);
         // the +1.0f rows the padding entries (value -0.0f) address: kWidePadRows of them, a shifted shared list points further in
 #pragma unroll
         for (int h = 0; h < H; ++h) *reinterpret_cast<float *>(lds + h * kWideHalfBytes + pad_row * 64 + 4 * tid) = 1.0f;   // 256 threads = 16 rows
@@ -316,23 +324,25 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
             }
     }
     // C: column (col0 + 16h + 4q + j) of this lane = uniform column base (col0 + 16h + j) + a per-lane byte offset
-    unsigned cvoff_in[SETS], cvoff_out[SETS], cvoff_row[SETS];
+    unsigned cvoff_in[SETS], cvoff_out[SETS], cvoff_rin[SETS], cvoff_rout[SETS];
 #pragma unroll
     for (int t = 0; t < SETS; ++t) {
         cvoff_in[t] = (4u * (unsigned)q * (unsigned)ldc_in + coff[t]) * 4u;
         cvoff_out[t] = (4u * (unsigned)q * (unsigned)ldc + coff[t]) * 4u;
-        cvoff_row[t] = ((unsigned)myrow[t] * 16u + 4u * (unsigned)q) * 4u;   // CROW: my 16 bytes of the tile (row-major staging)
+        // CROW: my 16 bytes of the tile -- row-major staging (rows of 16 floats), or the caller's own row-major C (RM)
+        cvoff_rin[t] = RM ? (coff[t] * (unsigned)ldc_in + 4u * (unsigned)q) * 4u : ((unsigned)myrow[t] * 16u + 4u * (unsigned)q) * 4u;
+        cvoff_rout[t] = RM ? (coff[t] * (unsigned)ldc + 4u * (unsigned)q) * 4u : cvoff_rin[t];
     }
+    const int64_t ct_in = RM ? 16 : ldc_in, ct_out = RM ? 16 : ldc;   // CROW: floats from one tile of C to the next
     // C_in of the FIRST super tile is requested here, in the same round trip as the panel and the row entries (for a
     // matrix of a few thousand rows the whole kernel is three round trips: one more is 15 % of its time)
-    const bool cvalid = H != 1 || 4 * q < last_cols;   // my 4 columns exist in the last tile too
     float cin[SETS][H][4];
     f32x4 cinv[SETS];
 #pragma unroll
     for (int t = 0; t < SETS; ++t) {
         cinv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (CROW) {
-            aload4(cinv[t], Cin + (int64_t)st_begin * ldc_in, cvoff_row[t]);
+            if (!RM || cvalid || st_begin + 1 < nsuper) aload4(cinv[t], Cin + (int64_t)st_begin * ct_in, cvoff_rin[t]);
         } else if (cvalid || st_begin + 1 < nsuper) {
 #pragma unroll
             for (int h = 0; h < H; ++h)
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
 #pragma unroll
             for (int t = 0; t < SETS; ++t) {
                 if constexpr (CROW) {
-                    aload4(cinv[t], Cin + (int64_t)st * ldc_in, cvoff_row[t]);
+                    if (!RM || cvalid || st + 1 < nsuper) aload4(cinv[t], Cin + (int64_t)st * ct_in, cvoff_rin[t]);
                 } else if (cvalid || st + 1 < nsuper) {
 #pragma unroll
                     for (int h = 0; h < H; ++h)
@@ -456,10 +466,10 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_pan
 #pragma unroll
         for (int t = 0; t < SETS; ++t) {
             if constexpr (CROW) {
-                if (cwrite[t]) {
+                if (cwrite[t] && (!RM || cvalid || st + 1 < nsuper)) {
                     const f32x4 o = {epilogue<EXACT>(alpha, acc[t][0].x, beta, cinv[t].x), epilogue<EXACT>(alpha, acc[t][0].y, beta, cinv[t].y),
                                      epilogue<EXACT>(alpha, acc[t][0].z, beta, cinv[t].z), epilogue<EXACT>(alpha, acc[t][0].w, beta, cinv[t].w)};
-                    astore4(Cout + (int64_t)st * ldc, cvoff_row[t], o);
+                    astore4(Cout + (int64_t)st * ct_out, cvoff_rout[t], o);
                 }
             } else if (cwrite[t] && (cvalid || st + 1 < nsuper)) {
 #pragma unroll

@@ -3,8 +3,11 @@
     C = spmm(A_csr, B, alpha=1.0, beta=0.0, C=None)
 
 A: torch.sparse_csr_tensor (fp32 values, int32/int64 indices) on a GPU; B: dense (K, N) fp32; returns a
-dense (M, N) tensor (row-major view of the engine's column-major result, no copy).  N is padded up to a
-multiple of 8 internally (the reference's N-tile granularity, sextans-host.cpp:51).  One cached engine per live
+dense (M, N) tensor.  Torch tensors are ROW-major, and so is the entry point used here (sextans_spmm_device_rm, round 5): a
+contiguous fp32 B with N % 8 == 0 is handed to the kernel where it lies -- for N = 16 it IS the kernel's B panel -- and the
+result is written straight into the (M, N) tensor that is returned: no transposes, no copies.  (Until round 4 this op transposed B
+into a column-major copy that the engine repacked into row-major panels again, and C likewise in reverse: two passes over B and two
+over C per call.)  N that is not a multiple of 8 is padded up internally (the reference's N-tile granularity, sextans-host.cpp:51).  One cached engine per live
 matrix (keyed on tensor addresses + version counters; the entry pins the tensors, at most 8 kept, clear_cache()
 drops them); not part of the reference, whose only front end is the CLI.
 """
@@ -66,22 +69,44 @@ def _engine_for(A, dev):
     return eng
 
 
-def spmm(A, B, alpha=1.0, beta=0.0, C=None):
+def _rowmajor(t, rows, cols, colsp):
+    """fp32, unit column stride, 16-byte aligned base and row stride: the tensor itself when it qualifies, else a padded copy"""
+    if (t.dtype == torch.float32 and cols == colsp and t.stride(1) == 1 and t.stride(0) >= cols and t.stride(0) % 4 == 0 and
+            t.data_ptr() % 16 == 0):
+        return t
+    out = torch.zeros((rows, colsp), dtype=torch.float32, device=t.device)
+    out[:, :cols] = t
+    return out
+
+
+def spmm(A, B, alpha=1.0, beta=0.0, C=None, out=None):
+    """out (optional): an (M, N) fp32 row-major tensor that receives the result (N % 8 == 0); may be C itself (in place)."""
     if A.layout != torch.sparse_csr or not A.is_cuda or not B.is_cuda:
         raise TypeError("spmm expects a CUDA/HIP torch.sparse_csr matrix and a CUDA/HIP dense B")
     M, K = A.shape
-    if B.shape[0] != K:
+    if B.dim() != 2 or B.shape[0] != K:
         raise ValueError("shape mismatch")
     N = B.shape[1]
     Np = api.round_up_n(N)
     dev = A.device.index or 0
     eng = _engine_for(A, dev)
-    # column-major K x Np = the transpose of a row-major (Np, K) tensor
-    Bcm = torch.zeros((Np, K), dtype=torch.float32, device=B.device)
-    Bcm[:N] = B.to(torch.float32).t()
-    Ccm = torch.zeros((Np, M), dtype=torch.float32, device=B.device)
+    Brm = _rowmajor(B, K, N, Np)
     if C is not None and beta != 0.0:
-        Ccm[:N] = C.to(torch.float32).t()
+        if tuple(C.shape) != (M, N):
+            raise ValueError("shape mismatch")
+        Cin = _rowmajor(C, M, N, Np)
+    else:
+        Cin = None
+    if out is not None and (tuple(out.shape) != (M, N) or _rowmajor(out, M, N, Np) is not out):
+        raise ValueError("out must be an (M, N) fp32 row-major tensor with N % 8 == 0, 16-byte aligned")
+    Cout = out if out is not None else (Cin if (Cin is not None and Cin is not C) else None)
+    if Cout is None:       # beta * C_in with C_in = 0 when no C is given: zeros, also for beta == 0 (0 * NaN would not be 0)
+        Cout = torch.zeros((M, Np), dtype=torch.float32, device=B.device) if Cin is None else torch.empty((M, Np), dtype=torch.float32, device=B.device)
+    if Cin is None:
+        if out is not None:
+            out.zero_()
+        Cin = Cout
     stream = torch.cuda.current_stream(B.device).cuda_stream
-    eng.spmm_device(Np, float(alpha), Bcm.data_ptr(), K, float(beta), Ccm.data_ptr(), Ccm.data_ptr(), M, stream)
-    return Ccm[:N].t()
+    eng.spmm_device_rm(Np, float(alpha), Brm.data_ptr(), Brm.stride(0), float(beta), Cin.data_ptr(), Cin.stride(0), Cout.data_ptr(),
+                       Cout.stride(0), stream)
+    return Cout if Np == N else Cout[:, :N]

@@ -67,6 +67,13 @@ def test_whole_matrix_against_the_oracle(engine, oracle, variant, numbering):
                     got = C0.copy()
                     engine.spmm(N, ALPHA, B, BETA, got, rp_time=rp_time)
                     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (variant, numbering, N, rc, rp_time, engine.last_kernel())
+                if rc == 2:      # forced: every variant clusters -- rectangular and unsymmetric patterns over the row-similarity graph
+                    assert int(engine.get_stat("row_cluster")) == 2 and engine.last_kernel() == "spmm_csr_panel_v2_reordered", (
+                        variant, numbering, N, engine.get_stat("cluster_decline"))
+                    # graph the rows were clustered over: the matrix itself / row similarity (rectangular) / A + A^T (unsymmetric pattern)
+                    # ("": 3 as well -- at this size a few rows sit on the long-row path, their mirrors are missing from the main matrix)
+                    assert int(engine.get_stat("cluster_graph_kind")) in {"": (0, 3), "rect": (2,), "unsym": (3,), "rectunsym": (2,)}[variant], (variant, engine.get_stat("pattern_symmetry"))
+                    assert engine.get_stat("panel_rows_clustered") < 12 * M      # (natural order: 11.7 dictionary rows per matrix row)
     finally:
         engine.set_option("row_cluster", -1)
 
@@ -90,7 +97,9 @@ def test_full_size_sampled_rows(variant, numbering):
             e.set_matrix_csr_device(M, K, nnz, p, i, v)
             e.spmm_device(N, float(ALPHA), B.data_ptr(), K, float(BETA), Cin.data_ptr(), out.data_ptr(), M, st)
             torch.cuda.synchronize()
-            print("holdout", variant or "sym", numbering, e.last_kernel(), "row_cluster", e.get_stat("row_cluster"), "decline", e.get_stat("cluster_decline"))
+            print("holdout", variant or "sym", numbering, e.last_kernel(), "row_cluster", e.get_stat("row_cluster"), "decline", e.get_stat("cluster_decline"),
+                  "graph", e.get_stat("cluster_graph_kind"), "symmetry", e.get_stat("pattern_symmetry"))
+            assert int(e.get_stat("cluster_decline")) != 1
         o = Oracle()
         Bh = B.cpu().numpy(); Ch = Cin.cpu().numpy().reshape(N, M); got = out.cpu().numpy().reshape(N, M)
         perm = holdout.random_permutation(M) if numbering == "random" else None

@@ -1,0 +1,136 @@
+"""Row-major operand entry point sextans_spmm_device_rm (round 5): B row-major K x N, C row-major M x N -- the layouts the kernels
+want, so no layout pass runs on the LDS-panel paths.  The reference lays B and C out for its kernel on the host, outside the timed
+call (sextans-host.cpp:150-195, 264-270).  Same per-row order and rounding: BIT-IDENTICAL to cpu_spmm_CSR (sparse_helper.h:262-290)
+on the natural-order, grid-brick and graph-clustered plans, with padded leading dimensions, in place, N = 8 / 16 / 24 / 128, and on
+everything that falls back to column-major copies (gather and lane-per-row kernels, long rows, unaligned operands)."""
+import numpy as np
+import pytest
+
+from util import ALPHA, BETA, random_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _want(oracle, M, K, N, rp, ci, v, B, C0, alpha=ALPHA, beta=BETA):
+    """B (K, N), C0 (M, N) row-major numpy -> oracle result as (M, N)"""
+    w = np.ascontiguousarray(C0.T).reshape(-1).copy()
+    oracle.spmm(M, N, K, alpha, rp, ci, v, np.ascontiguousarray(B.T).reshape(-1), beta, w)
+    return np.ascontiguousarray(w.reshape(N, M).T)
+
+
+def _run(e, M, K, N, B, C0, ldb=None, ldc_in=None, ldc=None, inplace=False, alpha=ALPHA, beta=BETA, offset=0):
+    import torch
+    ldb, ldc_in, ldc = ldb or N, ldc_in or N, ldc or N
+    tb = torch.full((K * ldb + offset,), 7.0, device="cuda"); tci = torch.full((M * ldc_in + offset,), 9.0, device="cuda")
+    tb[offset:].view(K, ldb)[:, :N] = torch.from_numpy(B).cuda(); tci[offset:].view(M, ldc_in)[:, :N] = torch.from_numpy(C0).cuda()
+    if inplace:
+        tco, ldc = tci, ldc_in
+    else:
+        tco = torch.full((M * ldc + offset,), -5.0, device="cuda")
+    e.spmm_device_rm(N, float(alpha), tb.data_ptr() + 4 * offset, ldb, float(beta), tci.data_ptr() + 4 * offset, ldc_in, tco.data_ptr() + 4 * offset, ldc,
+                     torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    full = tco[offset:].view(M, ldc).cpu().numpy()
+    if not inplace and ldc > N:
+        assert np.all(full[:, N:] == -5.0), "columns beyond N were written"
+    if ldb > N:
+        assert np.all(tb[offset:].view(K, ldb)[:, N:].cpu().numpy() == 7.0)
+    return np.ascontiguousarray(full[:, :N])
+
+
+def _matrices():
+    from sextans_amd import api, meshgen
+    rp, ci, v = api.gen_fem3d_host(9, 8, 7, 3, 5)                       # 1 512 rows: natural-order plan (no clustering below 4 096 rows)
+    yield "fem small, natural plan", (rp, ci, v, 1512, 1512), ("spmm_csr_panel_v2_rowmajor",), {}
+    rp, ci, v = api.gen_fem3d_host(20, 19, 18, 3, 5)                    # 20 520 rows: grid bricks
+    M = 20 * 19 * 18 * 3
+    yield "fem, grid bricks", (rp, ci, v, M, M), ("spmm_csr_panel_v2_rowmajor",), {}
+    q = meshgen.permute_symmetric(rp, ci, v, M, meshgen.node_permutation(M // 3, 3, 2))
+    yield "fem, random node order, graph clustering", (*q, M, M), ("spmm_csr_panel_v2_rowmajor_clustered",), {}
+    yield "fem, random node order, natural panels of the clustered plan", (*q, M, M), ("spmm_csr_panel_v2_rowmajor_clustered",), {"relabel_columns": 0}
+    rp1, ci1, v1 = api.gen_fem3d_host(30, 28, 26, 1, 3)                 # short rows: two row sets per block / 320-row panels
+    yield "27-point 1 dof, bricks with two row sets", (rp1, ci1, v1, 30 * 28 * 26, 30 * 28 * 26), ("spmm_csr_panel_v2_rowmajor",), {}
+
+
+@pytest.mark.parametrize("N", [8, 16, 24, 128])
+def test_rowmajor_panel_paths_are_bit_identical(engine, oracle, N):
+    for name, (rp, ci, v, M, K), kernels, opts in _matrices():
+        rs = np.random.RandomState(N + M % 13)
+        B = rs.uniform(-1, 1, (K, N)).astype(np.float32); C0 = rs.uniform(-1, 1, (M, N)).astype(np.float32)
+        want = _want(oracle, M, K, N, rp, ci, v, B, C0)
+        try:
+            for k, val in opts.items():
+                engine.set_option(k, val)
+            engine.set_matrix_csr(M, K, rp, ci, v)
+            for kw in ({}, {"ldb": N + 8, "ldc_in": N + 4, "ldc": N + 12}, {"inplace": True}, {"inplace": True, "ldc_in": N + 20}):
+                got = _run(engine, M, K, N, B, C0, **kw)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (name, N, kw, engine.last_kernel())
+                assert engine.last_kernel() in kernels, (name, N, engine.last_kernel(), engine.get_stat("row_cluster"), engine.get_stat("cluster_decline"))
+            # the column-major entry point on the same engine afterwards: same bits (plans are shared, layouts are per call)
+            cm = np.ascontiguousarray(C0.T).reshape(-1).copy()
+            engine.spmm(N, ALPHA, np.ascontiguousarray(B.T).reshape(-1), BETA, cm)
+            assert np.array_equal(np.ascontiguousarray(cm.reshape(N, M).T).view(np.uint32), want.view(np.uint32)), (name, N)
+        finally:
+            for k in opts:
+                engine.set_option(k, 1)
+
+
+def test_rowmajor_alpha_beta_special_values(engine, oracle):
+    from sextans_amd import api
+    rp, ci, v = api.gen_fem3d_host(9, 8, 7, 3, 5)
+    M = K = 1512
+    engine.set_matrix_csr(M, K, rp, ci, v)
+    rs = np.random.RandomState(3)
+    B = rs.uniform(-1, 1, (K, 16)).astype(np.float32); C0 = rs.uniform(-1, 1, (M, 16)).astype(np.float32)
+    for alpha, beta in ((0.0, 1.0), (1.0, 0.0), (-1.5, 0.25), (0.0, 0.0)):
+        want = _want(oracle, M, K, 16, rp, ci, v, B, C0, np.float32(alpha), np.float32(beta))
+        got = _run(engine, M, K, 16, B, C0, alpha=alpha, beta=beta)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (alpha, beta)
+
+
+def test_rowmajor_fallback_classes(engine, oracle):
+    """Matrices the LDS-panel kernels do not serve, rows on the long-row paths, and unaligned operands: through column-major copies."""
+    from sextans_amd import api
+    rs = np.random.RandomState(11)
+    cases = []
+    rp, ci, v = random_csr(rs, 5000, 7000, 12)                          # no reuse: row-group gather kernel
+    cases.append(("random columns", rp, ci, v, 5000, 7000, 0))
+    rp, ci, v = api.gen_stencil2d_host(90, 80, 5, 1, 3)                 # lane-per-row kernel
+    cases.append(("5-point stencil", rp, ci, v, 7200, 7200, 0))
+    rp, ci, v = random_csr(rs, 3000, 3000, 10, long_rows=3)             # rows on the piece path
+    cases.append(("long rows", rp, ci, v, 3000, 3000, 0))
+    rp, ci, v = api.gen_fem3d_host(9, 8, 7, 3, 5)
+    cases.append(("fem small, pointers 4 bytes off a 16-byte boundary", rp, ci, v, 1512, 1512, 1))
+    for name, rp, ci, v, M, K, off in cases:
+        engine.set_matrix_csr(M, K, rp, ci, v)
+        for N in (8, 24, 64):
+            B = rs.uniform(-1, 1, (K, N)).astype(np.float32); C0 = rs.uniform(-1, 1, (M, N)).astype(np.float32)
+            want = _want(oracle, M, K, N, rp, ci, v, B, C0)
+            for kw in ({}, {"ldb": N + 4, "ldc_in": N + 8, "ldc": N + 4}, {"inplace": True}):
+                got = _run(engine, M, K, N, B, C0, offset=off, **kw)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (name, N, kw, engine.last_kernel())
+            assert "rowmajor" not in engine.last_kernel(), (name, engine.last_kernel())
+
+
+def test_rowmajor_reconsiders_a_declined_clustered_plan(engine, oracle):
+    """The holdout class in its natural numbering: the graph-clustered plan copies ~36 % fewer B rows -- not enough for the column-major
+    form (two passes over C: decline 12), enough for row-major calls, which pay nothing for it.  Column-major calls on the same
+    engine keep the natural-order plan."""
+    from sextans_amd import holdout
+    rp, ci, v, M, K = holdout.kron_host(10)
+    engine.set_matrix_csr(M, K, rp, ci, v)
+    rs = np.random.RandomState(5)
+    N = 16
+    B = rs.uniform(-1, 1, (K, N)).astype(np.float32); C0 = rs.uniform(-1, 1, (M, N)).astype(np.float32)
+    want = _want(oracle, M, K, N, rp, ci, v, B, C0)
+    cm = np.ascontiguousarray(C0.T).reshape(-1).copy()
+    engine.spmm(N, ALPHA, np.ascontiguousarray(B.T).reshape(-1), BETA, cm)
+    first = (int(engine.get_stat("row_cluster")), int(engine.get_stat("cluster_decline")), engine.last_kernel())
+    got = _run(engine, M, K, N, B, C0)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    if first[:2] == (-1, 12):
+        assert engine.last_kernel() == "spmm_csr_panel_v2_rowmajor_clustered" and int(engine.get_stat("row_cluster")) == 2, (first, engine.last_kernel(), engine.get_stat("cluster_decline"))
+        cm2 = np.ascontiguousarray(C0.T).reshape(-1).copy()
+        engine.spmm(N, ALPHA, np.ascontiguousarray(B.T).reshape(-1), BETA, cm2)
+        assert engine.last_kernel() == first[2] and np.array_equal(cm2.view(np.uint32), cm.view(np.uint32))
+    assert np.array_equal(np.ascontiguousarray(cm.reshape(N, M).T).view(np.uint32), want.view(np.uint32))

@@ -32,6 +32,38 @@ def test_sparse_csr_op_matches_oracle(sx, oracle):
     assert np.array_equal(np.ascontiguousarray(got2).view(np.uint32), np.ascontiguousarray(ref2.reshape(Np, M).T[:, :N]).view(np.uint32))
 
 
+@pytest.mark.parametrize("N", [16, 24, 128])
+@pytest.mark.parametrize("numbering", ["grid", "random"])
+def test_op_on_rowmajor_tensors_without_copies(sx, oracle, N, numbering):
+    """Round 5: the op hands contiguous torch tensors to sextans_spmm_device_rm where they lie (natural + graph-clustered plans),
+    writes into `out` / in place, and stays bit-identical to cpu_spmm_CSR."""
+    import torch
+    from sextans_amd import api, meshgen, torch_op
+    rp, ci, v = api.gen_fem3d_host(18, 17, 16, 3, 7)
+    M = K = 18 * 17 * 16 * 3
+    if numbering == "random":
+        rp, ci, v = meshgen.permute_symmetric(rp, ci, v, M, meshgen.node_permutation(M // 3, 3, 4))
+    A = torch.sparse_csr_tensor(torch.from_numpy(rp.astype(np.int64)), torch.from_numpy(ci.astype(np.int64)), torch.from_numpy(v), size=(M, K)).cuda()
+    rs = np.random.RandomState(N)
+    B = rs.uniform(-1, 1, (K, N)).astype(np.float32); C0 = rs.uniform(-1, 1, (M, N)).astype(np.float32)
+    alpha, beta = np.float32(0.85), np.float32(-2.06)
+    want = np.ascontiguousarray(C0.T).reshape(-1).copy()
+    oracle.spmm(M, N, K, alpha, rp, ci, v, np.ascontiguousarray(B.T).reshape(-1), beta, want)
+    want = np.ascontiguousarray(want.reshape(N, M).T)
+    torch_op.clear_cache()
+    tB, tC = torch.from_numpy(B).cuda(), torch.from_numpy(C0).cuda()
+    got = torch_op.spmm(A, tB, float(alpha), float(beta), tC)
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)) and np.array_equal(tC.cpu().numpy(), C0)   # C untouched
+    eng = next(iter(torch_op._cache.values()))[0]
+    assert "rowmajor" in eng.last_kernel(), eng.last_kernel()
+    out = torch.empty((M, N), device="cuda")
+    assert torch_op.spmm(A, tB, float(alpha), float(beta), tC, out=out) is out
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert torch_op.spmm(A, tB, float(alpha), float(beta), tC, out=tC) is tC                                                     # in place
+    assert np.array_equal(tC.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    torch_op.clear_cache()
+
+
 def test_engine_cache_follows_the_matrix(sx, oracle):
     """the engine cache must not hand a stale engine to a different matrix that reuses the addresses of
     a dead one, must notice in-place updates of A's values, and must stay bounded."""
