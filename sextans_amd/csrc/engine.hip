@@ -122,6 +122,9 @@ int launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_t
 
 // Wide-N form of the panel kernel (spmm_panel_v2.h): `nsuper` super tiles of 32 columns starting at the pointers
 // given; dictionary-only plans built for 4 lanes per row.
+// Workgroup placement of the reordered form at N <= 32: false = row blocks to the XCDs round-robin (round 4, commit ad33d1a), true =
+// contiguous chunks like every other launch.  Re-decided in round 5 with fabric traffic as a criterion: DESIGN 9 / profiles/r05_xcd_placement_ab.txt.
+constexpr bool kReorderedContiguous = false;
 template <int H>
 int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc,
                       int nsuper, float alpha, float beta, hipStream_t s, int64_t bcol_ld, int blk_begin, int blk_end,
@@ -170,7 +173,8 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     const size_t lds = small_panel ? (size_t)(5 * 64 + sx::kWidePadRows) * 64 : (size_t)H * sx::kWideHalfBytes;
     // contiguous chunks of row blocks per XCD -- except the reordered form at N <= 32, where handing the blocks of the merge-tree order to
     // the XCDs round-robin measured 1.3 .. 4.5 % faster (renumbered FEM 607 -> 582 us, unstructured mesh 444 -> 424; N = 128: +1.4 % the other way)
-    const int xcd = (mode == 2 && nsuper <= 2) ? 0 : (int)h->opt_xcd;
+    // ("reordered_xcd": measurement switch for exactly this decision -- 0 round-robin, 1 contiguous chunks, -1 the rule above)
+    const int xcd = mode == 2 && h->opt_reordered_xcd >= 0 ? (int)h->opt_reordered_xcd : (mode == 2 && nsuper <= 2 && !kReorderedContiguous) ? 0 : (int)h->opt_xcd;
     auto go = [&](auto kern) -> int {
         if (int rc = allow_big_lds(h, reinterpret_cast<const void *>(kern), (int)lds)) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)P.d_row_off,
@@ -344,6 +348,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "row_offset")) return &h->opt_row_offset;
     if (!strcmp(key, "relabel_columns")) return &h->opt_relabel_columns;
     if (!strcmp(key, "row_similarity")) return &h->opt_row_similarity;
+    if (!strcmp(key, "reordered_xcd")) return &h->opt_reordered_xcd;
     if (!strcmp(key, "refine_sweeps")) return &h->opt_refine_sweeps;
     if (!strcmp(key, "share_index")) return &h->opt_share_index;
     if (!strcmp(key, "refine_rows")) return &h->opt_refine_rows;
@@ -370,7 +375,7 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
     // Measurement switches -- ablation bits that corrupt C on purpose ("bell_debug"), brick shapes and groupings of the clustered
     // row order, per-phase cycle counters -- are not part of the drop-in surface: they exist only for processes started with
     // SEXTANS_DEBUG_OPTIONS=1 (tools/), and a value other than the default is refused otherwise.
-    if (slot == &h->opt_bell_debug || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_phase_timing) {
+    if (slot == &h->opt_bell_debug || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_phase_timing || slot == &h->opt_reordered_xcd) {
         const char *dbg = getenv("SEXTANS_DEBUG_OPTIONS");
         if (!(dbg && dbg[0] == '1') && value != *slot) {
             g_last_error = std::string("option \"") + key + "\" is a measurement switch: set SEXTANS_DEBUG_OPTIONS=1 in the environment to use it";

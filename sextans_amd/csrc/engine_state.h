@@ -204,6 +204,7 @@ struct sextans_engine {
     int64_t opt_share_index = 1;        // plans at 4 lanes per row: consecutive rows with identical 16-bit index lists (dof rows of a mesh node) share one copy
     int64_t opt_refine_rows = 62;       // ... rows per block before the refinement (64 - room for rows that move in)
     int64_t opt_refine_sweeps = 8;      // graph clustering: sweeps of the block refinement (0 = blocks are runs of 64 rows of the merge-tree order)
+    int64_t opt_reordered_xcd = -1;     // measurement switch: workgroup placement of the reordered form (0 round-robin over the XCDs, 1 contiguous chunks, -1 the built-in rule)
     int64_t opt_row_similarity = -1;    // graph clustering over the row-similarity graph: -1 when the matrix is rectangular or its pattern unsymmetric, 0 never, 1 always
     int64_t opt_relabel_columns = 1;    // graph clustering: B rows relabelled in first-touch order (permuted panels); 0 = natural panels
     int64_t opt_small_panel = 1;        // clustered plans of short-row matrices are packed for a 320-row panel when every dictionary fits (more workgroups per CU)

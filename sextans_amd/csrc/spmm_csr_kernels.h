@@ -226,7 +226,10 @@ __device__ __forceinline__ int slot_bcast(int x) {
 // repacked panel.  For matrices whose B fits the L2s this saves the repack launch, which is a third of a
 // step when the whole SpMM is a few microseconds (nasa4704).
 template <int LPR, bool EXACT, bool MIXED, bool BCOL = false>
-__global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : 4)) void spmm_csr_panel(
+#ifndef SX_PANEL_MIXED_WGS
+#define SX_PANEL_MIXED_WGS 4
+#endif
+__global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : (MIXED && LPR == 4 ? SX_PANEL_MIXED_WGS : 4))) void spmm_csr_panel(
     const int2 *__restrict__ slot_info, const unsigned short *__restrict__ p_idx16,
     const int *__restrict__ p_col32, const float *__restrict__ p_val, const int *__restrict__ blk_row,
     const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,

@@ -136,7 +136,12 @@ __device__ __forceinline__ void astore4(float *sbase, unsigned voff_bytes, const
 // the timed call too (sextans-host.cpp:150-195).  The lanes whose 4 columns lie beyond N in the last tile (last_cols = 8) neither copy B
 // nor touch C there (a lane only ever reads its own 16-byte column slice of the LDS panel, so what those slices hold does not matter).
 template <int H, int NB, bool EXACT, bool BCOL, bool TIMED = false, int DCAP = 9, bool CROW = false, bool BIG = false, int SETS = 1, bool RM = false>
-__global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? 4 : 2)) void spmm_csr_panel_v2(
+// (BCOL at the full dictionary capacity keeps a 576-row panel in registers next to the row entries: 132 registers' worth -- at 4
+// workgroups per CU it spilled 4 registers to scratch in the prologue of the small-matrix launches it exists for; 3 per CU = 168.)
+#ifndef SX_V2_BCOL_WGS
+#define SX_V2_BCOL_WGS 3
+#endif
+__global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? (BCOL && DCAP == 9 ? SX_V2_BCOL_WGS : 4) : 2)) void spmm_csr_panel_v2(
     const int2 *__restrict__ slot_info, const unsigned short *__restrict__ p_idx16, const float *__restrict__ p_val,
     const int *__restrict__ blk_row, const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
     const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc,

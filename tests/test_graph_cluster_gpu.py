@@ -419,7 +419,8 @@ def test_reordered_form_row_counts_not_a_multiple_of_four(engine, oracle, dims):
 def test_row_slab_of_a_renumbered_matrix_clusters_with_its_row_offset(engine, oracle):
     """What a rank of the row-partitioned SpMM holds: rows [r0, r1) of a square matrix, all K columns.  Told where its rows sit (option
     row_offset -- sextans_dist_spmm sets it), the engine clusters the slab over its own square pattern (edges to rows of other ranks
-    dropped) and runs the reordered form on the rectangular matrix; without the offset a non-square matrix keeps the natural-order forms.
+    dropped) and runs the reordered form on the rectangular matrix; without the offset a non-square matrix is clustered over its
+    row-similarity graph since round 5 (rows joined through shared columns; until round 4 it kept the natural-order forms).
     Bit-identical to the same rows of cpu_spmm_CSR either way."""
     from sextans_amd import meshgen
     from sextans_amd import dist as sxd
@@ -436,15 +437,16 @@ def test_row_slab_of_a_renumbered_matrix_clusters_with_its_row_offset(engine, or
             m = r1 - r0
             Cl = np.ascontiguousarray(C0.reshape(N, M)[:, r0:r1]).reshape(-1)
             wl = np.ascontiguousarray(want.reshape(N, M)[:, r0:r1]).reshape(-1)
-            for off, state in ((r0, 2), (-1, -1)):
+            for off, kind in ((r0, 1), (-1, 2)):
                 _set(engine, row_cluster=-1, fuse_b=0)
                 engine.set_option("row_offset", off)
                 engine.set_matrix_csr(m, M, lrp, lci, lv)
                 out = Cl.copy()
                 engine.spmm(N, ALPHA, B, BETA, out)
                 assert np.array_equal(out.view(np.uint32), wl.view(np.uint32)), (r0, r1, off, engine.last_kernel())
-                if r1 - r0 > M // 3 or off < 0:
-                    assert int(engine.get_stat("row_cluster")) == state, (r0, r1, off, engine.get_stat("row_cluster"), engine.get_stat("cluster_decline"))
+                if r1 - r0 > M // 3:
+                    assert int(engine.get_stat("row_cluster")) == 2 and int(engine.get_stat("cluster_graph_kind")) == kind, (
+                        r0, r1, off, engine.get_stat("row_cluster"), engine.get_stat("cluster_decline"), engine.get_stat("cluster_graph_kind"))
     finally:
         engine.set_option("row_offset", -1)
         _set(engine)
