@@ -55,11 +55,15 @@ def main():
     ap.add_argument("--n", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--only", default="", help="run ONE secondary workload (its `also` key) without the headline and print its record")
     ap.add_argument("--chunks", type=int, default=4, help="N>1: row chunks for gather/compute overlap (1 = off)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value")
-    ap.add_argument("--native-dist", action="store_true",
-                    help="N>1: sextans_dist_spmm (RCCL called from the C ABI) instead of torch.distributed collectives")
+    ap.add_argument("--native-dist", action="store_true", help="(default since round 5; kept for old command lines)")
+    ap.add_argument("--torch-dist", action="store_true",
+                    help="N>1: torch.distributed collectives (PipelinedSlabGather) instead of sextans_dist_spmm, the native form "
+                         "behind the C ABI (RCCL called from the library), which is the default")
+    ap.add_argument("--even-rows", action="store_true", help="N>1: equal row counts per rank instead of nnz-balanced ranges")
     args = ap.parse_args()
 
     import torch
@@ -87,9 +91,38 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.only:
+        stream0 = torch.cuda.current_stream().cuda_stream
+        todo = dict(secondaries(api, torch, dev, stream0, args))
+        if args.only not in todo:
+            raise SystemExit("bench.py --only: unknown entry; one of " + ", ".join(todo))
+        print(json.dumps({args.only: todo[args.only]()}), flush=True)
+        return
     M = K = args.rows
     N = api.round_up_n(args.n)
+    args.native_dist = not args.torch_dist
     ranges = sxd.partition_rows_even(M, world)
+    if multi and not args.even_rows:
+        # north_star / SURVEY 8e: contiguous NNZ-BALANCED row ranges.  Every rank generates the row lengths of an even slice in HBM
+        # (the counter-based generator yields any row range), the per-row counts are all-gathered, and the split points are found by
+        # binary search in the whole matrix's row_ptr (sextans_partition_rows_by_nnz / dist.partition_rows_by_nnz).
+        e0, e1 = ranges[rank]
+        t_rp, t_ci, t_v, _ = api.gen_csr_device(local_rank, M, K, args.mean_nnz, 4, e0, e1)
+        lens = torch.zeros(max(b - a for a, b in ranges) + 1, dtype=torch.int32, device=dev)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        assert hip.hipMemcpy(lens.data_ptr(), t_rp, 4 * (e1 - e0 + 1), 3) == 0
+        for q in (t_rp, t_ci, t_v):
+            api.device_free(local_rank, q)
+        allp = [torch.empty_like(lens) for _ in range(world)]
+        dist.all_gather(allp, lens)
+        row_ptr = np.zeros(M + 1, np.int64)
+        for g, (a, b) in enumerate(ranges):
+            seg = allp[g][:b - a + 1].cpu().numpy().astype(np.int64)
+            row_ptr[a + 1:b + 1] = row_ptr[a] + seg[1:]
+        ranges = sxd.partition_rows_by_nnz(row_ptr, world)
+        del lens, allp, row_ptr
     r0, r1 = ranges[rank]
     m_loc = r1 - r0
 
@@ -235,7 +268,9 @@ def main():
         "config": {"workload": f"config4: synthetic CSR {M}x{K}, Poisson({args.mean_nnz:g}) nnz/row, "
                                f"U(-1,1) fp32, N={N}, alpha=0.85, beta=-2.06, column-major B/C, seed 4",
                    "M": M, "K": K, "N": N, "nnz": nnz_tot,
-                   "parallelism": f"A row-split x{world}, B replicated, all-gather(C)" if world > 1 else "1 GPU"},
+                   "parallelism": (f"A row-split x{world} ({'equal rows' if args.even_rows else 'nnz-balanced ranges'}), B replicated, "
+                                   f"all-gather(C) by {'sextans_dist_spmm (RCCL from the C ABI)' if args.native_dist else 'torch.distributed'}")
+                   if world > 1 else "1 GPU"},
         "hbm_gbs_algorithmic_step": round(alg_bytes(M, K, N, nnz_tot) / sec_per_step / 1e9, 1),
         "roofline": roofline,
     }
@@ -268,9 +303,41 @@ def main():
             out["cpu_baseline"] = cpu_baseline(api, M, K, N, args, Cout, flops_per_row=None)
         del B, Cin, Cout
         torch.cuda.empty_cache()
-        for key, fn in () if args.no_also else (("config2_nasa4704_N16", lambda: nasa_secondary(api, torch, dev, stream)),
+        for key, fn in () if args.no_also else secondaries(api, torch, dev, stream, args):
+            try:
+                also[key] = fn()
+            except Exception as e:   # secondary measurements only
+                also[key] = {"error": str(e)}
+    if also:
+        out["also"] = also
+
+    if comm is not None:
+        api.dist_comm_destroy(comm)
+    eng.close()
+    for q in (d_rp, d_ci, d_v):
+        api.device_free(local_rank, q)
+    # RCCL prints a version banner through C stdio (fully buffered when stdout is a pipe): push it out on
+    # every rank BEFORE the result so that the JSON line is the last thing on stdout.
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if multi:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if multi:
+        dist.destroy_process_group()
+
+
+def secondaries(api, torch, dev, stream, args):
+    """The `also` entries: (key, thunk).  `python bench.py --only <key>` runs ONE of them without the headline workload (one rocprofv3
+    pass per entry then gives per-workload kernel statistics: tools/evidence_r05.sh)."""
+    return (("config2_nasa4704_N16", lambda: nasa_secondary(api, torch, dev, stream)),
                         ("config3_pcrystk02_surrogate_N128",
-                         lambda: fem_secondary(api, torch, dev, stream, (35, 19, 7, 3), 128, 300)),
+                         lambda: fem_secondary(api, torch, dev, stream, (35, 19, 7, 3), 128, 300, rp_protocol=True)),
                         ("suitesparse_like_fem_4M_N16",
                          lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 100)),
                         ("suitesparse_like_fem_4M_N32",
@@ -302,33 +369,7 @@ def main():
                         ("config5_blocked_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream)),
                         ("blockbanded_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream, banded_half_width=127)),
                         ("powerlaw_1M_rows_N16", lambda: powerlaw_secondary(api, torch, dev, stream)),
-                        ("config4_matrix_N32", lambda: uniform_secondary(api, torch, dev, stream, args, 32))):
-            try:
-                also[key] = fn()
-            except Exception as e:   # secondary measurements only
-                also[key] = {"error": str(e)}
-    if also:
-        out["also"] = also
-
-    if comm is not None:
-        api.dist_comm_destroy(comm)
-    eng.close()
-    for q in (d_rp, d_ci, d_v):
-        api.device_free(local_rank, q)
-    # RCCL prints a version banner through C stdio (fully buffered when stdout is a pipe): push it out on
-    # every rank BEFORE the result so that the JSON line is the last thing on stdout.
-    import ctypes
-    try:
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    sys.stdout.flush()
-    if multi:
-        dist.barrier()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if multi:
-        dist.destroy_process_group()
+                        ("config4_matrix_N32", lambda: uniform_secondary(api, torch, dev, stream, args, 32)))
 
 
 def cpu_baseline(api, M, K, N, args, Cout, flops_per_row, all_cores=True):
@@ -568,7 +609,7 @@ def uniform_secondary(api, torch, dev, stream, args, N):
     return out
 
 
-def fem_secondary(api, torch, dev, stream, dims, N, iters, numbering="grid", options=None, layout="cm", torch_op=False):
+def fem_secondary(api, torch, dev, stream, dims, N, iters, numbering="grid", options=None, layout="cm", torch_op=False, rp_protocol=False):
     """SuiteSparse-like FEM input (27-point node stencil, `dof` unknowns per node): the class of
     matrices with B-row reuse, where the LDS-panel kernel applies.  dims = (nx, ny, nz, dof).
     numbering: "grid" (natural order), "random" (a seeded random renumbering of the NODES, applied in HBM: what an arbitrary
@@ -595,6 +636,14 @@ def fem_secondary(api, torch, dev, stream, dims, N, iters, numbering="grid", opt
     out["matrix"] = f"fem3d {nx}x{ny}x{nz}, {dof} dof/node" + ("" if numbering == "grid" else f", {numbering} node order")
     if options:
         out["options"] = options
+    if rp_protocol:   # the reference's own protocol: `sextans <A.mtx> <N> <rp_time>` = rp_time repeats on resident inputs (sextans-host.cpp:237-260)
+        Bh, Ch = api.init_dense_B(K, N), api.init_dense_C(M, N)
+        e.spmm(N, ALPHA, Bh, BETA, Ch.copy(), rp_time=10)
+        ns = e.spmm(N, ALPHA, Bh, BETA, Ch, rp_time=1000)
+        out["rp_time_1000_us_per_repeat"] = round(ns / 1000 / 1e3, 3)
+        out["rp_time_1000_gflops"] = round(api.gflops(M, N, nnz, ns * 1e-9 / 1000), 1)
+        out["rp_time_1000_kernel"] = e.last_kernel()
+        out["rp_time_1000_roofline_frac"] = round(alg_bytes(M, K, N, nnz) / (ns / 1000 * 1e-9) / 1e9 / HBM_PEAK_GBS, 4)
     e.close()
     if torch_op:     # the operator front end on the same matrix: wall time per call of torch_op.spmm on row-major tensors, in place
         from sextans_amd import torch_op as top

@@ -426,7 +426,14 @@ int sextans_invoke(sextans_handle_t h, const int32_t *edge_list_ptr, const uint6
  *                            i+1; a final pass writes every rank's rows into d_C_out.  Enqueued on `stream`,
  *                            returns without synchronising (host syncs only the first time a partition is used:
  *                            cut exchange and row tables).  d_C_out holds C = alpha*A*B + beta*C_in for ALL rows on
- *                            every rank. */
+ *                            every rank.
+ *                            CLUSTERED-ORDER CHUNKS (round 5): a rank whose slab runs on a graph-clustered plan ("row_cluster":
+ *                            a renumbered mesh) keeps the reordered form with nchunks > 1 -- a chunk is then a range of the plan's
+ *                            row blocks, its packed slab holds the rows in clustered order, and every rank scatters the received
+ *                            slabs through the senders' position -> row tables (exchanged once per partition) into a row-major
+ *                            staging copy of C that one streaming pass turns into column-major d_C_out.  Used when every rank of
+ *                            the partition can (one flag per rank is exchanged); N % 16 == 0.
+ *                            comm == NULL with world == 1: the same pipeline without collectives (single-GPU callers without RCCL). */
 /* Contiguous row ranges with (nearly) equal non-zero counts for `world` ranks: ranges[2g], ranges[2g+1] = rows of rank g
  * (split points by binary search in row_ptr; host function, no device needed). */
 int sextans_partition_rows_by_nnz(int M, const int *row_ptr, int world, int *ranges);

@@ -26,7 +26,12 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 
 # -ffp-contract=off: the EXACT kernels and the CLI golden need "multiply, round, add" (the
 # reference's arithmetic, sparse_helper.h:283); hipcc's default is to contract into FMA.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-pthread",
+# -fgpu-default-stream=per-thread: everything the library does on "stream 0" -- the one-time plan builders (kernels, hipcub scans and
+# sorts, synchronous copies) -- runs on the calling thread's own default stream instead of the process-wide LEGACY stream.  With the
+# legacy stream, a plan build in one host thread made HIP fail a hipGraph capture that another thread's engine had open ("operation
+# would make the legacy stream depend on a capturing blocking stream"): engines are re-entrant per handle only without it.
+# Found by tests/test_concurrency_gpu.py in round 5 (tools/capture_race.py reproduces it on a build without the flag).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fgpu-default-stream=per-thread", "-fPIC", "-pthread",
          "-Wall", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 
 

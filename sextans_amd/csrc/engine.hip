@@ -124,7 +124,7 @@ int launch_panel(sextans_engine *h, const float *dBp, const float *dCin, int64_t
 // given; dictionary-only plans built for 4 lanes per row.
 // Workgroup placement of the reordered form at N <= 32: false = row blocks to the XCDs round-robin (round 4, commit ad33d1a), true =
 // contiguous chunks like every other launch.  Re-decided in round 5 with fabric traffic as a criterion: DESIGN 9 / profiles/r05_xcd_placement_ab.txt.
-constexpr bool kReorderedContiguous = false;
+constexpr bool kReorderedContiguous = true;
 template <int H>
 int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc,
                       int nsuper, float alpha, float beta, hipStream_t s, int64_t bcol_ld, int blk_begin, int blk_end,
@@ -135,9 +135,12 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     // mode 1 (grid bricks): the plan over the rows in brick order, whole-matrix calls only; its slot -> row table addresses C.
     // mode 2 (graph clustering, the reordered form): dBp = permuted panels, dCin == dCout == the row-major staging buffer,
     // ldc_in == ldc == floats per tile; the same slot -> row table addresses the staging rows.
+    // mode 3 (clustered-order chunks of sextans_dist_spmm): the graph-clustered plan with C addressed BY POSITION in the clustered order
+    // (no slot -> row table): dCin == dCout == a packed slab [tile][position][16] of the chunk, ldc_in == ldc == floats per tile.
     const sextans_engine::PanelState &P = mode ? h->psc : h->ps;
-    const int *slot_row = mode ? h->d_slot_row : nullptr;
-    const unsigned char *skip = (const unsigned char *)h->d_skip;   // rows on the piece path: never written by this kernel (mode 2: their staging rows keep C_in)
+    const int *slot_row = (mode == 1 || mode == 2) ? h->d_slot_row : nullptr;
+    const unsigned char *skip = mode == 3 ? nullptr : (const unsigned char *)h->d_skip;   // rows on the piece path: never written by this kernel (mode 2: their staging rows keep C_in)
+    const bool crow = mode == 2 || mode == 3;
     const int nblk = blk_end - blk_begin;
     if (nblk <= 0 || nsuper <= 0) return SEXTANS_OK;
     if (mode == 0)
@@ -165,7 +168,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     const int ngrp = (nsuper + tpw - 1) / tpw;
     const bool rm = rm_ldb > 0;
     const int64_t pstride = rm ? rm_ldb : bcol_ld > 0 ? bcol_ld : (int64_t)h->K * 16;
-    const int *dict = (rm && mode == 2 && h->d_dict_nat) ? h->d_dict_nat : P.d_dict;
+    const int *dict = (rm && crow && h->d_dict_nat) ? h->d_dict_nat : P.d_dict;
     // LDS = the panel: plan capacity + the +1.0f row.  A clustered plan of a short-row matrix is packed for a 320-row panel
     // (engine_plan.hip: small_panel): 20.5 KB instead of 36.9 KB per workgroup, so the CU holds as many workgroups as the registers
     // allow (5 at <= 96 registers) instead of the 4 the full panel permits -- these launches are latency-bound
@@ -174,7 +177,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     // contiguous chunks of row blocks per XCD -- except the reordered form at N <= 32, where handing the blocks of the merge-tree order to
     // the XCDs round-robin measured 1.3 .. 4.5 % faster (renumbered FEM 607 -> 582 us, unstructured mesh 444 -> 424; N = 128: +1.4 % the other way)
     // ("reordered_xcd": measurement switch for exactly this decision -- 0 round-robin, 1 contiguous chunks, -1 the rule above)
-    const int xcd = mode == 2 && h->opt_reordered_xcd >= 0 ? (int)h->opt_reordered_xcd : (mode == 2 && nsuper <= 2 && !kReorderedContiguous) ? 0 : (int)h->opt_xcd;
+    const int xcd = crow && h->opt_reordered_xcd >= 0 ? (int)h->opt_reordered_xcd : (crow && nsuper <= 2 && !kReorderedContiguous) ? 0 : (int)h->opt_xcd;
     auto go = [&](auto kern) -> int {
         if (int rc = allow_big_lds(h, reinterpret_cast<const void *>(kern), (int)lds)) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)P.d_row_off,
@@ -192,8 +195,8 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
         if (h->opt_phase_timing && h->d_dbg && h->opt_exact && P.plan_sets == 1) {   // diagnostic instantiations: the forms the dispatcher uses most
             if (small_dict && nb == 3 && h->opt_small_v2 != 0) return go(sx::spmm_csr_panel_v2<H, 3, true, true, true, 5>);
             if (bcol_ld > 0) return go(sx::spmm_csr_panel_v2<H, 2, true, true, true>);
-            if (nb == 6 && mode != 2 && !small_panel) return go(sx::spmm_csr_panel_v2<H, 6, true, false, true>);
-            if (nb == 2 && mode != 2 && small_panel) return go(sx::spmm_csr_panel_v2<H, 2, true, false, true, 5>);
+            if (nb == 6 && !crow && !small_panel) return go(sx::spmm_csr_panel_v2<H, 6, true, false, true>);
+            if (nb == 2 && !crow && small_panel) return go(sx::spmm_csr_panel_v2<H, 2, true, false, true, 5>);
         }
         if (small_dict && h->opt_small_v2 != 0) {
             if (nb == 3) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 3, true, true, false, 5>) : go(sx::spmm_csr_panel_v2<H, 3, false, true, false, 5>);
@@ -216,10 +219,10 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
 #undef SX_RM
         }
         if (P.plan_sets == 2) {   // two row sets per block (short-row clustered plans: every row has <= 32 entries = 2 register-resident batches)
-            if (mode == 2) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false, false, 9, true, false, 2>) : go(sx::spmm_csr_panel_v2<H, 2, false, false, false, 9, true, false, 2>);
+            if (crow) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false, false, 9, true, false, 2>) : go(sx::spmm_csr_panel_v2<H, 2, false, false, false, 9, true, false, 2>);
             return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false, false, 9, false, false, 2>) : go(sx::spmm_csr_panel_v2<H, 2, false, false, false, 9, false, false, 2>);
         }
-        if (small_panel && mode == 2) {
+        if (small_panel && crow) {
             if (nb >= 3) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 3, true, false, false, 5, true>) : go(sx::spmm_csr_panel_v2<H, 3, false, false, false, 5, true>);
             return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false, false, 5, true>) : go(sx::spmm_csr_panel_v2<H, 2, false, false, false, 5, true>);
         }
@@ -227,7 +230,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
             if (nb >= 3) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 3, true, false, false, 5>) : go(sx::spmm_csr_panel_v2<H, 3, false, false, false, 5>);
             return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false, false, 5>) : go(sx::spmm_csr_panel_v2<H, 2, false, false, false, 5>);
         }
-        if (mode == 2) {   // block-major C staging
+        if (crow) {   // block-major C staging
             if (nb == 3) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 3, true, false, false, 9, true>) : go(sx::spmm_csr_panel_v2<H, 3, false, false, false, 9, true>);
             if (nb == 2) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, false, false, 9, true>) : go(sx::spmm_csr_panel_v2<H, 2, false, false, false, 9, true>);
             if (nb == 4) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 4, true, false, false, 9, true>) : go(sx::spmm_csr_panel_v2<H, 4, false, false, false, 9, true>);
@@ -256,6 +259,83 @@ void launch_window(sextans_engine *h, const float *dBp8, const float *dCin, int6
     };
     if (h->opt_win_unroll == 4) { if (h->opt_exact) go(sx::spmm_csr_window<true, 4>); else go(sx::spmm_csr_window<false, 4>); }
     else                        { if (h->opt_exact) go(sx::spmm_csr_window<true, 8>); else go(sx::spmm_csr_window<false, 8>); }
+}
+
+// ---- clustered-order chunks of the row-partitioned SpMM (engine_dist.hip: sextans_dist_spmm with nchunks > 1) -------------------
+// A rank whose slab runs on a graph-clustered plan used to lose it as soon as the slab was cut into chunks for the all-gather
+// pipeline: a row-range call needs consecutive rows, and the clustered plan has none.  Here a chunk is a range of the plan's ROW
+// BLOCKS; its rows are the positions [p0, p1) of the clustered order, and everything the chunk moves is addressed by position:
+//   cc_pre      (first chunk) B into the permuted panels, the slab of C_in into the natural row-major staging buffer (streaming passes);
+//   cc_chunk    C_in rows of the chunk gathered, 64 bytes each, into the chunk's packed slab [tile][position][16] -- which IS the
+//               rank's slot of the all-gather buffer -- then spmm_csr_panel_v2<..., CROW> over the chunk's blocks, in place;
+//   cc_scatter  (every rank, behind the all-gather) rows of a received slab to their places in a row-major staging buffer of the
+//               WHOLE C through the sender's position -> row table;
+//   cc_finish   one streaming pass staging -> column-major C.
+namespace {
+template <bool SCATTER>   // false: slab[t][i] = tiles[t][rows[i] - sub];  true: tiles[t][rows[i] - sub] = slab[t][i]   (16 floats each)
+__global__ __launch_bounds__(256) void slab_rows(float *tiles, int64_t tile_stride, const int *__restrict__ rows, int sub, int n, float *slab, int64_t slab_stride) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(idx >> 2), q = (int)(idx & 3), t = blockIdx.y;
+    if (i >= n) return;
+    sx::f32x4 *a = reinterpret_cast<sx::f32x4 *>(tiles + (int64_t)t * tile_stride + (int64_t)(rows[i] - sub) * 16 + 4 * q);
+    sx::f32x4 *b = reinterpret_cast<sx::f32x4 *>(slab + (int64_t)t * slab_stride + (int64_t)i * 16 + 4 * q);
+    if (SCATTER) *a = *b; else *b = *a;
+}
+__global__ __launch_bounds__(256) void position_rows(int nblk, int RB, const int *__restrict__ blk_row, const int *__restrict__ slot_row, int row0, int *__restrict__ out) {
+    const int b = blockIdx.x, s = threadIdx.x;
+    if (b >= nblk || s >= RB) return;
+    const int p0 = blk_row[b], n = blk_row[b + 1] - p0;
+    if (s < n) out[p0 + s] = slot_row[(int64_t)b * RB + s] + row0;
+}
+}  // namespace
+
+bool cc_usable(sextans_engine *h, int N, int W, const std::vector<Seg> &plan) {
+    return h->cluster_state == 2 && h->cluster_cm_pays && W == 16 && N % 16 == 0 && plan.size() == 1 && plan[0].width == 16 && h->nhub == 0 &&
+           h->nchain == 0 && h->dense_W == 0 && (h->opt_kernel == 0 || h->opt_kernel == 2) && h->opt_pipeline_tiles == 0 && h->d_Cs && h->d_slot_row &&
+           h->Cs_cap >= (size_t)(N / 16) * (size_t)h->M * 16 && h->Bp_cap >= (size_t)h->K * (size_t)N && h->psc.plan_sets == 1 &&
+           (h->M >= 65536 || h->m_nnz * (int64_t)N >= ((int64_t)24 << 20)) && (int)h->psc.h_blk_row.size() == h->psc.plan_nblk + 1;
+}
+void cc_table(sextans_engine *h, int row0, int *d_out, hipStream_t s) {
+    hipLaunchKernelGGL(position_rows, dim3((unsigned)h->psc.plan_nblk), dim3(64), 0, s, h->psc.plan_nblk, sx::kBlock / 4, h->psc.d_blk_row, h->d_slot_row, row0, d_out);
+}
+void cc_pre(sextans_engine *h, int N, const float *d_B, int64_t ldb, const float *d_C_in_slab, int64_t ldc_in, hipStream_t s) {
+    Prof p(h, &h->ev_repack, s);
+    if (h->d_colpos)
+        hipLaunchKernelGGL(sx::repack_b_panels_perm, dim3((unsigned)((h->col_hi - h->col_lo + sx::kBlock - 1) / sx::kBlock), (unsigned)(N / 16)), dim3(sx::kBlock), 0, s,
+                           d_B, ldb, h->d_Bp, h->K, 0, h->d_colpos, h->col_lo, h->col_hi, N);
+    else
+        launch_repack<16>(d_B, ldb, h->d_Bp, h->K, 0, N / 16, s, h->col_lo, h->col_hi);
+    launch_repack<16>(d_C_in_slab, ldc_in, h->d_Cs, h->M, 0, N / 16, s);
+    h->bp_layout = -16;
+}
+int cc_chunk(sextans_engine *h, int N, float alpha, float beta, int b0, int b1, const int *d_rows, int row0, float *slab, int64_t lmax, hipStream_t s) {
+    const int p0 = h->psc.h_blk_row[(size_t)b0], p1 = h->psc.h_blk_row[(size_t)b1];
+    if (p1 <= p0) return SEXTANS_OK;
+    Prof p(h, &h->ev_kernel, s);
+    hipLaunchKernelGGL(slab_rows<false>, dim3((unsigned)(((int64_t)(p1 - p0) * 4 + 255) / 256), (unsigned)(N / 16)), dim3(256), 0, s, h->d_Cs, (int64_t)h->M * 16,
+                       d_rows + p0, row0, p1 - p0, slab, lmax * 16);
+    float *base = slab - (int64_t)p0 * 16;     // position p of the clustered order -> slab row p - p0
+    if (int rc = launch_panel_v2<1>(h, h->d_Bp, base, lmax * 16, base, lmax * 16, N / 16, alpha, beta, s, 0, b0, b1, 0, 3)) return rc;
+    h->last_kernel = "spmm_csr_panel_v2_reordered";
+    return SEXTANS_OK;
+}
+void cc_scatter(const float *slab, int64_t lmax, const int *d_rows, int n, float *tiles, int64_t tile_stride, int N, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(slab_rows<true>, dim3((unsigned)(((int64_t)n * 4 + 255) / 256), (unsigned)(N / 16)), dim3(256), 0, s, tiles, tile_stride, d_rows, 0, n,
+                       const_cast<float *>(slab), lmax * 16);
+}
+void cc_finish(const float *tiles, float *C, int64_t ldc, int M_total, int N, hipStream_t s) {
+    hipLaunchKernelGGL(sx::tiles_to_colmajor, dim3((unsigned)((M_total + sx::kBlock - 1) / sx::kBlock), (unsigned)(N / 16)), dim3(sx::kBlock), 0, s, tiles, C, ldc,
+                       M_total, 0, N);
+}
+int cc_prepare(sextans_engine *h, int N, bool *ok) {
+    std::vector<Seg> plan;
+    int W = 0;
+    bool up = false, uw = false;
+    *ok = false;
+    if (int rc = prepare(h, N, plan, W, up, uw, true)) return rc;
+    *ok = cc_usable(h, N, W, plan);
+    return SEXTANS_OK;
 }
 
 }  // namespace sxe
@@ -314,6 +394,7 @@ int sextans_destroy(sextans_handle_t h) {
     (void)hipFree(h->d_dbg);
     (void)hipFree(h->d_chB); (void)hipFree(h->d_chC);
     (void)hipFree(h->d_stage);
+    (void)hipFree(h->d_Cfull); (void)hipFree(h->d_dist_rows);
     for (hipEvent_t e : h->dist_events) (void)hipEventDestroy(e);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
@@ -605,6 +686,7 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "row_cluster")) *value = (double)h->cluster_state;          // 1 grid bricks / 2 graph clustering in use, -1 declined, 0 not evaluated yet
     else if (!strcmp(key, "cluster_shared_fraction")) *value = h->cluster_shared;
     else if (!strcmp(key, "cluster_decline")) *value = (double)h->cluster_decline;
+    else if (!strcmp(key, "graph_fallbacks")) *value = (double)h->graph_fallbacks;   // rp_time loops launched one by one because their hipGraph capture was invalidated from outside
     else if (!strcmp(key, "cluster_graph_kind")) *value = (double)h->cluster_graph_kind;
     else if (!strcmp(key, "pattern_symmetry")) *value = h->pattern_symmetry;
     else if (!strcmp(key, "col_range_lo")) *value = (double)h->col_lo;
@@ -1212,16 +1294,29 @@ int run_repeats(sextans_engine *h, int N, float alpha, float beta, int rp_time, 
             if (e1) (void)hipEventDestroy(e1);
         }
     } c;
-    const bool use_graph = !h->opt_profile && !h->opt_phase_timing;
     const int per_graph = rp_time < 128 ? rp_time : 128;   // bound the graph; long loops replay it
+    bool use_graph = !h->opt_profile && !h->opt_phase_timing;
     if (use_graph) {
         // relaxed mode: the enqueue path calls hipSetDevice / hipGetLastError, which thread-local capture rejects
         SX_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
         const int rc = enqueue(per_graph);
         const hipError_t ce = hipStreamEndCapture(cs, &c.graph);
-        if (rc) return rc;
-        SX_HIP(ce);
-        SX_HIP(hipGraphInstantiate(&c.exec, c.graph, nullptr, nullptr, 0));
+        // A capture can be invalidated from OUTSIDE: any host thread of the process that touches the legacy default stream meanwhile (a
+        // plain hipMemcpy in the caller's own code is enough) makes HIP fail it.  The graph is an optimisation of the launch path, not
+        // a requirement: without it the repeats are launched one by one -- same kernels, same bits.
+        if (rc != SEXTANS_OK || ce != hipSuccess || !c.graph || hipGraphInstantiate(&c.exec, c.graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (c.graph) (void)hipGraphDestroy(c.graph);
+            c.graph = nullptr; c.exec = nullptr;
+            use_graph = false;
+            h->graph_fallbacks += 1;
+            // (the invalidated capture leaves the stream unusable in this HIP version -- every later launch on it reports "previous error
+            // during capture": the repeats run on a fresh stream)
+            (void)hipStreamDestroy(h->host_stream);
+            h->host_stream = nullptr;
+            for (int i = 0; i < 4 && hipGetLastError() != hipSuccess; ++i) {}
+            SX_HIP(hipStreamCreateWithFlags(&h->host_stream, hipStreamNonBlocking));
+            cs = h->host_stream;
+        }
     }
     SX_HIP(hipEventCreate(&c.e0));
     SX_HIP(hipEventCreate(&c.e1));

@@ -100,12 +100,14 @@ int sextans_dist_comm_destroy(void *comm) {
 int sextans_dist_spmm(sextans_handle_t h, void *comm, int world, int rank, const int *row_ranges, int N, float alpha,
                       const float *d_B, int64_t ldb, float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out,
                       int64_t ldc, int nchunks, void *stream) {
-    if (!h || !comm || world < 1 || rank < 0 || rank >= world || !row_ranges || N <= 0 || (N % 8) || !d_B || !d_C_in ||
+    // comm == NULL is allowed for world == 1: the rank's chunks are computed, staged and unpacked exactly as in a multi-rank run, only
+    // the collectives are skipped (a 1-rank all-gather is a no-op): single-GPU callers without RCCL, and tools/rank_slabs.py
+    if (!h || (!comm && world != 1) || world < 1 || rank < 0 || rank >= world || !row_ranges || N <= 0 || (N % 8) || !d_B || !d_C_in ||
         !d_C_out)
         return SEXTANS_ERR_INVALID;
     if (!h->d_rp) return SEXTANS_ERR_STATE;
-    Rccl *r = rccl();
-    if (!r) return SEXTANS_ERR_STATE;
+    Rccl *r = comm ? rccl() : nullptr;
+    if (comm && !r) return SEXTANS_ERR_STATE;
     // ranges must tile [0, M_total) in rank order and this rank's range must be the engine's matrix
     int64_t M_total = 0;
     for (int g = 0; g < world; ++g) {
@@ -117,55 +119,112 @@ int sextans_dist_spmm(sextans_handle_t h, void *comm, int world, int rank, const
     SX_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     // (where this rank's rows sit in the matrix: lets the graph clustering run on the slab -- used by whole-slab calls, nchunks = 1)
-    if (h->opt_row_offset != row0) (void)sextans_set_option(h, "row_offset", row0);
+    // (set once per partition: a change frees the clustered plan, and the first call after it rebuilds it -- ~0.3 s for 318 M non-zeros,
+    // inside that call: issue one warm-up call before timing, as bench.py does.  A 1-rank "world" keeps what the caller set: its slab
+    // may be a range of a larger matrix -- tools/rank_slabs.py.)
+    if (world > 1 && h->opt_row_offset != row0)
+        if (int rc = sextans_set_option(h, "row_offset", row0)) return rc;
     if (nchunks < 1) nchunks = 1;
     if (nchunks > 16) nchunks = 16;
+    // Clustered-order chunks (round 5): when this rank's slab runs on a graph-clustered plan, chunks are ranges of the plan's row
+    // BLOCKS and every chunk keeps the reordered form (engine.hip: cc_*) -- if every rank of the partition can do the same.
+    // (before anything is planned: the long-row thresholds follow the whole matrix's non-zeros, and a change rebuilds every packed form)
+    std::vector<int> nnz_key(row_ranges, row_ranges + 2 * world);
+    nnz_key.push_back(rank);
+    if (comm && h->dist_nnz_key != nnz_key) {   // Non-zeros of the whole matrix = sum over ranks: the automatic hub-split threshold ("split_rows" = -1) is
+        // derived from it, so a rank cuts a hub row into the same pieces as one GPU holding every row would and the
+        // N-GPU result equals the 1-GPU result bit for bit (a row lives on exactly one rank).
+        int *d_nz = nullptr;
+        SX_HIP(hipMalloc((void **)&d_nz, sizeof(int) * 2 * (size_t)world));
+        const int mine_nz[2] = {(int)(h->nnz & 0x7fffffff), (int)(h->nnz >> 31)};
+        SX_HIP(hipMemcpyAsync(d_nz + 2 * (size_t)rank, mine_nz, sizeof mine_nz, hipMemcpyHostToDevice, s));
+        const int rc = rccl_check(r->AllGather(d_nz + 2 * (size_t)rank, d_nz, 2, 2 /* ncclInt32 */, comm, s), "ncclAllGather(nnz)");
+        std::vector<int> all_nz(2 * (size_t)world);
+        hipError_t e1 = rc ? hipSuccess : hipMemcpyAsync(all_nz.data(), d_nz, sizeof(int) * all_nz.size(), hipMemcpyDeviceToHost, s);
+        hipError_t e2 = hipStreamSynchronize(s);
+        (void)hipFree(d_nz);
+        if (rc) return rc;
+        SX_HIP(e1);
+        SX_HIP(e2);
+        int64_t total = 0;
+        for (int g = 0; g < world; ++g) total += (int64_t)all_nz[2 * (size_t)g] + ((int64_t)all_nz[2 * (size_t)g + 1] << 31);
+        if (total != h->opt_global_nnz)
+            if (int rc = sextans_set_option(h, "global_nnz", total)) return rc;
+        h->dist_nnz_key = nnz_key;
+    }
+    bool want_cc = false;
+    if (nchunks > 1)
+        if (int rc = cc_prepare(h, N, &want_cc)) return rc;
+    if (want_cc && h->psc.plan_nblk < nchunks) want_cc = false;
     // Chunk c of rank g = local rows [cuts[g][c], cuts[g][c+1]).  Every rank snaps its OWN interior cuts to the
     // boundaries its kernels want (sextans_align_row: row blocks of the LDS-panel plan, wavefronts of the window kernel,
     // so every chunk keeps the whole-matrix kernel) and the cut positions are exchanged once per (partition, N, chunk
     // count) with a small ncclAllGather; they are cached in the engine afterwards.
     std::vector<int> key(row_ranges, row_ranges + 2 * world);
-    key.push_back(N); key.push_back(nchunks); key.push_back(rank);
+    key.push_back(N); key.push_back(nchunks); key.push_back(rank); key.push_back(want_cc ? 1 : 0);
+    int m_max = 0;
+    for (int g = 0; g < world; ++g) m_max = std::max(m_max, row_ranges[2 * g + 1] - row_ranges[2 * g]);
     if (h->dist_cut_key != key) {
-        {   // Non-zeros of the whole matrix = sum over ranks: the automatic hub-split threshold ("split_rows" = -1) is
-            // derived from it, so a rank cuts a hub row into the same pieces as one GPU holding every row would and the
-            // N-GPU result equals the 1-GPU result bit for bit (a row lives on exactly one rank).
-            int *d_nz = nullptr;
-            SX_HIP(hipMalloc((void **)&d_nz, sizeof(int) * 2 * (size_t)world));
-            const int mine_nz[2] = {(int)(h->nnz & 0x7fffffff), (int)(h->nnz >> 31)};
-            SX_HIP(hipMemcpyAsync(d_nz + 2 * (size_t)rank, mine_nz, sizeof mine_nz, hipMemcpyHostToDevice, s));
-            const int rc = rccl_check(r->AllGather(d_nz + 2 * (size_t)rank, d_nz, 2, 2 /* ncclInt32 */, comm, s), "ncclAllGather(nnz)");
-            std::vector<int> all_nz(2 * (size_t)world);
-            hipError_t e1 = rc ? hipSuccess : hipMemcpyAsync(all_nz.data(), d_nz, sizeof(int) * all_nz.size(), hipMemcpyDeviceToHost, s);
+        bool all_cc = want_cc;
+        if (comm) {   // does every rank want clustered-order chunks?  (one int per rank)
+            int *d_f = nullptr;
+            SX_HIP(hipMalloc((void **)&d_f, sizeof(int) * (size_t)world));
+            const int mine_f = want_cc ? 1 : 0;
+            SX_HIP(hipMemcpyAsync(d_f + rank, &mine_f, sizeof(int), hipMemcpyHostToDevice, s));
+            const int rc = rccl_check(r->AllGather(d_f + rank, d_f, 1, 2 /* ncclInt32 */, comm, s), "ncclAllGather(mode)");
+            std::vector<int> f((size_t)world, 0);
+            hipError_t e1 = rc ? hipSuccess : hipMemcpyAsync(f.data(), d_f, sizeof(int) * (size_t)world, hipMemcpyDeviceToHost, s);
             hipError_t e2 = hipStreamSynchronize(s);
-            (void)hipFree(d_nz);
+            (void)hipFree(d_f);
             if (rc) return rc;
             SX_HIP(e1);
             SX_HIP(e2);
-            int64_t total = 0;
-            for (int g = 0; g < world; ++g) total += (int64_t)all_nz[2 * (size_t)g] + ((int64_t)all_nz[2 * (size_t)g + 1] << 31);
-            h->opt_global_nnz = total;
+            for (int g = 0; g < world; ++g) all_cc = all_cc && f[(size_t)g] != 0;
+        }
+        h->dist_cc = all_cc;
+        if (all_cc) {   // every rank's position -> global row table, exchanged once per partition: [world][m_max] ints
+            const size_t need = (size_t)world * (size_t)m_max;
+            if (h->dist_rows_cap < need) {
+                (void)hipFree(h->d_dist_rows);
+                h->d_dist_rows = nullptr; h->dist_rows_cap = 0;
+                SX_HIP(hipMalloc((void **)&h->d_dist_rows, sizeof(int) * std::max<size_t>(need, 1)));
+                h->dist_rows_cap = need;
+            }
+            cc_table(h, row0, h->d_dist_rows + (size_t)rank * m_max, s);
+            if (comm)
+                if (int rc = rccl_check(r->AllGather(h->d_dist_rows + (size_t)rank * m_max, h->d_dist_rows, (size_t)m_max, 2 /* ncclInt32 */, comm, s),
+                                        "ncclAllGather(row tables)"))
+                    return rc;
+            SX_HIP(hipStreamSynchronize(s));
         }
         std::vector<int> mine((size_t)nchunks + 1, 0);
         mine[(size_t)nchunks] = m_loc;
         for (int c = 1; c < nchunks; ++c) {
+            if (all_cc) {   // positions of the clustered order at block boundaries
+                mine[(size_t)c] = h->psc.h_blk_row[(size_t)((int64_t)h->psc.plan_nblk * c / nchunks)];
+                continue;
+            }
             int a = (int)((int64_t)m_loc * c / nchunks);
             if (int rc = sextans_align_row(h, N, a, &a)) return rc;
             mine[(size_t)c] = std::min(std::max(a, mine[(size_t)c - 1]), m_loc);
         }
+        std::vector<int> all((size_t)world * ((size_t)nchunks + 1));
+        if (!comm) {
+            all = mine;
+        } else {
         int *d_cuts = nullptr;
         SX_HIP(hipMalloc((void **)&d_cuts, sizeof(int) * (size_t)world * ((size_t)nchunks + 1)));
         SX_HIP(hipMemcpyAsync(d_cuts + (size_t)rank * (nchunks + 1), mine.data(), sizeof(int) * mine.size(),
                               hipMemcpyHostToDevice, s));
         const int rc = rccl_check(r->AllGather(d_cuts + (size_t)rank * (nchunks + 1), d_cuts, (size_t)nchunks + 1, 2 /* ncclInt32 */,
                                                comm, s), "ncclAllGather(cuts)");
-        std::vector<int> all((size_t)world * ((size_t)nchunks + 1));
         hipError_t e1 = rc ? hipSuccess : hipMemcpyAsync(all.data(), d_cuts, sizeof(int) * all.size(), hipMemcpyDeviceToHost, s);
         hipError_t e2 = hipStreamSynchronize(s);
         (void)hipFree(d_cuts);
         if (rc) return rc;
         SX_HIP(e1);
         SX_HIP(e2);
+        }
         for (int g = 0; g < world; ++g) {   // what arrived must be a monotone cut list of that rank's range
             const int len = row_ranges[2 * g + 1] - row_ranges[2 * g];
             const int *cg = all.data() + (size_t)g * (nchunks + 1);
@@ -205,12 +264,20 @@ int sextans_dist_spmm(sextans_handle_t h, void *comm, int world, int rank, const
         h->dist_meta = meta;
         h->dist_meta_at = d_meta;
     }
+    const bool cc = h->dist_cc;
+    if (cc)   // row-major staging of the whole C: received slabs are scattered into it, one streaming pass writes column-major C at the end
+        if (int rc = ensure(&h->d_Cfull, &h->Cfull_cap, (size_t)M_total * (size_t)N)) return rc;
     bool first = true;
     for (int c = 0; c < nchunks; ++c) {
         float *S = h->d_stage + off[(size_t)c];
         const int c0 = cut(rank, c), c1 = cut(rank, c + 1);
         float *mine = S + (size_t)rank * N * lmax[(size_t)c];
-        if (c1 > c0) {
+        if (cc) {
+            if (first) cc_pre(h, N, d_B, ldb, d_C_in + row0, ldc_in, s);
+            first = false;
+            const int b0 = (int)((int64_t)h->psc.plan_nblk * c / nchunks), b1 = c + 1 == nchunks ? h->psc.plan_nblk : (int)((int64_t)h->psc.plan_nblk * (c + 1) / nchunks);
+            if (int rc = cc_chunk(h, N, alpha, beta, b0, b1, h->d_dist_rows + (size_t)rank * m_max, row0, mine, lmax[(size_t)c], s)) return rc;
+        } else if (c1 > c0) {
             if (int rc = sextans_spmm_device_rows(h, N, alpha, d_B, ldb, beta, d_C_in + row0 + c0, ldc_in, mine,
                                                   lmax[(size_t)c], c0, c1, first ? 0 : SEXTANS_ROWS_REUSE_B_PANELS, stream))
                 return rc;
@@ -221,13 +288,21 @@ int sextans_dist_spmm(sextans_handle_t h, void *comm, int world, int rank, const
         // so only the last chunk's unpack is exposed
         SX_HIP(hipEventRecord(h->dist_events[(size_t)c], s));
         SX_HIP(hipStreamWaitEvent(h->comm_stream, h->dist_events[(size_t)c], 0));
-        if (int rc = rccl_check(r->AllGather(mine, S, (size_t)N * (size_t)lmax[(size_t)c], 7 /* ncclFloat */, comm,
-                                             h->comm_stream), "ncclAllGather"))
-            return rc;
+        if (comm)
+            if (int rc = rccl_check(r->AllGather(mine, S, (size_t)N * (size_t)lmax[(size_t)c], 7 /* ncclFloat */, comm,
+                                                 h->comm_stream), "ncclAllGather"))
+                return rc;
+        if (cc) {   // slabs hold rows in the senders' clustered order: 64-byte rows to their places in the staging buffer of the whole C
+            for (int g = 0; g < world; ++g)
+                cc_scatter(S + (size_t)g * N * lmax[(size_t)c], lmax[(size_t)c], h->d_dist_rows + (size_t)g * m_max + cut(g, c), cut(g, c + 1) - cut(g, c),
+                           h->d_Cfull, M_total * 16, N, h->comm_stream);
+            continue;
+        }
         const unsigned gx = (unsigned)((lmax[(size_t)c] + 255) / 256);
         hipLaunchKernelGGL(dist_unpack_slabs, dim3(gx, (unsigned)N, (unsigned)world), dim3(256), 0, h->comm_stream, S,
                            lmax[(size_t)c], N, reinterpret_cast<const int2 *>(d_meta) + (size_t)c * world, d_C_out, ldc);
     }
+    if (cc) cc_finish(h->d_Cfull, d_C_out, ldc, (int)M_total, N, h->comm_stream);
     SX_HIP(hipEventRecord(h->dist_events[(size_t)nchunks], h->comm_stream));
     SX_HIP(hipStreamWaitEvent(s, h->dist_events[(size_t)nchunks], 0));
     SX_HIP(hipGetLastError());

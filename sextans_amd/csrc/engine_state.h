@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "sextans_amd.h"
+#include "thread_stream.h"
 
 namespace sxe {
 extern thread_local std::string g_last_error;   // text behind sextans_last_error()
@@ -195,8 +196,15 @@ struct sextans_engine {
     // native multi-GPU form (sextans_dist_spmm): slab staging S[chunk][world][N][lmax_chunk], communication stream
     float *d_stage = nullptr;
     size_t stage_cap = 0;
+    int64_t graph_fallbacks = 0;        // host-entry repeat loops whose hipGraph capture failed (another thread touched the legacy stream): launched one by one instead
     hipStream_t comm_stream = nullptr;
     std::vector<hipEvent_t> dist_events;
+    float *d_Cfull = nullptr;           // clustered-order chunks: row-major staging of the WHOLE C ([N / 16][M_total][16]) the received slabs are scattered into
+    size_t Cfull_cap = 0;
+    int *d_dist_rows = nullptr;         //   ... and every rank's position -> global row table ([world][longest slab])
+    size_t dist_rows_cap = 0;
+    bool dist_cc = false;               //   ... in use for the partition of dist_cut_key (every rank agreed)
+    std::vector<int> dist_nnz_key;      // (ranges, rank) the whole matrix's non-zero count was exchanged for
     std::vector<int> dist_cut_key, dist_cuts;   // (ranges, N, nchunks, rank) the chunk cuts of all ranks were exchanged for
     std::vector<int> dist_meta;     // {first row, rows} per (chunk, rank) as last uploaded, and where
     const int *dist_meta_at = nullptr;
@@ -302,6 +310,14 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
 // dense 32x32 tiles on the matrix cores (engine_bell.hip): C_out = alpha * (A_dense * bf16(B)) + beta * C_in for the full block rows
 int launch_dense_tiles(sextans_engine *h, int N, float alpha, const float *d_B, int64_t ldb, float beta, const float *d_C_in,
                        int64_t ldc_in, float *d_C_out, int64_t ldc, hipStream_t s);
+
+// clustered-order chunks of sextans_dist_spmm (engine.hip)
+int cc_prepare(sextans_engine *h, int N, bool *ok);
+void cc_table(sextans_engine *h, int row0, int *d_out, hipStream_t s);
+void cc_pre(sextans_engine *h, int N, const float *d_B, int64_t ldb, const float *d_C_in_slab, int64_t ldc_in, hipStream_t s);
+int cc_chunk(sextans_engine *h, int N, float alpha, float beta, int b0, int b1, const int *d_rows, int row0, float *slab, int64_t lmax, hipStream_t s);
+void cc_scatter(const float *slab, int64_t lmax, const int *d_rows, int n, float *tiles, int64_t tile_stride, int N, hipStream_t s);
+void cc_finish(const float *tiles, float *C, int64_t ldc, int M_total, int N, hipStream_t s);
 
 template <class T>
 int upload(T **dst, const std::vector<T> &src) {

@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "graph_cluster.h"
+#include "thread_stream.h"
 
 namespace sx {
 namespace {

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "plan_device.h"
+#include "thread_stream.h"
 
 namespace sx {
 namespace {

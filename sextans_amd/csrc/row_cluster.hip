@@ -19,6 +19,7 @@
 #include <map>
 
 #include "row_cluster.h"
+#include "thread_stream.h"
 
 namespace sx {
 namespace {

@@ -23,6 +23,7 @@
 #include "graph_cluster.h"
 #include "row_cluster.h"
 #include "sextans_amd.h"
+#include "thread_stream.h"
 
 #define SX_HD __host__ __device__ __forceinline__
 

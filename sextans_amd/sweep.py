@@ -138,9 +138,10 @@ def _synth(spec, device):
     raise ValueError("unknown synthetic class: " + spec)
 
 
-def sweep_synthetic(specs, n_values, steps=20, alpha=0.85, beta=-2.06, device=0, options=None, out=sys.stdout):
+def sweep_synthetic(specs, n_values, steps=20, alpha=0.85, beta=-2.06, device=0, options=None, out=sys.stdout, layout="cm"):
     """The same record per (matrix, N) for matrices generated directly in HBM: device-resident B/C (seeded U(-1,1)),
-    steady-state step time (repack + kernels) over `steps` back-to-back steps."""
+    steady-state step time (repack + kernels) over `steps` back-to-back steps.  layout "rm": the operands read as ROW-major
+    K x N / M x N through sextans_spmm_device_rm (records carry "layout": "rm")."""
     import torch
     records = []
     dev = torch.device("cuda", device)
@@ -157,6 +158,8 @@ def sweep_synthetic(specs, n_values, steps=20, alpha=0.85, beta=-2.06, device=0,
                 api.gen_uniform_device(device, B.data_ptr(), K * N, 41, st)
                 api.gen_uniform_device(device, Cin.data_ptr(), M * N, 42, st)
                 f = lambda: eng.spmm_device(N, alpha, B.data_ptr(), K, beta, Cin.data_ptr(), Cout.data_ptr(), M, st)
+                if layout == "rm":
+                    f = lambda: eng.spmm_device_rm(N, alpha, B.data_ptr(), N, beta, Cin.data_ptr(), N, Cout.data_ptr(), N, st)
                 for _ in range(3):
                     f()
                 torch.cuda.synchronize(dev)
@@ -183,7 +186,7 @@ def sweep_synthetic(specs, n_values, steps=20, alpha=0.85, beta=-2.06, device=0,
                        "row_cluster": int(eng.get_stat("row_cluster")),
                        "panel_rows_natural": int(eng.get_stat("panel_rows_natural")),
                        "panel_rows_clustered": int(eng.get_stat("panel_rows_clustered")),
-                       "cluster_decline": int(eng.get_stat("cluster_decline"))}
+                       "cluster_decline": int(eng.get_stat("cluster_decline")), "layout": layout}
                 records.append(rec)
                 print(json.dumps(rec), file=out, flush=True)
                 del B, Cin, Cout
@@ -205,6 +208,7 @@ def main(argv=None):
     ap.add_argument("--cache", action="store_true",
                     help="read each matrix through its binary container (<file>.csr.sxbin), writing it on first use")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value")
+    ap.add_argument("--rm", action="store_true", help="synthetic classes: row-major operands (sextans_spmm_device_rm)")
     a = ap.parse_args(argv)
     paths, synth = [], []
     for p in a.paths:
@@ -217,7 +221,7 @@ def main(argv=None):
     if paths:
         sweep(paths, ns, a.rp, a.alpha, a.beta, a.check, a.device, opts, cache=a.cache)
     if synth:
-        sweep_synthetic(synth, ns, max(a.rp, 1), a.alpha, a.beta, a.device, opts)
+        sweep_synthetic(synth, ns, max(a.rp, 1), a.alpha, a.beta, a.device, opts, layout="rm" if a.rm else "cm")
 
 
 if __name__ == "__main__":

@@ -133,6 +133,47 @@ def test_native_dist_spmm_single_rank(engine, oracle, sx):
         api.dist_comm_destroy(comm)
 
 
+@pytest.mark.parametrize("with_comm", [True, False])
+def test_clustered_order_chunks_keep_the_reordered_form(sx, oracle, with_comm):
+    """VERDICT r04 task 4a: a slab that runs on a graph-clustered plan (a mesh in a random node order) used to fall back to the
+    natural-order forms as soon as sextans_dist_spmm cut it into chunks.  Chunks are now ranges of the plan's row blocks: every chunk
+    runs the reordered form, the slabs travel in clustered order and are unpacked through the position -> row tables.  1-rank RCCL
+    communicator (and no communicator at all): bit-identical to cpu_spmm_CSR for 1, 2, 4 and 7 chunks."""
+    import torch
+    from sextans_amd import api, meshgen
+    rp, ci, v = api.gen_fem3d_host(30, 28, 26, 3, 7)
+    M = K = 30 * 28 * 26 * 3
+    rp, ci, v = meshgen.permute_symmetric(rp, ci, v, M, meshgen.node_permutation(M // 3, 3, 9))
+    rs = np.random.RandomState(2)
+    comm = api.dist_comm_init(0, 1, 0, api.dist_unique_id()) if with_comm else None
+    st = torch.cuda.current_stream().cuda_stream
+    try:
+        with api.Engine(0) as e:
+            e.set_matrix_csr(M, K, rp, ci, v)
+            for N in (16, 48, 24):
+                B = rs.uniform(-1, 1, K * N).astype(np.float32); C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+                want = C0.copy()
+                oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+                dB = torch.from_numpy(B).cuda(); dCin = torch.from_numpy(C0).cuda()
+                for nchunks in (1, 2, 4, 7):
+                    for rep in range(2):                     # (the second call reuses the exchanged cuts and tables)
+                        out = torch.full((M * N,), float("nan"), device="cuda")
+                        e.dist_spmm(comm, 1, 0, [(0, M)], N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr(), M, out.data_ptr(), M, nchunks=nchunks, stream=st)
+                        torch.cuda.synchronize()
+                        assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (N, nchunks, rep, e.last_kernel())
+                    assert int(e.get_stat("row_cluster")) == 2
+                    if N % 16 == 0:
+                        assert e.last_kernel() == "spmm_csr_panel_v2_reordered", (N, nchunks, e.last_kernel())
+                # a whole-matrix call in between (other B panels, other staging) does not disturb the next chunked call
+                out = torch.empty(M * N, device="cuda")
+                e.spmm_device(N, float(ALPHA), dB.data_ptr(), K, float(BETA), dCin.data_ptr(), out.data_ptr(), M, st)
+                torch.cuda.synchronize()
+                assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    finally:
+        if comm is not None:
+            api.dist_comm_destroy(comm)
+
+
 def _rccl_worker(rank, world, port, q):
     """One rank of a real multi-GPU run: its own GPU, its own engine on its row range of A, B replicated,
     RCCL all-gather of the C slabs (single-collective and pipelined forms)."""

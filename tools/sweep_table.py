@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""tools/sweep_table.py [profiles/r04_sweep.jsonl] -- the markdown table of DESIGN 9 (fraction of 8 TB/s on algorithmic bytes per STEP, per class and N)."""
+"""tools/sweep_table.py [profiles/r05_sweep.jsonl] -- the markdown table of DESIGN 9 (fraction of 8 TB/s on algorithmic bytes per STEP, per class and N)."""
 import json, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_sweep.jsonl")
+path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_sweep.jsonl")
 recs = [json.loads(l) for l in open(path) if l.startswith("{")]
 Ns = [8, 16, 32, 64, 128, 256, 512]
 rows = {}
 for r in recs:
-    key = (r["matrix"], r.get("options", ""))
+    key = (r["matrix"], (r.get("options", "") + (" row-major operands" if r.get("layout") == "rm" else "")).strip())
     rows.setdefault(key, {})[r["N"]] = r
 short = lambda k: k.replace("spmm_csr_", "").replace("spmm_", "")
 print("| Class | kernels (N = 8 / 16 / 128) | " + " | ".join(f"N={n}" if n == 8 else str(n) for n in Ns) + " |")

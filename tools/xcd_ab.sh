@@ -13,7 +13,7 @@ for SPEC in synth:femperm:110:110:110:3:random synth:mesh3d:110:3:random synth:k
 done
 for X in 0 1; do
   for N in 16 32; do
-    PMC_SETS="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" PMC_PASS_TIMEOUT=300 bash tools/pmc.sh gpurun_out/xcd_pmc_$1_x${X}_n$N python tools/run_one_opts.py synth:femperm:110:110:110:3:random $N 6 reordered_xcd=$X
+    PMC_SETS="FETCH_SIZE;WRITE_SIZE;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" PMC_PASS_TIMEOUT=300 bash tools/pmc.sh gpurun_out/xcd_pmc_$1_x${X}_n$N python $(pwd)/tools/run_one_opts.py synth:femperm:110:110:110:3:random $N 6 reordered_xcd=$X
     echo "== femperm random N=$N reordered_xcd=$X: counters per launch of the SpMM kernel (FETCH_SIZE / WRITE_SIZE in KB; reads = 2 x FETCH_SIZE on gfx950)" >> $OUT
     grep "spmm_csr_panel_v2" gpurun_out/xcd_pmc_$1_x${X}_n$N/summary.txt | awk '{print "   ", $(NF-2), $(NF-1), $NF}' >> $OUT
   done
