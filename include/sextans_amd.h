@@ -316,6 +316,12 @@ int sextans_reassociated_rows(sextans_handle_t h, int *rows, int capacity, int *
  * sextans_packed_free.  Analogue being replaced: generate_edge_list_for_all_PEs + edge_list_64bit on the host,
  * sparse_helper.h:345-473, sextans-host.cpp:114-148. */
 int sextans_export_plan(sextans_handle_t h, int lanes_per_row, struct sextans_packed *out);
+/* The order in which the clustered plan ("row_cluster") visits the rows of the current matrix: order[i] = row at position i (M ints,
+ * host); *clustered (optional) = 0 none (order = identity) / 1 grid bricks / 2 graph clustering.  For callers that can renumber their
+ * matrix once -- P A P^T with new_of_old[order[i]] = i, what FEM packages do with RCM: contiguous row ranges of the renumbered matrix are
+ * compact pieces of the matrix graph, which is what the row-range partition of sextans_dist_spmm needs on a mesh whose numbering has
+ * no locality.  The reference fixes the order of its non-zeros once on the host as well (sparse_helper.h:345-403). */
+int sextans_export_row_order(sextans_handle_t h, int *order, int *clustered);
 /* Read-only figures about the matrix currently set.  key: "plan_build_s" (seconds spent so far
  * building packed forms of A -- on the device for the panel plan, on the host for the window stream; outside every timed
  * region like the reference's scheduling/packing, sextans-host.cpp:114-148), "window_padded_entries",

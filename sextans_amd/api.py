@@ -61,6 +61,20 @@ class SextansError(RuntimeError):
         super().__init__(f"{where}: [{code}] {msg}" + (f" ({detail})" if detail else ""))
 
 
+class _Optional:
+    """ctypes library proxy for lib(): declaring the prototype of an entry point that an OLDER build lacks (tools/nasa_ab.py loads
+    the libraries of earlier rounds for same-box comparisons) is skipped instead of failing the whole load."""
+    class _Missing:
+        argtypes = restype = None
+    def __init__(self, L):
+        object.__setattr__(self, "_L", L)
+    def __getattr__(self, name):
+        try:
+            return getattr(self._L, name)
+        except AttributeError:
+            return _Optional._Missing()
+
+
 def lib():
     """Load libsextans_amd.so once.  torch (if importable) is imported first so that this library
     binds to the same libamdhip64.so.7 instance torch uses (one HIP runtime per process)."""
@@ -75,7 +89,8 @@ def lib():
         import torch  # noqa: F401
     except Exception:
         pass
-    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    raw = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L = _Optional(raw)      # (prototypes of entry points an older build lacks are skipped)
     pi, pf = C.POINTER(C.POINTER(C.c_int)), C.POINTER(C.POINTER(C.c_float))
     ip = C.POINTER(C.c_int)
     L.sextans_error_string.restype = C.c_char_p
@@ -153,8 +168,9 @@ def lib():
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.sextans_spmm_device2.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
-    L.sextans_spmm_device_rm.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
-                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    if hasattr(L, "sextans_spmm_device_rm"):      # (absent from the older builds tools/nasa_ab.py compares against)
+        L.sextans_spmm_device_rm.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
+                                             C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     L.sextans_spmm_device_rows.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p]
@@ -210,8 +226,8 @@ def lib():
     L.sextans_gen_uniform_device.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_uint64,
                                              C.c_void_p]
     L.sextans_device_free.argtypes = [C.c_int, C.c_void_p]
-    _lib = L
-    return L
+    _lib = raw
+    return raw
 
 
 def _check(rc, where):
@@ -518,6 +534,14 @@ class Engine:
             return out
         finally:
             lib().sextans_packed_free(C.byref(P))
+
+    def export_row_order(self):
+        """(order, kind): order[i] = row at position i of the clustered plan (identity when kind == 0); see include/sextans_amd.h."""
+        L = lib()
+        L.sextans_export_row_order.argtypes = [C.c_void_p, _i32p, C.POINTER(C.c_int)]
+        order, kind = np.empty(max(self.M, 1), np.int32), C.c_int()
+        _check(L.sextans_export_row_order(self._h, order, C.byref(kind)), "export_row_order")
+        return order[:self.M], kind.value
 
     def reassociated_rows(self):
         """Hub rows whose sums are formed in pieces under the current "split_rows" setting (ascending)."""

@@ -49,13 +49,13 @@ int check_device(int device) {
 
 template <int W>
 void launch_repack(const float *dB, int64_t ldb, float *dBp, int K, int col_base, int ntiles,
-                   hipStream_t s, int k_begin = 0, int k_end = -1, int ncols = -1) {
+                   hipStream_t s, int k_begin = 0, int k_end = -1, int ncols = -1, const unsigned char *touched = nullptr) {
     if (k_end < 0) k_end = K;
     if (k_end <= k_begin) return;
     if (ncols < 0) ncols = ntiles * W;   // (fewer: the last panel is zero-filled past them)
     dim3 grid((unsigned)((k_end - k_begin + sx::kBlock - 1) / sx::kBlock), (unsigned)ntiles);
     hipLaunchKernelGGL(sx::repack_b_panels<W>, grid, dim3(sx::kBlock), 0, s, dB, ldb, dBp, K,
-                       col_base, k_begin, k_end, ncols);
+                       col_base, k_begin, k_end, ncols, touched);
 }
 
 template <int LPR>
@@ -296,15 +296,16 @@ bool cc_usable(sextans_engine *h, int N, int W, const std::vector<Seg> &plan) {
            (h->M >= 65536 || h->m_nnz * (int64_t)N >= ((int64_t)24 << 20)) && (int)h->psc.h_blk_row.size() == h->psc.plan_nblk + 1;
 }
 void cc_table(sextans_engine *h, int row0, int *d_out, hipStream_t s) {
-    hipLaunchKernelGGL(position_rows, dim3((unsigned)h->psc.plan_nblk), dim3(64), 0, s, h->psc.plan_nblk, sx::kBlock / 4, h->psc.d_blk_row, h->d_slot_row, row0, d_out);
+    const int slots = sx::kBlock / 4 * std::max(1, h->psc.plan_sets);   // (grid-brick plans of short-row matrices: two row sets per block)
+    hipLaunchKernelGGL(position_rows, dim3((unsigned)h->psc.plan_nblk), dim3((unsigned)slots), 0, s, h->psc.plan_nblk, slots, h->psc.d_blk_row, h->d_slot_row, row0, d_out);
 }
 void cc_pre(sextans_engine *h, int N, const float *d_B, int64_t ldb, const float *d_C_in_slab, int64_t ldc_in, hipStream_t s) {
     Prof p(h, &h->ev_repack, s);
     if (h->d_colpos)
         hipLaunchKernelGGL(sx::repack_b_panels_perm, dim3((unsigned)((h->col_hi - h->col_lo + sx::kBlock - 1) / sx::kBlock), (unsigned)(N / 16)), dim3(sx::kBlock), 0, s,
-                           d_B, ldb, h->d_Bp, h->K, 0, h->d_colpos, h->col_lo, h->col_hi, N);
+                           d_B, ldb, h->d_Bp, h->K, 0, h->d_colpos, h->col_lo, h->col_hi, N, h->d_touched);
     else
-        launch_repack<16>(d_B, ldb, h->d_Bp, h->K, 0, N / 16, s, h->col_lo, h->col_hi);
+        launch_repack<16>(d_B, ldb, h->d_Bp, h->K, 0, N / 16, s, h->col_lo, h->col_hi, -1, h->d_touched);
     launch_repack<16>(d_C_in_slab, ldc_in, h->d_Cs, h->M, 0, N / 16, s);
     h->bp_layout = -16;
 }
@@ -691,6 +692,7 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "pattern_symmetry")) *value = h->pattern_symmetry;
     else if (!strcmp(key, "col_range_lo")) *value = (double)h->col_lo;
     else if (!strcmp(key, "col_range_hi")) *value = (double)h->col_hi;
+    else if (!strcmp(key, "b_rows_repacked")) *value = h->d_touched ? (double)h->touched_segments * 64.0 : (double)(h->col_hi - h->col_lo);
     else if (!strcmp(key, "colwise")) *value = (double)h->colwise_state;
     else if (!strcmp(key, "row_sets")) *value = (double)(h->cluster_state > 0 ? h->psc.plan_sets : h->ps.plan_sets);
     else if (!strcmp(key, "row_coherence")) *value = h->row_coherence;
@@ -865,7 +867,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         // B in 8-column panels (the reference's N tile), then one tile-major launch
         if (!(flags & SEXTANS_ROWS_REUSE_B_PANELS) || h->bp_layout != 8) {
             Prof p(h, &h->ev_repack, s);
-            launch_repack<8>(d_B, ldb, h->d_Bp, h->K, 0, N / 8, s, h->col_lo, h->col_hi);
+            launch_repack<8>(d_B, ldb, h->d_Bp, h->K, 0, N / 8, s, h->col_lo, h->col_hi, -1, h->d_touched);
             h->bp_layout = 8;
         }
         {
@@ -971,14 +973,14 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         auto pre = [&](int t0, int t1, hipStream_t st) {
             float *dst = h->d_Bp + (size_t)h->K * (size_t)(g.col0 + 16 * t0);
             if (reordered && !h->d_colpos) {
-                launch_repack<16>(d_B, ldb, dst, h->K, g.col0 + 16 * t0, t1 - t0, st, h->col_lo, h->col_hi);
+                launch_repack<16>(d_B, ldb, dst, h->K, g.col0 + 16 * t0, t1 - t0, st, h->col_lo, h->col_hi, -1, h->d_touched);
                 launch_repack<16>(d_C_in, ldc_in, h->d_Cs + (int64_t)t0 * cs_tile, h->M, g.col0 + 16 * t0, t1 - t0, st);
             } else if (reordered) {
                 hipLaunchKernelGGL(sx::repack_b_panels_perm, dim3((unsigned)((h->col_hi - h->col_lo + sx::kBlock - 1) / sx::kBlock), (unsigned)(t1 - t0)),
-                                   dim3(sx::kBlock), 0, st, d_B, ldb, dst, h->K, g.col0 + 16 * t0, h->d_colpos, h->col_lo, h->col_hi, 16 * (t1 - t0));
+                                   dim3(sx::kBlock), 0, st, d_B, ldb, dst, h->K, g.col0 + 16 * t0, h->d_colpos, h->col_lo, h->col_hi, 16 * (t1 - t0), h->d_touched);
                 launch_repack<16>(d_C_in, ldc_in, h->d_Cs + (int64_t)t0 * cs_tile, h->M, g.col0 + 16 * t0, t1 - t0, st);
             } else {
-                launch_repack<16>(d_B, ldb, dst, h->K, g.col0 + 16 * t0, t1 - t0, st, h->col_lo, h->col_hi);
+                launch_repack<16>(d_B, ldb, dst, h->K, g.col0 + 16 * t0, t1 - t0, st, h->col_lo, h->col_hi, -1, h->d_touched);
             }
         };
         auto kern = [&](int t0, int t1) -> int {
@@ -1002,7 +1004,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             pre(0, t_cut, s);
             for (size_t i = 1; i < plan.size(); ++i) {                  // an 8-column remainder tile keeps the plain panels
                 const Seg &r = plan[i];
-                launch_repack<8>(d_B, ldb, h->d_Bp + (size_t)h->K * (size_t)r.col0, h->K, r.col0, r.ntiles, s, h->col_lo, h->col_hi);
+                launch_repack<8>(d_B, ldb, h->d_Bp + (size_t)h->K * (size_t)r.col0, h->K, r.col0, r.ntiles, s, h->col_lo, h->col_hi, -1, h->d_touched);
             }
         }
         pre(t_cut, g.ntiles, side);
@@ -1042,13 +1044,13 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
                 float *dst = h->d_Bp + (size_t)h->K * (size_t)g.col0;
                 if (reordered && g.width == 16 && h->d_colpos) {
                     hipLaunchKernelGGL(sx::repack_b_panels_perm, dim3((unsigned)((h->col_hi - h->col_lo + sx::kBlock - 1) / sx::kBlock), (unsigned)g.ntiles),
-                                       dim3(sx::kBlock), 0, s, d_B, ldb, dst, h->K, g.col0, h->d_colpos, h->col_lo, h->col_hi, seg_cols(g));
+                                       dim3(sx::kBlock), 0, s, d_B, ldb, dst, h->K, g.col0, h->d_colpos, h->col_lo, h->col_hi, seg_cols(g), h->d_touched);
                     continue;
                 }
                 switch (g.width) {
-                    case 32: launch_repack<32>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s, h->col_lo, h->col_hi); break;
-                    case 16: launch_repack<16>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s, h->col_lo, h->col_hi, seg_cols(g)); break;
-                    default: launch_repack<8>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s, h->col_lo, h->col_hi); break;
+                    case 32: launch_repack<32>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s, h->col_lo, h->col_hi, -1, h->d_touched); break;
+                    case 16: launch_repack<16>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s, h->col_lo, h->col_hi, seg_cols(g), h->d_touched); break;
+                    default: launch_repack<8>(d_B, ldb, dst, h->K, g.col0, g.ntiles, s, h->col_lo, h->col_hi, -1, h->d_touched); break;
                 }
             }
         }
@@ -1175,6 +1177,35 @@ __global__ __launch_bounds__(256) void translate_dict(long long n, int K, const 
 }
 }  // namespace
 extern "C" {
+
+// The order in which the clustered plan visits the rows, for callers that can RENUMBER their matrix once (what FEM packages do with
+// RCM): order[i] = row at position i.  A contiguous range of the renumbered matrix is a compact piece of the matrix graph, so the
+// row-range partition of sextans_dist_spmm hands every rank a cluster -- its own part of B plus a halo instead of all of B -- and the
+// natural-order forms of the renumbered matrix run like the reordered form without its passes.  (A contiguous range of a RANDOMLY
+// numbered mesh holds 1 / world of every row's neighbours: 3.3 x compute-phase speed-up at 8 ranks, profiles/r05_rank_slab_times.json.)
+// The reference's scheduler likewise fixes the order of the non-zeros once, on the host (sparse_helper.h:345-403).
+int sextans_export_row_order(sextans_handle_t h, int *order, int *clustered) {
+    if (!h || !order) return SEXTANS_ERR_INVALID;
+    if (!h->d_rp) return SEXTANS_ERR_STATE;
+    SX_HIP(hipSetDevice(h->device));
+    std::vector<Seg> plan;
+    int W = 0;
+    bool up = false, uw = false;
+    if (int rc = prepare(h, 16, plan, W, up, uw, true)) return rc;
+    const bool have = h->cluster_state > 0 && h->d_slot_row && h->psc.plan_built && h->nhub == 0 && h->nchain == 0;
+    if (clustered) *clustered = have ? h->cluster_state : 0;
+    if (!have) {
+        for (int i = 0; i < h->M; ++i) order[i] = i;
+        return SEXTANS_OK;
+    }
+    int *d_tab = nullptr;
+    SX_HIP(hipMalloc((void **)&d_tab, sizeof(int) * (size_t)std::max(h->M, 1)));
+    cc_table(h, 0, d_tab, nullptr);
+    const hipError_t e = hipMemcpy(order, d_tab, sizeof(int) * (size_t)h->M, hipMemcpyDeviceToHost);
+    (void)hipFree(d_tab);
+    SX_HIP(e);
+    return SEXTANS_OK;
+}
 
 // Row-major operands.  The reference lays B and C out for its kernel on the host, OUTSIDE the timed call (sextans-host.cpp:150-195,
 // 264-270); a caller whose operands are row-major (torch tensors; the natural layout of a "K x N feature matrix") gets the same here:

@@ -135,6 +135,8 @@ void free_matrix(sextans_engine *h) {
     h->owns_matrix = false;
     h->device_matrix_checked = false;
     h->col_range_known = false;
+    (void)hipFree(h->d_touched);
+    h->d_touched = nullptr; h->touched_segments = 0;
     h->m_rp = h->m_ci = h->s_rp = h->s_ci = nullptr; h->m_v = h->s_v = nullptr; h->m_nnz = h->s_nnz = 0;
     h->dist_cut_key.clear();   // chunk cuts are aligned to the packed forms of one matrix
     h->bp_layout = 0;          // B panels belong to one (K, B)
@@ -294,6 +296,16 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
         h->ps.plan_panel_frac = 0.0;
         h->ps.plan_built = false;
         return SEXTANS_OK;
+    }
+    // A handful of row blocks without reuse (the tail of a cluster order, a few unstructured rows in a mesh matrix) made the whole plan
+    // "mixed" and took the register-resident kernel away from EVERY block: 815 us instead of ~620 for a 4M-row mesh matrix renumbered by
+    // a cluster order (round 5).  When the blocks without a dictionary hold under 2 % of the non-zeros they get one as well (a block
+    // always fits the panel by construction; a dictionary without reuse costs those few blocks a panel copy they do not amortise).
+    if (brc == 0 && dp.mixed && lpr == 4 && h->m_nnz > 0 && (double)dp.nnz_in_panel_blocks >= 0.98 * (double)h->m_nnz) {
+        sx::DevicePlan all;
+        const int rc2 = sx::build_panel_plan_device(h->M, h->K, h->m_rp, h->m_ci, h->m_v, lpr, cap, 0.0, all, err, nullptr, h->opt_share_index != 0);
+        if (rc2 == 0 && !all.mixed && all.dict_stride <= 9 * RB) { sx::free_device_plan(dp); dp = all; all = sx::DevicePlan(); h->ps.plan_all_dict = true; }
+        else { sx::free_device_plan(all); if (rc2 == 2) (void)hipGetLastError(); }
     }
     if (dp.dict_stride > 9 * RB) { sx::free_device_plan(dp); return SEXTANS_ERR_STATE; }   // capacity = 9 * RB by construction
     h->ps.plan_nblk = dp.nblk;
@@ -544,6 +556,18 @@ int ensure_col_range(sextans_engine *h) {
         h->col_lo = std::max(0, lo / 64 * 64);
         h->col_hi = std::min(h->K, (hi / 64 + 1) * 64);
     }
+    // ... and inside that range only the 64-row segments that hold one of the matrix's columns (round 5): the slab of a renumbered
+    // mesh reaches a handful of far-away columns, which stretched [col_lo, col_hi) over all of B -- 85 us of repack per rank at 8
+    // ranks against 17 us for its share (profiles/r05_rank_slab_times.json).  Kept only when it skips at least an eighth.
+    {
+        unsigned char *f = nullptr;
+        int64_t touched = 0;
+        if (sx::column_touch_flags_device(h->K, h->nnz, h->d_ci, &f, &touched, err) == 0) {
+            const int64_t in_range = (h->col_hi - h->col_lo + 63) / 64;
+            if (touched * 8 <= in_range * 7) { h->d_touched = f; h->touched_segments = touched; }
+            else (void)hipFree(f);
+        } else (void)hipGetLastError();
+    }
     return SEXTANS_OK;
 }
 
@@ -583,7 +607,7 @@ int restore_plan_streams(sextans_engine *h) {
     std::string err;
     const int lpr = p.plan_lpr, cap = kPanelFloats / (4 * lpr);
     const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;
-    const int brc = sx::build_panel_plan_device(h->M, h->K, h->m_rp, h->m_ci, h->m_v, lpr, cap, min_reuse, dp, err, nullptr,
+    const int brc = sx::build_panel_plan_device(h->M, h->K, h->m_rp, h->m_ci, h->m_v, lpr, cap, p.plan_all_dict ? 0.0 : min_reuse, dp, err, nullptr,
                                                 lpr == 4 && h->opt_share_index != 0);
     if (brc != 0 || dp.nblk != p.plan_nblk || dp.stream_len != p.plan_stream_len) {
         sx::free_device_plan(dp);

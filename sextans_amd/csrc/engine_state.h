@@ -69,6 +69,7 @@ struct sextans_engine {
     // callers that alternate between N classes (N = 8 -> 2 lanes, N >= 16 -> 4) do not rebuild on every switch.
     struct PanelState {
         int plan_lpr = 0;               // 0 = no plan
+        bool plan_all_dict = false;     // built with a dictionary for EVERY block (the few blocks without reuse would have made the plan mixed)
         int plan_sets = 1;              // row slots per block = plan_sets * (256 / plan_lpr): 2 for the short-row clustered plan (spmm_panel_v2.h: SETS)
         int64_t plan_min_reuse = -1;
         // d_dict_ptr: entries per block dictionary; d_dict: dictionaries at stride plan_dict_stride;
@@ -109,6 +110,8 @@ struct sextans_engine {
     size_t Cs_cap = 0;
     int col_lo = 0, col_hi = 0;         // columns [col_lo, col_hi) the matrix as set has entries in: the only rows of B a call repacks
     bool col_range_known = false;
+    unsigned char *d_touched = nullptr; // one byte per 64 rows of B: does the matrix have a column there (null = repack everything in [col_lo, col_hi))
+    int64_t touched_segments = 0;
     int colwise_state = 0;              // spmm_csr_colwise for this matrix: 0 not evaluated, 1 short rows in a numbering with locality, -1 no
     double row_coherence = 0.0;         // sampled share of consecutive rows' entries with neighbouring columns
     int cluster_decline = 0;            // why the graph clustering was declined (engine_plan.hip: cluster_graph), 0 = it was not

@@ -41,6 +41,8 @@ struct DevicePlan {                   // device arrays in exactly the form the L
 int validate_csr_device(int M, int K, int64_t nnz, const int *d_rp, const int *d_ci, int *bad, std::string &err);
 // smallest / largest column index of a device CSR matrix (lo > hi: no entries).  Returns non-zero on a HIP error.
 int column_range_device(int64_t nnz, const int *d_ci, int *lo, int *hi, std::string &err);
+// flag[k / 64] = 1 where the matrix has an entry in that 64-column segment (the only rows of B a call repacks); ceil(K / 64) + 4 bytes
+int column_touch_flags_device(int K, int64_t nnz, const int *d_ci, unsigned char **d_flag, int64_t *touched_segments, std::string &err);
 void free_device_plan(DevicePlan &d);
 int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, const float *d_v, int lpr, int max_unique,
                             double min_reuse, DevicePlan &out, std::string &err, const unsigned char *d_cut = nullptr,

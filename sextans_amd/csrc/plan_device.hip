@@ -381,6 +381,31 @@ int column_range_device(int64_t nnz, const int *d_ci, int *lo, int *hi, std::str
     return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void col_touch(const int *__restrict__ ci, long long nnz, unsigned char *__restrict__ flag) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+    for (long long j = t; j < nnz; j += stride) flag[ci[j] >> 6] = 1;     // (every writer stores the same value)
+}
+}  // namespace
+
+// flag[k / 64] = 1 where the matrix has an entry in columns [64 (k / 64), 64 (k / 64) + 64): the 64-row segments of B a call has to
+// repack.  ceil(K / 64) + 4 bytes on the device (the tail zero), caller frees.
+int column_touch_flags_device(int K, int64_t nnz, const int *d_ci, unsigned char **d_flag, int64_t *touched_segments, std::string &err) {
+    *d_flag = nullptr;
+    if (touched_segments) *touched_segments = 0;
+    const size_t n = (size_t)(K + 63) / 64 + 4;
+    unsigned char *f = nullptr;
+    PD_HIP(hipMalloc((void **)&f, n));
+    hipError_t e = hipMemsetAsync(f, 0, n, nullptr);
+    if (nnz > 0) hipLaunchKernelGGL(col_touch, dim3(2048), dim3(256), 0, nullptr, d_ci, (long long)nnz, f);
+    std::vector<unsigned char> host(n);
+    hipError_t e2 = hipMemcpy(host.data(), f, n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess || e2 != hipSuccess) { (void)hipFree(f); PD_HIP(e); PD_HIP(e2); }
+    if (touched_segments) for (unsigned char x : host) *touched_segments += x;
+    *d_flag = f;
+    return 0;
+}
+
 void free_device_plan(DevicePlan &d) {
     (void)hipFree(d.d_blk_row); (void)hipFree(d.d_dict_cnt); (void)hipFree(d.d_dict); (void)hipFree(d.d_slot_info);
     (void)hipFree(d.d_idx16); (void)hipFree(d.d_col32); (void)hipFree(d.d_val); (void)hipFree(d.d_ioff);

@@ -21,12 +21,14 @@ namespace sx {
 
 // Workgroup = 256 consecutive k of one 16-column panel t: Bp[t][colpos[k]][0..15] = B[k][col_base + 16 t + 0..15].
 __global__ __launch_bounds__(kBlock) void repack_b_panels_perm(const float *__restrict__ B, int64_t ldb, float *__restrict__ Bp, int K,
-                                                               int col_base, const int *__restrict__ colpos, int k_begin, int k_end, int ncols) {
+                                                               int col_base, const int *__restrict__ colpos, int k_begin, int k_end, int ncols,
+                                                               const unsigned char *__restrict__ touched) {
     __shared__ float s[16][kBlock + 1];
     const int tid = threadIdx.x;
     const int k0 = k_begin + blockIdx.x * kBlock;
     const int t = blockIdx.y;
     const float *src = B + (int64_t)(col_base + t * 16) * ldb;
+    if (touched && !(touched[k0 >> 6] | touched[(k0 >> 6) + 1] | touched[(k0 >> 6) + 2] | touched[(k0 >> 6) + 3])) return;   // (see repack_b_panels)
     if ((t + 1) * 16 > ncols) {   // (ncols: see repack_b_panels -- uniform test, the zero-padded last panel only)
         if (k0 + tid < k_end)
             for (int c = 0; c < 16; ++c) s[c][tid] = t * 16 + c < ncols ? src[(int64_t)c * ldb + k0 + tid] : 0.f;

@@ -868,7 +868,9 @@ __global__ __launch_bounds__(chain_fused_threads(NT)) void chain_fused(
 template <int W>
 __global__ __launch_bounds__(kBlock) void repack_b_panels(const float *__restrict__ B, int64_t ldb,
                                                           float *__restrict__ Bp, int K,
-                                                          int col_base, int k_begin, int k_end, int ncols) {
+                                                          int col_base, int k_begin, int k_end, int ncols, const unsigned char *__restrict__ touched) {
+    // touched (may be null): one byte per 64 rows of B -- segments without a single column index of the matrix are skipped (a rank of a
+    // row-partitioned SpMM whose slab reaches a few far-away columns still repacks 1 / world of B, not everything between min and max)
     // ncols: columns of B from col_base on; a last panel that reaches past them is filled with zeros there (N = 16 t + 8 run as t + 1
     // 16-column tiles: the padded columns multiply zeros and are never stored, spmm_panel_v2.h `last_cols`)
     // Rows [k_begin, k_end) of B only: the rows the matrix of this engine has columns in (a rank of a row-partitioned SpMM
@@ -880,6 +882,7 @@ __global__ __launch_bounds__(kBlock) void repack_b_panels(const float *__restric
     const int t = blockIdx.y;
     const int k = k0 + tid;
     const float *src = B + (int64_t)(col_base + t * W) * ldb;
+    if (touched && !(touched[k0 >> 6] | touched[(k0 >> 6) + 1] | touched[(k0 >> 6) + 2] | touched[(k0 >> 6) + 3])) return;   // (k_begin is a multiple of 64; uniform)
     if ((t + 1) * W > ncols) {   // (uniform: the zero-padded last panel only -- a per-element test in the loop below cost 35 % of the pass)
         if (k < k_end)
             for (int c = 0; c < W; ++c) s[c][tid] = t * W + c < ncols ? src[(int64_t)c * ldb + k] : 0.f;

@@ -450,3 +450,47 @@ def test_row_slab_of_a_renumbered_matrix_clusters_with_its_row_offset(engine, or
     finally:
         engine.set_option("row_offset", -1)
         _set(engine)
+
+
+def test_exported_row_order_renumbers_a_matrix_into_compact_row_ranges(engine, oracle):
+    """sextans_export_row_order: the clustered plan's row order, for callers that can renumber their matrix once (P A P^T, like RCM).
+    A randomly numbered mesh renumbered by it has full natural-order row blocks again (so contiguous row ranges -- the partition of
+    sextans_dist_spmm -- are compact pieces of the graph), and its SpMM is the same SpMM: bit-identical to cpu_spmm_CSR after the
+    rows of B and C are permuted along."""
+    from sextans_amd import meshgen
+    rp, ci, v, M = _fem(22, 20, 18, 3)
+    rp, ci, v = meshgen.permute_symmetric(rp, ci, v, M, meshgen.node_permutation(M // 3, 3, 21))
+    try:
+        _set(engine)
+        engine.set_matrix_csr(M, M, rp, ci, v)
+        order, kind = engine.export_row_order()
+        assert kind == 2 and np.array_equal(np.sort(order), np.arange(M))
+        nat_random = engine.get_stat("panel_rows_natural")
+        new_of_old = np.empty(M, np.int64); new_of_old[order] = np.arange(M)
+        rp2, ci2, v2 = meshgen.permute_symmetric(rp, ci, v, M, new_of_old)
+        N = 16
+        rs = np.random.RandomState(1)
+        B, C0 = _operands(rs, M, M, N)
+        want = C0.copy()
+        oracle.spmm(M, N, M, ALPHA, rp, ci, v, B, BETA, want)
+        # the renumbered problem: row / column i of the old matrix is row / column new_of_old[i] of the new one
+        B2 = np.ascontiguousarray(B.reshape(N, M)[:, order]).reshape(-1); C2 = np.ascontiguousarray(C0.reshape(N, M)[:, order]).reshape(-1)
+        engine.set_option("row_cluster", 0)                       # natural-order forms only: the numbering itself now has the locality
+        engine.set_matrix_csr(M, M, rp2, ci2, v2)
+        out = C2.copy()
+        engine.spmm(N, ALPHA, B2, BETA, out)
+        # (the new matrix's rows hold the same entries in a different column order: sums may associate differently -- compare against
+        # the oracle ON THE RENUMBERED MATRIX for bits, against the original for the value)
+        want2 = C2.copy()
+        oracle.spmm(M, N, M, ALPHA, rp2, ci2, v2, B2, BETA, want2)
+        assert np.array_equal(out.view(np.uint32), want2.view(np.uint32))
+        assert np.allclose(out.reshape(N, M), want.reshape(N, M)[:, order], rtol=1e-4, atol=1e-4)
+        assert engine.get_stat("panel_rows_natural") < 0.5 * nat_random and M / engine.get_stat("panel_blocks") > 50
+        # a matrix without a clustered order: identity
+        urp, uci, uv = random_csr(rs, 6000, 6000, 9)
+        _set(engine)
+        engine.set_matrix_csr(6000, 6000, urp, uci, uv)
+        order, kind = engine.export_row_order()
+        assert kind == 0 and np.array_equal(order, np.arange(6000))
+    finally:
+        _set(engine)

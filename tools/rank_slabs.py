@@ -77,6 +77,18 @@ _base = api.gen_fem3d_device(0, 110, 110, 110, 3, 3)
 _perm = api.permute_symmetric_device(0, 3_993_000, _base[3], *_base[:3], meshgen.node_permutation(3_993_000 // 3, 3, 1))
 for q in _base[:3]: api.device_free(0, q)
 _slab = lambda r0, r1: api.slice_rows_device(0, r0, r1, *_perm)
+def _renumbered_by_engine():
+    """the randomly numbered matrix renumbered ONCE by the engine's own clustered row order (sextans_export_row_order), in HBM"""
+    import numpy as np
+    e = api.Engine(0)
+    e.set_matrix_csr_device(3_993_000, 3_993_000, _base[3], *_perm)
+    order, kind = e.export_row_order()
+    e.close()
+    new_of_old = np.empty(3_993_000, np.int64); new_of_old[order] = np.arange(3_993_000)
+    q = api.permute_symmetric_device(0, 3_993_000, _base[3], *_perm, new_of_old)
+    return (lambda r0, r1: api.slice_rows_device(0, r0, r1, *q)), kind
+
+
 _all = lambda name, *a: run(name, *a) if ONLY in name else None
 doc = {"what": "per-rank slabs of a row-partitioned SpMM run sequentially on ONE MI355X (tools/rank_slabs.py); not a scaling measurement"
                + (f"; every slab in {CHUNKS} row chunks through sextans_dist_spmm without collectives (its own rows staged and unpacked)" if CHUNKS > 1 else ""),
@@ -84,5 +96,8 @@ doc = {"what": "per-rank slabs of a row-partitioned SpMM run sequentially on ONE
                     _all("fem3d 110x110x110 x 3 dof (natural order)", 3_993_000, 3_993_000, lambda r0, r1: api.gen_fem3d_device(0, 110, 110, 110, 3, 3, r0, r1)),
                     _all("fem3d 110x110x110 x 3 dof, random node order, slabs without their position (row-similarity graph since round 5)", 3_993_000, 3_993_000, _slab, False, 1),
                     _all("fem3d 110x110x110 x 3 dof, random node order, slabs that know their row offset (graph clustering per slab)", 3_993_000, 3_993_000, _slab, True, 1)]}
+if ONLY in "renumbered by the engine":
+    _slab2, _kind = _renumbered_by_engine()
+    doc["matrices"].append(run(f"fem3d 110x110x110 x 3 dof, random node order, renumbered by the engine's clustered row order first (sextans_export_row_order, kind {_kind}), then contiguous row ranges", 3_993_000, 3_993_000, _slab2, False, 1))
 doc["matrices"] = [m for m in doc["matrices"] if m]
 print(json.dumps(doc, indent=1))
