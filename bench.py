@@ -94,6 +94,9 @@ def main():
     if args.only:
         stream0 = torch.cuda.current_stream().cuda_stream
         todo = dict(secondaries(api, torch, dev, stream0, args))
+        if args.only == "list":
+            print(" ".join(todo))
+            return
         if args.only not in todo:
             raise SystemExit("bench.py --only: unknown entry; one of " + ", ".join(todo))
         print(json.dumps({args.only: todo[args.only]()}), flush=True)
@@ -242,9 +245,7 @@ def main():
     # (tools/prof.sh -> profiles/*_traffic.json); only valid for the default single-GPU workload.
     # It is NOT measured in this run: the value and its provenance are reported side by side.
     traffic = traffic_source = None
-    tpath = os.path.join(ROOT, "profiles", "r04_config4_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r03_config4_traffic.json")
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_config4_traffic.json") for r in (5, 4, 3)) if os.path.exists(q)), "")
     if world == 1 and args.rows == 4_000_000 and args.mean_nnz == 40.0 and N == 16 and not args.opt \
             and os.path.exists(tpath):
         tj = json.load(open(tpath))

@@ -731,6 +731,7 @@ int sextans_export_plan(sextans_handle_t h, int lanes_per_row, sextans_packed *o
         SX_HIP(hipMemcpy(cnt.data(), ps.d_dict_ptr, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost));
         SX_HIP(hipMemcpy(bd.data(), ps.d_dict, sizeof(int) * bd.size(), hipMemcpyDeviceToHost));
     }
+#define SX_HIP_OUT(call) do { if ((call) != hipSuccess) { g_last_error = #call; (void)hipGetLastError(); sextans_packed_free(out); return SEXTANS_ERR_HIP; } } while (0)   /* (no leak of the arrays allocated above) */
     auto alloc = [](size_t bytes) { return calloc(bytes ? bytes : 1, 1); };
     out->blk_row = (int *)alloc(sizeof(int) * ((size_t)nblk + 1));
     out->dict_ptr = (int *)alloc(sizeof(int) * ((size_t)nblk + 1));
@@ -754,13 +755,13 @@ int sextans_export_plan(sextans_handle_t h, int lanes_per_row, sextans_packed *o
     out->dict_ptr[nblk] = (int)w;
     for (int r = 0; r < M; ++r) out->row_off[r + 1] = out->row_off[r] + ((rp[(size_t)r + 1] - rp[(size_t)r] + 3) & ~3);
     if (!ps.d_ioff) {
-        SX_HIP(hipMemcpy(out->idx16, ps.d_lidx, sizeof(uint16_t) * L, hipMemcpyDeviceToHost));
+        SX_HIP_OUT(hipMemcpy(out->idx16, ps.d_lidx, sizeof(uint16_t) * L, hipMemcpyDeviceToHost));
     } else {   // index lists shared between consecutive rows: the public form carries every row's own list
         std::vector<uint16_t> comp((size_t)ps.plan_idx_len);
         std::vector<int> ioff((size_t)nblk * RB * 2), sinfo((size_t)nblk * RB * 2);
-        SX_HIP(hipMemcpy(comp.data(), ps.d_lidx, sizeof(uint16_t) * comp.size(), hipMemcpyDeviceToHost));
-        SX_HIP(hipMemcpy(ioff.data(), ps.d_ioff, sizeof(int) * ioff.size(), hipMemcpyDeviceToHost));
-        SX_HIP(hipMemcpy(sinfo.data(), ps.d_row_off, sizeof(int) * sinfo.size(), hipMemcpyDeviceToHost));
+        SX_HIP_OUT(hipMemcpy(comp.data(), ps.d_lidx, sizeof(uint16_t) * comp.size(), hipMemcpyDeviceToHost));
+        SX_HIP_OUT(hipMemcpy(ioff.data(), ps.d_ioff, sizeof(int) * ioff.size(), hipMemcpyDeviceToHost));
+        SX_HIP_OUT(hipMemcpy(sinfo.data(), ps.d_row_off, sizeof(int) * sinfo.size(), hipMemcpyDeviceToHost));
         const unsigned pad = (unsigned)ps.plan_pad_row * 16u * (unsigned)lanes_per_row;
         for (size_t i = 0; i < (size_t)nblk * RB; ++i) {
             const int o0 = sinfo[2 * i], len = sinfo[2 * i + 1], src = ioff[2 * i], shift = ioff[2 * i + 1];
@@ -770,13 +771,14 @@ int sextans_export_plan(sextans_handle_t h, int lanes_per_row, sextans_packed *o
             }
         }
     }
-    SX_HIP(hipMemcpy(out->val, ps.d_pval, sizeof(float) * L, hipMemcpyDeviceToHost));
-    if (ps.plan_mixed) SX_HIP(hipMemcpy(out->col32, ps.d_pcol32, sizeof(int) * L, hipMemcpyDeviceToHost));
+    SX_HIP_OUT(hipMemcpy(out->val, ps.d_pval, sizeof(float) * L, hipMemcpyDeviceToHost));
+    if (ps.plan_mixed) SX_HIP_OUT(hipMemcpy(out->col32, ps.d_pcol32, sizeof(int) * L, hipMemcpyDeviceToHost));
     // device stream: byte offset of the B row in the panel; public form: dictionary index, 0xFFFF in the padding
     const unsigned row_bytes = 16u * (unsigned)lanes_per_row, pad_off = (unsigned)ps.plan_pad_row * row_bytes;
     for (size_t i = 0; i < L; ++i) out->idx16[i] = out->idx16[i] == pad_off ? (uint16_t)0xFFFF : (uint16_t)(out->idx16[i] / row_bytes);
     (void)RB;
     return SEXTANS_OK;
+#undef SX_HIP_OUT
 }
 
 int sextans_reassociated_rows(sextans_handle_t h, int *rows, int capacity, int *count) {

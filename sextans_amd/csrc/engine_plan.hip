@@ -400,6 +400,9 @@ int cluster_grid(sextans_engine *h) {   // 0 = in use, 1 = declined
         cap_used = cap;
         brc = sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, min_reuse, dp, err, d_cut, h->opt_share_index != 0, sets);
         if (sets == 2 && (brc != 0 || dp.mixed || dp.max_dict > sx::kWideMaxDict || dp.dict_stride > 9 * RB)) continue;   // 128-row bricks do not fit the panel
+        // ... which the builder reports as blocks cut by the capacity: it cuts a block when its dictionary is full, so an overflowing
+        // 128-row brick comes back as uneven pieces, not as an error -- then 64-row bricks
+        if (sets == 2 && dp.capacity_cuts > 0) continue;
         if (brc == 0 && sets == 1 && small_panel_fits(h, dp)) {   // short rows, small dictionaries: packed again for a 320-row panel (same blocks, less LDS)
             sx::free_device_plan(dp);
             cap_used = 5 * RB;

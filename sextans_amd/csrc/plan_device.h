@@ -30,6 +30,7 @@ struct DevicePlan {                   // device arrays in exactly the form the L
     float *d_val = nullptr;
     int64_t stream_len = 0;
     int max_dict = 0;
+    int64_t capacity_cuts = 0;        // blocks that ended because the next row's columns no longer fit the dictionary capacity
     int max_row_len = 0;              // longest row of the matrix the plan was built from
     bool mixed = false;
     int64_t nnz_in_panel_blocks = 0;

@@ -87,13 +87,14 @@ __global__ __launch_bounds__(256) void plan_row_off(const int *__restrict__ rp, 
 // ---- pass B: block formation, one workgroup per part
 __global__ __launch_bounds__(256) void plan_blocks(const int *__restrict__ rp, const int *__restrict__ ci, int M, int PR, int RB,
                                                    int cap, double min_reuse, int *__restrict__ pb_row, int *__restrict__ pb_cnt,
-                                                   int *__restrict__ part_nblk, const unsigned char *__restrict__ cut) {
+                                                   int *__restrict__ part_nblk, const unsigned char *__restrict__ cut, int *__restrict__ part_capcuts) {
+    // part_capcuts: blocks of this part that ended because the next row's columns no longer fit the dictionary capacity
     // cut (may be null): rows at which a block MUST start (brick boundaries of the clustered row order, row_cluster.hip)
     __shared__ int keys[kHT], stamp[kHT];
     __shared__ int s_count;
     const int tid = threadIdx.x;
     const int p = blockIdx.x, part_begin = p * PR, part_end = min(M, part_begin + PR);
-    int nb = 0;
+    int nb = 0, capcuts = 0;
     for (int r = part_begin; r < part_end;) {
         for (int i = tid; i < kHT; i += 256) keys[i] = kEmpty;
         if (tid == 0) s_count = 0;
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void plan_blocks(const int *__restrict__ rp, c
             if (over) {                                           // row e does not fit: its keys (stamp == e - r) are not part
                 uniq = before;                                    // of the block; the set is rebuilt for the next block anyway
                 if (e == r) fits = false;                         // a single row already exceeds the panel
+                ++capcuts;
                 break;
             }
             ++e;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void plan_blocks(const int *__restrict__ rp, c
         r = e;
         __syncthreads();
     }
-    if (tid == 0) part_nblk[p] = nb;
+    if (tid == 0) { part_nblk[p] = nb; part_capcuts[p] = capcuts; }
 }
 
 // blocks of all parts -> contiguous arrays + plan statistics
@@ -467,10 +469,15 @@ int build_panel_plan_device(int M, int K, const int *d_rp, const int *d_ci, cons
     PD_HIP(tmp.alloc(&d_pb_cnt, (size_t)nparts * (size_t)PR));
     PD_HIP(tmp.alloc(&d_part_nblk, (size_t)nparts));
     PD_HIP(tmp.alloc(&d_part_blk_base, (size_t)nparts));
+    int *d_part_capcuts = nullptr;
+    PD_HIP(tmp.alloc(&d_part_capcuts, (size_t)nparts));
     hipLaunchKernelGGL(plan_blocks, dim3((unsigned)nparts), dim3(256), 0, nullptr, d_rp, d_ci, M, PR, RBS, max_unique, min_reuse,
-                       d_pb_row, d_pb_cnt, d_part_nblk, d_cut);
-    std::vector<int> h_nblk((size_t)nparts), h_bbase((size_t)nparts);
+                       d_pb_row, d_pb_cnt, d_part_nblk, d_cut, d_part_capcuts);
+    std::vector<int> h_nblk((size_t)nparts), h_bbase((size_t)nparts), h_capcuts((size_t)nparts);
     PD_HIP(hipMemcpy(h_nblk.data(), d_part_nblk, sizeof(int) * (size_t)nparts, hipMemcpyDeviceToHost));
+    PD_HIP(hipMemcpy(h_capcuts.data(), d_part_capcuts, sizeof(int) * (size_t)nparts, hipMemcpyDeviceToHost));
+    out.capacity_cuts = 0;
+    for (int c : h_capcuts) out.capacity_cuts += c;
     long long nblk = 0;
     for (int p = 0; p < nparts; ++p) { h_bbase[(size_t)p] = (int)nblk; nblk += h_nblk[(size_t)p]; }
     PD_HIP(hipMemcpy(d_part_blk_base, h_bbase.data(), sizeof(int) * (size_t)nparts, hipMemcpyHostToDevice));

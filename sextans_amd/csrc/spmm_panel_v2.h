@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? (BCOL && DCAP == 9 ? SX_V
     // copied by the 4 lanes of `slot`, a wave's 64 lanes write 1 KiB of consecutive LDS; rows past the dictionary stay
     // unwritten and are never read).
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool cvalid = H != 1 || 4 * q < last_cols;   // my 4 columns exist in the last tile too
+    const bool cvalid = BCOL || H != 1 || 4 * q < last_cols;   // my 4 columns exist in the last tile too (column-major staging never merges a tail)
     auto dma_panel = [&](int st) {
 #pragma unroll
         for (int u = 0; u < MAXD; ++u)

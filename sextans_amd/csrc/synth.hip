@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "graph_cluster.h"
+#include "plan_device.h"
 #include "row_cluster.h"
 #include "sextans_amd.h"
 #include "thread_stream.h"
@@ -762,6 +763,12 @@ int sextans_csr_permute_symmetric_device(int device, int M, int64_t nnz, const i
                                          const int *new_of_old, int **o_row_ptr, int **o_col_idx, float **o_val) {
     if (M < 0 || nnz < 0 || !d_row_ptr || !new_of_old || !o_row_ptr || !o_col_idx || !o_val) return SEXTANS_ERR_INVALID;
     SY_HIP(hipSetDevice(device));
+    {   // a public entry point: the columns are relabelled through a table of M entries, so they must be rows
+        int bad = 0;
+        std::string verr;
+        if (M > 0 && sx::validate_csr_device(M, M, nnz, d_row_ptr, d_col_idx, &bad, verr)) return SEXTANS_ERR_HIP;
+        if (bad) return (bad & 1) ? SEXTANS_ERR_INVALID : SEXTANS_ERR_INDEX;
+    }
     std::vector<int> old_of_new((size_t)M, -1), rp((size_t)M + 1);
     for (int i = 0; i < M; ++i) {
         const int p = new_of_old[i];
