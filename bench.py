@@ -366,6 +366,8 @@ def secondaries(api, torch, dev, stream, args):
                         ("holdout_kron_nasa4704_4M_unsym_N16", lambda: holdout_secondary(api, torch, dev, stream, 16, 40, variant="unsym")),
                         ("fem27pt_1dof_4M_N16", lambda: fem_secondary(api, torch, dev, stream, (160, 160, 160, 1), 16, 50)),
                         ("stencil2d_5pt_4M_N16", lambda: stencil_secondary(api, torch, dev, stream, 2000, 2000, 5, 16, 50)),
+                        ("rowmajor_stencil2d_5pt_4M_N16", lambda: stencil_secondary(api, torch, dev, stream, 2000, 2000, 5, 16, 50, layout="rm")),
+                        ("rowmajor_fem27pt_1dof_4M_N16", lambda: fem_secondary(api, torch, dev, stream, (160, 160, 160, 1), 16, 50, layout="rm")),
                         ("stencil2d_9pt_4M_N16", lambda: stencil_secondary(api, torch, dev, stream, 2000, 2000, 9, 16, 50)),
                         ("config5_blocked_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream)),
                         ("blockbanded_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream, banded_half_width=127)),
@@ -478,7 +480,8 @@ def _measure(api, torch, e, M, K, N, nnz, dev, stream, iters, layout="cm"):
         out["post_us"] = round(post_ns / 1e3, 2)
     state = int(e.get_stat("row_cluster"))
     if state > 0:
-        out["row_order"] = {1: "grid bricks", 2: "graph clustering (reordered form)"}[state]
+        out["row_order"] = {1: "runs of 16 rows clustered over the graph of runs" if e.get_stat("cluster_runs") else "grid bricks",
+                            2: "graph clustering"}[state]
         out["panel_rows_natural"] = int(e.get_stat("panel_rows_natural"))
         out["panel_rows_clustered"] = int(e.get_stat("panel_rows_clustered"))
     return out
@@ -697,13 +700,13 @@ def holdout_secondary(api, torch, dev, stream, N, iters, n=850, variant="", numb
     return out
 
 
-def stencil_secondary(api, torch, dev, stream, nx, ny, points, N, iters):
+def stencil_secondary(api, torch, dev, stream, nx, ny, points, N, iters, layout="cm"):
     """2-D stencil on an nx x ny grid (short rows: 5 or 9 entries): 5-point runs on spmm_csr_colwise (no B repack)."""
     M = K = nx * ny
     p, i, v, nnz = api.gen_stencil2d_device(dev.index, nx, ny, points, 1, 3)
     e = api.Engine(dev.index)
     e.set_matrix_csr_device(M, K, nnz, p, i, v)
-    out = _measure(api, torch, e, M, K, N, nnz, dev, stream, iters)
+    out = _measure(api, torch, e, M, K, N, nnz, dev, stream, iters, layout)
     out["matrix"] = f"2-D {points}-point stencil {nx}x{ny}"
     e.close()
     for q in (p, i, v):

@@ -274,6 +274,12 @@ int sextans_destroy(sextans_handle_t h);
  *   every row <= 32 entries -- use 128-row bricks as two 64-slot row sets on one panel; 3 = 2-D grids too; 1 = never; stat
  *   "row_sets"), "refine_sweeps" (8) / "refine_rows" (62): block refinement of the graph-clustered order, "relabel_columns" (1),
  *   "cluster_top" (depth of the merge tree).
+ * "run_cluster" (default 0 = off; 1 = when it copies >= 10 % fewer panel rows; 2 = always): run-level clustering -- matrices in a
+ *   numbering WITH locality whose natural row blocks are cut short by the panel capacity and whose graph-clustered plan is not worth
+ *   the reordered form's passes ("cluster_decline" 12) keep runs of 16 consecutive rows together and build each row block from up to 4
+ *   runs chosen over the graph of runs (no staging, natural B panels; stat "cluster_runs").  Built and measured in round 5: 11.6 % fewer
+ *   panel rows on the holdout class, kernel 687 -> 706 us (the C accesses become 64-byte runs, neighbouring blocks stop sharing B lines
+ *   in L2): OFF by default, kept as a tested negative result.
  * "row_similarity" (-1 auto / 0 never / 1 always): which graph form (2) clusters the rows over.  A square matrix with a symmetric
  *   pattern is its own graph (column c = row c).  RECTANGULAR matrices have no such reading: their rows are joined to the 16 rows that share the most columns with them
  *   (found through the transposed pattern, csrc/graph_cluster.hip: row_similarity_graph_device) -- the reference schedules any

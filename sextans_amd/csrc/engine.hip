@@ -431,6 +431,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "relabel_columns")) return &h->opt_relabel_columns;
     if (!strcmp(key, "row_similarity")) return &h->opt_row_similarity;
     if (!strcmp(key, "reordered_xcd")) return &h->opt_reordered_xcd;
+    if (!strcmp(key, "run_cluster")) return &h->opt_run_cluster;
     if (!strcmp(key, "refine_sweeps")) return &h->opt_refine_sweeps;
     if (!strcmp(key, "share_index")) return &h->opt_share_index;
     if (!strcmp(key, "refine_rows")) return &h->opt_refine_rows;
@@ -482,7 +483,7 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
         (void)hipSetDevice(h->device);
         free_window(h);   // the stream is built for one (rows per wavefront, window) pair
     }
-    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_top || slot == &h->opt_small_panel || slot == &h->opt_row_sets || slot == &h->opt_row_offset || slot == &h->opt_relabel_columns || slot == &h->opt_row_similarity || slot == &h->opt_refine_sweeps || slot == &h->opt_refine_rows || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
+    if ((slot == &h->opt_row_cluster || slot == &h->opt_cluster_top || slot == &h->opt_small_panel || slot == &h->opt_row_sets || slot == &h->opt_row_offset || slot == &h->opt_relabel_columns || slot == &h->opt_row_similarity || slot == &h->opt_run_cluster || slot == &h->opt_refine_sweeps || slot == &h->opt_refine_rows || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_min_reuse_x100 || slot == &h->opt_min_reuse_wide_x100) && *slot != value) {
         (void)hipSetDevice(h->device);   // the clustered-order plan is (re)considered under the new setting
         free_cluster_plan(h);
         h->cluster_rm_tried = false;
@@ -689,6 +690,7 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "cluster_decline")) *value = (double)h->cluster_decline;
     else if (!strcmp(key, "graph_fallbacks")) *value = (double)h->graph_fallbacks;   // rp_time loops launched one by one because their hipGraph capture was invalidated from outside
     else if (!strcmp(key, "cluster_graph_kind")) *value = (double)h->cluster_graph_kind;
+    else if (!strcmp(key, "cluster_runs")) *value = h->cluster_runs ? 1.0 : 0.0;
     else if (!strcmp(key, "pattern_symmetry")) *value = h->pattern_symmetry;
     else if (!strcmp(key, "col_range_lo")) *value = (double)h->col_lo;
     else if (!strcmp(key, "col_range_hi")) *value = (double)h->col_hi;
@@ -1228,7 +1230,7 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
     if (int rc = prepare(h, Nplan, plan, W, use_panel, use_window, true)) return rc;
     // A clustered plan that was declined only because the column-major form has to pay two passes over C for it (decline 12) is
     // reconsidered for this layout, where it costs nothing: built once, used by row-major calls only unless it pays for both.
-    if (h->cluster_state == -1 && h->cluster_decline == 12 && !h->cluster_rm_tried && W == 16 && h->opt_row_cluster < 0) {
+    if ((h->cluster_state == -1 || h->cluster_runs) && h->cluster_decline == 12 && !h->cluster_rm_tried && W == 16 && h->opt_row_cluster < 0) {
         h->cluster_rm_tried = true;
         free_cluster_plan(h);
         h->cluster_for_rm = true;
@@ -1260,6 +1262,20 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
             SX_HIP(hipStreamSynchronize(s));
             (void)hipFree(colinv);
         }
+    }
+    if (colwise && aligned && h->nhub == 0 && h->nchain == 0 && h->dense_W == 0 && h->m_nnz > 0) {   // short rows in a local numbering: lane per row, 16-byte accesses
+        Prof p(h, &h->ev_kernel, s);
+        const int nrowblk = (h->M + sx::kBlock - 1) / sx::kBlock;
+        auto go = [&](auto kern, int col0, int ntiles) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)nrowblk, (unsigned)ntiles), dim3(sx::kBlock), 0, s, h->m_rp, h->m_ci, h->m_v, d_B, ldb, d_C_in, ldc_in, d_C_out,
+                               ldc, 0, h->M, nrowblk, col0, alpha, beta, (int)h->opt_xcd, (const unsigned char *)h->d_skip);
+        };
+        const int n16 = N / 16;
+        if (n16 > 0) { if (h->opt_exact) go(sx::spmm_csr_colwise<true, 16, true>, 0, n16); else go(sx::spmm_csr_colwise<false, 16, true>, 0, n16); }
+        if (N % 16) { if (h->opt_exact) go(sx::spmm_csr_colwise<true, 8, true>, n16 * 16, 1); else go(sx::spmm_csr_colwise<false, 8, true>, n16 * 16, 1); }
+        h->last_kernel = "spmm_csr_colwise_rowmajor";
+        SX_HIP(hipGetLastError());
+        return SEXTANS_OK;
     }
     if (mode >= 0) {
         Prof p(h, &h->ev_kernel, s);

@@ -31,6 +31,7 @@ void free_cluster_plan(sextans_engine *h) {   // the clustered-order plan and it
     (void)hipFree(h->d_slot_row); (void)hipFree(h->d_colpos); (void)hipFree(h->d_dict_nat);
     h->d_slot_row = h->d_colpos = h->d_dict_nat = nullptr;
     h->cluster_cm_pays = true;
+    h->cluster_runs = false;
     (void)hipFree(h->d_chain_ci_perm); (void)hipFree(h->d_chain_beg_c); (void)hipFree(h->d_chain_v_c);
     h->d_chain_ci_perm = h->d_chain_beg_c = nullptr; h->d_chain_v_c = nullptr;
     h->cluster_state = 0;
@@ -425,6 +426,46 @@ int cluster_grid(sextans_engine *h) {   // 0 = in use, 1 = declined
     return 0;
 }
 
+// Run-level clustering (round 5; graph_cluster.hip: run_graph_device): the rows stay in runs of 16 consecutive rows -- a wavefront's 16
+// row slots, so C is accessed exactly as in natural order and B needs no permutation -- and a row block is 4 runs chosen over the graph
+// of runs.  For matrices whose numbering has locality but whose natural blocks are cut short by the panel capacity (real FEM files in
+// their file order, RCM orders): the graph-clustered plan copies 25-40 % fewer panel rows there, not enough to pay for the reordered
+// form's passes (decline 12); this form has no passes.  Uses the grid-brick machinery (slot -> row table, cluster_state 1).
+int cluster_runs(sextans_engine *h) {   // 0 = in use, 1 = declined
+    if (!h->ps.plan_built || h->ps.plan_lpr != 4 || h->ps.plan_mixed || h->M != h->K || h->M < 65536 || h->ps.plan_nblk <= 0) return 1;
+    if ((double)h->M / h->ps.plan_nblk >= 56.0 || h->dense_W > 0) return 1;               // natural blocks (nearly) full: nothing to gain
+    const int lpr = 4, RB = sx::kBlock / lpr, cap = kPanelFloats / (4 * lpr), run = 16;
+    std::string err;
+    int *g_rp = nullptr, *g_ci = nullptr, *s_rp = nullptr, *s_ci = nullptr, *d_order_r = nullptr, *d_order = nullptr, *prp = nullptr, *pci = nullptr;
+    unsigned char *d_cut = nullptr, *g_w = nullptr, *s_w = nullptr;
+    float *pv = nullptr;
+    sx::DevicePlan dp;
+    auto drop = [&]() { for (void *q : {(void *)g_rp, (void *)g_ci, (void *)s_rp, (void *)s_ci, (void *)d_order_r, (void *)d_order, (void *)prp, (void *)pci, (void *)d_cut, (void *)pv, (void *)g_w, (void *)s_w}) (void)hipFree(q);
+                        sx::free_device_plan(dp); (void)hipGetLastError(); return 1; };
+    int64_t g_nnz = 0, s_nnz = 0;
+    int Mr = 0;
+    if (sx::run_graph_device(h->M, run, h->m_rp, h->m_ci, &g_rp, &g_ci, &g_w, &g_nnz, &Mr, err)) return drop();
+    if (sx::symmetrize_graph_device(Mr, g_nnz, g_rp, g_ci, g_w, &s_rp, &s_ci, &s_w, &s_nnz, err)) return drop();   // (the matching needs symmetric weights)
+    // (blocks = the clusters of the level at which they hold up to 4 runs: cutting the final order every 4 runs would straddle them)
+    int *d_group = nullptr;
+    if (sx::cluster_rows_graph_device(Mr, Mr, s_nnz, s_rp, s_ci, (int)std::min<int64_t>(h->opt_cluster_top, 0x40000000), &d_order_r, err, s_w, RB / run, &d_group)) return drop();
+    const int erc = sx::expand_run_order_device(h->M, Mr, run, RB / run, d_order_r, d_group, &d_order, &d_cut, err);
+    (void)hipFree(d_group);
+    if (erc) return drop();
+    if (sx::permute_csr_rows_device(h->M, h->m_nnz, h->m_rp, h->m_ci, h->m_v, d_order, &prp, &pci, &pv, err)) return drop();
+    const double min_reuse = std::min((double)h->opt_min_reuse_x100, (double)h->opt_min_reuse_wide_x100) / 100.0;
+    if (sx::build_panel_plan_device(h->M, h->K, prp, pci, pv, lpr, cap, min_reuse, dp, err, d_cut, h->opt_share_index != 0) != 0) return drop();
+    if (dp.mixed || dp.dict_stride > 9 * RB || dp.max_dict > sx::kWideMaxDict) return drop();
+    h->cluster_total_dict = dp.total_dict;
+    if (h->opt_run_cluster < 2 && (double)dp.total_dict > 0.9 * (double)h->plan_total_dict) return drop();   // (>= 10 % fewer panel rows; "run_cluster" = 2 keeps it regardless: measurements)
+    if (sx::build_slot_rows_device(dp.nblk, RB, dp.d_blk_row, d_order, &h->d_slot_row, err)) return drop();
+    adopt_device_plan(h->psc, dp, h, lpr, cap);
+    h->psc.plan_panel_frac = h->ps.plan_panel_frac;
+    h->psc.plan_narrow_frac = h->ps.plan_narrow_frac;
+    for (void *q : {(void *)g_rp, (void *)g_ci, (void *)s_rp, (void *)s_ci, (void *)d_order_r, (void *)d_order, (void *)prp, (void *)pci, (void *)d_cut, (void *)pv, (void *)g_w, (void *)s_w}) (void)hipFree(q);
+    return 0;
+}
+
 int cluster_graph(sextans_engine *h) {   // 0 = in use, else declined: the reason (stat "cluster_decline")
     // Which graph are the rows clustered over?
     //   (a) square matrix with a (nearly) symmetric pattern: the matrix itself, a column index read as the row of the neighbour;
@@ -673,6 +714,10 @@ int ensure_cluster_plan(sextans_engine *h) {
             }
         }
     } else if ((h->cluster_decline = cluster_graph(h)) == 0) h->cluster_state = 2;
+    else if (h->cluster_decline == 12 && h->opt_row_cluster < 0 && h->opt_run_cluster != 0 && cluster_runs(h) == 0) {
+        h->cluster_state = 1;     // the slot -> row machinery of the grid bricks; the graph plan stays declined (12) for column-major calls
+        h->cluster_runs = true;
+    }
     if (h->cluster_state == 2 && h->nchain > 0 && h->d_colpos) {
         // the exact-chain kernels read B rows by column index: for the permuted panels of the reordered form they get the chain rows'
         // entries once more, compact, with relabelled columns (a few thousand entries)
@@ -1007,7 +1052,10 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
                 if (int rc = ensure(&h->d_Cs, &h->Cs_cap, (n16 / 16) * (size_t)h->M * 16)) return rc;
         }
         use_panel = h->ps.plan_built && ((h->opt_kernel == 2) || (h->ps.plan_panel_frac >= 0.5 && (N >= 32 || h->ps.plan_narrow_frac >= 0.5)));
-        if (n8_wide && !(use_panel && !h->ps.plan_mixed && h->ps.plan_max_dict <= sx::kWideMaxDict)) {   // not a case for the wide kernel after all
+        // (a matrix that runs in the reordered form needs no natural-order plan for that: a randomly numbered mesh without any reuse between
+        // consecutive rows has none -- its N = 8 calls fell to the gather kernel, 0.06 against 0.37 at N = 16 on the holdout class)
+        const bool reorder8 = whole && h->cluster_state == 2 && h->cluster_cm_pays && h->opt_kernel != 1 && h->opt_kernel != 3;
+        if (n8_wide && !reorder8 && !(use_panel && !h->ps.plan_mixed && h->ps.plan_max_dict <= sx::kWideMaxDict)) {   // not a case for the wide kernel after all
             n8_wide = false;
             lpr = 4;
             tiles();

@@ -102,6 +102,7 @@ struct sextans_engine {
     int64_t cluster_ref_dict = 0;       // panel rows of the grid-brick plan while the graph plan is weighed against it (ensure_cluster_plan)
     int *d_slot_row = nullptr;          // psc: row of the main matrix per (block, slot)
     int *d_dict_nat = nullptr;          // psc, graph clustering: the block dictionaries in the CALLER's column numbers (row-major calls read B where it lies)
+    bool cluster_runs = false;          // cluster_state 1 by run-level clustering (runs of 16 consecutive rows over the graph of runs), not grid bricks
     bool cluster_for_rm = false;        // the plan is being (re)considered for row-major calls: no passes over C to pay for
     bool cluster_rm_tried = false;      //   ... once per matrix
     bool cluster_cm_pays = true;        // the graph-clustered plan also serves column-major calls (>= 40 % fewer panel rows: it pays two passes over C)
@@ -215,6 +216,7 @@ struct sextans_engine {
     int64_t opt_share_index = 1;        // plans at 4 lanes per row: consecutive rows with identical 16-bit index lists (dof rows of a mesh node) share one copy
     int64_t opt_refine_rows = 62;       // ... rows per block before the refinement (64 - room for rows that move in)
     int64_t opt_refine_sweeps = 8;      // graph clustering: sweeps of the block refinement (0 = blocks are runs of 64 rows of the merge-tree order)
+    int64_t opt_run_cluster = 0;        // run-level clustering for matrices whose graph plan is not worth the reordered form: 0 off (measured: no gain), 1 when >= 10 % fewer panel rows, 2 always
     int64_t opt_reordered_xcd = -1;     // measurement switch: workgroup placement of the reordered form (0 round-robin over the XCDs, 1 contiguous chunks, -1 the built-in rule)
     int64_t opt_row_similarity = -1;    // graph clustering over the row-similarity graph: -1 when the matrix is rectangular or its pattern unsymmetric, 0 never, 1 always
     int64_t opt_relabel_columns = 1;    // graph clustering: B rows relabelled in first-touch order (permuted panels); 0 = natural panels

@@ -29,7 +29,9 @@ int probe_row_coherence_device(int M, const int *d_rp, const int *d_ci, int nsam
 // d_weights (optional): one byte per entry of the pattern, the weight of that edge, instead of the shared-neighbourhood count
 // computed here (the row-similarity graph below brings its own).
 int cluster_rows_graph_device(int M, int K, int64_t nnz, const int *d_rp, const int *d_ci, int max_cluster_rows, int **d_order,
-                              std::string &err, const unsigned char *d_weights = nullptr);
+                              std::string &err, const unsigned char *d_weights = nullptr, int snapshot_limit = 0, int **d_snapshot = nullptr);
+// (d_snapshot, optional: cluster number of every row at the level where clusters hold up to snapshot_limit rows; later levels only
+// concatenate whole clusters, so in the final order a change of that number is a cluster boundary.  M ints on the device, caller frees.)
 
 // Row-similarity graph of a RECTANGULAR matrix (the reference schedules any M x K matrix: sparse_helper.h:345-403): row r joined to
 // the 16 rows that share the most columns with it (found through the transposed pattern), weight = shared columns.  A square
@@ -64,6 +66,16 @@ int local_square_pattern_device(int M, const int *d_rp, const int *d_ci, int row
 // frees.  Returns 0 = built, 1 = declined (empty / too large), 2 = HIP error.
 int symmetrize_graph_device(int M, int64_t nnz, const int *d_rp, const int *d_ci, const unsigned char *d_w, int **s_rp, int **s_ci,
                             unsigned char **s_w, int64_t *s_nnz, std::string &err);
+
+// Graph of RUNS of `run` consecutive rows (node R = rows [R run, R run + run), R -> c / run for every entry, deduplicated, no self
+// loops) and the expansion of an order of the runs into an order of the rows (+ block cuts every `runs_per_block` runs): the
+// run-level clustering of engine_plan.hip (cluster_runs) -- matrices in a numbering with locality whose row blocks are cut short by
+// the panel capacity get blocks of 4 well-chosen runs instead of 64 consecutive rows, without the reordered form's passes.
+// run_graph_device: 0 = built, 1 = declined (a run with more than 512 neighbouring runs, too few rows), 2 = HIP error.
+int run_graph_device(int M, int run, const int *d_rp, const int *d_ci, int **r_rp, int **r_ci, unsigned char **r_w, int64_t *r_nnz, int *Mr_out,
+                     std::string &err);   // r_w: entries of the run's rows that lie in the neighbouring run (1 .. 255)
+int expand_run_order_device(int M, int Mr, int run, int runs_per_block, const int *d_order_r, const int *d_group, int **d_order, unsigned char **d_cut,
+                            std::string &err);
 
 // in place: ci[j] = colpos[ci[j]]
 int relabel_columns_device(int64_t nnz, int *d_ci, const int *d_colpos, std::string &err);

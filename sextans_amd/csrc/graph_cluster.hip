@@ -604,9 +604,19 @@ int probe_row_coherence_device(int M, const int *d_rp, const int *d_ci, int nsam
     return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void snapshot_clusters(int M, const int2 *__restrict__ cinfo, int *__restrict__ id) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < M) id[r] = cinfo[r].x;
+}
+}  // namespace
+
 int cluster_rows_graph_device(int M, int K, int64_t nnz, const int *d_rp, const int *d_ci, int max_cluster_rows, int **d_order,
-                              std::string &err, const unsigned char *d_weights) {
+                              std::string &err, const unsigned char *d_weights, int snapshot_limit, int **d_snapshot) {
     *d_order = nullptr;
+    int *snap = nullptr;
+    bool snapped = false;
+    if (d_snapshot) *d_snapshot = nullptr;
     if (M != K || M < 2 || nnz <= 0) return 1;
     Scratch tmp;
     unsigned char *t = nullptr;
@@ -615,6 +625,7 @@ int cluster_rows_graph_device(int M, int K, int64_t nnz, const int *d_rp, const 
     int *cand = nullptr, *matched = nullptr, *want = nullptr, *mate = nullptr, *is_leader = nullptr, *new_idx = nullptr, *new_size = nullptr,
         *new_start = nullptr;
     GC_HIP(tmp.alloc(&t, (size_t)nnz));
+    if (d_snapshot) GC_HIP(tmp.alloc(&snap, (size_t)M));
     for (int i = 0; i < 2; ++i) {
         GC_HIP(tmp.alloc(&ord[i], (size_t)M));
         GC_HIP(tmp.alloc(&cstart[i], (size_t)M + 1));
@@ -689,14 +700,20 @@ int cluster_rows_graph_device(int M, int K, int64_t nnz, const int *d_rp, const 
         }
         cur ^= 1;
         if (nc_new <= 0 || nc_new > nc) { err = "graph clustering: inconsistent level"; return 2; }
+        if (snap && !snapped && limit >= snapshot_limit) {   // cluster of every row once clusters hold up to snapshot_limit rows: later levels only concatenate (and reverse) whole clusters
+            hipLaunchKernelGGL(snapshot_clusters, dim3(blocks_for(M, 256)), dim3(256), 0, nullptr, M, cinfo[cur], snap);
+            snapped = true;
+        }
         const bool stalled = nc_new == nc || (limit >= 4096 && (long long)(nc - nc_new) * 32 < nc);
         nc = nc_new;
         if (stalled && limit >= 64) break;   // nothing (or only a trickle) merges any more: disconnected pieces, rows without neighbours
     }
+    if (snap && !snapped) hipLaunchKernelGGL(snapshot_clusters, dim3(blocks_for(M, 256)), dim3(256), 0, nullptr, M, cinfo[cur], snap);
     GC_HIP(hipDeviceSynchronize());
     GC_HIP(hipGetLastError());
     tmp.keep(ord[cur]);
     *d_order = ord[cur];
+    if (snap) { tmp.keep(snap); *d_snapshot = snap; }
     return 0;
 }
 
@@ -1119,6 +1136,129 @@ int symmetrize_graph_device(int M, int64_t nnz, const int *d_rp, const int *d_ci
     tmp.keep(orp); tmp.keep(oci);
     if (ow) { tmp.keep(ow); *s_w = ow; }
     *s_rp = orp; *s_ci = oci; *s_nnz = total;
+    return 0;
+}
+
+// ---- run graph ---------------------------------------------------------------------------------------------------------------
+// A matrix in a numbering WITH locality (a SuiteSparse file in the order its generator wrote, RCM) whose row blocks are nevertheless
+// cut short by the panel capacity: 64 CONSECUTIVE rows are a 1-D run of the numbering and share less than 64 well-chosen rows would
+// (holdout class: 11.7 dictionary rows per matrix row in file order, 7.4 fully clustered).  The full clustering pays for its gain
+// with the reordered form -- C rows scattered, two passes over C through a staging buffer -- which needs >= 40 % fewer panel rows to
+// win.  The middle way keeps the numbering's locality where the kernel needs it: the units that are clustered are RUNS of `run`
+// consecutive rows (one wavefront's 16 row slots: its C accesses stay 64-byte runs per column, no staging, natural B panels), and a
+// row block is 4 runs chosen over the graph of runs.  This builds that graph: node R = rows [R run, R run + run); R -> c / run for
+// every entry of its rows, deduplicated, self loops dropped.  One wavefront per run, LDS hash set, count pass + fill pass.
+namespace {
+constexpr int kRunHT = 1024;      // hash slots per run (<= 512 distinct neighbouring runs)
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void run_graph_rows(int Mr, int run, const int *__restrict__ rp, const int *__restrict__ ci, int *__restrict__ cnt,
+                                                      const int *__restrict__ out_rp, int *__restrict__ out_ci, unsigned char *__restrict__ out_w,
+                                                      int *__restrict__ overflow) {
+    // out_w: how many entries of the run's rows lie in the neighbouring run (1 .. 255): runs that are strongly connected share their
+    // neighbourhood -- with unit weights every neighbouring run of a mesh ties
+    __shared__ int tabs[4][kRunHT];
+    __shared__ int cnts[4][kRunHT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int R = blockIdx.x * 4 + wave;
+    if (R >= Mr) return;
+    int *tab = tabs[wave], *cc = cnts[wave];
+    for (int i = lane; i < kRunHT; i += 64) { tab[i] = -1; cc[i] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    const int j0 = rp[R * run], j1 = rp[(R + 1) * run];
+    int distinct = 0;
+    for (int base = j0; base < j1; base += 64) {          // (whole wavefronts: the ballot below)
+        const int j = base + lane;
+        bool fresh = false;
+        if (j < j1) {
+            const int q = ci[j] / run;
+            if (q != R && q < Mr) {
+                unsigned h = mix32((unsigned)q) & (kRunHT - 1);
+                for (int probe = 0; probe < kRunHT; ++probe) {
+                    const int prev = atomicCAS(&tab[h], -1, q);
+                    if (prev == -1 || prev == q) { fresh = prev == -1; if (FILL) atomicAdd(&cc[h], 1); break; }
+                    h = (h + 1) & (kRunHT - 1);
+                }
+            }
+        }
+        distinct += (int)__popcll(__ballot(fresh));
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (!FILL) {
+        if (lane == 0) { cnt[R] = distinct; if (distinct > kRunHT / 2) atomicAdd(overflow, 1); }
+        return;
+    }
+    int o = out_rp[R];
+    for (int i0 = 0; i0 < kRunHT; i0 += 64) {
+        const int q = tab[i0 + lane];
+        const unsigned long long m = __ballot(q >= 0);
+        if (q >= 0) {
+            const int at = o + (int)__popcll(m & ((1ull << lane) - 1ull));
+            out_ci[at] = q;
+            out_w[at] = (unsigned char)min(255, max(1, cc[i0 + lane]));
+        }
+        o += (int)__popcll(m);
+    }
+}
+// order[i * run + j] = order_r[i] * run + j; rows past the last whole run keep their places at the end; cut = 1 every `per` runs
+__global__ __launch_bounds__(256) void expand_run_order(int M, int Mr, int run, int per, const int *__restrict__ order_r, const int *__restrict__ group,
+                                                        int *__restrict__ order, unsigned char *__restrict__ cut) {
+    // group (may be null): cluster of every run at the level where clusters hold up to `per` runs -- a block starts where it changes
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= M) return;
+    const int i = p / run, j = p % run;
+    order[p] = i < Mr ? order_r[i] * run + j : p;
+    bool c = j == 0 && (i == 0 || i == Mr);
+    if (j == 0 && i > 0 && i < Mr) c = group ? group[order_r[i]] != group[order_r[i - 1]] : i % per == 0;
+    cut[p] = c ? 1 : 0;
+}
+}  // namespace
+
+int run_graph_device(int M, int run, const int *d_rp, const int *d_ci, int **r_rp, int **r_ci, unsigned char **r_w, int64_t *r_nnz, int *Mr_out,
+                     std::string &err) {
+    *r_rp = *r_ci = nullptr; *r_w = nullptr; *r_nnz = 0; *Mr_out = 0;
+    const int Mr = M / run;
+    if (Mr < 2 || run < 1) return 1;
+    Scratch tmp;
+    int *cnt = nullptr, *orp = nullptr, *oci = nullptr, *d_over = nullptr;
+    unsigned char *ow = nullptr;
+    GC_HIP(tmp.alloc(&cnt, (size_t)Mr + 1));
+    GC_HIP(tmp.alloc(&orp, (size_t)Mr + 1));
+    GC_HIP(tmp.alloc(&d_over, 1));
+    GC_HIP(hipMemsetAsync(d_over, 0, sizeof(int), nullptr));
+    GC_HIP(hipMemsetAsync(cnt + Mr, 0, sizeof(int), nullptr));
+    hipLaunchKernelGGL(run_graph_rows<false>, dim3(blocks_for(Mr, 4)), dim3(256), 0, nullptr, Mr, run, d_rp, d_ci, cnt, (const int *)nullptr, (int *)nullptr, (unsigned char *)nullptr, d_over);
+    void *scan_tmp = nullptr;
+    size_t bytes = 0;
+    GC_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, cnt, orp, Mr + 1, nullptr));
+    GC_HIP(tmp.alloc((char **)&scan_tmp, bytes));
+    GC_HIP(hipcub::DeviceScan::ExclusiveSum(scan_tmp, bytes, cnt, orp, Mr + 1, nullptr));
+    int total = 0, over = 0;
+    GC_HIP(hipMemcpy(&total, orp + Mr, sizeof(int), hipMemcpyDeviceToHost));
+    GC_HIP(hipMemcpy(&over, d_over, sizeof(int), hipMemcpyDeviceToHost));
+    if (over || total <= 0) return 1;                     // (runs with more than 512 neighbouring runs: not a matrix for this)
+    GC_HIP(tmp.alloc(&oci, (size_t)total));
+    GC_HIP(tmp.alloc(&ow, (size_t)total));
+    hipLaunchKernelGGL(run_graph_rows<true>, dim3(blocks_for(Mr, 4)), dim3(256), 0, nullptr, Mr, run, d_rp, d_ci, (int *)nullptr, orp, oci, ow, (int *)nullptr);
+    GC_HIP(hipDeviceSynchronize());
+    GC_HIP(hipGetLastError());
+    tmp.keep(orp); tmp.keep(oci); tmp.keep(ow);
+    *r_rp = orp; *r_ci = oci; *r_w = ow; *r_nnz = total; *Mr_out = Mr;
+    return 0;
+}
+
+int expand_run_order_device(int M, int Mr, int run, int runs_per_block, const int *d_order_r, const int *d_group, int **d_order, unsigned char **d_cut,
+                            std::string &err) {
+    *d_order = nullptr; *d_cut = nullptr;
+    Scratch tmp;
+    int *o = nullptr;
+    unsigned char *c = nullptr;
+    GC_HIP(tmp.alloc(&o, (size_t)M));
+    GC_HIP(tmp.alloc(&c, (size_t)M));
+    hipLaunchKernelGGL(expand_run_order, dim3(blocks_for(M, 256)), dim3(256), 0, nullptr, M, Mr, run, runs_per_block, d_order_r, d_group, o, c);
+    GC_HIP(hipDeviceSynchronize());
+    tmp.keep(o); tmp.keep(c);
+    *d_order = o; *d_cut = c;
     return 0;
 }
 

@@ -29,7 +29,10 @@ namespace sx {
 
 // rows [row_begin, row_end); C pointers address row_begin as their row 0; grid = (row blocks of 256) x tiles of NC columns from col_base, row blocks
 // spread over the XCDs in contiguous chunks (neighbouring row blocks share B lines in L2).
-template <bool EXACT, int NC>   // NC = columns of a tile: 16, or 8 for a remainder tile
+// RM (round 5): ROW-major operands (sextans_spmm_device_rm) -- B[c * ldb + n], C[r * ldc + n]: the NC values of a B row and of a C row are
+// contiguous, so every access is a 16-byte load / store (4 per entry instead of 16 four-byte ones) and a wavefront's C rows are one
+// contiguous 4 KB run.
+template <bool EXACT, int NC, bool RM = false>   // NC = columns of a tile: 16, or 8 for a remainder tile
 __global__ __launch_bounds__(kBlock) void spmm_csr_colwise(const int *__restrict__ rp, const int *__restrict__ ci, const float *__restrict__ va,
                                                            const float *__restrict__ B, int64_t ldb, const float *Cin, int64_t ldc_in, float *Cout,
                                                            int64_t ldc, int row_begin, int row_end, int nrowblk, int col_base, float alpha, float beta,
@@ -40,7 +43,19 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_colwise(const int *__restrict
     if (r >= row_end) return;
     const int tile = blockIdx.y;
     const int col0 = col_base + tile * NC;
-    const float *b = B + (int64_t)col0 * ldb;
+    const float *b = RM ? B + col0 : B + (int64_t)col0 * ldb;
+    auto load_b = [&](float (&dst)[NC], int c) {
+        if constexpr (RM) {
+#pragma unroll
+            for (int n = 0; n < NC; n += 4) {
+                const f32x4 x = *reinterpret_cast<const f32x4 *>(b + (int64_t)c * ldb + n);
+                dst[n] = x.x; dst[n + 1] = x.y; dst[n + 2] = x.z; dst[n + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NC; ++n) dst[n] = b[c + (int64_t)n * ldb];
+        }
+    };
     int j = rp[r];
     const int j1 = rp[r + 1];
     float acc[NC];
@@ -49,8 +64,16 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_colwise(const int *__restrict
     // C_in early: its 16 loads fly under the row loop
     const int64_t lr = r - row_begin;
     float cin[NC];
+    if constexpr (RM) {
 #pragma unroll
-    for (int n = 0; n < NC; ++n) cin[n] = Cin[lr + (int64_t)(col0 + n) * ldc_in];
+        for (int n = 0; n < NC; n += 4) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(Cin + lr * ldc_in + col0 + n);
+            cin[n] = x.x; cin[n + 1] = x.y; cin[n + 2] = x.z; cin[n + 3] = x.w;
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < NC; ++n) cin[n] = Cin[lr + (int64_t)(col0 + n) * ldc_in];
+    }
     // The first PRE entries of the row: columns and values first (one round trip), then the B values of entry e + 1 are requested
     // before the products of entry e are formed (two register sets): a 5-entry row costs ~3 dependent round trips instead of 6.
     // Same-box, 5-point stencil 4M rows: N = 16 250 -> 230 us, N = 32 475 -> 430, N = 128 1 840 -> 1 610 (9 entries per row, forced: 397 -> 351,
@@ -69,17 +92,11 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_colwise(const int *__restrict
         float bv[DEPTH + 1][NC];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
-            if (d < len) {
-#pragma unroll
-                for (int n = 0; n < NC; ++n) bv[d][n] = b[cc[d] + (int64_t)n * ldb];
-            }
+            if (d < len) load_b(bv[d], cc[d]);
 #pragma unroll
         for (int e = 0; e < PRE; ++e) {
             if (e < len) {
-                if (e + DEPTH < PRE && e + DEPTH < len) {
-#pragma unroll
-                    for (int n = 0; n < NC; ++n) bv[(e + DEPTH) % (DEPTH + 1)][n] = b[cc[(e + DEPTH) % PRE] + (int64_t)n * ldb];
-                }
+                if (e + DEPTH < PRE && e + DEPTH < len) load_b(bv[(e + DEPTH) % (DEPTH + 1)], cc[(e + DEPTH) % PRE]);
 #pragma unroll
                 for (int n = 0; n < NC; ++n) acc[n] = mac<EXACT>(acc[n], aa[e], bv[e % (DEPTH + 1)][n]);
             }
@@ -91,8 +108,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_colwise(const int *__restrict
         float a = va[j];
         while (true) {
             float bv[NC];
-#pragma unroll
-            for (int n = 0; n < NC; ++n) bv[n] = b[c + (int64_t)n * ldb];
+            load_b(bv, c);
             const float a0 = a;
             ++j;
             if (j < j1) { c = ci[j]; a = va[j]; }          // the next entry is requested before this one's products are formed
@@ -102,8 +118,15 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_colwise(const int *__restrict
         }
     }
     if (skip && skip[r]) return;
+    if constexpr (RM) {
 #pragma unroll
-    for (int n = 0; n < NC; ++n) Cout[lr + (int64_t)(col0 + n) * ldc] = epilogue<EXACT>(alpha, acc[n], beta, cin[n]);
+        for (int n = 0; n < NC; n += 4)
+            *reinterpret_cast<f32x4 *>(Cout + lr * ldc + col0 + n) = f32x4{epilogue<EXACT>(alpha, acc[n], beta, cin[n]), epilogue<EXACT>(alpha, acc[n + 1], beta, cin[n + 1]),
+                                                                            epilogue<EXACT>(alpha, acc[n + 2], beta, cin[n + 2]), epilogue<EXACT>(alpha, acc[n + 3], beta, cin[n + 3])};
+    } else {
+#pragma unroll
+        for (int n = 0; n < NC; ++n) Cout[lr + (int64_t)(col0 + n) * ldc] = epilogue<EXACT>(alpha, acc[n], beta, cin[n]);
+    }
 }
 
 }  // namespace sx

@@ -1,4 +1,6 @@
-"""Randomised parity of the round-4 plan forms: grid / mesh matrices of odd sizes, with rows removed or emptied, in natural, random and
+"""(Round 5: + unsymmetric patterns and rectangular matrices -- clustered over A + A^T / the row-similarity graph -- and every trial once
+more through the ROW-major entry point sextans_spmm_device_rm with padded leading dimensions.)
+Randomised parity of the round-4 plan forms: grid / mesh matrices of odd sizes, with rows removed or emptied, in natural, random and
 partially shuffled numberings, at N that are and are not multiples of 16, under random settings of the options that select a plan form
 (row_cluster, share_index, row_sets, small_panel, relabel_columns, refine_sweeps, kernel, lanes_per_row).  Every result is compared
 bit for bit with cpu_spmm_CSR (oracle/), whole-matrix calls and rp_time replays alike.  The point is the corners no hand-written case
@@ -54,7 +56,8 @@ def _matrix(rs):
     rp, ci, v = np.array(rp, np.int32), np.array(ci, np.int32), np.array(v, np.float32)
     lens = np.diff(rp)
     keep = np.ones(len(ci), bool)
-    mode = rs.randint(0, 4)
+    K = M
+    mode = rs.randint(0, 6)
     if mode == 1:     # a few rows emptied
         for r in rs.randint(0, M, max(1, M // 50)):
             keep[rp[r]:rp[r + 1]] = False
@@ -69,19 +72,29 @@ def _matrix(rs):
         lens[r] += len(extra)
         rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
         keep = np.ones(len(ci), bool)
+    elif mode == 4:   # unsymmetric pattern: 30 % of the strictly lower entries dropped (clustered over A + A^T)
+        rows = np.repeat(np.arange(M), lens)
+        keep &= ~((ci < rows) & (rs.rand(len(ci)) < 0.3))
+    elif mode == 5:   # rectangular: a random third of the columns dropped, the rest renumbered (clustered over the row-similarity graph)
+        colkeep = rs.rand(M) > 0.33
+        colkeep[int(rs.randint(0, M))] = True
+        newcol = np.cumsum(colkeep) - 1
+        keep &= colkeep[ci]
+        ci = newcol[ci].astype(np.int32)
+        K = int(colkeep.sum())
     if not keep.all():
         rows = np.repeat(np.arange(M), lens)
         lens = np.bincount(rows[keep], minlength=M)
         ci, v = ci[keep], v[keep]
         rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-    return name + f" mode {mode}", M, rp, ci.astype(np.int32), v.astype(np.float32)
+    return name + f" mode {mode}", M, K, rp, ci.astype(np.int32), v.astype(np.float32)
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("SEXTANS_FUZZ_SEEDS", "96"))))   # (a soak run: SEXTANS_FUZZ_SEEDS=3000)
 def test_random_plan_forms_are_bit_identical(engine, oracle, seed):
     rs = np.random.RandomState(1000 + seed)
-    name, M, rp, ci, v = _matrix(rs)
-    K = M
+    import torch
+    name, M, K, rp, ci, v = _matrix(rs)
     try:
         for trial in range(4):
             N = int(rs.choice([8, 16, 16, 24, 32, 40, 64, 136]))
@@ -99,6 +112,16 @@ def test_random_plan_forms_are_bit_identical(engine, oracle, seed):
                 out = C0.copy()
                 engine.spmm(N, ALPHA, B, BETA, out, rp_time=rp_time)
                 assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (name, N, opts, rp_time, engine.last_kernel())
+            # the same through the row-major entry point (padded leading dimensions, separate C_out)
+            ldb, ldi, ldo = N + 4 * int(rs.randint(0, 3)), N + 4 * int(rs.randint(0, 3)), N + 4 * int(rs.randint(0, 3))
+            tb = torch.zeros((K, ldb), device="cuda"); tb[:, :N] = torch.from_numpy(np.ascontiguousarray(B.reshape(N, K).T)).cuda()
+            ti = torch.zeros((M, ldi), device="cuda"); ti[:, :N] = torch.from_numpy(np.ascontiguousarray(C0.reshape(N, M).T)).cuda()
+            to = torch.full((M, ldo), -3.0, device="cuda")
+            engine.spmm_device_rm(N, float(ALPHA), tb.data_ptr(), ldb, float(BETA), ti.data_ptr(), ldi, to.data_ptr(), ldo, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got = np.ascontiguousarray(to[:, :N].cpu().numpy().T).reshape(-1)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (name, N, opts, "row-major", engine.last_kernel())
+            assert ldo == N or bool((to[:, N:] == -3.0).all()), (name, N, "columns beyond N written")
             if os.environ.get("SEXTANS_FUZZ_VERBOSE"):
                 print(f"[fuzz] {name} N={N} rc={opts['row_cluster']}: {engine.last_kernel()} state={int(engine.get_stat('row_cluster'))} "
                       f"sets={int(engine.get_stat('row_sets'))} idx/val={engine.get_stat('index_stream_entries') / max(engine.get_stat('value_stream_entries'), 1):.2f}")

@@ -119,3 +119,35 @@ def test_full_size_sampled_rows(variant, numbering):
     finally:
         for q in (p, i, v):
             api.device_free(0, q)
+
+
+def test_run_level_clustering_on_the_file_order(engine, oracle):
+    """Round 5, a measured negative kept behind option "run_cluster" (default off): a matrix in a numbering WITH locality whose natural
+    row blocks are cut short by the panel capacity (the holdout class in its file order) keeps runs of 16 consecutive rows together and
+    builds its row blocks from runs chosen over the graph of runs.  Fewer panel rows, no staging passes (the plain panel kernel through
+    a slot -> row table), bit-identical -- and no faster, hence off by default."""
+    from sextans_amd import holdout
+    n = 16                                                  # 75 264 rows (the form needs >= 65 536)
+    rp, ci, v, M, K = holdout.kron_host(n)
+    rs = np.random.RandomState(4)
+    try:
+        for N in (16, 40, 128):
+            B = rs.uniform(-1, 1, K * N).astype(np.float32); C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+            want = C0.copy()
+            oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+            for run_cluster in (2, 0):
+                engine.set_option("row_cluster", -1); engine.set_option("run_cluster", run_cluster)
+                engine.set_option("fuse_b", 0)              # (B of this size would be staged from column-major: the repacked path is what is tested)
+                engine.set_matrix_csr(M, K, rp, ci, v)
+                for rp_time in (1, 3):
+                    got = C0.copy()
+                    engine.spmm(N, ALPHA, B, BETA, got, rp_time=rp_time)
+                    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (N, run_cluster, rp_time, engine.last_kernel())
+                assert engine.last_kernel() == "spmm_csr_panel_v2"
+                if run_cluster and int(engine.get_stat("cluster_decline")) == 12:
+                    assert int(engine.get_stat("cluster_runs")) == 1 and int(engine.get_stat("row_cluster")) == 1
+                    assert engine.get_stat("panel_rows_clustered") < engine.get_stat("panel_rows_natural")
+                else:
+                    assert int(engine.get_stat("cluster_runs")) == 0
+    finally:
+        engine.set_option("run_cluster", 0); engine.set_option("row_cluster", -1); engine.set_option("fuse_b", 1)

@@ -88,6 +88,22 @@ def test_rowmajor_alpha_beta_special_values(engine, oracle):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (alpha, beta)
 
 
+def test_rowmajor_lane_per_row_kernel(engine, oracle):
+    """Very short rows in a local numbering (5-point stencil): spmm_csr_colwise on the row-major operands -- 16-byte accesses."""
+    from sextans_amd import api
+    rp, ci, v = api.gen_stencil2d_host(90, 80, 5, 1, 3)
+    M = K = 7200
+    engine.set_matrix_csr(M, K, rp, ci, v)
+    rs = np.random.RandomState(12)
+    for N in (8, 16, 24, 64):
+        B = rs.uniform(-1, 1, (K, N)).astype(np.float32); C0 = rs.uniform(-1, 1, (M, N)).astype(np.float32)
+        want = _want(oracle, M, K, N, rp, ci, v, B, C0)
+        for kw in ({}, {"ldb": N + 4, "ldc_in": N + 8, "ldc": N + 4}, {"inplace": True}):
+            got = _run(engine, M, K, N, B, C0, **kw)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (N, kw, engine.last_kernel())
+            assert engine.last_kernel() == "spmm_csr_colwise_rowmajor", engine.last_kernel()
+
+
 def test_rowmajor_fallback_classes(engine, oracle):
     """Matrices the LDS-panel kernels do not serve, rows on the long-row paths, and unaligned operands: through column-major copies."""
     from sextans_amd import api
@@ -95,8 +111,6 @@ def test_rowmajor_fallback_classes(engine, oracle):
     cases = []
     rp, ci, v = random_csr(rs, 5000, 7000, 12)                          # no reuse: row-group gather kernel
     cases.append(("random columns", rp, ci, v, 5000, 7000, 0))
-    rp, ci, v = api.gen_stencil2d_host(90, 80, 5, 1, 3)                 # lane-per-row kernel
-    cases.append(("5-point stencil", rp, ci, v, 7200, 7200, 0))
     rp, ci, v = random_csr(rs, 3000, 3000, 10, long_rows=3)             # rows on the piece path
     cases.append(("long rows", rp, ci, v, 3000, 3000, 0))
     rp, ci, v = api.gen_fem3d_host(9, 8, 7, 3, 5)
