@@ -339,6 +339,9 @@ def secondaries(api, torch, dev, stream, args):
     return (("config2_nasa4704_N16", lambda: nasa_secondary(api, torch, dev, stream)),
                         ("config3_pcrystk02_surrogate_N128",
                          lambda: fem_secondary(api, torch, dev, stream, (35, 19, 7, 3), 128, 300, rp_protocol=True)),
+                        ("rowmajor_config2_nasa4704_N16", lambda: nasa_secondary(api, torch, dev, stream, layout="rm")),
+                        ("rowmajor_config3_pcrystk02_surrogate_N128",
+                         lambda: fem_secondary(api, torch, dev, stream, (35, 19, 7, 3), 128, 300, layout="rm")),
                         ("suitesparse_like_fem_4M_N16",
                          lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 100)),
                         ("suitesparse_like_fem_4M_N32",
@@ -487,14 +490,17 @@ def _measure(api, torch, e, M, K, N, nnz, dev, stream, iters, layout="cm"):
     return out
 
 
-def nasa_secondary(api, torch, dev, stream):
+def nasa_secondary(api, torch, dev, stream, layout="cm"):
     """BASELINE config 2: nasa4704.mtx, N=16 -- latency-bound and cache-resident; per-launch mean
     over 1000 back-to-back steps."""
     path = os.path.join(ROOT, "matrices", "nasa4704", "nasa4704.mtx")
     rp, ci, v, M, K, nnz = api.read_suitsparse_matrix(path)
     e = api.Engine(dev.index)
     e.set_matrix_csr(M, K, rp, ci, v)
-    out = _measure(api, torch, e, M, K, 16, nnz, dev, stream, 1000)
+    out = _measure(api, torch, e, M, K, 16, nnz, dev, stream, 1000, layout)
+    if layout == "rm":   # (eager steps on the row-major entry point: the LDS-panel kernel reads the caller's B by LDS-DMA, no 4-byte staging loads)
+        e.close()
+        return out
     # the reference's own protocol: `sextans nasa4704.mtx 16 <rp_time>` = rp_time repeats of the kernel on
     # resident inputs (sextans-host.cpp:237-260); the engine replays them as one hipGraph
     Bh, Ch = api.init_dense_B(K, 16), api.init_dense_C(M, 16)

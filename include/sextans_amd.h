@@ -378,10 +378,11 @@ int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_
  * column-major entry points above pay for that inside the call (B repack; two more passes over C in the reordered form).  Here the
  * caller's B IS the kernel's panel (N = 16: exactly; N > 16: tile t = columns 16 t .. at row stride ldb) and C is read and written in
  * the caller's rows, 16 bytes per lane: no layout pass on the LDS-panel paths (natural-order, grid-brick and graph-clustered plans;
- * sextans_last_kernel = "spmm_csr_panel_v2_rowmajor[_clustered]"), and a graph-clustered plan is used from 25 % fewer panel rows on
- * instead of 40 %.  Needs 16-byte aligned pointers, ld % 4 == 0, K * ldb < 2^32 and M * ldc < 2^30; everything else (gather /
- * lane-per-row kernels, rows on the long-row paths, dense tiles on MFMA, unaligned operands) goes through column-major copies in the
- * engine's workspaces.  Same arithmetic, same order: bit-identical to cpu_spmm_CSR. */
+ * sextans_last_kernel = "spmm_csr_panel_v2_rowmajor[_clustered]") nor on the lane-per-row kernel ("spmm_csr_colwise_rowmajor"), and a
+ * graph-clustered plan is used from 25 % fewer panel rows on instead of 40 %.  Needs 16-byte aligned pointers and ld % 4 == 0 (panel
+ * paths: also K * ldb < 2^32 and M * ldc < 2^30); everything else (gather kernel, rows on the long-row paths, dense tiles on MFMA,
+ * unaligned operands, N = 512 on 4 M rows) goes through column-major copies in the engine's workspaces.  Same arithmetic, same order:
+ * bit-identical to cpu_spmm_CSR. */
 int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb, float beta, const float *d_C_in,
                            int64_t ldc_in, float *d_C_out, int64_t ldc, void *stream);
 

@@ -90,7 +90,7 @@ def _matrix(rs):
     return name + f" mode {mode}", M, K, rp, ci.astype(np.int32), v.astype(np.float32)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("SEXTANS_FUZZ_SEEDS", "96"))))   # (a soak run: SEXTANS_FUZZ_SEEDS=3000)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SEXTANS_FUZZ_SEEDS", "256"))))   # (a soak run: SEXTANS_FUZZ_SEEDS=3000)
 def test_random_plan_forms_are_bit_identical(engine, oracle, seed):
     rs = np.random.RandomState(1000 + seed)
     import torch
