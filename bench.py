@@ -357,6 +357,10 @@ def secondaries(api, torch, dev, stream, args):
                         ("rowmajor_fem_4M_N128", lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 128, 10, layout="rm")),
                         ("rowmajor_fem_random_N16",
                          lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 40, numbering="random", layout="rm", torch_op=True)),
+                        ("renumbered_by_engine_order_fem_random_N16", lambda: renumbered_secondary(api, torch, dev, stream, "fem_random", 16, 40)),
+                        ("renumbered_by_engine_order_fem_random_rowmajor_N16", lambda: renumbered_secondary(api, torch, dev, stream, "fem_random", 16, 40, "rm")),
+                        ("renumbered_by_engine_order_holdout_N16", lambda: renumbered_secondary(api, torch, dev, stream, "holdout", 16, 40)),
+                        ("renumbered_by_engine_order_holdout_rowmajor_N16", lambda: renumbered_secondary(api, torch, dev, stream, "holdout", 16, 40, "rm")),
                         ("fem_4M_rcm_node_order_N16",
                          lambda: fem_secondary(api, torch, dev, stream, (110, 110, 110, 3), 16, 40, numbering="rcm")),
                         ("holdout_kron_nasa4704_4M_N16", lambda: holdout_secondary(api, torch, dev, stream, 16, 40)),
@@ -703,6 +707,45 @@ def holdout_secondary(api, torch, dev, stream, N, iters, n=850, variant="", numb
     e.close()
     for q in (p, i, v):
         api.device_free(dev.index, q)
+    return out
+
+
+def renumbered_secondary(api, torch, dev, stream, which, N, iters, layout="cm"):
+    """A matrix RENUMBERED ONCE by the engine's own clustered row order (sextans_export_row_order; P A P^T in HBM, what FEM packages do
+    with RCM -- the caller permutes the rows of B and C the same way): its natural-order forms then run without any layout pass and
+    its contiguous row ranges are compact pieces of the graph.  which: "fem_random" | "holdout"."""
+    if which == "fem_random":
+        from sextans_amd import meshgen
+        M = K = 110 * 110 * 110 * 3
+        p, i, v, nnz = api.gen_fem3d_device(dev.index, 110, 110, 110, 3, 3)
+        q = api.permute_symmetric_device(dev.index, M, nnz, p, i, v, meshgen.node_permutation(M // 3, 3, 1))
+        for old in (p, i, v):
+            api.device_free(dev.index, old)
+        p, i, v = q
+        name = "fem3d 110x110x110, 3 dof/node, random node order"
+    else:
+        from sextans_amd import holdout
+        M, K, p, i, v, nnz = holdout.kron_device(dev.index, 850)
+        name = "kron(T_850, nasa4704), as generated"
+    e = api.Engine(dev.index)
+    e.set_option("row_cluster", 2)
+    e.set_matrix_csr_device(M, K, nnz, p, i, v)
+    order, kind = e.export_row_order()
+    e.close()
+    new_of_old = np.empty(M, np.int64)
+    new_of_old[order] = np.arange(M)
+    q = api.permute_symmetric_device(dev.index, M, nnz, p, i, v, new_of_old)
+    for old in (p, i, v):
+        api.device_free(dev.index, old)
+    p, i, v = q
+    e = api.Engine(dev.index)
+    e.set_matrix_csr_device(M, K, nnz, p, i, v)
+    out = _measure(api, torch, e, M, K, N, nnz, dev, stream, iters, layout)
+    out["matrix"] = name + f", renumbered once by sextans_export_row_order (kind {kind}): P A P^T"
+    out["cluster_decline"] = int(e.get_stat("cluster_decline"))
+    e.close()
+    for x in (p, i, v):
+        api.device_free(dev.index, x)
     return out
 
 
