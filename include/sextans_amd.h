@@ -362,8 +362,10 @@ int sextans_spmm_host(sextans_handle_t h, int N, float alpha, const float *B, fl
 
 /* Device-resident form: all pointers are device pointers on the engine's device, column major
  * with explicit leading dimensions (ldb >= K, ldc >= M).  d_C_in and d_C_out may alias.
- * Enqueues on `stream` (a hipStream_t passed as void*; NULL = default stream) and returns
- * without synchronising. */
+ * Enqueues on `stream` (a hipStream_t passed as void*) and returns without synchronising.  NULL = the CALLING THREAD's default
+ * stream: the library is built with per-thread default streams (it never touches HIP's process-wide legacy stream, see
+ * INTEGRATION.md section 9); that stream is a blocking stream, so it still orders itself after work the caller put on the legacy
+ * stream. */
 int sextans_spmm_device(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb,
                         float beta, const float *d_C_in, float *d_C_out, int64_t ldc, void *stream);
 

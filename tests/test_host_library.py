@@ -153,3 +153,22 @@ def test_symmetric_file_with_rectangular_size_line(sx, tmp_path):
     ok.write_text("%%MatrixMarket matrix coordinate real symmetric\n2 5 2\n1 1 3.0\n2 1 4.0\n")
     rp, ci, v, M, K, nnz = api.read_suitsparse_matrix(str(ok))
     assert (M, K, nnz) == (2, 5, 3) and list(rp) == [0, 2, 3] and list(ci) == [0, 1, 0] and list(v) == [3.0, 4.0, 4.0]
+
+
+def test_round5_entry_points_reject_bad_arguments(sx):
+    """The entry points added in round 5 validate before they touch a device (error codes, never exit(); no GPU needed)."""
+    import ctypes as C
+    from sextans_amd import api
+    L = api.lib()
+    L.sextans_spmm_device_rm.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    L.sextans_export_row_order.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.sextans_spmm_device_rm(None, 16, 1.0, None, 16, 0.0, None, 16, None, 16, None) == 9          # SEXTANS_ERR_INVALID
+    assert L.sextans_export_row_order(None, None, None) == 9
+    L.sextans_mtx_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.sextans_mtx_write(None, 1, 1, None, None, None) == 9
+    assert L.sextans_mtx_write(b"/nonexistent-directory/x.mtx", 0, 0, (C.c_int * 1)(0), None, None) == 1  # SEXTANS_ERR_OPEN
+    prp = np.array([0, 1, 2], np.int32); pci = np.array([0, 5], np.int32)                                   # column 5 outside a 2-column pattern
+    with pytest.raises(api.SextansError):
+        api.gen_kron_host(3, prp, pci, 2, 0, 1)
+    with pytest.raises(api.SextansError):
+        api.gen_kron_host(3, prp, np.array([0, 1], np.int32), 2, 7, 1)                                      # unknown variant
