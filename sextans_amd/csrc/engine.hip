@@ -395,7 +395,7 @@ int sextans_destroy(sextans_handle_t h) {
     (void)hipFree(h->d_dbg);
     (void)hipFree(h->d_chB); (void)hipFree(h->d_chC);
     (void)hipFree(h->d_stage);
-    (void)hipFree(h->d_Cfull); (void)hipFree(h->d_dist_rows);
+    (void)hipFree(h->d_Cfull); (void)hipFree(h->d_dist_rows); (void)hipFree(h->d_rmB); (void)hipFree(h->d_rmC);
     for (hipEvent_t e : h->dist_events) (void)hipEventDestroy(e);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
@@ -1259,8 +1259,9 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
         } else {
             hipLaunchKernelGGL(invert_positions, dim3((unsigned)((h->K + 255) / 256)), dim3(256), 0, s, h->K, h->d_colpos, colinv);
             hipLaunchKernelGGL(translate_dict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, h->K, h->psc.d_dict, colinv, h->d_dict_nat);
-            SX_HIP(hipStreamSynchronize(s));
+            const hipError_t se = hipStreamSynchronize(s);
             (void)hipFree(colinv);
+            SX_HIP(se);
         }
     }
     if (colwise && aligned && h->nhub == 0 && h->nchain == 0 && h->dense_W == 0 && h->m_nnz > 0) {   // short rows in a local numbering: lane per row, 16-byte accesses
@@ -1288,20 +1289,20 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
     }
     // Everything else (gather / lane-per-row / window kernels, rows on the piece and chain paths, dense tiles, unaligned operands):
     // through column-major copies in the engine's workspaces -- two transposes in front, one behind.
+    // (workspaces of their own -- not the host-buffer entry points' d_B / d_Cin / d_Cout, which are filled on another stream; C_in and
+    // C_out may alias, so one C buffer)
     const size_t nB = (size_t)h->K * (size_t)N, nC = (size_t)h->M * (size_t)N;
-    if (int rc = ensure(&h->d_B, &h->B_cap, nB)) return rc;
-    size_t ccap = h->C_cap;
-    if (int rc = ensure(&h->d_Cin, &ccap, nC)) return rc;
-    if (int rc = ensure(&h->d_Cout, &h->C_cap, nC)) return rc;
+    if (int rc = ensure(&h->d_rmB, &h->rmB_cap, nB)) return rc;
+    if (int rc = ensure(&h->d_rmC, &h->rmC_cap, nC)) return rc;
     {
         Prof p(h, &h->ev_repack, s);
-        launch_transpose(d_B, ldb, h->d_B, h->K, h->K, N, s);
-        launch_transpose(d_C_in, ldc_in, h->d_Cin, h->M, h->M, N, s);
+        launch_transpose(d_B, ldb, h->d_rmB, h->K, h->K, N, s);
+        launch_transpose(d_C_in, ldc_in, h->d_rmC, h->M, h->M, N, s);
     }
-    if (int rc = sextans_spmm_device_rows(h, N, alpha, h->d_B, h->K, beta, h->d_Cin, h->M, h->d_Cout, h->M, 0, h->M, 0, stream)) return rc;
+    if (int rc = sextans_spmm_device_rows(h, N, alpha, h->d_rmB, h->K, beta, h->d_rmC, h->M, h->d_rmC, h->M, 0, h->M, 0, stream)) return rc;
     {
         Prof p(h, &h->ev_post, s);
-        launch_transpose(h->d_Cout, h->M, d_C_out, ldc, N, h->M, s);
+        launch_transpose(h->d_rmC, h->M, d_C_out, ldc, N, h->M, s);
     }
     SX_HIP(hipGetLastError());
     return SEXTANS_OK;

@@ -203,6 +203,8 @@ struct sextans_engine {
     int64_t graph_fallbacks = 0;        // host-entry repeat loops whose hipGraph capture failed (another thread touched the legacy stream): launched one by one instead
     hipStream_t comm_stream = nullptr;
     std::vector<hipEvent_t> dist_events;
+    float *d_rmB = nullptr, *d_rmC = nullptr;   // column-major copies of the row-major entry point's fallback path
+    size_t rmB_cap = 0, rmC_cap = 0;
     float *d_Cfull = nullptr;           // clustered-order chunks: row-major staging of the WHOLE C ([N / 16][M_total][16]) the received slabs are scattered into
     size_t Cfull_cap = 0;
     int *d_dist_rows = nullptr;         //   ... and every rank's position -> global row table ([world][longest slab])
