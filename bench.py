@@ -111,21 +111,15 @@ def main():
         # binary search in the whole matrix's row_ptr (sextans_partition_rows_by_nnz / dist.partition_rows_by_nnz).
         e0, e1 = ranges[rank]
         t_rp, t_ci, t_v, _ = api.gen_csr_device(local_rank, M, K, args.mean_nnz, 4, e0, e1)
-        lens = torch.zeros(max(b - a for a, b in ranges) + 1, dtype=torch.int32, device=dev)
+        lens = torch.empty(e1 - e0 + 1, dtype=torch.int32, device=dev)
         import ctypes
         hip = ctypes.CDLL("libamdhip64.so")
         hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
         assert hip.hipMemcpy(lens.data_ptr(), t_rp, 4 * (e1 - e0 + 1), 3) == 0
         for q in (t_rp, t_ci, t_v):
             api.device_free(local_rank, q)
-        allp = [torch.empty_like(lens) for _ in range(world)]
-        dist.all_gather(allp, lens)
-        row_ptr = np.zeros(M + 1, np.int64)
-        for g, (a, b) in enumerate(ranges):
-            seg = allp[g][:b - a + 1].cpu().numpy().astype(np.int64)
-            row_ptr[a + 1:b + 1] = row_ptr[a] + seg[1:]
-        ranges = sxd.partition_rows_by_nnz(row_ptr, world)
-        del lens, allp, row_ptr
+        ranges = sxd.balanced_ranges_from_even_slices(lens, M, rank)
+        del lens
     r0, r1 = ranges[rank]
     m_loc = r1 - r0
 

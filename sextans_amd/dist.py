@@ -40,6 +40,34 @@ def partition_rows_even(M, world):
     return out
 
 
+def balanced_ranges_from_even_slices(local_row_ptr, M, rank, group=None):
+    """NNZ-balanced contiguous row ranges of a matrix NO rank holds whole: rank g passes the row_ptr (rebased to 0,
+    int32 torch tensor, CPU or GPU) of the rows partition_rows_even(M, world)[g] -- with a counter-based generator or a
+    row-sliced file every rank can produce exactly those -- the row lengths are all-gathered (4 bytes per row) and
+    every rank finds the same cuts by binary search in the whole matrix's row_ptr (partition_rows_by_nnz).
+    bench.py's default at N > 1."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    even = partition_rows_even(M, world)
+    e0, e1 = even[rank]
+    if local_row_ptr.numel() != e1 - e0 + 1:
+        raise ValueError(f"rank {rank}: row_ptr of {local_row_ptr.numel() - 1} rows, the even slice has {e1 - e0}")
+    width = max(b - a for a, b in even) + 1
+    lens = torch.zeros(width, dtype=torch.int32, device=local_row_ptr.device)
+    lens[:e1 - e0 + 1] = local_row_ptr.to(torch.int32)
+    if world > 1:
+        allp = [torch.empty_like(lens) for _ in range(world)]
+        dist.all_gather(allp, lens, group=group)
+    else:
+        allp = [lens]
+    row_ptr = np.zeros(M + 1, np.int64)
+    for g, (a, b) in enumerate(even):
+        seg = allp[g][:b - a + 1].cpu().numpy().astype(np.int64)
+        row_ptr[a + 1:b + 1] = row_ptr[a] + seg[1:] - seg[0]
+    return partition_rows_by_nnz(row_ptr, world)
+
+
 def global_nnz(local_nnz, device="cpu", group=None):
     """Non-zeros of the whole matrix = sum of the ranks' local counts.  Handed to every rank's engine as option
     "global_nnz", it makes the automatic hub-split threshold ("split_rows" = -1) the one a single GPU holding all rows

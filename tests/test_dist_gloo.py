@@ -121,3 +121,49 @@ def test_partition_properties():
     assert sxd.partition_rows_by_nnz(np.zeros(4, np.int32), 2)[-1][1] == 3
     lrp, lci, lv = sxd.slice_csr(rp, np.arange(rp[-1]), np.arange(rp[-1]), 10, 20)
     assert lrp[0] == 0 and lrp[-1] == len(lci) == rp[20] - rp[10]
+
+
+def _balance_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    import torch.distributed as dist
+    from sextans_amd import dist as sxd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        M = 1003                                         # not a multiple of the world size: the even slices differ in length
+        rp, _, _ = random_csr(np.random.RandomState(5), M, 300, 12, long_rows=4)
+        e0, e1 = sxd.partition_rows_even(M, world)[rank]
+        local = torch.from_numpy((rp[e0:e1 + 1] - rp[e0]).astype(np.int32))   # what a rank holds: ITS slice, rebased
+        got = sxd.balanced_ranges_from_even_slices(local, M, rank)
+        ok = got == sxd.partition_rows_by_nnz(rp, world)
+        try:                                             # a slice of the wrong length is refused, not gathered
+            sxd.balanced_ranges_from_even_slices(local[:-1], M, rank)
+            ok = False
+        except ValueError:
+            pass
+        q.put((rank, ok, got))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_nnz_balanced_ranges_without_a_whole_row_ptr(world):
+    """bench.py's N > 1 default: no rank holds the matrix; the cuts come out of all-gathered row lengths and equal the cuts
+    of the whole row_ptr on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_balance_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert len({tuple(r) for _, _, r in res}) == 1
