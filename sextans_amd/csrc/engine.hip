@@ -208,14 +208,18 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
         }
         if (bcol_ld > 0) return h->opt_exact ? go(sx::spmm_csr_panel_v2<H, 2, true, true>) : go(sx::spmm_csr_panel_v2<H, 2, false, true>);
         if (rm) {   // the caller's row-major operands: the 16-byte C accesses of the staging form on the caller's own rows, B without a repack
-#define SX_RM(NBV, DC, ST) (h->opt_exact ? go(sx::spmm_csr_panel_v2<H, NBV, true, false, false, DC, true, false, ST, true>) \
-                                          : go(sx::spmm_csr_panel_v2<H, NBV, false, false, false, DC, true, false, ST, true>))
+// (C beyond 4 GB -- M * ldc * 4 bytes -- takes the instantiations with 64-bit lane addresses: RM == 2)
+            const bool c64 = (int64_t)h->M * std::max(ldc, ldc_in) * 4 >= ((int64_t)1 << 32);
+#define SX_RM1(NBV, DC, ST, R) (h->opt_exact ? go(sx::spmm_csr_panel_v2<H, NBV, true, false, false, DC, true, false, ST, R>) \
+                                             : go(sx::spmm_csr_panel_v2<H, NBV, false, false, false, DC, true, false, ST, R>))
+#define SX_RM(NBV, DC, ST) (c64 ? SX_RM1(NBV, DC, ST, 2) : SX_RM1(NBV, DC, ST, 1))
             if (P.plan_sets == 2) return SX_RM(2, 9, 2);
             if (small_panel) return nb >= 3 ? SX_RM(3, 5, 1) : SX_RM(2, 5, 1);
             if (nb == 3) return SX_RM(3, 9, 1);
             if (nb == 2) return SX_RM(2, 9, 1);
             if (nb == 4) return SX_RM(4, 9, 1);
             return SX_RM(6, 9, 1);
+#undef SX_RM1
 #undef SX_RM
         }
         if (P.plan_sets == 2) {   // two row sets per block (short-row clustered plans: every row has <= 32 entries = 2 register-resident batches)
@@ -1241,8 +1245,8 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
     const bool colwise = h->opt_kernel == 4 || (h->opt_kernel == 0 && h->colwise_state == 1);
     const bool aligned = ((reinterpret_cast<uintptr_t>(d_B) | reinterpret_cast<uintptr_t>(d_C_in) | reinterpret_cast<uintptr_t>(d_C_out)) & 15) == 0 &&
                          ldb % 4 == 0 && ldc_in % 4 == 0 && ldc % 4 == 0;
-    // 32-bit offsets inside the kernel: floats into B, bytes into C
-    const bool fits = (int64_t)h->K * ldb < ((int64_t)1 << 32) && (int64_t)h->M * std::max(ldc, ldc_in) * 4 < ((int64_t)1 << 32);
+    // 32-bit offsets inside the kernel: floats into B (C beyond 4 GB: the kernel's 64-bit form, launch_panel_v2)
+    const bool fits = (int64_t)h->K * ldb < ((int64_t)1 << 32);
     int mode = -1;
     if (W == 16 && (h->opt_kernel == 0 || h->opt_kernel == 2) && h->opt_panel_v2 != 0 && h->opt_cols_per_lane != 8 && h->nhub == 0 && h->nchain == 0 &&
         h->dense_W == 0 && !colwise && aligned && fits && h->m_nnz > 0) {

@@ -104,6 +104,13 @@ __device__ __forceinline__ void astore1(float *sbase, unsigned voff_bytes, float
 __device__ __forceinline__ void astore4(float *sbase, unsigned voff_bytes, const f32x4 &val) {
     asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(voff_bytes), "v"(val), "s"(sbase) : "memory");
 }
+// (the same with a 64-bit address per lane: row-major C beyond 4 GB, RM == 2)
+__device__ __forceinline__ void aload4p(f32x4 &dst, const float *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void astore4p(float *p, const f32x4 &val) {
+    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(val) : "memory");
+}
 
 // BCOL: Bp is the caller's column-major B (panel_stride = its leading dimension), staged with 4-byte loads; else Bp
 // holds row-major K x 16 panels at stride panel_stride floats.
@@ -135,7 +142,9 @@ __device__ __forceinline__ void astore4(float *sbase, unsigned voff_bytes, const
 // rows, C_in + row * ldc_in + 16 st).  No repack launch, no staging passes: the reference lays its operands out for its kernel outside
 // the timed call too (sextans-host.cpp:150-195).  The lanes whose 4 columns lie beyond N in the last tile (last_cols = 8) neither copy B
 // nor touch C there (a lane only ever reads its own 16-byte column slice of the LDS panel, so what those slices hold does not matter).
-template <int H, int NB, bool EXACT, bool BCOL, bool TIMED = false, int DCAP = 9, bool CROW = false, bool BIG = false, int SETS = 1, bool RM = false>
+// RM == 2: the same with 64-bit lane addresses into C (row * ldc * 4 bytes does not fit 32 bits: 4M rows x 512 columns are 8 GB) -- two
+// more registers per row set and direction, a 64-bit add per access; RM == 1 keeps the scalar-base + 32-bit-offset form.
+template <int H, int NB, bool EXACT, bool BCOL, bool TIMED = false, int DCAP = 9, bool CROW = false, bool BIG = false, int SETS = 1, int RM = 0>
 // (BCOL at the full dictionary capacity keeps a 576-row panel in registers next to the row entries: 132 registers' worth -- at 4
 // workgroups per CU it spilled 4 registers to scratch in the prologue of the small-matrix launches it exists for; 3 per CU = 168.)
 #ifndef SX_V2_BCOL_WGS
@@ -339,6 +348,13 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? (BCOL && DCAP == 9 ? SX_V
         cvoff_rout[t] = RM ? (coff[t] * (unsigned)ldc + 4u * (unsigned)q) * 4u : cvoff_rin[t];
     }
     const int64_t ct_in = RM ? 16 : ldc_in, ct_out = RM ? 16 : ldc;   // CROW: floats from one tile of C to the next
+    const float *cp_in[SETS];   // RM == 2: this lane's 16 bytes of tile 0, as 64-bit addresses
+    float *cp_out[SETS];
+#pragma unroll
+    for (int t = 0; t < SETS; ++t) {
+        cp_in[t] = Cin + (int64_t)coff[t] * ldc_in + 4 * q;
+        cp_out[t] = Cout + (int64_t)coff[t] * ldc + 4 * q;
+    }
     // C_in of the FIRST super tile is requested here, in the same round trip as the panel and the row entries (for a
     // matrix of a few thousand rows the whole kernel is three round trips: one more is 15 % of its time)
     float cin[SETS][H][4];
@@ -347,7 +363,10 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? (BCOL && DCAP == 9 ? SX_V
     for (int t = 0; t < SETS; ++t) {
         cinv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (CROW) {
-            if (!RM || cvalid || st_begin + 1 < nsuper) aload4(cinv[t], Cin + (int64_t)st_begin * ct_in, cvoff_rin[t]);
+            if (!RM || cvalid || st_begin + 1 < nsuper) {
+                if constexpr (RM == 2) aload4p(cinv[t], cp_in[t] + (int64_t)st_begin * 16);
+                else aload4(cinv[t], Cin + (int64_t)st_begin * ct_in, cvoff_rin[t]);
+            }
         } else if (cvalid || st_begin + 1 < nsuper) {
 #pragma unroll
             for (int h = 0; h < H; ++h)
@@ -383,7 +402,10 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? (BCOL && DCAP == 9 ? SX_V
 #pragma unroll
             for (int t = 0; t < SETS; ++t) {
                 if constexpr (CROW) {
-                    if (!RM || cvalid || st + 1 < nsuper) aload4(cinv[t], Cin + (int64_t)st * ct_in, cvoff_rin[t]);
+                    if (!RM || cvalid || st + 1 < nsuper) {
+                        if constexpr (RM == 2) aload4p(cinv[t], cp_in[t] + (int64_t)st * 16);
+                        else aload4(cinv[t], Cin + (int64_t)st * ct_in, cvoff_rin[t]);
+                    }
                 } else if (cvalid || st + 1 < nsuper) {
 #pragma unroll
                     for (int h = 0; h < H; ++h)
@@ -474,7 +496,8 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? (BCOL && DCAP == 9 ? SX_V
                 if (cwrite[t] && (!RM || cvalid || st + 1 < nsuper)) {
                     const f32x4 o = {epilogue<EXACT>(alpha, acc[t][0].x, beta, cinv[t].x), epilogue<EXACT>(alpha, acc[t][0].y, beta, cinv[t].y),
                                      epilogue<EXACT>(alpha, acc[t][0].z, beta, cinv[t].z), epilogue<EXACT>(alpha, acc[t][0].w, beta, cinv[t].w)};
-                    astore4(Cout + (int64_t)st * ct_out, cvoff_rout[t], o);
+                    if constexpr (RM == 2) astore4p(cp_out[t] + (int64_t)st * 16, o);
+                    else astore4(Cout + (int64_t)st * ct_out, cvoff_rout[t], o);
                 }
             } else if (cwrite[t] && (cvalid || st + 1 < nsuper)) {
 #pragma unroll

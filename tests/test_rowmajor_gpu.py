@@ -148,3 +148,39 @@ def test_rowmajor_reconsiders_a_declined_clustered_plan(engine, oracle):
         engine.spmm(N, ALPHA, np.ascontiguousarray(B.T).reshape(-1), BETA, cm2)
         assert engine.last_kernel() == first[2] and np.array_equal(cm2.view(np.uint32), cm.view(np.uint32))
     assert np.array_equal(np.ascontiguousarray(cm.reshape(N, M).T).view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("N", [16, 40])
+def test_rowmajor_c_beyond_4gb_takes_64bit_addresses(engine, oracle, N):
+    """M * ldc * 4 bytes >= 4 GB (4M rows x 512 columns in production; here 20 520 rows with a leading dimension of 53 248 floats): the
+    kernel's 32-bit byte offsets into C do not reach -- the RM == 2 instantiations (64-bit lane addresses) run instead of the detour
+    through column-major copies, on every plan kind."""
+    import torch
+    for name, (rp, ci, v, M, K), kernels, opts in _matrices():
+        ld = -(-((1 << 32) // (4 * M) + 8) // 4) * 4
+        assert M * ld * 4 >= 1 << 32
+        rs = np.random.RandomState(N + 3)
+        B = rs.uniform(-1, 1, (K, N)).astype(np.float32); C0 = rs.uniform(-1, 1, (M, N)).astype(np.float32)
+        want = _want(oracle, M, K, N, rp, ci, v, B, C0)
+        try:
+            for k, val in opts.items():
+                engine.set_option(k, val)
+            engine.set_matrix_csr(M, K, rp, ci, v)
+            tb = torch.from_numpy(B).cuda()
+            tci = torch.empty(M * ld, device="cuda"); tco = torch.empty(M * ld, device="cuda")
+            tci.view(M, ld)[:, :N] = torch.from_numpy(C0).cuda(); tco.view(M, ld)[:, :N + 4] = -5.0
+            engine.spmm_device_rm(N, ALPHA, tb.data_ptr(), N, BETA, tci.data_ptr(), ld, tco.data_ptr(), ld, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got = tco.view(M, ld)[:, :N + 4].cpu().numpy()
+            assert engine.last_kernel() in kernels, (name, engine.last_kernel())
+            assert np.all(got[:, N:] == -5.0)
+            assert np.array_equal(np.ascontiguousarray(got[:, :N]).view(np.uint32), want.view(np.uint32)), (name, N)
+            # in place, too
+            engine.spmm_device_rm(N, ALPHA, tb.data_ptr(), N, BETA, tci.data_ptr(), ld, tci.data_ptr(), ld, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(np.ascontiguousarray(tci.view(M, ld)[:, :N].cpu().numpy()).view(np.uint32), want.view(np.uint32)), (name, N)
+            del tci, tco
+            torch.cuda.empty_cache()
+        finally:
+            for k in opts:
+                engine.set_option(k, 1)
