@@ -373,7 +373,9 @@ def secondaries(api, torch, dev, stream, args):
                         ("config5_blocked_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream)),
                         ("blockbanded_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream, banded_half_width=127)),
                         ("powerlaw_1M_rows_N16", lambda: powerlaw_secondary(api, torch, dev, stream)),
-                        ("config4_matrix_N32", lambda: uniform_secondary(api, torch, dev, stream, args, 32)))
+                        ("config4_matrix_N32", lambda: uniform_secondary(api, torch, dev, stream, args, 32)),
+                        ("rowmajor_config4_matrix_N16", lambda: uniform_secondary(api, torch, dev, stream, args, 16, layout="rm")),
+                        ("rowmajor_config4_matrix_N32", lambda: uniform_secondary(api, torch, dev, stream, args, 32, layout="rm")))
 
 
 def cpu_baseline(api, M, K, N, args, Cout, flops_per_row, all_cores=True):
@@ -603,14 +605,15 @@ def powerlaw_secondary(api, torch, dev, stream):
     return out
 
 
-def uniform_secondary(api, torch, dev, stream, args, N):
+def uniform_secondary(api, torch, dev, stream, args, N, layout="cm"):
     """The config-4 matrix at N = 32: a B row is a whole 128-byte line, one fabric request per non-zero carries twice
-    the payload of N = 16 (8 lanes per row, chosen automatically)."""
+    the payload of N = 16 (8 lanes per row, chosen automatically).  layout "rm": the headline matrix through the row-major entry
+    point -- the gather kernel reads the caller's B rows (no repack) and writes 16 bytes of a C row per lane."""
     M = K = args.rows
     p, i, v, nnz = api.gen_csr_device(dev.index, M, K, args.mean_nnz, 4)
     e = api.Engine(dev.index)
     e.set_matrix_csr_device(M, K, nnz, p, i, v)
-    out = _measure(api, torch, e, M, K, N, nnz, dev, stream, 10)
+    out = _measure(api, torch, e, M, K, N, nnz, dev, stream, 10, layout)
     e.close()
     for q in (p, i, v):
         api.device_free(dev.index, q)

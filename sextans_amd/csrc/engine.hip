@@ -62,23 +62,29 @@ template <int LPR>
 void launch_rowgroup(sextans_engine *h, const int *rp, const int *rend, const int *ci, const float *va, bool pieces,
                      const unsigned char *skip, const float *dBp,
                      const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc, int row_begin, int row_end, int ntiles,
-                     float alpha, float beta, hipStream_t s) {
+                     float alpha, float beta, hipStream_t s, int64_t rm_ldb = 0) {
+    // rm_ldb > 0: dBp / dCin / dCout are the caller's ROW-major operands at this segment's first column (sextans_spmm_device_rm)
     constexpr int RB = sx::kBlock / LPR;
     constexpr int CH = 2048;
     const int nrowblk = (row_end - row_begin + RB - 1) / RB;
     if (nrowblk <= 0) return;
     const unsigned nwg = (unsigned)nrowblk * (unsigned)ntiles;
-    const int64_t pstride = (int64_t)h->K * 4 * LPR;
+    const int64_t pstride = rm_ldb > 0 ? rm_ldb : (int64_t)h->K * 4 * LPR;
     const int xcd = (int)h->opt_xcd;
-#define SX_LAUNCH(EX, ST)                                                                       \
-    hipLaunchKernelGGL((sx::spmm_csr_rowgroup<LPR, CH, EX, ST>), dim3(nwg), dim3(sx::kBlock), 0, \
+#define SX_LAUNCH(EX, ST, R)                                                                       \
+    hipLaunchKernelGGL((sx::spmm_csr_rowgroup<LPR, CH, EX, ST, R>), dim3(nwg), dim3(sx::kBlock), 0, \
                        s, rp, rend, ci, va, dBp, pstride, dCin, ldc_in, dCout, ldc, row_begin,          \
                        row_end, ntiles, nrowblk, alpha, beta, xcd, skip)
     // The LDS-staged A stream walks a block's non-zeros in order, which serialises row groups when rows
     // are long pieces of one hub row (split mode): there every row group streams its own piece directly.
     const bool stage = h->opt_stage && !pieces;
-    if (h->opt_exact) { if (stage) SX_LAUNCH(true, true); else SX_LAUNCH(true, false); }
-    else              { if (stage) SX_LAUNCH(false, true); else SX_LAUNCH(false, false); }
+    if (rm_ldb > 0) {
+        if (h->opt_exact) { if (stage) SX_LAUNCH(true, true, true); else SX_LAUNCH(true, false, true); }
+        else              { if (stage) SX_LAUNCH(false, true, true); else SX_LAUNCH(false, false, true); }
+        return;
+    }
+    if (h->opt_exact) { if (stage) SX_LAUNCH(true, true, false); else SX_LAUNCH(true, false, false); }
+    else              { if (stage) SX_LAUNCH(false, true, false); else SX_LAUNCH(false, false, false); }
 #undef SX_LAUNCH
 }
 
@@ -1291,7 +1297,28 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
         SX_HIP(hipGetLastError());
         return SEXTANS_OK;
     }
-    // Everything else (gather / lane-per-row / window kernels, rows on the piece and chain paths, dense tiles, unaligned operands):
+    // The gather kernel on a matrix without rows on the piece / chain / dense-tile paths: a row of row-major B IS what its lanes fetch
+    // per non-zero (the 4 * LPR floats of a panel row), and a lane's 4 accumulators are 16 bytes of its C row -- no repack, no passes.
+    if (!use_panel && !use_window && !colwise && aligned && (h->opt_kernel == 0 || h->opt_kernel == 1) && h->nhub == 0 && h->nchain == 0 && h->dense_W == 0 &&
+        h->m_nnz > 0) {
+        Prof p(h, &h->ev_kernel, s);
+        std::vector<Seg> segs = plan;
+        if (N == 8) segs.assign(1, Seg{8, 0, 1});   // (the plan above was made for 16 columns)
+        for (const Seg &g : segs) {
+#define SX_SEG(L) launch_rowgroup<L>(h, h->m_rp, h->m_rp + 1, h->m_ci, h->m_v, false, h->d_skip, d_B + g.col0, d_C_in + g.col0, ldc_in, d_C_out + g.col0, ldc, 0, \
+                                     h->M, g.ntiles, alpha, beta, s, ldb)
+            switch (g.width) {
+                case 32: SX_SEG(8); break;
+                case 16: SX_SEG(4); break;
+                default: SX_SEG(2); break;
+            }
+#undef SX_SEG
+        }
+        h->last_kernel = "spmm_csr_rowgroup_rowmajor";
+        SX_HIP(hipGetLastError());
+        return SEXTANS_OK;
+    }
+    // Everything else (lane-per-row / window kernels, mixed plans, rows on the piece and chain paths, dense tiles, unaligned operands):
     // through column-major copies in the engine's workspaces -- two transposes in front, one behind.
     // (workspaces of their own -- not the host-buffer entry points' d_B / d_Cin / d_Cout, which are filled on another stream; C_in and
     // C_out may alias, so one C buffer)

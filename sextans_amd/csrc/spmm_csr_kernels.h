@@ -78,8 +78,12 @@ __device__ __forceinline__ float epilogue(float alpha, float acc, float beta, fl
 //   nrowblk * ntiles workgroups; logical id -> (rowblk = id / ntiles, tile = id % ntiles).
 // Bp: panels, panel t is a row-major K x NT matrix at Bp + t*panel_stride.
 // Cin/Cout: column-major, already offset to the first column of tile 0 of this launch.
+// RM (round 5, sextans_spmm_device_rm): the caller's ROW-major operands -- Bp = B at the launch's first column, panel_stride = its
+// leading dimension (B row c of tile t = the NT floats at Bp + c * ldb + t * NT: what a panel row is, without the repack pass), C rows
+// of ldc_in / ldc floats: a lane's 4 accumulators are 16 consecutive bytes of its C row, so the tile goes out (and C_in comes in)
+// with one 16-byte access per lane and the LDS transpose is not needed.
 // ------------------------------------------------------------------------------------------------
-template <int LPR, int CH, bool EXACT, bool STAGE>
+template <int LPR, int CH, bool EXACT, bool STAGE, bool RM = false>
 __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
     const int *__restrict__ row_ptr, const int *__restrict__ row_end, const int *__restrict__ col_idx,
     const float *__restrict__ val, const float *__restrict__ Bp, int64_t panel_stride, const float *Cin,
@@ -108,10 +112,18 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
     const int row0 = row_begin + rowblk * RB;
     const int row = row0 + slot;
 
-    const float *bq = Bp + (int64_t)tile * panel_stride + 4 * q;
+    const float *bq = RM ? Bp + (int64_t)tile * NT + 4 * q : Bp + (int64_t)tile * panel_stride + 4 * q;
+    auto brow = [&](int c) -> const float4 * {   // my 16 bytes of B row c
+        if constexpr (RM) return reinterpret_cast<const float4 *>(bq + (int64_t)c * panel_stride);
+        else return reinterpret_cast<const float4 *>(bq + (int64_t)c * NT);
+    };
     int j = 0, jend = 0;
     if (row < M) { j = row_ptr[row]; jend = row_end[row]; }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 cin4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool cwrite = RM && row < M && !(skip && skip[row]);
+    if constexpr (RM)   // C_in early: in flight under the row loop
+        if (cwrite) cin4 = *reinterpret_cast<const float4 *>(Cin + (int64_t)(row - row_begin) * ldc_in + tile * NT + 4 * q);
 
     if constexpr (STAGE) {
         int2 *s_nz = reinterpret_cast<int2 *>(smem);
@@ -126,10 +138,10 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
             while (j + 4 <= hi) {
                 const int2 e0 = s_nz[j - cs], e1 = s_nz[j - cs + 1], e2 = s_nz[j - cs + 2],
                            e3 = s_nz[j - cs + 3];
-                const float4 b0 = *reinterpret_cast<const float4 *>(bq + (int64_t)e0.x * NT);
-                const float4 b1 = *reinterpret_cast<const float4 *>(bq + (int64_t)e1.x * NT);
-                const float4 b2 = *reinterpret_cast<const float4 *>(bq + (int64_t)e2.x * NT);
-                const float4 b3 = *reinterpret_cast<const float4 *>(bq + (int64_t)e3.x * NT);
+                const float4 b0 = *brow(e0.x);
+                const float4 b1 = *brow(e1.x);
+                const float4 b2 = *brow(e2.x);
+                const float4 b3 = *brow(e3.x);
                 mac4<EXACT>(acc, __int_as_float(e0.y), b0);
                 mac4<EXACT>(acc, __int_as_float(e1.y), b1);
                 mac4<EXACT>(acc, __int_as_float(e2.y), b2);
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
             }
             while (j < hi) {
                 const int2 e = s_nz[j - cs];
-                const float4 b = *reinterpret_cast<const float4 *>(bq + (int64_t)e.x * NT);
+                const float4 b = *brow(e.x);
                 mac4<EXACT>(acc, __int_as_float(e.y), b);
                 ++j;
             }
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
 #pragma unroll
             for (int u = 0; u < LPR; ++u) {
                 const int cu = __shfl(c, u, LPR);
-                b[u] = (u < cnt) ? *reinterpret_cast<const float4 *>(bq + (int64_t)cu * NT)
+                b[u] = (u < cnt) ? *brow(cu)
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
@@ -169,6 +181,13 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
         }
     }
 
+    if constexpr (RM) {
+        if (cwrite)
+            *reinterpret_cast<float4 *>(Cout + (int64_t)(row - row_begin) * ldc + tile * NT + 4 * q) =
+                make_float4(epilogue<EXACT>(alpha, acc.x, beta, cin4.x), epilogue<EXACT>(alpha, acc.y, beta, cin4.y),
+                            epilogue<EXACT>(alpha, acc.z, beta, cin4.z), epilogue<EXACT>(alpha, acc.w, beta, cin4.w));
+        return;
+    }
     // Transpose the RB x NT tile through LDS so that column-major C traffic is coalesced.
     float *s_c = reinterpret_cast<float *>(smem);
     s_c[(4 * q + 0) * TS + slot] = acc.x;

@@ -2,7 +2,7 @@
 want, so no layout pass runs on the LDS-panel paths.  The reference lays B and C out for its kernel on the host, outside the timed
 call (sextans-host.cpp:150-195, 264-270).  Same per-row order and rounding: BIT-IDENTICAL to cpu_spmm_CSR (sparse_helper.h:262-290)
 on the natural-order, grid-brick and graph-clustered plans, with padded leading dimensions, in place, N = 8 / 16 / 24 / 128, and on
-everything that falls back to column-major copies (gather and lane-per-row kernels, long rows, unaligned operands)."""
+the row-group gather kernel, and on everything that falls back to column-major copies (mixed plans, long rows, unaligned operands)."""
 import numpy as np
 import pytest
 
@@ -109,8 +109,8 @@ def test_rowmajor_fallback_classes(engine, oracle):
     from sextans_amd import api
     rs = np.random.RandomState(11)
     cases = []
-    rp, ci, v = random_csr(rs, 5000, 7000, 12)                          # no reuse: row-group gather kernel
-    cases.append(("random columns", rp, ci, v, 5000, 7000, 0))
+    rp, ci, v = random_csr(rs, 5000, 7000, 12)                          # no reuse: row-group gather kernel, unaligned here
+    cases.append(("random columns, pointers 8 bytes off", rp, ci, v, 5000, 7000, 2))
     rp, ci, v = random_csr(rs, 3000, 3000, 10, long_rows=3)             # rows on the piece path
     cases.append(("long rows", rp, ci, v, 3000, 3000, 0))
     rp, ci, v = api.gen_fem3d_host(9, 8, 7, 3, 5)
@@ -124,6 +124,39 @@ def test_rowmajor_fallback_classes(engine, oracle):
                 got = _run(engine, M, K, N, B, C0, offset=off, **kw)
                 assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (name, N, kw, engine.last_kernel())
             assert "rowmajor" not in engine.last_kernel(), (name, engine.last_kernel())
+
+
+@pytest.mark.parametrize("stage", [1, 0])
+def test_rowmajor_gather_kernel(engine, oracle, stage):
+    """No reuse between rows (random columns: config 4's class): the row-group gather kernel reads the caller's row-major B rows where
+    the column-major form reads repacked panel rows, and writes 16 bytes of a C row per lane -- no repack, no transposes; 32-column
+    tiles at N >= 32, a 16- / 8-column tail, both A-stream forms (LDS-staged / direct)."""
+    rs = np.random.RandomState(12)
+    M, K = 5003, 7001
+    rp, ci, v = random_csr(rs, M, K, 12)
+    try:
+        engine.set_option("stage_a", stage)
+        engine.set_matrix_csr(M, K, rp, ci, v)
+        for N in (8, 16, 24, 32, 40, 56, 64, 128):
+            B = rs.uniform(-1, 1, (K, N)).astype(np.float32); C0 = rs.uniform(-1, 1, (M, N)).astype(np.float32)
+            want = _want(oracle, M, K, N, rp, ci, v, B, C0)
+            for kw in ({}, {"ldb": N + 4, "ldc_in": N + 8, "ldc": N + 4}, {"inplace": True}):
+                got = _run(engine, M, K, N, B, C0, **kw)
+                assert engine.last_kernel() == "spmm_csr_rowgroup_rowmajor", (N, engine.last_kernel())
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (N, kw)
+        # an empty row, a row of one entry, alpha = 0 / beta = 0 with non-finite C_in
+        rp2 = rp.copy(); drop = rp2[11] - rp2[10]; rp2[11:] -= drop
+        ci2 = np.concatenate([ci[:rp[10]], ci[rp[11]:]]); v2 = np.concatenate([v[:rp[10]], v[rp[11]:]])
+        engine.set_matrix_csr(M, K, rp2, ci2, v2)
+        N = 16
+        B = rs.uniform(-1, 1, (K, N)).astype(np.float32); C0 = rs.uniform(-1, 1, (M, N)).astype(np.float32)
+        C0[5, 3] = np.inf; C0[6, 0] = np.nan
+        for a, b in ((ALPHA, 0.0), (0.0, BETA), (1.0, 1.0)):
+            want = _want(oracle, M, K, N, rp2, ci2, v2, B, C0, a, b)
+            got = _run(engine, M, K, N, B, C0, alpha=a, beta=b)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (a, b)
+    finally:
+        engine.set_option("stage_a", 1)
 
 
 def test_rowmajor_reconsiders_a_declined_clustered_plan(engine, oracle):
