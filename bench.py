@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--torch-dist", action="store_true",
                     help="N>1: torch.distributed collectives (PipelinedSlabGather) instead of sextans_dist_spmm, the native form "
                          "behind the C ABI (RCCL called from the library), which is the default")
+    ap.add_argument("--rowmajor", action="store_true",
+                    help="the same workload with ROW-major B and C (sextans_spmm_device_rm; N>1: sextans_dist_spmm_rm, slabs in place, in-place all-gather). "
+                         "Not the default: BASELINE.json's configuration is column-major")
     ap.add_argument("--even-rows", action="store_true", help="N>1: equal row counts per rank instead of nnz-balanced ranges")
     args = ap.parse_args()
 
@@ -104,6 +107,8 @@ def main():
     M = K = args.rows
     N = api.round_up_n(args.n)
     args.native_dist = not args.torch_dist
+    if args.rowmajor and args.torch_dist:
+        raise SystemExit("bench.py: --rowmajor uses the native collectives (sextans_dist_spmm_rm); drop --torch-dist")
     ranges = sxd.partition_rows_even(M, world)
     if multi and not args.even_rows:
         # north_star / SURVEY 8e: contiguous NNZ-BALANCED row ranges.  Every rank generates the row lengths of an even slice in HBM
@@ -165,7 +170,9 @@ def main():
                              reuse_b_panels=not first, stream=stream)
 
     def compute():
-        if not multi:
+        if args.rowmajor:   # row-major B (K x N) and C (M x N): the rank's rows are one contiguous run of C
+            eng.spmm_device_rm(N, ALPHA, B.data_ptr(), N, BETA, Cin.data_ptr() + 4 * r0 * N, N, Cout.data_ptr() + 4 * r0 * N, N, stream)
+        elif not multi:
             eng.spmm_device(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr, cout_ptr, M, stream)
         elif pg is not None:
             for i, ((c0, c1), S, lmax) in enumerate(zip(pg.chunks, pg.S, pg.lmax)):
@@ -178,6 +185,8 @@ def main():
     def step():
         if not multi:
             compute()
+        elif args.rowmajor:
+            eng.dist_spmm_rm(comm, world, rank, ranges, N, ALPHA, B.data_ptr(), N, BETA, Cin.data_ptr(), N, Cout.data_ptr(), N, stream=stream)
         elif comm is not None:
             eng.dist_spmm(comm, world, rank, ranges, N, ALPHA, B.data_ptr(), K, BETA, Cin.data_ptr(), M, Cout.data_ptr(), M,
                           nchunks=args.chunks, stream=stream)
@@ -261,10 +270,10 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"config4: synthetic CSR {M}x{K}, Poisson({args.mean_nnz:g}) nnz/row, "
-                               f"U(-1,1) fp32, N={N}, alpha=0.85, beta=-2.06, column-major B/C, seed 4",
+                               f"U(-1,1) fp32, N={N}, alpha=0.85, beta=-2.06, {'ROW-major B/C (--rowmajor)' if args.rowmajor else 'column-major B/C'}, seed 4",
                    "M": M, "K": K, "N": N, "nnz": nnz_tot,
                    "parallelism": (f"A row-split x{world} ({'equal rows' if args.even_rows else 'nnz-balanced ranges'}), B replicated, "
-                                   f"all-gather(C) by {'sextans_dist_spmm (RCCL from the C ABI)' if args.native_dist else 'torch.distributed'}")
+                                   f"all-gather(C) by {'sextans_dist_spmm_rm (in place, RCCL from the C ABI)' if args.rowmajor else 'sextans_dist_spmm (RCCL from the C ABI)' if args.native_dist else 'torch.distributed'}")
                    if world > 1 else "1 GPU"},
         "hbm_gbs_algorithmic_step": round(alg_bytes(M, K, N, nnz_tot) / sec_per_step / 1e9, 1),
         "roofline": roofline,
@@ -279,23 +288,27 @@ def main():
         also["per_rank"] = {"rows": m_loc, "nnz": nnz_loc, "kernel": eng.last_kernel(),
                             "kernel_us_per_step": round(k_ns / 1e3, 2), "repack_us_per_step": round(rp_ns / 1e3, 2),
                             "allgather_bytes_received": 4 * N * (M - m_loc), "chunks": args.chunks,
-                            "collectives": "sextans_dist_spmm (RCCL from the C ABI)" if comm is not None
+                            "collectives": "sextans_dist_spmm_rm: in-place all-gather of row runs (RCCL from the C ABI)" if args.rowmajor
+                            else "sextans_dist_spmm (RCCL from the C ABI)" if comm is not None
                             else "torch.distributed all_gather_into_tensor"}
 
     if rank == 0 and world > 1 and not args.no_cpu_baseline:
         # N > 1: the same CPU leg on a smaller bounded sample (the other ranks wait at the final barrier meanwhile);
         # C_out is complete on every rank after the all-gather, so rank 0 also checks the first rows bit for bit
         args.cpu_seconds = min(args.cpu_seconds, 5.0)
-        out["cpu_baseline"] = cpu_baseline(api, M, K, N, args, Cout, flops_per_row=None, all_cores=False)
+        out["cpu_baseline"] = cpu_baseline(api, M, K, N, args, Cout, flops_per_row=None, all_cores=False, rowmajor=args.rowmajor)
     if rank == 0 and world == 1:
         if multi:   # forced single-rank distributed run: check the gathered C against the plain path
             ref = torch.empty_like(Cout)
-            eng.spmm_device(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr, ref.data_ptr(), M, stream)
+            if args.rowmajor:
+                eng.spmm_device_rm(N, ALPHA, B.data_ptr(), N, BETA, Cin.data_ptr(), N, ref.data_ptr(), N, stream)
+            else:
+                eng.spmm_device(N, ALPHA, B.data_ptr(), K, BETA, cin_ptr, ref.data_ptr(), M, stream)
             torch.cuda.synchronize()
             also["dist_path_matches_plain_path"] = bool(torch.equal(ref, Cout))
             del ref
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(api, M, K, N, args, Cout, flops_per_row=None)
+            out["cpu_baseline"] = cpu_baseline(api, M, K, N, args, Cout, flops_per_row=None, rowmajor=args.rowmajor)
         del B, Cin, Cout
         torch.cuda.empty_cache()
         for key, fn in () if args.no_also else secondaries(api, torch, dev, stream, args):
@@ -378,7 +391,7 @@ def secondaries(api, torch, dev, stream, args):
                         ("rowmajor_config4_matrix_N32", lambda: uniform_secondary(api, torch, dev, stream, args, 32, layout="rm")))
 
 
-def cpu_baseline(api, M, K, N, args, Cout, flops_per_row, all_cores=True):
+def cpu_baseline(api, M, K, N, args, Cout, flops_per_row, all_cores=True, rowmajor=False):
     """Single-thread CPU baseline on the first R rows of the same matrix (same B, same C_in):
     the reference's own cpu_spmm_CSR when oracle/_ref is present, else our C restatement.
     Also cross-checks the GPU result on those rows bit-for-bit."""
@@ -392,6 +405,9 @@ def cpu_baseline(api, M, K, N, args, Cout, flops_per_row, all_cores=True):
         pass
     Bh = api.gen_uniform_host(K * N, 41)
     Cin_h = api.gen_uniform_host(M * N, 42)      # element i of stream 42 is C_in[i] (column-major M x N)
+    if rowmajor:   # (--rowmajor: element i is B[k][n] / C_in[r][n] with i = k N + n -- the CPU loops want column-major copies)
+        Bh = np.ascontiguousarray(Bh.reshape(K, N).T).reshape(-1)
+        Cin_h = np.ascontiguousarray(Cin_h.reshape(M, N).T).reshape(-1)
     cores = 1
 
     def run(R):
@@ -410,7 +426,7 @@ def cpu_baseline(api, M, K, N, args, Cout, flops_per_row, all_cores=True):
         R = int(min(M, max(R, R * args.cpu_seconds / max(sec, 1e-3))))
         sec, nnz_s, Cs, csr = run(R)
     gf = 2.0 * N * (nnz_s + R) / sec / 1e9
-    got = Cout.view(N, M)[:, :R].cpu().numpy().reshape(-1)
+    got = (Cout.view(M, N)[:R].t().contiguous() if rowmajor else Cout.view(N, M)[:, :R]).cpu().numpy().reshape(-1)
     match = bool(np.array_equal(got.view(np.uint32), Cs.view(np.uint32)))
     out = {"value": round(gf, 3), "unit": "GFLOP/s", "cores": cores, "kind": kind,
            "sample": f"rows [0,{R}) of the same matrix ({nnz_s} nnz), same B and C_in, "

@@ -458,6 +458,14 @@ int sextans_dist_comm_destroy(void *comm);
 int sextans_dist_spmm(sextans_handle_t h, void *comm, int world, int rank, const int *row_ranges, int N, float alpha,
                       const float *d_B, int64_t ldb, float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out,
                       int64_t ldc, int nchunks, void *stream);
+/* The same for ROW-major operands (round 5; d_B K x N with ldb >= N, d_C_in / d_C_out M_total x N with ldc_in / ldc >= N, all of it on
+ * every rank): the rank's rows are computed by sextans_spmm_device_rm straight into their place in d_C_out -- rows [r0, r1) of a
+ * row-major matrix with ldc == N are ONE contiguous run -- and exchanged by an in-place all-gather on `stream` (ncclAllGather for
+ * ranges of equal length, a group of ncclBroadcast otherwise): no repack of the replicated B on every rank, no staging buffer, no
+ * unpack pass, and every plan kind (natural, bricks, graph-clustered) keeps its whole-slab kernel.  ldc > N: through a packed copy.
+ * C_in is read in this rank's rows only.  comm == NULL with world == 1: the SpMM alone. */
+int sextans_dist_spmm_rm(sextans_handle_t h, void *comm, int world, int rank, const int *row_ranges, int N, float alpha, const float *d_B,
+                         int64_t ldb, float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out, int64_t ldc, void *stream);
 
 /* One-shot convenience with exactly cpu_spmm_CSR's argument list (sparse_helper.h:262-272):
  * create + upload + run + download + destroy on device 0. */

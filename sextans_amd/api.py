@@ -133,6 +133,9 @@ def lib():
     L.sextans_dist_spmm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i32p, C.c_int, C.c_float, C.c_void_p,
                                     C.c_int64, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
                                     C.c_void_p]
+    if hasattr(L, "sextans_dist_spmm_rm"):
+        L.sextans_dist_spmm_rm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i32p, C.c_int, C.c_float, C.c_void_p,
+                                           C.c_int64, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     pp = C.POINTER(C.c_void_p)
     L.sextans_edges_pack_csc.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f32p, C.POINTER(Edges)]
     L.sextans_edges_free.argtypes = [C.POINTER(Edges)]
@@ -517,6 +520,13 @@ class Engine:
         rr = np.ascontiguousarray(np.asarray(ranges, np.int32).reshape(-1))
         _check(lib().sextans_dist_spmm(self._h, comm, world, rank, rr, N, alpha, d_B, ldb, beta, d_C_in, ldc_in,
                                        d_C_out, ldc, nchunks, stream), "dist_spmm")
+
+    def dist_spmm_rm(self, comm, world, rank, ranges, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out, ldc, stream=None):
+        """Native multi-GPU SpMM on ROW-major operands (sextans_dist_spmm_rm): the rank's rows are written in place, the exchange is an
+        in-place all-gather of contiguous row runs."""
+        rr = np.ascontiguousarray(np.asarray(ranges, np.int32).reshape(-1))
+        _check(lib().sextans_dist_spmm_rm(self._h, comm, world, rank, rr, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out, ldc, stream),
+               "dist_spmm_rm")
 
     def export_plan(self, lanes_per_row=4):
         """The packed row-bucketed form the engine built ON THE DEVICE for the current matrix, read back in the layout of

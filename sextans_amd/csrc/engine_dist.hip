@@ -22,6 +22,9 @@ struct Rccl {
     int (*CommInitRank)(void **, int, Id128, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;   // (optional: unequal row-major slabs)
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
 std::string g_rccl_error;   // written once, inside the call_once below
@@ -42,6 +45,9 @@ void rccl_bind(Rccl &r) {
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
     r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    r.Broadcast = (decltype(r.Broadcast))dlsym(r.lib, "ncclBroadcast");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) {
         g_rccl_error = "RCCL library lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllGather";
         dlclose(r.lib); r.lib = nullptr;
@@ -305,6 +311,101 @@ int sextans_dist_spmm(sextans_handle_t h, void *comm, int world, int rank, const
     if (cc) cc_finish(h->d_Cfull, d_C_out, ldc, (int)M_total, N, h->comm_stream);
     SX_HIP(hipEventRecord(h->dist_events[(size_t)nchunks], h->comm_stream));
     SX_HIP(hipStreamWaitEvent(s, h->dist_events[(size_t)nchunks], 0));
+    SX_HIP(hipGetLastError());
+    return SEXTANS_OK;
+}
+
+// Row-major form (round 5).  The rows [row0, row1) of a row-major M_total x N matrix with ldc == N ARE one contiguous run: the rank's
+// SpMM (sextans_spmm_device_rm: no repack of the replicated B, no staging, natural / brick / graph-clustered plans alike -- every
+// kernel writes a row where it belongs) lands in its place inside d_C_out and the exchange is an IN-PLACE all-gather -- one
+// ncclAllGather when the ranges have equal lengths, one group of ncclBroadcast (root g sends its run) for nnz-balanced ranges.
+// Nothing is packed, nothing unpacked: what sextans_dist_spmm spends per rank on the B repack (O(K N) on EVERY rank, it does not
+// shrink with the world size: 17 of 85 us per rank at 8 ranks on the 4M-row FEM matrix, 125 of 279 us on its randomly numbered form,
+// profiles/r05_rank_slab_times.json) and on the unpack pass over all of C is gone.  ldc > N (rows not adjacent): the runs travel
+// through a packed staging copy (two strided copies around the same collective).
+int sextans_dist_spmm_rm(sextans_handle_t h, void *comm, int world, int rank, const int *row_ranges, int N, float alpha, const float *d_B,
+                         int64_t ldb, float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out, int64_t ldc, void *stream) {
+    if (!h || (!comm && world != 1) || world < 1 || rank < 0 || rank >= world || !row_ranges || N <= 0 || (N % 8) || !d_B || !d_C_in || !d_C_out ||
+        ldb < N || ldc_in < N || ldc < N)
+        return SEXTANS_ERR_INVALID;
+    if (!h->d_rp) return SEXTANS_ERR_STATE;
+    Rccl *r = comm ? rccl() : nullptr;
+    if (comm && !r) return SEXTANS_ERR_STATE;
+    int64_t M_total = 0;
+    bool equal = true;
+    for (int g = 0; g < world; ++g) {
+        if (row_ranges[2 * g] != (int)M_total || row_ranges[2 * g + 1] < row_ranges[2 * g]) return SEXTANS_ERR_INVALID;
+        M_total = row_ranges[2 * g + 1];
+        equal = equal && row_ranges[2 * g + 1] - row_ranges[2 * g] == row_ranges[1] - row_ranges[0];
+    }
+    const int row0 = row_ranges[2 * rank], m_loc = row_ranges[2 * rank + 1] - row0;
+    if (m_loc != h->M) return SEXTANS_ERR_INVALID;
+    if (getenv("SEXTANS_DIST_BROADCAST_RUNS")) equal = false;   // (tests: the grouped-broadcast exchange on ranges of equal length too)
+    if (comm && !equal && (!r->Broadcast || !r->GroupStart || !r->GroupEnd)) {
+        g_last_error = "RCCL library lacks ncclBroadcast / ncclGroupStart / ncclGroupEnd (row ranges of unequal length)";
+        return SEXTANS_ERR_STATE;
+    }
+    SX_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (world > 1 && h->opt_row_offset != row0)
+        if (int rc = sextans_set_option(h, "row_offset", row0)) return rc;
+    std::vector<int> nnz_key(row_ranges, row_ranges + 2 * world);
+    nnz_key.push_back(rank);
+    if (comm && h->dist_nnz_key != nnz_key) {   // the long-row thresholds follow the whole matrix's non-zeros (as in sextans_dist_spmm)
+        int *d_nz = nullptr;
+        SX_HIP(hipMalloc((void **)&d_nz, sizeof(int) * 2 * (size_t)world));
+        const int mine_nz[2] = {(int)(h->nnz & 0x7fffffff), (int)(h->nnz >> 31)};
+        SX_HIP(hipMemcpyAsync(d_nz + 2 * (size_t)rank, mine_nz, sizeof mine_nz, hipMemcpyHostToDevice, s));
+        const int rc = rccl_check(r->AllGather(d_nz + 2 * (size_t)rank, d_nz, 2, 2 /* ncclInt32 */, comm, s), "ncclAllGather(nnz)");
+        std::vector<int> all_nz(2 * (size_t)world);
+        hipError_t e1 = rc ? hipSuccess : hipMemcpyAsync(all_nz.data(), d_nz, sizeof(int) * all_nz.size(), hipMemcpyDeviceToHost, s);
+        hipError_t e2 = hipStreamSynchronize(s);
+        (void)hipFree(d_nz);
+        if (rc) return rc;
+        SX_HIP(e1);
+        SX_HIP(e2);
+        int64_t total = 0;
+        for (int g = 0; g < world; ++g) total += (int64_t)all_nz[2 * (size_t)g] + ((int64_t)all_nz[2 * (size_t)g + 1] << 31);
+        if (total != h->opt_global_nnz)
+            if (int rc = sextans_set_option(h, "global_nnz", total)) return rc;
+        h->dist_nnz_key = nnz_key;
+    }
+    if (m_loc > 0)
+        if (int rc = sextans_spmm_device_rm(h, N, alpha, d_B, ldb, beta, d_C_in + (int64_t)row0 * ldc_in, ldc_in, d_C_out + (int64_t)row0 * ldc, ldc, stream))
+            return rc;
+    if (!comm) return SEXTANS_OK;
+    float *X = d_C_out;   // where the runs are exchanged: C_out itself, or a packed copy of it
+    const bool packed = ldc != N;
+    if (packed) {
+        if (int rc = ensure(&h->d_stage, &h->stage_cap, (size_t)M_total * (size_t)N)) return rc;
+        h->dist_meta_at = nullptr;   // (the column-major form keeps its row tables behind its staging area)
+        X = h->d_stage;
+        if (m_loc > 0)
+            SX_HIP(hipMemcpy2DAsync(X + (int64_t)row0 * N, sizeof(float) * (size_t)N, d_C_out + (int64_t)row0 * ldc, sizeof(float) * (size_t)ldc, sizeof(float) * (size_t)N,
+                                    (size_t)m_loc, hipMemcpyDeviceToDevice, s));
+    }
+    if (equal) {
+        const size_t count = (size_t)m_loc * (size_t)N;
+        if (int rc = rccl_check(r->AllGather(X + (size_t)rank * count, X, count, 7 /* ncclFloat */, comm, s), "ncclAllGather(row-major C)")) return rc;
+    } else {
+        if (int rc = rccl_check(r->GroupStart(), "ncclGroupStart")) return rc;
+        int rc = SEXTANS_OK;
+        for (int g = 0; g < world && rc == SEXTANS_OK; ++g) {
+            const size_t count = (size_t)(row_ranges[2 * g + 1] - row_ranges[2 * g]) * (size_t)N;
+            float *run = X + (int64_t)row_ranges[2 * g] * N;
+            if (count) rc = rccl_check(r->Broadcast(run, run, count, 7 /* ncclFloat */, g, comm, s), "ncclBroadcast(row-major C)");
+        }
+        const int rc2 = rccl_check(r->GroupEnd(), "ncclGroupEnd");
+        if (rc) return rc;
+        if (rc2) return rc2;
+    }
+    if (packed)   // the other ranks' rows: two strided copies around this rank's own run
+        for (int part = 0; part < 2; ++part) {
+            const int64_t a = part ? row0 + m_loc : 0, b = part ? M_total : row0;
+            if (b > a)
+                SX_HIP(hipMemcpy2DAsync(d_C_out + a * ldc, sizeof(float) * (size_t)ldc, X + a * N, sizeof(float) * (size_t)N, sizeof(float) * (size_t)N, (size_t)(b - a),
+                                        hipMemcpyDeviceToDevice, s));
+        }
     SX_HIP(hipGetLastError());
     return SEXTANS_OK;
 }

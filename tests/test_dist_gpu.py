@@ -133,6 +133,51 @@ def test_native_dist_spmm_single_rank(engine, oracle, sx):
         api.dist_comm_destroy(comm)
 
 
+@pytest.mark.parametrize("exchange", ["allgather", "broadcast_runs"])
+def test_native_dist_spmm_rowmajor_single_rank(engine, oracle, sx, exchange, monkeypatch):
+    """sextans_dist_spmm_rm on a 1-rank communicator: the slab computed in place inside row-major C_out by the row-major entry point,
+    exchanged in place (ncclAllGather, or the group of ncclBroadcast that ranges of unequal length use), ldc == N and ldc > N (packed
+    copy), natural / brick / gather-kernel matrices; C_in == C_out allowed."""
+    import torch
+    from sextans_amd import api
+    if exchange == "broadcast_runs":
+        monkeypatch.setenv("SEXTANS_DIST_BROADCAST_RUNS", "1")
+    comm = api.dist_comm_init(0, 1, 0, api.dist_unique_id())
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        rs = np.random.RandomState(6)
+        for name in ("random", "fem", "fem bricks"):
+            if name == "random":
+                M, K, N = 2003, 1500, 16
+                rp, ci, v = random_csr(rs, M, K, 9)
+            elif name == "fem":
+                rp, ci, v = api.gen_fem3d_host(12, 11, 10, 3, 7); M = K = 12 * 11 * 10 * 3; N = 24
+            else:
+                rp, ci, v = api.gen_fem3d_host(20, 19, 18, 3, 5); M = K = 20 * 19 * 18 * 3; N = 32
+            B = rs.uniform(-1, 1, (K, N)).astype(np.float32); C0 = rs.uniform(-1, 1, (M, N)).astype(np.float32)
+            w = np.ascontiguousarray(C0.T).reshape(-1).copy()
+            oracle.spmm(M, N, K, ALPHA, rp, ci, v, np.ascontiguousarray(B.T).reshape(-1), BETA, w)
+            want = np.ascontiguousarray(w.reshape(N, M).T)
+            engine.set_matrix_csr(M, K, rp, ci, v)
+            dB = torch.from_numpy(B).cuda()
+            for ld in (N, N + 8):
+                cin = torch.full((M, ld), 3.0, device="cuda"); cin[:, :N] = torch.from_numpy(C0).cuda()
+                out = torch.full((M, ld), -5.0, device="cuda")
+                engine.dist_spmm_rm(comm, 1, 0, [(0, M)], N, ALPHA, dB.data_ptr(), N, BETA, cin.data_ptr(), ld, out.data_ptr(), ld, stream=st)
+                torch.cuda.synchronize()
+                got = out.cpu().numpy()
+                assert np.array_equal(np.ascontiguousarray(got[:, :N]).view(np.uint32), want.view(np.uint32)), (name, ld, engine.last_kernel())
+                assert np.all(got[:, N:] == -5.0)
+                assert "rowmajor" in engine.last_kernel(), (name, engine.last_kernel())
+                engine.dist_spmm_rm(comm, 1, 0, [(0, M)], N, ALPHA, dB.data_ptr(), N, BETA, cin.data_ptr(), ld, cin.data_ptr(), ld, stream=st)   # in place
+                torch.cuda.synchronize()
+                assert np.array_equal(np.ascontiguousarray(cin.cpu().numpy()[:, :N]).view(np.uint32), want.view(np.uint32)), (name, ld)
+        with pytest.raises(Exception):
+            engine.dist_spmm_rm(comm, 1, 0, [(0, M - 1)], N, ALPHA, dB.data_ptr(), N, BETA, cin.data_ptr(), ld, out.data_ptr(), ld, stream=st)
+    finally:
+        api.dist_comm_destroy(comm)
+
+
 @pytest.mark.parametrize("with_comm", [True, False])
 def test_clustered_order_chunks_keep_the_reordered_form(sx, oracle, with_comm):
     """VERDICT r04 task 4a: a slab that runs on a graph-clustered plan (a mesh in a random node order) used to fall back to the
@@ -234,6 +279,15 @@ def _rccl_worker(rank, world, port, q):
                             nchunks=3, stream=st)
                 torch.cuda.synchronize()
                 ok["native_" + mode] = bool(np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)))
+                # row-major operands: slabs written in place, in-place all-gather (equal ranges) / grouped broadcasts (nnz-balanced)
+                want_rm = np.ascontiguousarray(want.reshape(N, M).T)
+                dBr = torch.from_numpy(np.ascontiguousarray(B.reshape(N, K).T)).to(dev)
+                for ld in (N, N + 4):
+                    cin = torch.zeros((M, ld), device=dev); cin[:, :N] = torch.from_numpy(np.ascontiguousarray(C0.reshape(N, M).T)).to(dev)
+                    out = torch.full((M, ld), float("nan"), device=dev)
+                    e.dist_spmm_rm(comm, world, rank, ranges, N, ALPHA, dBr.data_ptr(), N, BETA, cin.data_ptr(), ld, out.data_ptr(), ld, stream=st)
+                    torch.cuda.synchronize()
+                    ok[f"native_rowmajor_{mode}_ld{ld}"] = bool(np.array_equal(np.ascontiguousarray(out.cpu().numpy()[:, :N]).view(np.uint32), want_rm.view(np.uint32)))
                 api.dist_comm_destroy(comm)
         q.put((rank, ok))
     finally:

@@ -14,6 +14,7 @@ from sextans_amd import api, dist as sxd
 
 N = 16
 CHUNKS = int(sys.argv[sys.argv.index("--chunks") + 1]) if "--chunks" in sys.argv else 1   # > 1: the chunk pipeline of sextans_dist_spmm without collectives (comm = NULL)
+RM = "--rm" in sys.argv                                                                     # row-major operands: what a rank of sextans_dist_spmm_rm runs (no repack, no staging)
 ONLY = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""               # substring of the matrix names to run
 st = torch.cuda.current_stream().cuda_stream
 ALPHA, BETA = 0.85, -2.06
@@ -23,6 +24,8 @@ def measure(e, m_loc, K, nnz):
     B = torch.empty(K * N, device="cuda"); Cin = torch.empty(m_loc * N, device="cuda"); Cout = torch.empty(m_loc * N, device="cuda")
     api.gen_uniform_device(0, B.data_ptr(), K * N, 41, st); api.gen_uniform_device(0, Cin.data_ptr(), m_loc * N, 42, st)
     f = lambda: e.spmm_device2(N, ALPHA, B.data_ptr(), K, BETA, Cin.data_ptr(), m_loc, Cout.data_ptr(), m_loc, st)
+    if RM:
+        f = lambda: e.spmm_device_rm(N, ALPHA, B.data_ptr(), N, BETA, Cin.data_ptr(), N, Cout.data_ptr(), N, st)
     if CHUNKS > 1:   # the rank's slab in CHUNKS row chunks, staged and unpacked as in a multi-rank run, no collective (world = 1, comm = NULL)
         f = lambda: e.dist_spmm(None, 1, 0, [(0, m_loc)], N, ALPHA, B.data_ptr(), K, BETA, Cin.data_ptr(), m_loc, Cout.data_ptr(), m_loc, nchunks=CHUNKS, stream=st)
     for _ in range(3): f()
@@ -41,7 +44,7 @@ def measure(e, m_loc, K, nnz):
     k *= max(1, n // 10)          # (chunked: one timed launch group per chunk -> the step's total)
     e.set_option("profile", 0)
     by = 8 * nnz + 4 * (m_loc + 1) + 4 * K * N + 8 * m_loc * N
-    return {"rows": m_loc, "nnz": nnz, "chunks": CHUNKS, "kernel": e.last_kernel(), "kernel_us": round(k / 1e3, 1), "repack_us": round(r / 1e3, 1), "post_us": round(p / 1e3, 1),
+    return {"rows": m_loc, "nnz": nnz, "chunks": CHUNKS, "layout": "row-major (sextans_spmm_device_rm)" if RM else "column-major", "kernel": e.last_kernel(), "kernel_us": round(k / 1e3, 1), "repack_us": round(r / 1e3, 1), "post_us": round(p / 1e3, 1),
             "us_per_step": round(wall * 1e6, 1), "alg_bytes": by, "roofline_frac_kernel": round(by / (k * 1e-9) / 8e12, 4)}
 
 
@@ -91,6 +94,7 @@ def _renumbered_by_engine():
 
 _all = lambda name, *a: run(name, *a) if ONLY in name else None
 doc = {"what": "per-rank slabs of a row-partitioned SpMM run sequentially on ONE MI355X (tools/rank_slabs.py); not a scaling measurement"
+               + ("; ROW-major operands: a rank of sextans_dist_spmm_rm computes its slab in place, nothing is repacked or staged" if RM else "")
                + (f"; every slab in {CHUNKS} row chunks through sextans_dist_spmm without collectives (its own rows staged and unpacked)" if CHUNKS > 1 else ""),
        "matrices": [_all("config4: uniform 4M x 4M, Poisson(40)", 4_000_000, 4_000_000, lambda r0, r1: api.gen_csr_device(0, 4_000_000, 4_000_000, 40.0, 4, r0, r1)),
                     _all("fem3d 110x110x110 x 3 dof (natural order)", 3_993_000, 3_993_000, lambda r0, r1: api.gen_fem3d_device(0, 110, 110, 110, 3, 3, r0, r1)),
