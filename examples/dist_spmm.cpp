@@ -1,7 +1,8 @@
 // examples/dist_spmm.cpp -- multi-GPU SpMM through the C ABI alone (no Python, no torch): what a maintainer of the
 // reference host program would write to shard  C = alpha*A*B + beta*C  over the GPUs of one node.
 //
-//   dist_spmm <A.mtx> <N> [gpus]      one host thread per GPU; default gpus = all visible gfx950 devices
+//   dist_spmm <A.mtx> <N> [gpus] [rm]  one host thread per GPU; default gpus = all visible gfx950 devices;
+//                                      rm: row-major B and C through sextans_dist_spmm_rm as well (slabs in place, in-place all-gather)
 //
 // Every rank loads the matrix (sextans_mtx_read), takes an nnz-balanced row range (sextans_partition_rows_by_nnz),
 // keeps its rows in its own engine, holds the full B and C_in, and calls sextans_dist_spmm; C_out is complete on
@@ -29,7 +30,8 @@
 #define HIP(call) do { if ((call) != hipSuccess) { fprintf(stderr, "%s failed\n", #call); exit(2); } } while (0)
 
 int main(int argc, char **argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s <A.mtx> <N> [gpus]\n", argv[0]); return 1; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <A.mtx> <N> [gpus] [rm]\n", argv[0]); return 1; }
+    const bool rm = argc > 4 && !strcmp(argv[4], "rm");
     const int N = sextans_round_up_n(atoi(argv[2]));
     int world = 0;
     if (sextans_device_count(&world) != SEXTANS_OK || world < 1) { fprintf(stderr, "no gfx950 device\n"); return 2; }
@@ -45,7 +47,13 @@ int main(int argc, char **argv) {
     const float alpha = 0.85f, beta = -2.06f;                        // sextans-host.cpp:29-30
     char id[128];
     CHECK(sextans_dist_unique_id(id));
-    std::vector<std::vector<float>> result((size_t)world);
+    std::vector<std::vector<float>> result((size_t)world), result_rm((size_t)world);
+    std::vector<float> Br, Cr;   // row-major copies of the same operands
+    if (rm) {
+        Br.resize(B.size()); Cr.resize(Cin.size());
+        for (int k = 0; k < K; ++k) for (int n = 0; n < N; ++n) Br[(size_t)k * N + n] = B[(size_t)n * K + k];
+        for (int r = 0; r < M; ++r) for (int n = 0; n < N; ++n) Cr[(size_t)r * N + n] = Cin[(size_t)n * M + r];
+    }
     std::vector<std::thread> ranks;
     for (int g = 0; g < world; ++g)
         ranks.emplace_back([&, g]() {
@@ -69,6 +77,16 @@ int main(int argc, char **argv) {
             HIP(hipStreamSynchronize(st));
             result[(size_t)g].resize(Cin.size());
             HIP(hipMemcpy(result[(size_t)g].data(), dCout, Cin.size() * 4, hipMemcpyDeviceToHost));
+            if (rm) {   // the same product on row-major operands: in place inside C (C_in == C_out), runs exchanged in place
+                HIP(hipMemcpy(dB, Br.data(), Br.size() * 4, hipMemcpyHostToDevice));
+                HIP(hipMemcpy(dCin, Cr.data(), Cr.size() * 4, hipMemcpyHostToDevice));
+                CHECK(sextans_dist_spmm_rm(h, comm, world, g, ranges.data(), N, alpha, dB, N, beta, dCin, N, dCin, N, (void *)st));
+                HIP(hipStreamSynchronize(st));
+                std::vector<float> t(Cin.size());
+                HIP(hipMemcpy(t.data(), dCin, Cin.size() * 4, hipMemcpyDeviceToHost));
+                result_rm[(size_t)g].resize(Cin.size());
+                for (int r = 0; r < M; ++r) for (int n = 0; n < N; ++n) result_rm[(size_t)g][(size_t)n * M + r] = t[(size_t)r * N + n];
+            }
             sextans_destroy(h);
             sextans_dist_comm_destroy(comm);
             (void)hipFree(dB); (void)hipFree(dCin); (void)hipFree(dCout); (void)hipStreamDestroy(st);
@@ -83,14 +101,16 @@ int main(int argc, char **argv) {
     CHECK(sextans_spmm_host(h, N, alpha, B.data(), beta, single.data(), 1, nullptr));
     sextans_destroy(h);
     int bad = 0;
+    for (int form = 0; form < (rm ? 2 : 1); ++form)
     for (int g = 0; g < world; ++g) {
-        if (memcmp(result[(size_t)g].data(), single.data(), single.size() * 4) == 0) continue;
+        const std::vector<float> &got = form ? result_rm[(size_t)g] : result[(size_t)g];
+        if (memcmp(got.data(), single.data(), single.size() * 4) == 0) continue;
         float pct = 0.f;                                             // hub rows are cut differently per rank range
-        const int mism = sextans_verify(M, N, single.data(), result[(size_t)g].data(), &pct);
-        printf("rank %d: not bit-identical; reference criterion: %d mismatches (%.4f %%)\n", g, mism, pct);
+        const int mism = sextans_verify(M, N, single.data(), got.data(), &pct);
+        printf("rank %d%s: not bit-identical; reference criterion: %d mismatches (%.4f %%)\n", g, form ? " (row-major)" : "", mism, pct);
         bad += mism;
     }
-    printf("dist_spmm: %d GPU(s), M=%d K=%d nnz=%d N=%d: %s\n", world, M, K, nnz, N, bad ? "MISMATCH" : "all ranks match the single-GPU result");
+    printf("dist_spmm: %d GPU(s), M=%d K=%d nnz=%d N=%d%s: %s\n", world, M, K, nnz, N, rm ? ", column-major and row-major forms" : "", bad ? "MISMATCH" : "all ranks match the single-GPU result");
     sextans_host_free(rp); sextans_host_free(ci); sextans_host_free(va);
     return bad ? 3 : 0;
 }

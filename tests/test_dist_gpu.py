@@ -329,6 +329,9 @@ def test_cpp_example_multi_gpu_through_the_c_abi(sx):
     for n in ("16", "40"):
         r = subprocess.run([exe, nasa, n], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and "all ranks match the single-GPU result" in r.stdout, r.stdout + r.stderr
+    # ... and with the row-major form next to it (sextans_dist_spmm_rm: slabs in place, in-place exchange)
+    r = subprocess.run([exe, nasa, "24", "8", "rm"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "column-major and row-major forms: all ranks match the single-GPU result" in r.stdout, r.stdout + r.stderr
 
 
 def test_new_b_after_a_fused_chunk_repacks_for_later_chunks(engine, oracle):
