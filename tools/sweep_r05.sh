@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/sweep_r05.sh -- the paper-style sweep (reference README.md:18,31: N up to 512 over many matrices) on one MI355X: every synthetic
 # class of round 4 + the HOLDOUT classes of round 5 (kron(T_850, nasa4704) in three numberings, rectangular, unsymmetric pattern) at
-# N in {8 ... 512}, column-major entry points; the classes with an LDS-panel plan once more through the ROW-major entry point
+# N in {8 ... 512}, column-major entry points; every class but the power-law one once more through the ROW-major entry point
 # (records carry "layout": "rm").  One JSON record per (matrix, N); step time = layout passes + kernels.
 OUT=gpurun_out/r05_sweep.jsonl
 ERR=gpurun_out/r05_sweep.err
@@ -13,7 +13,8 @@ python -m sextans_amd.sweep --rp 20 --n $NS \
   synth:stencil2d:2000:2000:5:1 synth:stencil2d:1400:1400:9:2 synth:kkt:2000000:4 \
   synth:femperm:110:110:110:3:random synth:femperm:110:110:110:3:rcm synth:mesh3d:110:3:sweep synth:mesh3d:110:3:random \
   synth:mesh3d:159:1:random $HOLD 2>>$ERR | grep '^{' >> $OUT
-python -m sextans_amd.sweep --rp 20 --n $NS --rm synth:fem3d:110:110:110:3 synth:fem3d:160:160:160:1 synth:stencil2d:1400:1400:9:2 \
+python -m sextans_amd.sweep --rp 20 --n $NS --rm synth:uniform:4000000:40 synth:banded:4000000:40:2000 synth:stencil2d:2000:2000:5:1 synth:kkt:2000000:4 \
+  synth:fem3d:110:110:110:3 synth:fem3d:160:160:160:1 synth:stencil2d:1400:1400:9:2 \
   synth:femperm:110:110:110:3:random synth:mesh3d:110:3:random synth:mesh3d:159:1:random $HOLD 2>>$ERR | grep '^{' >> $OUT
 python -m sextans_amd.sweep --rp 20 --n $NS --opt row_cluster=0 synth:femperm:110:110:110:3:random 2>>$ERR | grep '^{' | sed 's/"matrix": "synth:femperm/"options": "row_cluster=0 (natural-order forms)", "matrix": "synth:femperm/' >> $OUT
 python -m sextans_amd.sweep --rp 20 --n 64,128,256 --opt exact=0 synth:fem3d:110:110:110:3 2>>$ERR | grep '^{' | sed 's/"matrix": "synth:fem3d/"options": "exact=0 (FMA, opt-in)", "matrix": "synth:fem3d/' >> $OUT
