@@ -1237,6 +1237,10 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
     // (N = 8 runs as one half-empty 16-column tile of the 16-column plan: without a repack to pay for there is no reason for a second
     // packed plan at 2 lanes per row)
     const int Nplan = N == 8 ? 16 : N;
+    // (no B-panel / C-staging workspaces on behalf of this call: 8 GB each at K = M = 4M, N = 512, for paths that repack and stage nothing;
+    // the fallback at the end plans again through the column-major entry and gets them)
+    struct Lean { sextans_engine *h; ~Lean() { h->lean_prepare = false; } } lean{h};
+    h->lean_prepare = true;
     if (int rc = prepare(h, Nplan, plan, W, use_panel, use_window, true)) return rc;
     // A clustered plan that was declined only because the column-major form has to pay two passes over C for it (decline 12) is
     // reconsidered for this layout, where it costs nothing: built once, used by row-major calls only unless it pays for both.
@@ -1322,6 +1326,7 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
     // through column-major copies in the engine's workspaces -- two transposes in front, one behind.
     // (workspaces of their own -- not the host-buffer entry points' d_B / d_Cin / d_Cout, which are filled on another stream; C_in and
     // C_out may alias, so one C buffer)
+    h->lean_prepare = false;
     const size_t nB = (size_t)h->K * (size_t)N, nC = (size_t)h->M * (size_t)N;
     if (int rc = ensure(&h->d_rmB, &h->rmB_cap, nB)) return rc;
     if (int rc = ensure(&h->d_rmC, &h->rmC_cap, nC)) return rc;

@@ -76,7 +76,7 @@ int64_t device_bytes(const sextans_engine *h) {
     if (h->d_dense_Af) b += (int64_t)h->dense_mb * h->dense_W * (2048 + 4);
     if (h->d_bell_Af) b += (int64_t)(h->bell_M / 32) * h->bell_W * (2048 + (h->d_bell_col_owned ? 4 : 0));
     b += (int64_t)h->bell_Bf_cap;
-    b += 4 * (int64_t)(h->Bp_cap + h->B_cap + (h->d_Cin ? h->C_cap : 0) + h->C_cap + h->P_cap + h->stage_cap + h->chB_cap + h->chC_cap + h->Cs_cap);
+    b += 4 * (int64_t)(h->Bp_cap + h->B_cap + (h->d_Cin ? h->C_cap : 0) + h->C_cap + h->P_cap + h->stage_cap + h->chB_cap + h->chC_cap + h->Cs_cap + h->rmB_cap + h->rmC_cap + h->Cfull_cap + h->dist_rows_cap);
     return b;
 }
 
@@ -1007,8 +1007,9 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
         }
     }
     const size_t n16 = (size_t)((N + 15) / 16) * 16;   // (N = 16 t + 8: room for the tail as a zero-padded 16-column tile)
-    if (h->Bp_cap < (size_t)h->K * n16 || !h->d_Bp) h->bp_layout = 0;   // new workspace: nothing to reuse
-    if (int rc = ensure(&h->d_Bp, &h->Bp_cap, (size_t)h->K * n16)) return rc;
+    if (!h->lean_prepare && (h->Bp_cap < (size_t)h->K * n16 || !h->d_Bp)) h->bp_layout = 0;   // new workspace: nothing to reuse
+    if (!h->lean_prepare)
+        if (int rc = ensure(&h->d_Bp, &h->Bp_cap, (size_t)h->K * n16)) return rc;
     // main tile width: 4*lanes_per_row, but never wider than N itself (N = 8 -> 2 lanes per row); then
     // 16- and 8-wide tiles for the remainder (N is a multiple of 8, the reference's N-tile
     // granularity: sextans.cpp:57-60).
@@ -1048,7 +1049,7 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
         // use the clustered plan and do not pay for it.)
         if (lpr == 4 && whole && h->opt_kernel != 3) {
             if (int rc = ensure_cluster_plan(h)) return rc;
-            if (h->cluster_state == 2 && h->cluster_cm_pays && (N >= 16 || n8_wide))   // row-major C staging of the reordered form: ceil(N / 16) tiles of M x 16
+            if (h->cluster_state == 2 && h->cluster_cm_pays && (N >= 16 || n8_wide) && !h->lean_prepare)   // row-major C staging of the reordered form: ceil(N / 16) tiles of M x 16
                 if (int rc = ensure(&h->d_Cs, &h->Cs_cap, (n16 / 16) * (size_t)h->M * 16)) return rc;
         }
         use_panel = h->ps.plan_built && ((h->opt_kernel == 2) || (h->ps.plan_panel_frac >= 0.5 && (N >= 32 || h->ps.plan_narrow_frac >= 0.5)));

@@ -104,6 +104,7 @@ struct sextans_engine {
     int *d_dict_nat = nullptr;          // psc, graph clustering: the block dictionaries in the CALLER's column numbers (row-major calls read B where it lies)
     bool cluster_runs = false;          // cluster_state 1 by run-level clustering (runs of 16 consecutive rows over the graph of runs), not grid bricks
     bool cluster_for_rm = false;        // the plan is being (re)considered for row-major calls: no passes over C to pay for
+    bool lean_prepare = false;         // prepare() on behalf of a row-major call: no B-panel / C-staging workspaces (nothing is repacked or staged there)
     bool cluster_rm_tried = false;      //   ... once per matrix
     bool cluster_cm_pays = true;        // the graph-clustered plan also serves column-major calls (>= 40 % fewer panel rows: it pays two passes over C)
     int *d_colpos = nullptr;            // psc, graph clustering: row of the permuted B panels that holds column c (K ints)

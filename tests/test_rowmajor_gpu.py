@@ -217,3 +217,28 @@ def test_rowmajor_c_beyond_4gb_takes_64bit_addresses(engine, oracle, N):
         finally:
             for k in opts:
                 engine.set_option(k, 1)
+
+
+def test_rowmajor_calls_allocate_no_layout_workspaces(sx, oracle):
+    """An engine that only ever serves row-major calls on the native paths holds the matrix and its plan, not the B-panel / C-staging
+    workspaces of the column-major entry points (K x N and M x N floats each: 8 GB apiece at 4M rows and N = 512)."""
+    import torch
+    from sextans_amd import api
+    rp, ci, v = api.gen_fem3d_host(20, 19, 18, 3, 5)
+    M = K = 20 * 19 * 18 * 3
+    N = 64
+    rs = np.random.RandomState(2)
+    B = rs.uniform(-1, 1, (K, N)).astype(np.float32); C0 = rs.uniform(-1, 1, (M, N)).astype(np.float32)
+    want = _want(oracle, M, K, N, rp, ci, v, B, C0)
+    with api.Engine(0) as e:
+        e.set_matrix_csr(M, K, rp, ci, v)
+        got = _run(e, M, K, N, B, C0)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and e.last_kernel() == "spmm_csr_panel_v2_rowmajor"
+        lean = e.get_stat("device_bytes")
+        cm = np.ascontiguousarray(C0.T).reshape(-1).copy()
+        e.spmm(N, ALPHA, np.ascontiguousarray(B.T).reshape(-1), BETA, cm)
+        full = e.get_stat("device_bytes")
+        assert np.array_equal(np.ascontiguousarray(cm.reshape(N, M).T).view(np.uint32), want.view(np.uint32))
+        assert full - lean >= 4 * K * N, (lean, full)      # the column-major call brought (at least) the B panels
+        got = _run(e, M, K, N, B, C0)                       # and the row-major call still works afterwards
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
