@@ -485,6 +485,17 @@ int sextans_set_matrix_bell_device(sextans_handle_t h, int M, int K, int ell_wid
                                    const int *d_block_col, const uint16_t *d_block_val);
 int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint16_t *d_B, int64_t ldb,
                              float beta, const float *d_C_in, float *d_C_out, int64_t ldc, void *stream);
+/* The same with separate leading dimensions for C_in and C_out (a rank of sextans_dist_spmm_bell reads its rows inside the whole C_in
+ * and writes a packed slab). */
+int sextans_spmm_bell_device2(sextans_handle_t h, int N, float alpha, const uint16_t *d_B, int64_t ldb, float beta, const float *d_C_in,
+                              int64_t ldc_in, float *d_C_out, int64_t ldc, void *stream);
+/* Blocked-ELL over the GPUs of one node (block-row ranges): the engine holds the block rows of
+ * [row_ranges[2*rank], row_ranges[2*rank+1]) -- multiples of 32, tiling [0, M_total) in rank order -- d_B is the whole bf16 K x N matrix,
+ * d_C_in / d_C_out the whole column-major fp32 M_total x N matrices on this rank's device.  The rank's slab is written packed into a
+ * staging buffer, one ncclAllGather on `stream` moves all slabs, one pass writes d_C_out: complete on every rank, stream-ordered,
+ * bit-identical to sextans_spmm_bell_device on the whole matrix.  comm == NULL with world == 1: no collective. */
+int sextans_dist_spmm_bell(sextans_handle_t h, void *comm, int world, int rank, const int *row_ranges, int N, float alpha, const uint16_t *d_B,
+                           int64_t ldb, float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out, int64_t ldc, void *stream);
 
 /* Per-kernel device timing collected while option "profile" = 1: mean duration in ns of the
  * dominant SpMM kernel launches since the last reset, and how many were timed. */

@@ -216,6 +216,11 @@ def lib():
     L.sextans_set_matrix_bell_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.sextans_spmm_bell_device.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
                                            C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    if hasattr(L, "sextans_dist_spmm_bell"):
+        L.sextans_spmm_bell_device2.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
+                                                C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+        L.sextans_dist_spmm_bell.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i32p, C.c_int, C.c_float, C.c_void_p,
+                                             C.c_int64, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     L.sextans_gen_bell_banded_host.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, pi, C.POINTER(C.POINTER(C.c_uint16))]
     L.sextans_gen_bell_banded_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_void_p),
                                                  C.POINTER(C.c_void_p)]
@@ -645,6 +650,15 @@ class Engine:
     def spmm_bell_device(self, N, alpha, d_B_bf16, ldb, beta, d_C_in, d_C_out, ldc, stream=None):
         _check(lib().sextans_spmm_bell_device(self._h, N, alpha, d_B_bf16, ldb, beta, d_C_in, d_C_out, ldc,
                                               stream), "spmm_bell_device")
+
+    def spmm_bell_device2(self, N, alpha, d_B_bf16, ldb, beta, d_C_in, ldc_in, d_C_out, ldc, stream=None):
+        _check(lib().sextans_spmm_bell_device2(self._h, N, alpha, d_B_bf16, ldb, beta, d_C_in, ldc_in, d_C_out, ldc, stream), "spmm_bell_device2")
+
+    def dist_spmm_bell(self, comm, world, rank, ranges, N, alpha, d_B_bf16, ldb, beta, d_C_in, ldc_in, d_C_out, ldc, stream=None):
+        """Blocked-ELL over several GPUs (sextans_dist_spmm_bell): this engine holds the block rows of ranges[rank]."""
+        rr = np.ascontiguousarray(np.asarray(ranges, np.int32).reshape(-1))
+        _check(lib().sextans_dist_spmm_bell(self._h, comm, world, rank, rr, N, alpha, d_B_bf16, ldb, beta, d_C_in, ldc_in, d_C_out, ldc, stream),
+               "dist_spmm_bell")
 
     def spmm_device2(self, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out, ldc_out, stream=None):
         _check(lib().sextans_spmm_device2(self._h, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out,

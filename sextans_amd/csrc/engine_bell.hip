@@ -273,9 +273,16 @@ int sextans_set_matrix_bell(sextans_handle_t h, int M, int K, int ell_width, con
 
 int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint16_t *d_B, int64_t ldb,
                              float beta, const float *d_C_in, float *d_C_out, int64_t ldc, void *stream) {
+    return sextans_spmm_bell_device2(h, N, alpha, d_B, ldb, beta, d_C_in, ldc, d_C_out, ldc, stream);
+}
+
+// (separate leading dimensions of C_in and C_out: a rank of sextans_dist_spmm_bell reads its rows inside the whole C_in and writes a
+// packed slab)
+int sextans_spmm_bell_device2(sextans_handle_t h, int N, float alpha, const uint16_t *d_B, int64_t ldb, float beta, const float *d_C_in,
+                              int64_t ldc_in, float *d_C_out, int64_t ldc, void *stream) {
     if (!h || N <= 0 || (N % 32) || !d_B || !d_C_in || !d_C_out) return SEXTANS_ERR_INVALID;
     if (!h->d_bell_Af) return SEXTANS_ERR_STATE;
-    if (ldb < h->bell_K || (ldb % 8) || ldc < h->bell_M) return SEXTANS_ERR_INVALID;
+    if (ldb < h->bell_K || (ldb % 8) || ldc < h->bell_M || ldc_in < h->bell_M) return SEXTANS_ERR_INVALID;
     SX_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const int kblocks = h->bell_K / 32, mblocks = h->bell_M / 32, ntiles = N / 32;
@@ -300,7 +307,7 @@ int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint1
     {                                                                                                  \
         const int64_t waves = (int64_t)mblocks * (ntiles / NSUB);                                      \
         hipLaunchKernelGGL((sx::spmm_bell_mfma<NSUB>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, \
-                           h->d_bell_col, Af, Bf, d_C_in, ldc, d_C_out, ldc, mblocks, h->bell_W, ntiles,    \
+                           h->d_bell_col, Af, Bf, d_C_in, ldc_in, d_C_out, ldc, mblocks, h->bell_W, ntiles,    \
                            alpha, beta);                                                                      \
     }
         const bool shared = ntiles == 8 && h->opt_bell_shared != 0 && sx::kShRows * h->bell_W <= sx::kShMaxRowCols &&
@@ -311,7 +318,7 @@ int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint1
                                   (size_t)sx::kShMaxRowCols * sizeof(int);
             if (int rc = allow_big_lds(h, reinterpret_cast<const void *>(sx::spmm_bell_mfma_shared), (int)lds)) return rc;
             hipLaunchKernelGGL(sx::spmm_bell_mfma_shared, dim3((unsigned)((mblocks + sx::kShRows - 1) / sx::kShRows)), dim3(sx::kShThreads), lds,
-                               s, h->d_bell_col, Af, Bf, d_C_in, ldc, d_C_out, ldc, mblocks, h->bell_W, alpha, beta, (int)h->opt_bell_debug);
+                               s, h->d_bell_col, Af, Bf, d_C_in, ldc_in, d_C_out, ldc, mblocks, h->bell_W, alpha, beta, (int)h->opt_bell_debug);
             h->last_kernel = "spmm_bell_mfma_shared";
             SX_HIP(hipGetLastError());
             return SEXTANS_OK;
@@ -322,7 +329,7 @@ int sextans_spmm_bell_device(sextans_handle_t h, int N, float alpha, const uint1
             for (int b0 = 0; b0 < mblocks; b0 += G) {
                 const int nb = std::min(G, mblocks - b0);
                 hipLaunchKernelGGL(sx::spmm_bell_mfma_n256, dim3((unsigned)((nb + 3) / 4)), dim3(256), 0, s, h->d_bell_col, Af,
-                                   Bf, d_C_in, ldc, d_C_out, ldc, std::min(mblocks, b0 + nb), h->bell_W, alpha, beta, b0);
+                                   Bf, d_C_in, ldc_in, d_C_out, ldc, std::min(mblocks, b0 + nb), h->bell_W, alpha, beta, b0);
             }
         } else if (ntiles % 4 == 0) SX_BELL(4) else if (ntiles % 2 == 0) SX_BELL(2) else SX_BELL(1)
 #undef SX_BELL

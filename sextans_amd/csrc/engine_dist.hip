@@ -410,4 +410,50 @@ int sextans_dist_spmm_rm(sextans_handle_t h, void *comm, int world, int rank, co
     return SEXTANS_OK;
 }
 
+// Blocked-ELL bf16 (BASELINE config 5) over several GPUs -- SURVEY 8e: "Config 5 likewise (block-row ranges)".  Block rows are
+// independent (every wavefront owns 32 rows of C), so the engine of a rank holds the block rows of its row range
+// (sextans_set_matrix_bell[_device] with M = its rows; ranges are multiples of 32), B (bf16) is replicated, and the rank's fp32 slab is
+// written PACKED (ldc = longest range) into its slot of the staging buffer, moved by ONE ncclAllGather and written into column-major
+// C_out by one HBM-local pass -- the column-major CSR form without chunks: at N = 256 the slab of a rank is 128 MB at 8 ranks, the
+// kernel 27 ms / world.  Every element is computed by the same wavefront code on the same operands as on one GPU: bit-identical to
+// sextans_spmm_bell_device on the whole matrix.  comm == NULL with world == 1: the same without the collective.
+int sextans_dist_spmm_bell(sextans_handle_t h, void *comm, int world, int rank, const int *row_ranges, int N, float alpha, const uint16_t *d_B,
+                           int64_t ldb, float beta, const float *d_C_in, int64_t ldc_in, float *d_C_out, int64_t ldc, void *stream) {
+    if (!h || (!comm && world != 1) || world < 1 || rank < 0 || rank >= world || !row_ranges || N <= 0 || (N % 32) || !d_B || !d_C_in || !d_C_out)
+        return SEXTANS_ERR_INVALID;
+    if (!h->d_bell_Af) return SEXTANS_ERR_STATE;
+    Rccl *r = comm ? rccl() : nullptr;
+    if (comm && !r) return SEXTANS_ERR_STATE;
+    int64_t M_total = 0, lmax = 1;
+    for (int g = 0; g < world; ++g) {
+        if (row_ranges[2 * g] != (int)M_total || row_ranges[2 * g + 1] < row_ranges[2 * g] || (row_ranges[2 * g + 1] % 32)) return SEXTANS_ERR_INVALID;
+        lmax = std::max<int64_t>(lmax, row_ranges[2 * g + 1] - row_ranges[2 * g]);
+        M_total = row_ranges[2 * g + 1];
+    }
+    const int row0 = row_ranges[2 * rank], m_loc = row_ranges[2 * rank + 1] - row0;
+    if (m_loc != h->bell_M || ldc < M_total || ldc_in < M_total) return SEXTANS_ERR_INVALID;
+    SX_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t slab = (size_t)N * (size_t)lmax, meta_floats = (size_t)world * 2;
+    if (h->stage_cap < (size_t)world * slab + meta_floats) h->dist_meta_at = nullptr;
+    if (int rc = ensure(&h->d_stage, &h->stage_cap, (size_t)world * slab + meta_floats)) return rc;
+    std::vector<int> meta(meta_floats);
+    for (int g = 0; g < world; ++g) { meta[2 * (size_t)g] = row_ranges[2 * g]; meta[2 * (size_t)g + 1] = row_ranges[2 * g + 1] - row_ranges[2 * g]; }
+    int *d_meta = reinterpret_cast<int *>(h->d_stage + (size_t)world * slab);
+    if (h->dist_meta != meta || h->dist_meta_at != d_meta) {   // the row table changes only with the partition
+        SX_HIP(hipMemcpyAsync(d_meta, meta.data(), sizeof(int) * meta.size(), hipMemcpyHostToDevice, s));
+        SX_HIP(hipStreamSynchronize(s));
+        h->dist_meta = meta;
+        h->dist_meta_at = d_meta;
+    }
+    float *mine = h->d_stage + (size_t)rank * slab;
+    if (int rc = sextans_spmm_bell_device2(h, N, alpha, d_B, ldb, beta, d_C_in + row0, ldc_in, mine, lmax, stream)) return rc;
+    if (comm)
+        if (int rc = rccl_check(r->AllGather(mine, h->d_stage, slab, 7 /* ncclFloat */, comm, s), "ncclAllGather(blocked-ELL C)")) return rc;
+    hipLaunchKernelGGL(dist_unpack_slabs, dim3((unsigned)((lmax + 255) / 256), (unsigned)N, (unsigned)world), dim3(256), 0, s, h->d_stage, lmax, N,
+                       reinterpret_cast<const int2 *>(d_meta), d_C_out, ldc);
+    SX_HIP(hipGetLastError());
+    return SEXTANS_OK;
+}
+
 }  // extern "C"

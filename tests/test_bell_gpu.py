@@ -243,3 +243,50 @@ def test_measurement_options_are_gated(sx):
             os.environ.pop("SEXTANS_DEBUG_OPTIONS", None)
         else:
             os.environ["SEXTANS_DEBUG_OPTIONS"] = old
+
+
+@pytest.mark.gpu
+def test_bell_block_row_ranges_and_the_dist_entry_point(engine, sx):
+    """config 5 shards by block-row ranges.  (i) The slabs of a 3-way partition, each computed by an engine that holds only its
+    block rows and written PACKED (sextans_spmm_bell_device2: C_in inside the whole matrix, C_out with its own leading dimension), equal
+    the whole-matrix result bit for bit -- a wavefront's 32 rows never depend on the others.  (ii) sextans_dist_spmm_bell on a 1-rank
+    RCCL communicator and without one: staging, ncclAllGather, unpack -> the same bits, C_in == C_out allowed."""
+    import torch
+    from sextans_amd import api
+    M, K, N, W = 768, 1024, 256, 6
+    st = torch.cuda.current_stream().cuda_stream
+    bcol, bval = api.gen_bell_host(M, K, W, 9)
+    B16 = api.gen_uniform_bf16_host(K * N, 3)
+    C0 = np.random.RandomState(1).uniform(-1, 1, M * N).astype(np.float32)
+    alpha, beta = np.float32(0.85), np.float32(-2.06)
+    dB = torch.from_numpy(B16.view(np.int16)).cuda(); dCin = torch.from_numpy(C0).cuda()
+    whole = torch.zeros(M * N, device="cuda")
+    engine.set_matrix_bell(M, K, W, bcol, bval)
+    engine.spmm_bell_device(N, alpha, dB.data_ptr(), K, beta, dCin.data_ptr(), whole.data_ptr(), M, st)
+    torch.cuda.synchronize()
+    ranges = [(0, 256), (256, 576), (576, 768)]
+    out = torch.full((M * N,), float("nan"), device="cuda")
+    with api.Engine(0) as e:
+        for r0, r1 in ranges:
+            e.set_matrix_bell(r1 - r0, K, W, bcol[r0 // 32 * W:r1 // 32 * W], bval[r0 // 32 * W * 1024:r1 // 32 * W * 1024])
+            slab = torch.full(((r1 - r0) * N,), float("nan"), device="cuda")
+            e.spmm_bell_device2(N, alpha, dB.data_ptr(), K, beta, dCin.data_ptr() + 4 * r0, M, slab.data_ptr(), r1 - r0, st)
+            out.view(N, M)[:, r0:r1] = slab.view(N, r1 - r0)
+        torch.cuda.synchronize()
+        assert torch.equal(out, whole)
+    for with_comm in (True, False):
+        comm = api.dist_comm_init(0, 1, 0, api.dist_unique_id()) if with_comm else None
+        try:
+            out = torch.full((M * N,), float("nan"), device="cuda")
+            engine.dist_spmm_bell(comm, 1, 0, [(0, M)], N, alpha, dB.data_ptr(), K, beta, dCin.data_ptr(), M, out.data_ptr(), M, stream=st)
+            torch.cuda.synchronize()
+            assert torch.equal(out, whole), with_comm
+            inpl = dCin.clone()
+            engine.dist_spmm_bell(comm, 1, 0, [(0, M)], N, alpha, dB.data_ptr(), K, beta, inpl.data_ptr(), M, inpl.data_ptr(), M, stream=st)
+            torch.cuda.synchronize()
+            assert torch.equal(inpl, whole), with_comm
+            with pytest.raises(Exception):   # ranges are whole block rows
+                engine.dist_spmm_bell(comm, 1, 0, [(0, M - 8)], N, alpha, dB.data_ptr(), K, beta, dCin.data_ptr(), M, out.data_ptr(), M, stream=st)
+        finally:
+            if comm is not None:
+                api.dist_comm_destroy(comm)

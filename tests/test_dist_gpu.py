@@ -288,6 +288,23 @@ def _rccl_worker(rank, world, port, q):
                     e.dist_spmm_rm(comm, world, rank, ranges, N, ALPHA, dBr.data_ptr(), N, BETA, cin.data_ptr(), ld, out.data_ptr(), ld, stream=st)
                     torch.cuda.synchronize()
                     ok[f"native_rowmajor_{mode}_ld{ld}"] = bool(np.array_equal(np.ascontiguousarray(out.cpu().numpy()[:, :N]).view(np.uint32), want_rm.view(np.uint32)))
+                if mode == "even":   # blocked-ELL bf16 over the same communicator: block-row ranges, packed slabs, one all-gather
+                    Mb, Kb, Nb, Wb = 1024, 1024, 64, 5
+                    bcol, bval = api.gen_bell_host(Mb, Kb, Wb, 9)
+                    B16 = api.gen_uniform_bf16_host(Kb * Nb, 3)
+                    Cb = np.random.RandomState(1).uniform(-1, 1, Mb * Nb).astype(np.float32)
+                    dBb = torch.from_numpy(B16.view(np.int16)).to(dev); dCb = torch.from_numpy(Cb).to(dev)
+                    with api.Engine(rank) as eb:
+                        eb.set_matrix_bell(Mb, Kb, Wb, bcol, bval)
+                        whole = torch.zeros(Mb * Nb, device=dev)
+                        eb.spmm_bell_device(Nb, ALPHA, dBb.data_ptr(), Kb, BETA, dCb.data_ptr(), whole.data_ptr(), Mb, st)
+                        rg = [(g * (Mb // world // 32) * 32, (g + 1) * (Mb // world // 32) * 32 if g + 1 < world else Mb) for g in range(world)]
+                        b0, b1 = rg[rank]
+                        eb.set_matrix_bell(b1 - b0, Kb, Wb, bcol[b0 // 32 * Wb:b1 // 32 * Wb], bval[b0 // 32 * Wb * 1024:b1 // 32 * Wb * 1024])
+                        outb = torch.full((Mb * Nb,), float("nan"), device=dev)
+                        eb.dist_spmm_bell(comm, world, rank, rg, Nb, ALPHA, dBb.data_ptr(), Kb, BETA, dCb.data_ptr(), Mb, outb.data_ptr(), Mb, stream=st)
+                        torch.cuda.synchronize()
+                        ok["native_blocked_ell"] = bool(torch.equal(outb, whole))
                 api.dist_comm_destroy(comm)
         q.put((rank, ok))
     finally:

@@ -75,6 +75,41 @@ def run(name, M, K, gen, slab_offset=False, owned=3):
     return out
 
 
+if "--bell" in sys.argv:
+    # BASELINE config 5 (blocked-ELL bf16, 1M x 1M, 328 blocks per block row, N = 256) in block-row ranges: every rank's slab through
+    # sextans_dist_spmm_bell without a communicator (packed slab into the staging buffer + the unpack pass of its own rows), one after
+    # the other on this GPU.  A slab is a pointer offset into the generated arrays.
+    M = K = 1_048_576; W = 328; NB = 256
+    dc, dv = api.gen_bell_device(0, M, K, W, 5)
+    B = torch.empty(K * NB, dtype=torch.int16, device="cuda"); Cin = torch.empty(M * NB, device="cuda")
+    api.gen_uniform_bf16_device(0, B.data_ptr(), K * NB, 51, st); api.gen_uniform_device(0, Cin.data_ptr(), M * NB, 52, st)
+    doc = {"what": "config 5 (blocked-ELL bf16, N = 256): per-rank block-row slabs run sequentially on ONE MI355X through sextans_dist_spmm_bell (comm = NULL); not a scaling measurement", "worlds": {}}
+    for world in (1, 2, 4, 8):
+        ranks = []
+        for g in range(world):
+            r0, r1 = g * (M // world), (g + 1) * (M // world)
+            e = api.Engine(0)
+            e.set_matrix_bell_device(r1 - r0, K, W, dc + 4 * (r0 // 32) * W, dv + 2048 * (r0 // 32) * W)
+            Cout = torch.empty((r1 - r0) * NB, device="cuda")
+            f = lambda: e.dist_spmm_bell(None, 1, 0, [(0, r1 - r0)], NB, ALPHA, B.data_ptr(), K, BETA, Cin.data_ptr() + 4 * r0, M, Cout.data_ptr(), r1 - r0, stream=st)
+            f(); f(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3): f()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / 3
+            e.set_option("profile", 1); e.profile_reset()
+            for _ in range(3): f()
+            torch.cuda.synchronize()
+            k, n, r = e.profile_read()
+            ranks.append({"rank": g, "row_range": [r0, r1], "kernel": e.last_kernel(), "kernel_ms": round(k / 1e6, 3), "repack_b_us": round(r / 1e3, 1), "ms_per_step": round(wall * 1e3, 3)})
+            e.close(); del Cout
+        doc["worlds"][str(world)] = {"ranks": ranks, "max_ms_per_step": max(x["ms_per_step"] for x in ranks), "allgather_bytes_received_per_rank": 4 * NB * (M - M // world)}
+        print(f"# config 5 world {world}: slowest rank {doc['worlds'][str(world)]['max_ms_per_step']:.2f} ms/step", file=sys.stderr, flush=True)
+    base = doc["worlds"]["1"]["max_ms_per_step"]
+    for w in doc["worlds"].values(): w["compute_only_speedup_if_ranks_ran_in_parallel"] = round(base / w["max_ms_per_step"], 2)
+    print(json.dumps(doc, indent=1))
+    sys.exit(0)
+
 from sextans_amd import meshgen
 _base = api.gen_fem3d_device(0, 110, 110, 110, 3, 3)
 _perm = api.permute_symmetric_device(0, 3_993_000, _base[3], *_base[:3], meshgen.node_permutation(3_993_000 // 3, 3, 1))
