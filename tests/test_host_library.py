@@ -164,6 +164,10 @@ def test_round5_entry_points_reject_bad_arguments(sx):
     L.sextans_export_row_order.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     assert L.sextans_spmm_device_rm(None, 16, 1.0, None, 16, 0.0, None, 16, None, 16, None) == 9          # SEXTANS_ERR_INVALID
     assert L.sextans_export_row_order(None, None, None) == 9
+    rr = np.array([0, 64], np.int32)
+    assert L.sextans_dist_spmm_rm(None, None, 1, 0, rr, 16, 1.0, None, 16, 0.0, None, 16, None, 16, None) == 9
+    assert L.sextans_dist_spmm_bell(None, None, 1, 0, rr, 32, 1.0, None, 64, 0.0, None, 64, None, 64, None) == 9
+    assert L.sextans_spmm_bell_device2(None, 32, 1.0, None, 64, 0.0, None, 64, None, 64, None) == 9
     L.sextans_mtx_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     assert L.sextans_mtx_write(None, 1, 1, None, None, None) == 9
     assert L.sextans_mtx_write(b"/nonexistent-directory/x.mtx", 0, 0, (C.c_int * 1)(0), None, None) == 1  # SEXTANS_ERR_OPEN
