@@ -138,6 +138,29 @@ def all_gather_c(C_full, M, N, ranges, rank, group=None, _force=False):
             cols[:, a:b] = recv[g, :, :b - a]
 
 
+def all_gather_rows(C_rm, ranges, rank, group=None, _force=False):
+    """Row-major form: complete the M x N tensor `C_rm` (contiguous, CPU or GPU) on every rank IN PLACE.  On entry rank g has written
+    rows ranges[g] -- one contiguous run of a row-major matrix -- on return all rows are present.  Equal ranges: one
+    all_gather_into_tensor whose send buffer is the rank's own run inside the receive tensor; nnz-balanced ranges: one broadcast per
+    run (root = its owner).  The torch.distributed twin of sextans_dist_spmm_rm's exchange: nothing is packed or unpacked."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if world == 1 and not _force:
+        return
+    if not C_rm.is_contiguous():
+        raise ValueError("all_gather_rows: C must be a contiguous row-major tensor (a padded leading dimension needs a packed copy)")
+    M = C_rm.shape[0]
+    lens = [r1 - r0 for r0, r1 in ranges]
+    r0, r1 = ranges[rank]
+    if len(set(lens)) == 1 and lens[0] * world == M:
+        dist.all_gather_into_tensor(C_rm.view(-1), C_rm[r0:r1].reshape(-1), group=group)
+        return
+    for g, (a, b) in enumerate(ranges):
+        if b > a:
+            dist.broadcast(C_rm[a:b], src=dist.get_global_rank(group, g) if group is not None else g, group=group)
+
+
 class SlabGather:
     """All-gather of C as ONE large collective (the form bench.py uses at N > 1).
 

@@ -49,6 +49,11 @@ def _worker(rank, world, port, mode, q):
         t = torch.from_numpy(Cfull)
         sxd.all_gather_c(t, M, N, ranges, rank)
         ok = np.array_equal(t.numpy().view(np.uint32), want.view(np.uint32))
+        # row-major operands: the rank's rows are one contiguous run, the exchange is in place (dist.all_gather_rows)
+        Crm = torch.full((M, N), float("nan"))
+        Crm[r0:r1] = torch.from_numpy(slab.reshape(N, r1 - r0).T.copy())
+        sxd.all_gather_rows(Crm, ranges, rank)
+        ok = ok and np.array_equal(np.ascontiguousarray(Crm.numpy().T).reshape(-1).view(np.uint32), want.view(np.uint32))
         # single-collective form: the slab is written packed (ldc_out = lmax) into the staging buffer
         sg = sxd.SlabGather(M, N, ranges, rank, torch.device("cpu"))
         sg.local_slab()[:, :r1 - r0] = torch.from_numpy(slab.reshape(N, r1 - r0))
