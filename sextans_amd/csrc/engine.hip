@@ -166,6 +166,14 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     int tpw = (int)h->opt_tiles_per_wg;
     if (tpw <= 0 && big) {   // ... in ONE round of workgroups
         tpw = std::min<int>(nsuper, std::max<int>(1, (int)(((int64_t)nblk * nsuper + 2 * h->num_cus - 1) / ((int64_t)2 * h->num_cus))));
+    } else if (tpw <= 0 && rm_ldb > 0 && P.plan_sets == 2 && nsuper >= 4) {
+        // row-major operands, two row sets per block (short-row 3-D grids), N >= 64: one tile per workgroup.  The workgroups of a block's
+        // tiles are neighbours in the launch order, so the 64-byte halves of the B lines their panels are made of are asked for together,
+        // and the panel copy is most of what such a block moves (3.4 dictionary rows per matrix row and tile against 26 entries once).
+        // Same-box, 27-point 1-dof 4M rows: N = 64 / 128 / 256 0.459 / 0.389 / 0.335 -> 0.491 / 0.446 / 0.406 of the roofline; every other
+        // class measured (long rows, one row set, column-major panels) loses 5 .. 20 % to the re-read of its entries
+        // (profiles/r05_tiles_per_wg_ab.txt).
+        tpw = 1;
     } else if (tpw <= 0) {   // all of N in one workgroup while that still leaves >= 4 rounds of workgroups (2 per CU)
         const int64_t rounds = (int64_t)nblk * nsuper / ((int64_t)8 * h->num_cus);
         tpw = (int)std::max<int64_t>(1, std::min<int64_t>(nsuper, rounds));
@@ -446,6 +454,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "share_index")) return &h->opt_share_index;
     if (!strcmp(key, "refine_rows")) return &h->opt_refine_rows;
     if (!strcmp(key, "colwise_max_len")) return &h->opt_colwise_max_len;
+    if (!strcmp(key, "colwise_tiles_adjacent")) return &h->opt_colwise_tiles_adjacent;
     if (!strcmp(key, "cluster_shape")) return &h->opt_cluster_shape;
     if (!strcmp(key, "cluster_group")) return &h->opt_cluster_group;
     if (!strcmp(key, "window_rows")) return &h->opt_win_rows;
@@ -904,8 +913,15 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         Prof p(h, &h->ev_kernel, s);
         const int nrowblk = (nrows + sx::kBlock - 1) / sx::kBlock;
         auto go = [&](auto kern, int col0, int ntiles) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)nrowblk, (unsigned)ntiles), dim3(sx::kBlock), 0, s, h->m_rp, h->m_ci, h->m_v, d_B, ldb, d_C_in,
-                               ldc_in, d_C_out, ldc, row_begin, row_end, nrowblk, col0, alpha, beta, (int)h->opt_xcd, (const unsigned char *)h->d_skip);
+            // (tiles of a row block neighbours in the launch order: the row block's CSR entries come from HBM once -- measured on the 4M-row
+            // 5-point stencil, two boxes: N = 32 0.513 / 0.527 -> 0.532 / 0.550 of the roofline; N = 48 / 64 equal or 1 % behind; N = 128 / 256
+            // 0.51 -> 0.43 .. 0.49: more column streams in flight per XCD than its L2 keeps; "colwise_tiles_adjacent" 1 = two tiles, 2 = always,
+            // 0 = never; profiles/r05_colwise_tile_order_ab.txt)
+            const int adj = ntiles > 1 && (h->opt_colwise_tiles_adjacent == 2 || (h->opt_colwise_tiles_adjacent == 1 && ntiles <= 2)) &&
+                            (int64_t)nrowblk * ntiles < ((int64_t)1 << 31) ? ntiles : 0;
+            hipLaunchKernelGGL(kern, adj ? dim3((unsigned)nrowblk * (unsigned)ntiles) : dim3((unsigned)nrowblk, (unsigned)ntiles), dim3(sx::kBlock), 0, s, h->m_rp, h->m_ci,
+                               h->m_v, d_B, ldb, d_C_in, ldc_in, d_C_out, ldc, row_begin, row_end, nrowblk, col0, alpha, beta, (int)h->opt_xcd,
+                               (const unsigned char *)h->d_skip, adj, 1);
         };
         const int n16 = N / 16;
         if (n16 > 0) { if (h->opt_exact) go(sx::spmm_csr_colwise<true, 16>, 0, n16); else go(sx::spmm_csr_colwise<false, 16>, 0, n16); }
@@ -1177,6 +1193,53 @@ __global__ __launch_bounds__(256) void transpose_tiles(const float *__restrict__
     for (int i = ty; i < 32; i += 8)
         if (c0 + i < cols && r0 + tx < rows) dst[(int64_t)(c0 + i) * ld_dst + r0 + tx] = t[tx][i];
 }
+// The same for the skinny matrices of the row-major fallback (rows x N, N a few tiles of 16): 64 rows x 16 columns per workgroup, the
+// row-major side in 16-byte accesses (one wavefront = 16 rows x 64 bytes), the column-major side in 256-byte runs (one wavefront = 64
+// consecutive rows of one column).  The row-major side must be 16-byte aligned with a leading dimension that is a multiple of 4.
+template <bool TO_CM, int CW>   // TO_CM: rm[r * ld_rm + c] -> cm[c * ld_cm + r]; else the other way.  CW = 16 or 32 columns per workgroup
+__global__ __launch_bounds__(256) void transpose_skinny(const float *__restrict__ src, float *__restrict__ dst, int64_t ld_rm, int64_t ld_cm, int rows, int cols) {
+    // (CW = 32 from N = 32 on: the row-major side then moves whole 128-byte lines)
+    __shared__ float t[CW][65];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * CW, tid = threadIdx.x;
+    constexpr int Q = CW / 4;                              // 16-byte pieces per row of the tile
+    const int cc = tid >> 6, rc = tid & 63;               // column-major side: my column group (4 of them, Q columns each) and my row
+    auto rm_side = [&](auto f) {
+#pragma unroll
+        for (int p = 0; p < 64 * Q / 256; ++p) {
+            const int idx = tid + p * 256, rr = idx / Q, c4 = (idx % Q) * 4;
+            if (r0 + rr < rows && c0 + c4 < cols) f(rr, c4);
+        }
+    };
+    if constexpr (TO_CM) {
+        rm_side([&](int rr, int c4) {
+            const sx::f32x4 x = *reinterpret_cast<const sx::f32x4 *>(src + (int64_t)(r0 + rr) * ld_rm + c0 + c4);
+            t[c4][rr] = x.x; t[c4 + 1][rr] = x.y; t[c4 + 2][rr] = x.z; t[c4 + 3][rr] = x.w;
+        });
+        __syncthreads();
+        if (r0 + rc < rows)
+#pragma unroll
+            for (int i = 0; i < Q; ++i)
+                if (c0 + cc * Q + i < cols) dst[(int64_t)(c0 + cc * Q + i) * ld_cm + r0 + rc] = t[cc * Q + i][rc];
+    } else {
+        if (r0 + rc < rows)
+#pragma unroll
+            for (int i = 0; i < Q; ++i)
+                if (c0 + cc * Q + i < cols) t[cc * Q + i][rc] = src[(int64_t)(c0 + cc * Q + i) * ld_cm + r0 + rc];
+        __syncthreads();
+        rm_side([&](int rr, int c4) {
+            *reinterpret_cast<sx::f32x4 *>(dst + (int64_t)(r0 + rr) * ld_rm + c0 + c4) = sx::f32x4{t[c4][rr], t[c4 + 1][rr], t[c4 + 2][rr], t[c4 + 3][rr]};
+        });
+    }
+}
+// row-major rows x cols (ld_rm) <-> column-major (ld_cm); cols % 4 == 0
+void launch_transpose_skinny(bool to_cm, const float *src, float *dst, int64_t ld_rm, int64_t ld_cm, int rows, int cols, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return;
+    const int cw = cols >= 32 ? 32 : 16;
+    const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((cols + cw - 1) / cw));
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, src, dst, ld_rm, ld_cm, rows, cols); };
+    if (cw == 32) { if (to_cm) go(transpose_skinny<true, 32>); else go(transpose_skinny<false, 32>); }
+    else { if (to_cm) go(transpose_skinny<true, 16>); else go(transpose_skinny<false, 16>); }
+}
 void launch_transpose(const float *src, int64_t ld_src, float *dst, int64_t ld_dst, int rows, int cols, hipStream_t s) {
     if (rows <= 0 || cols <= 0) return;
     hipLaunchKernelGGL(transpose_tiles, dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32)), dim3(256), 0, s, src, ld_src, dst, ld_dst, rows, cols);
@@ -1280,10 +1343,17 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
     }
     if (colwise && aligned && h->nhub == 0 && h->nchain == 0 && h->dense_W == 0 && h->m_nnz > 0) {   // short rows in a local numbering: lane per row, 16-byte accesses
         Prof p(h, &h->ev_kernel, s);
-        const int nrowblk = (h->M + sx::kBlock - 1) / sx::kBlock;
         auto go = [&](auto kern, int col0, int ntiles) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)nrowblk, (unsigned)ntiles), dim3(sx::kBlock), 0, s, h->m_rp, h->m_ci, h->m_v, d_B, ldb, d_C_in, ldc_in, d_C_out,
-                               ldc, 0, h->M, nrowblk, col0, alpha, beta, (int)h->opt_xcd, (const unsigned char *)h->d_skip);
+            // groups of T neighbouring lanes per row, one 16-column tile each (T = the largest divisor of the tile count up to 8): a
+            // wavefront's loads cover T * 64 consecutive bytes of every row it touches
+            int T = 1;
+            if (h->opt_colwise_tiles_adjacent != 0)
+                for (int t = 8; t > 1; --t)
+                    if (ntiles % t == 0) { T = t; break; }
+            const int rows_per = sx::kBlock / T, nrowblk = (h->M + rows_per - 1) / rows_per, ygrid = ntiles / T;
+            const int adj = T == 1 && ntiles > 1 && h->opt_colwise_tiles_adjacent != 0 && (int64_t)nrowblk * ntiles < ((int64_t)1 << 31) ? ntiles : 0;
+            hipLaunchKernelGGL(kern, adj ? dim3((unsigned)nrowblk * (unsigned)ntiles) : dim3((unsigned)nrowblk, (unsigned)ygrid), dim3(sx::kBlock), 0, s, h->m_rp, h->m_ci,
+                               h->m_v, d_B, ldb, d_C_in, ldc_in, d_C_out, ldc, 0, h->M, nrowblk, col0, alpha, beta, (int)h->opt_xcd, (const unsigned char *)h->d_skip, adj, T);
         };
         const int n16 = N / 16;
         if (n16 > 0) { if (h->opt_exact) go(sx::spmm_csr_colwise<true, 16, true>, 0, n16); else go(sx::spmm_csr_colwise<false, 16, true>, 0, n16); }
@@ -1332,13 +1402,19 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
     if (int rc = ensure(&h->d_rmC, &h->rmC_cap, nC)) return rc;
     {
         Prof p(h, &h->ev_repack, s);
-        launch_transpose(d_B, ldb, h->d_rmB, h->K, h->K, N, s);
-        launch_transpose(d_C_in, ldc_in, h->d_rmC, h->M, h->M, N, s);
+        if (aligned) {
+            launch_transpose_skinny(true, d_B, h->d_rmB, ldb, h->K, h->K, N, s);
+            launch_transpose_skinny(true, d_C_in, h->d_rmC, ldc_in, h->M, h->M, N, s);
+        } else {
+            launch_transpose(d_B, ldb, h->d_rmB, h->K, h->K, N, s);
+            launch_transpose(d_C_in, ldc_in, h->d_rmC, h->M, h->M, N, s);
+        }
     }
     if (int rc = sextans_spmm_device_rows(h, N, alpha, h->d_rmB, h->K, beta, h->d_rmC, h->M, h->d_rmC, h->M, 0, h->M, 0, stream)) return rc;
     {
         Prof p(h, &h->ev_post, s);
-        launch_transpose(h->d_rmC, h->M, d_C_out, ldc, N, h->M, s);
+        if (aligned) launch_transpose_skinny(false, h->d_rmC, d_C_out, ldc, h->M, h->M, N, s);
+        else launch_transpose(h->d_rmC, h->M, d_C_out, ldc, N, h->M, s);
     }
     SX_HIP(hipGetLastError());
     return SEXTANS_OK;

@@ -223,6 +223,7 @@ struct sextans_engine {
     int64_t opt_reordered_xcd = -1;     // measurement switch: workgroup placement of the reordered form (0 round-robin over the XCDs, 1 contiguous chunks, -1 the built-in rule)
     int64_t opt_row_similarity = -1;    // graph clustering over the row-similarity graph: -1 when the matrix is rectangular or its pattern unsymmetric, 0 never, 1 always
     int64_t opt_relabel_columns = 1;    // graph clustering: B rows relabelled in first-touch order (permuted panels); 0 = natural panels
+    int64_t opt_colwise_tiles_adjacent = 1;   // lane-per-row kernel, N >= 32: the tiles of a row block neighbours in the launch order (one XCD, same time)
     int64_t opt_small_panel = 1;        // clustered plans of short-row matrices are packed for a 320-row panel when every dictionary fits (more workgroups per CU)
     int64_t opt_cluster_top = 1 << 30;  // graph clustering: the aggregation stops when clusters reach this many rows.  Default: never -- the whole
                                         // matrix becomes one merge tree, so that each XCD's contiguous chunk of row blocks is one region of the graph and

@@ -39,12 +39,36 @@ template <bool EXACT, int NC, bool RM = false>   // NC = columns of a tile: 16, 
 __global__ __launch_bounds__(kBlock) void spmm_csr_colwise(const int *__restrict__ rp, const int *__restrict__ ci, const float *__restrict__ va,
                                                            const float *__restrict__ B, int64_t ldb, const float *Cin, int64_t ldc_in, float *Cout,
                                                            int64_t ldc, int row_begin, int row_end, int nrowblk, int col_base, float alpha, float beta,
-                                                           int use_xcd_remap, const unsigned char *__restrict__ skip) {
+                                                           int use_xcd_remap, const unsigned char *__restrict__ skip, int tiles_adjacent, int tgroup) {
+    // tiles_adjacent > 0 (= the number of tiles; a 1-D grid of nrowblk * tiles workgroups): the tiles of one row block are NEIGHBOURS in
+    // the launch order and, through the XCD remap, run on one XCD at about the same time -- the row block's rp / ci / va are read from
+    // HBM once instead of once per tile, and in the row-major form the two 64-byte halves of a 128-byte line of B / C are asked for
+    // together (with the tile as the slow grid axis they are fetched twice, tiles apart: 5-point stencil 4M rows, row-major N = 32,
+    // 0.27 of the roofline against 0.50 at N = 16).
+    // tgroup > 1 (row-major form only): `tgroup` neighbouring lanes share a row and take neighbouring tiles of it, so one load instruction
+    // of the wavefront covers tgroup * 64 consecutive bytes of every B / C row it touches -- whole 128-byte lines from N = 32 on (one
+    // lane per row and tile asks for 64 of the 128 bytes, the other half travels again for the next tile: 0.25 of the roofline at
+    // N = 32 .. 128 against 0.48 at N = 16).  The lanes of a group fetch the row's columns and values together (one address: a broadcast).
     unsigned wg = blockIdx.x;
-    if (use_xcd_remap) wg = xcd_remap(wg, (unsigned)nrowblk);
-    const int r = row_begin + (int)wg * kBlock + (int)threadIdx.x;
+    int tile = blockIdx.y;
+    int r;
+    if (RM && tgroup > 1) {
+        if (use_xcd_remap) wg = xcd_remap(wg, (unsigned)nrowblk);
+        const int rows_per = kBlock / tgroup, lr_ = (int)threadIdx.x / tgroup;
+        if (lr_ >= rows_per) return;
+        r = row_begin + (int)wg * rows_per + lr_;
+        tile = (int)blockIdx.y * tgroup + (int)threadIdx.x % tgroup;
+    } else {
+        if (tiles_adjacent > 0) {
+            if (use_xcd_remap) wg = xcd_remap(wg, (unsigned)nrowblk * (unsigned)tiles_adjacent);
+            tile = (int)(wg % (unsigned)tiles_adjacent);
+            wg /= (unsigned)tiles_adjacent;
+        } else if (use_xcd_remap) {
+            wg = xcd_remap(wg, (unsigned)nrowblk);
+        }
+        r = row_begin + (int)wg * kBlock + (int)threadIdx.x;
+    }
     if (r >= row_end) return;
-    const int tile = blockIdx.y;
     const int col0 = col_base + tile * NC;
     const float *b = RM ? B + col0 : B + (int64_t)col0 * ldb;
     auto load_b = [&](float (&dst)[NC], int c) {

@@ -348,6 +348,18 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? (BCOL && DCAP == 9 ? SX_V
         cvoff_rout[t] = RM ? (coff[t] * (unsigned)ldc + 4u * (unsigned)q) * 4u : cvoff_rin[t];
     }
     const int64_t ct_in = RM ? 16 : ldc_in, ct_out = RM ? 16 : ldc;   // CROW: floats from one tile of C to the next
+    // (row-major operands with two row sets: the two byte offsets per set are formed again where they are used -- kept live across the
+    // tile loop they cost the two registers that sent a 64-bit value to scratch, and its reload inside the loop is a vector-memory
+    // operation whose wait drains the C stores and the next panel in flight: 27-point 1-dof grid, N = 64 .. 256, 8 .. 16 % of the launch)
+    constexpr bool kRematC = RM == 1 && SETS == 2;
+    auto off_rin = [&](int t) -> unsigned {
+        if constexpr (kRematC) { unsigned c = coff[t]; asm volatile("" : "+v"(c)); return (c * (unsigned)ldc_in + 4u * (unsigned)q) * 4u; }
+        else return cvoff_rin[t];
+    };
+    auto off_rout = [&](int t) -> unsigned {
+        if constexpr (kRematC) { unsigned c = coff[t]; asm volatile("" : "+v"(c)); return (c * (unsigned)ldc + 4u * (unsigned)q) * 4u; }
+        else return cvoff_rout[t];
+    };
     const float *cp_in[SETS];   // RM == 2: this lane's 16 bytes of tile 0, as 64-bit addresses
     float *cp_out[SETS];
 #pragma unroll
@@ -355,6 +367,14 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? (BCOL && DCAP == 9 ? SX_V
         cp_in[t] = Cin + (int64_t)coff[t] * ldc_in + 4 * q;
         cp_out[t] = Cout + (int64_t)coff[t] * ldc + 4 * q;
     }
+    auto ptr_in = [&](int t) -> const float * {   // (RM == 2: the 64-bit lane addresses likewise)
+        if constexpr (RM == 2 && SETS == 2) { unsigned c = coff[t]; asm volatile("" : "+v"(c)); return Cin + (int64_t)c * ldc_in + 4 * q; }
+        else return cp_in[t];
+    };
+    auto ptr_out = [&](int t) -> float * {
+        if constexpr (RM == 2 && SETS == 2) { unsigned c = coff[t]; asm volatile("" : "+v"(c)); return Cout + (int64_t)c * ldc + 4 * q; }
+        else return cp_out[t];
+    };
     // C_in of the FIRST super tile is requested here, in the same round trip as the panel and the row entries (for a
     // matrix of a few thousand rows the whole kernel is three round trips: one more is 15 % of its time)
     float cin[SETS][H][4];
@@ -364,8 +384,8 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? (BCOL && DCAP == 9 ? SX_V
         cinv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (CROW) {
             if (!RM || cvalid || st_begin + 1 < nsuper) {
-                if constexpr (RM == 2) aload4p(cinv[t], cp_in[t] + (int64_t)st_begin * 16);
-                else aload4(cinv[t], Cin + (int64_t)st_begin * ct_in, cvoff_rin[t]);
+                if constexpr (RM == 2) aload4p(cinv[t], ptr_in(t) + (int64_t)st_begin * 16);
+                else aload4(cinv[t], Cin + (int64_t)st_begin * ct_in, off_rin(t));
             }
         } else if (cvalid || st_begin + 1 < nsuper) {
 #pragma unroll
@@ -403,8 +423,8 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? (BCOL && DCAP == 9 ? SX_V
             for (int t = 0; t < SETS; ++t) {
                 if constexpr (CROW) {
                     if (!RM || cvalid || st + 1 < nsuper) {
-                        if constexpr (RM == 2) aload4p(cinv[t], cp_in[t] + (int64_t)st * 16);
-                        else aload4(cinv[t], Cin + (int64_t)st * ct_in, cvoff_rin[t]);
+                        if constexpr (RM == 2) aload4p(cinv[t], ptr_in(t) + (int64_t)st * 16);
+                        else aload4(cinv[t], Cin + (int64_t)st * ct_in, off_rin(t));
                     }
                 } else if (cvalid || st + 1 < nsuper) {
 #pragma unroll
@@ -496,8 +516,8 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? (BCOL && DCAP == 9 ? SX_V
                 if (cwrite[t] && (!RM || cvalid || st + 1 < nsuper)) {
                     const f32x4 o = {epilogue<EXACT>(alpha, acc[t][0].x, beta, cinv[t].x), epilogue<EXACT>(alpha, acc[t][0].y, beta, cinv[t].y),
                                      epilogue<EXACT>(alpha, acc[t][0].z, beta, cinv[t].z), epilogue<EXACT>(alpha, acc[t][0].w, beta, cinv[t].w)};
-                    if constexpr (RM == 2) astore4p(cp_out[t] + (int64_t)st * 16, o);
-                    else astore4(Cout + (int64_t)st * ct_out, cvoff_rout[t], o);
+                    if constexpr (RM == 2) astore4p(ptr_out(t) + (int64_t)st * 16, o);
+                    else astore4(Cout + (int64_t)st * ct_out, off_rout(t), o);
                 }
             } else if (cwrite[t] && (cvalid || st + 1 < nsuper)) {
 #pragma unroll

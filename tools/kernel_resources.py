@@ -17,6 +17,8 @@ pat = sys.argv[sys.argv.index("--grep") + 1] if "--grep" in sys.argv else None
 cmd = [b.hipcc()] + b.FLAGS + ["-c", "-o", "/dev/null", src, "-Rpass-analysis=kernel-resource-usage"]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 names = re.findall(r"remark: Function Name: (\S+)", err)
+if not names:   # the translation unit did not compile
+    sys.exit("no kernels reported -- compiler output:\n" + err[-3000:])
 dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
 blocks = re.split(r"remark: Function Name: \S+", err)[1:]
 print(f"# {src}: {len(names)} kernels; columns: VGPRs AGPRs scratch[B/lane] spilledVGPRs waves/SIMD LDS[B]")
