@@ -634,7 +634,9 @@ const char *kernel_name(int main, bool hubs, bool dense) {   // static strings f
 // Exact chains of the chain rows [c0, c1) (chain_fused, spmm_csr_kernels.h): products from the repacked B panels (segment by
 // segment, like the piece kernel) and the serial sum of every (row, column) in one workgroup, epilogue included.
 void launch_chains(sextans_engine *h, const std::vector<Seg> &plan, const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc,
-                   int N, int c0, int c1, int row_base, float alpha, float beta, hipStream_t s, bool permuted_panels = false) {
+                   int N, int c0, int c1, int row_base, float alpha, float beta, hipStream_t s, bool permuted_panels = false,
+                   const float *rm_B = nullptr, int64_t rm_ldb = 0) {
+    // rm_B (sextans_spmm_device_rm): the caller's row-major B and C -- B is one "panel" with rows rm_ldb floats apart
     // permuted_panels (the reordered form): the 16-column panels hold B row k at row colpos[k]; the chain rows' entries come from
     // their compact relabelled copy (ensure_cluster_plan); 8-column remainder tiles keep the natural panels and the source arrays
     // one workgroup per (chain row, 16- or 8-column tile): chain_fused
@@ -649,7 +651,7 @@ void launch_chains(sextans_engine *h, const std::vector<Seg> &plan, const float 
             }
         }
         for (const Seg &g : segs) {
-            const float *bp = h->d_Bp + (size_t)h->K * (size_t)g.col0;
+            const float *bp = rm_B ? rm_B + g.col0 : h->d_Bp + (size_t)h->K * (size_t)g.col0;
             const int NT = (g.width >= 16 && g.last_cols != 8) ? 16 : 8;   // (the tail: the first 8-column half of its 16-column panel)
             const int ntiles = g.last_cols == 8 ? 1 : g.ntiles * (g.width / NT);
             auto go = [&](auto kern, int lds, int threads) {
@@ -657,8 +659,8 @@ void launch_chains(sextans_engine *h, const std::vector<Seg> &plan, const float 
                 const bool perm = permuted_panels && g.width == 16;
                 hipLaunchKernelGGL(kern, dim3((unsigned)(c1 - c0) * (unsigned)ntiles), dim3((unsigned)threads), (size_t)lds, s, h->d_chain_row,
                                    perm ? h->d_chain_beg_c : h->d_chain_beg, h->d_chain_off, (c0 == 0 && c1 == h->nchain) ? h->d_chain_perm : (const int *)nullptr,
-                                   perm ? (const int *)h->d_chain_ci_perm : h->s_ci, perm ? (const float *)h->d_chain_v_c : h->s_v, bp, (int64_t)h->K * g.width, g.width, dCin, ldc_in, dCout,
-                                   ldc, g.col0, ntiles, c0, row_base, alpha, beta);
+                                   perm ? (const int *)h->d_chain_ci_perm : h->s_ci, perm ? (const float *)h->d_chain_v_c : h->s_v, bp, rm_B ? (int64_t)0 : (int64_t)h->K * g.width,
+                                   rm_B ? (int)rm_ldb : g.width, dCin, ldc_in, dCout, ldc, g.col0, ntiles, c0, row_base, alpha, beta, rm_B ? 1 : 0);
             };
 #define SX_FUSED(W) if (h->opt_exact) go(sx::chain_fused<W, true>, sx::chain_fused_lds_bytes(W), sx::chain_fused_threads(W)); \
                     else go(sx::chain_fused<W, false>, sx::chain_fused_lds_bytes(W), sx::chain_fused_threads(W))
@@ -670,16 +672,18 @@ void launch_chains(sextans_engine *h, const std::vector<Seg> &plan, const float 
 
 template <int LPR>
 void launch_hub_pieces(sextans_engine *h, const sextans_engine::PieceTable &t, const float *dBp, int ntiles, int col0,
-                       int v0, int v1, hipStream_t s, const int *colpos = nullptr) {
+                       int v0, int v1, hipStream_t s, const int *colpos = nullptr, int64_t rm_ldb = 0) {
+    // rm_ldb > 0: dBp is the caller's row-major B at column col0 (sextans_spmm_device_rm)
     constexpr int RB = sx::kBlock / LPR;
     const int nblk = (v1 - v0 + RB - 1) / RB;
     if (nblk <= 0) return;
     float *P = h->d_P + (int64_t)col0 * h->split_nv;
     auto go = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ntiles), dim3(sx::kBlock), 0, s, t.d_vrp, t.d_vend, h->s_ci,
-                           h->s_v, dBp, (int64_t)h->K * 4 * LPR, P, (int64_t)h->split_nv, v0, v1, ntiles, colpos);
+                           h->s_v, dBp, rm_ldb > 0 ? rm_ldb : (int64_t)h->K * 4 * LPR, P, (int64_t)h->split_nv, v0, v1, ntiles, colpos);
     };
-    if (h->opt_exact) go(sx::spmm_csr_pieces<LPR, true>); else go(sx::spmm_csr_pieces<LPR, false>);
+    if (rm_ldb > 0) { if (h->opt_exact) go(sx::spmm_csr_pieces<LPR, true, true>); else go(sx::spmm_csr_pieces<LPR, false, true>); }
+    else if (h->opt_exact) go(sx::spmm_csr_pieces<LPR, true>); else go(sx::spmm_csr_pieces<LPR, false>);
 }
 }  // namespace
 extern "C" {
@@ -882,7 +886,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         const int64_t tot = (int64_t)(hub1 - hub0) * N;
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, pt.d_vfirst, pt.d_row, h->d_P,
-                               (int64_t)h->split_nv, d_C_in, ldc_in, d_C_out, ldc, hub0, hub1 - hub0, N, row_begin, alpha, beta);
+                               (int64_t)h->split_nv, d_C_in, ldc_in, d_C_out, ldc, hub0, hub1 - hub0, N, row_begin, alpha, beta, 0);
         };
         if (h->opt_exact) go(sx::fold_hub_pieces<true>); else go(sx::fold_hub_pieces<false>);
     };
@@ -1321,8 +1325,8 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
     // 32-bit offsets inside the kernel: floats into B (C beyond 4 GB: the kernel's 64-bit form, launch_panel_v2)
     const bool fits = (int64_t)h->K * ldb < ((int64_t)1 << 32);
     int mode = -1;
-    if (W == 16 && (h->opt_kernel == 0 || h->opt_kernel == 2) && h->opt_panel_v2 != 0 && h->opt_cols_per_lane != 8 && h->nhub == 0 && h->nchain == 0 &&
-        h->dense_W == 0 && !colwise && aligned && fits && h->m_nnz > 0) {
+    if (W == 16 && (h->opt_kernel == 0 || h->opt_kernel == 2) && h->opt_panel_v2 != 0 && h->opt_cols_per_lane != 8 &&
+        h->dense_W == 0 && !(colwise && h->nhub == 0 && h->nchain == 0) && aligned && fits && h->m_nnz > 0) {
         if (h->cluster_state == 2) mode = 2;
         else if (h->cluster_state == 1) mode = 1;
         else if (use_panel && !h->ps.plan_mixed && h->ps.plan_max_dict <= sx::kWideMaxDict) mode = 0;
@@ -1341,6 +1345,43 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
             SX_HIP(se);
         }
     }
+    // Rows on the long-row paths (pieces, exact chains): from the caller's row-major B into its row-major C as well -- the piece kernel's
+    // 16-byte gathers and the chain producers' LDS-DMA read B rows ldb floats apart instead of panel rows, the fold and the chain
+    // consumer write C[r * ldc + n].  The main kernels skip those rows (d_skip), so the order between the launches does not matter;
+    // the chains run beside the main kernel on the engine's side stream, as in the column-major form.
+    const bool hubs = h->nhub > 0, chains = h->nchain > 0;
+    std::vector<Seg> lsegs;   // tiles of the long-row kernels: 16-column tiles and an 8-column tail (never past column N of a B row)
+    if (N / 16) lsegs.push_back(Seg{16, 0, N / 16});
+    if (N % 16) lsegs.push_back(Seg{8, N / 16 * 16, 1});
+    auto chains_fork = [&]() -> int {
+        if (!chains) return SEXTANS_OK;
+        SX_HIP(hipEventRecord(h->ev_fork, s));
+        SX_HIP(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+        launch_chains(h, lsegs, d_C_in, ldc_in, d_C_out, ldc, N, 0, h->nchain, 0, alpha, beta, h->aux_stream, false, d_B, ldb);
+        SX_HIP(hipEventRecord(h->ev_join, h->aux_stream));
+        return SEXTANS_OK;
+    };
+    auto long_rows_join = [&]() -> int {
+        if (hubs) {
+            const sextans_engine::PieceTable &pt = h->by_len;
+            const int v0 = pt.h_vfirst[0], v1 = pt.h_vfirst[(size_t)h->nhub];
+            // (32-column tiles first: a piece's gathers then take whole 128-byte lines of the B rows)
+            int col = 0;
+            if (N / 32) { launch_hub_pieces<8>(h, pt, d_B, N / 32, 0, v0, v1, s, nullptr, ldb); col = N / 32 * 32; }
+            if ((N - col) / 16) { launch_hub_pieces<4>(h, pt, d_B + col, 1, col, v0, v1, s, nullptr, ldb); col += 16; }
+            if (N - col) launch_hub_pieces<2>(h, pt, d_B + col, 1, col, v0, v1, s, nullptr, ldb);
+            const int64_t tot = (int64_t)h->nhub * N;
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, pt.d_vfirst, pt.d_row, h->d_P, (int64_t)h->split_nv, d_C_in, ldc_in,
+                                   d_C_out, ldc, 0, h->nhub, N, 0, alpha, beta, 1);
+            };
+            if (h->opt_exact) go(sx::fold_hub_pieces<true>); else go(sx::fold_hub_pieces<false>);
+        }
+        if (chains) SX_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+        return SEXTANS_OK;
+    };
+    const bool long_ok = (!hubs && !chains) || (aligned && (!chains || (h->aux_stream && h->ev_fork && h->ev_join && ldb < ((int64_t)1 << 31))));
+    if (!long_ok) mode = -1;
     if (colwise && aligned && h->nhub == 0 && h->nchain == 0 && h->dense_W == 0 && h->m_nnz > 0) {   // short rows in a local numbering: lane per row, 16-byte accesses
         Prof p(h, &h->ev_kernel, s);
         auto go = [&](auto kern, int col0, int ntiles) {
@@ -1366,18 +1407,21 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
         Prof p(h, &h->ev_kernel, s);
         const int ntiles = (N + 15) / 16, last_cols = N % 16 ? 8 : 16;
         const sextans_engine::PanelState &P = mode ? h->psc : h->ps;
+        if (int rc = chains_fork()) return rc;
         if (int rc = launch_panel_v2<1>(h, d_B, d_C_in, ldc_in, d_C_out, ldc, ntiles, alpha, beta, s, 0, 0, P.plan_nblk, 0, mode, last_cols, ldb)) return rc;
-        h->last_kernel = mode == 2 ? "spmm_csr_panel_v2_rowmajor_clustered" : "spmm_csr_panel_v2_rowmajor";
+        if (int rc = long_rows_join()) return rc;
+        h->last_kernel = mode == 2 ? (hubs || chains ? "spmm_csr_panel_v2_rowmajor_clustered+long_rows" : "spmm_csr_panel_v2_rowmajor_clustered")
+                                   : (hubs || chains ? "spmm_csr_panel_v2_rowmajor+long_rows" : "spmm_csr_panel_v2_rowmajor");
         SX_HIP(hipGetLastError());
         return SEXTANS_OK;
     }
     // The gather kernel on a matrix without rows on the piece / chain / dense-tile paths: a row of row-major B IS what its lanes fetch
     // per non-zero (the 4 * LPR floats of a panel row), and a lane's 4 accumulators are 16 bytes of its C row -- no repack, no passes.
-    if (!use_panel && !use_window && !colwise && aligned && (h->opt_kernel == 0 || h->opt_kernel == 1) && h->nhub == 0 && h->nchain == 0 && h->dense_W == 0 &&
-        h->m_nnz > 0) {
+    if (!use_panel && !use_window && !(colwise && !hubs && !chains) && aligned && long_ok && (h->opt_kernel == 0 || h->opt_kernel == 1) && h->dense_W == 0 && h->m_nnz > 0) {
         Prof p(h, &h->ev_kernel, s);
         std::vector<Seg> segs = plan;
         if (N == 8) segs.assign(1, Seg{8, 0, 1});   // (the plan above was made for 16 columns)
+        if (int rc = chains_fork()) return rc;
         for (const Seg &g : segs) {
 #define SX_SEG(L) launch_rowgroup<L>(h, h->m_rp, h->m_rp + 1, h->m_ci, h->m_v, false, h->d_skip, d_B + g.col0, d_C_in + g.col0, ldc_in, d_C_out + g.col0, ldc, 0, \
                                      h->M, g.ntiles, alpha, beta, s, ldb)
@@ -1388,7 +1432,8 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
             }
 #undef SX_SEG
         }
-        h->last_kernel = "spmm_csr_rowgroup_rowmajor";
+        if (int rc = long_rows_join()) return rc;
+        h->last_kernel = hubs || chains ? "spmm_csr_rowgroup_rowmajor+long_rows" : "spmm_csr_rowgroup_rowmajor";
         SX_HIP(hipGetLastError());
         return SEXTANS_OK;
     }

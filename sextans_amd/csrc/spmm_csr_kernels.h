@@ -548,7 +548,7 @@ __global__ __launch_bounds__(kBlock, (LPR == 8 ? 2 : (MIXED && LPR == 4 ? SX_PAN
 // batch k + 1 are used (three entry sets; the loop is unrolled over the six phases of the two rotations).
 // Order inside a piece = CSR order; one lane per output element (exact).
 // ------------------------------------------------------------------------------------------------
-template <int LPR, bool EXACT>
+template <int LPR, bool EXACT, bool RM = false>   // RM: Bp = the caller's row-major B at the launch's first column, panel_stride = its leading dimension
 __global__ __launch_bounds__(kBlock) void spmm_csr_pieces(const int *__restrict__ vbeg, const int *__restrict__ vend,
                                                           const int *__restrict__ col_idx, const float *__restrict__ val,
                                                           const float *__restrict__ Bp, int64_t panel_stride, float *P,
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_pieces(const int *__restrict_
     const int v = v_begin + blk * RB + slot;
     int j = 0, jend = 0;
     if (v < v_end) { j = vbeg[v]; jend = vend[v]; }
-    const float *bq = Bp + (int64_t)tile * panel_stride + 4 * q;
+    const float *bq = RM ? Bp + (int64_t)tile * NT + 4 * q : Bp + (int64_t)tile * panel_stride + 4 * q;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
     struct Ent { int c[E]; float a[E]; };
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_pieces(const int *__restrict_
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
             const int cu = __shfl(x.c[u % E], u / E, LPR);   // entry u of the batch sits in lane u / E, slot u % E
-            b[u] = *reinterpret_cast<const float4 *>(bq + (int64_t)cu * NT);
+            b[u] = *reinterpret_cast<const float4 *>(bq + (int64_t)cu * (RM ? panel_stride : (int64_t)NT));
         }
     };
     auto macs = [&](const Ent &x, const float4 (&b)[BATCH], int cnt) {
@@ -630,15 +630,17 @@ template <bool EXACT>
 __global__ __launch_bounds__(kBlock) void fold_hub_pieces(const int *__restrict__ vfirst, const int *__restrict__ hub_row,
                                                           const float *__restrict__ P, int64_t ldp, const float *Cin,
                                                           int64_t ldc_in, float *Cout, int64_t ldc, int hub_begin, int nhub,
-                                                          int N, int row_base, float alpha, float beta) {
+                                                          int N, int row_base, float alpha, float beta, int c_rm) {
+    // c_rm: C row-major (C[r * ldc + n]; consecutive threads then take the columns of one row)
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= (int64_t)nhub * N) return;
-    const int k = hub_begin + (int)(t % nhub), n = (int)(t / nhub);
+    const int k = hub_begin + (c_rm ? (int)(t / N) : (int)(t % nhub)), n = c_rm ? (int)(t % N) : (int)(t / nhub);
     const int v0 = vfirst[k], v1 = vfirst[k + 1];
     float acc = P[(int64_t)v0 + n * ldp];
     for (int v = v0 + 1; v < v1; ++v) acc = acc + P[(int64_t)v + n * ldp];
     const int64_t r = (int64_t)(hub_row[k] - row_base);
-    Cout[r + n * ldc] = epilogue<EXACT>(alpha, acc, beta, Cin[r + n * ldc_in]);
+    if (c_rm) Cout[r * ldc + n] = epilogue<EXACT>(alpha, acc, beta, Cin[r * ldc_in + n]);
+    else Cout[r + n * ldc] = epilogue<EXACT>(alpha, acc, beta, Cin[r + n * ldc_in]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -684,7 +686,8 @@ template <int NT, bool EXACT>
 __global__ __launch_bounds__(chain_fused_threads(NT)) void chain_fused(
     const int *__restrict__ crow, const int *__restrict__ cbeg, const long long *__restrict__ coff, const int *__restrict__ perm,
     const int *__restrict__ col_idx, const float *__restrict__ val, const float *__restrict__ Bp, int64_t panel_stride, int panel_width, const float *Cin,
-    int64_t ldc_in, float *Cout, int64_t ldc, int col0, int ntiles, int k0, int row_base, float alpha, float beta) {
+    int64_t ldc_in, float *Cout, int64_t ldc, int col0, int ntiles, int k0, int row_base, float alpha, float beta, int c_rm) {
+    // c_rm (row-major operands): C[r * ldc + n]; the caller's row-major B is "one panel" whose rows are panel_width = ldb floats apart
     // (NT = 16 or 8 columns per workgroup: a 32-column panel is walked as two 16-column halves -- `ntiles` counts NT-column tiles,
     // `panel_width` = floats per B row of the panel they live in)
     static_assert(NT == 16 || NT == 8, "one task per producer lane and chunk");
@@ -815,7 +818,8 @@ __global__ __launch_bounds__(chain_fused_threads(NT)) void chain_fused(
 #undef SX_PIN16
             const int64_t r = (int64_t)(crow[k] - row_base);
             const int64_t n = (int64_t)col0 + (int64_t)tile * NT + tid;
-            Cout[r + n * ldc] = epilogue<EXACT>(alpha, acc, beta, Cin[r + n * ldc_in]);
+            if (c_rm) Cout[r * ldc + n] = epilogue<EXACT>(alpha, acc, beta, Cin[r * ldc_in + n]);
+            else Cout[r + n * ldc] = epilogue<EXACT>(alpha, acc, beta, Cin[r + n * ldc_in]);
         }
         return;
     }

@@ -105,14 +105,14 @@ def test_rowmajor_lane_per_row_kernel(engine, oracle):
 
 
 def test_rowmajor_fallback_classes(engine, oracle):
-    """Matrices the LDS-panel kernels do not serve, rows on the long-row paths, and unaligned operands: through column-major copies."""
+    """Unaligned operands (whatever the matrix): through column-major copies."""
     from sextans_amd import api
     rs = np.random.RandomState(11)
     cases = []
     rp, ci, v = random_csr(rs, 5000, 7000, 12)                          # no reuse: row-group gather kernel, unaligned here
     cases.append(("random columns, pointers 8 bytes off", rp, ci, v, 5000, 7000, 2))
-    rp, ci, v = random_csr(rs, 3000, 3000, 10, long_rows=3)             # rows on the piece path
-    cases.append(("long rows", rp, ci, v, 3000, 3000, 0))
+    rp, ci, v = random_csr(rs, 3000, 3000, 10, long_rows=3)             # rows on the piece path, unaligned
+    cases.append(("long rows, pointers 4 bytes off", rp, ci, v, 3000, 3000, 1))
     rp, ci, v = api.gen_fem3d_host(9, 8, 7, 3, 5)
     cases.append(("fem small, pointers 4 bytes off a 16-byte boundary", rp, ci, v, 1512, 1512, 1))
     for name, rp, ci, v, M, K, off in cases:
@@ -242,3 +242,65 @@ def test_rowmajor_calls_allocate_no_layout_workspaces(sx, oracle):
         assert full - lean >= 4 * K * N, (lean, full)      # the column-major call brought (at least) the B panels
         got = _run(e, M, K, N, B, C0)                       # and the row-major call still works afterwards
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("N", [8, 16, 40, 96])
+def test_rowmajor_long_rows_pieces_and_exact_chains(engine, oracle, N):
+    """Rows on the long-row paths from row-major operands, without copies: the piece kernel gathers B rows ldb floats apart, the chain
+    producers stage them by LDS-DMA, fold and chain consumer write C[r][n].  (i) power-law matrix on the gather kernel: bucketed rows +
+    exact chains (strict order: bit-identical); (ii) FEM matrix with hub rows on the LDS-panel kernel, natural and graph-clustered plans;
+    padded leading dimensions and in place."""
+    from sextans_amd import api, meshgen
+    cases = []
+    M = K = 20000
+    rp, ci, v = api.gen_powerlaw_host(M, K, 3, 120, 15000, 11)
+    cases.append(("power law", rp, ci, v, M, K, "spmm_csr_rowgroup_rowmajor+long_rows", True))
+    frp, fci, fv = api.gen_fem3d_host(20, 19, 12, 3, 5)
+    M0 = 20 * 19 * 12 * 3
+    rs = np.random.RandomState(17)
+    rows = []
+    for r in range(M0):
+        c, x = fci[frp[r]:frp[r + 1]], fv[frp[r]:frp[r + 1]]
+        if r in (7, 5000, M0 - 1):
+            c = np.sort(rs.choice(M0, size=6000 + r % 100, replace=False)).astype(np.int32)
+            x = rs.uniform(-1, 1, len(c)).astype(np.float32)
+        rows.append((c, x))
+    rp2 = np.zeros(M0 + 1, np.int32); rp2[1:] = np.cumsum([len(c) for c, _ in rows])
+    ci2 = np.concatenate([c for c, _ in rows]).astype(np.int32); v2 = np.concatenate([x for _, x in rows]).astype(np.float32)
+    cases.append(("fem + hub rows", rp2, ci2, v2, M0, M0, "spmm_csr_panel_v2_rowmajor+long_rows", True))
+    q = meshgen.permute_symmetric(rp2, ci2, v2, M0, meshgen.node_permutation(M0 // 3, 3, 2))
+    cases.append(("fem + hub rows, random node order", *q, M0, M0, ("spmm_csr_panel_v2_rowmajor_clustered+long_rows", "spmm_csr_panel_v2_rowmajor+long_rows"), False))
+    for name, rp, ci, v, M, K, kernel, strict in cases:
+        rs = np.random.RandomState(N + len(name))
+        B = rs.uniform(-1, 1, (K, N)).astype(np.float32); C0 = rs.uniform(-1, 1, (M, N)).astype(np.float32)
+        want = _want(oracle, M, K, N, rp, ci, v, B, C0)
+        engine.set_matrix_csr(M, K, rp, ci, v)
+        for kw in ({}, {"ldb": N + 4, "ldc_in": N + 8, "ldc": N + 12}, {"inplace": True}):
+            got = _run(engine, M, K, N, B, C0, **kw)
+            assert engine.last_kernel() == kernel or engine.last_kernel() in kernel, (name, N, engine.last_kernel())
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (name, N, kw)
+        assert engine.get_stat("piece_path_rows") > 0 and len(engine.reassociated_rows()) == 0
+        # the column-major entry point on the same engine afterwards
+        cm = np.ascontiguousarray(C0.T).reshape(-1).copy()
+        engine.spmm(N, ALPHA, np.ascontiguousarray(B.T).reshape(-1), BETA, cm)
+        assert np.array_equal(np.ascontiguousarray(cm.reshape(N, M).T).view(np.uint32), want.view(np.uint32)), (name, N)
+    # re-association opted in (split_rows = -1): hub rows cut into pieces, folded in order -- within the stated 1e-4 bound, the rest bit-identical
+    name, rp, ci, v, M, K, kernel, _ = cases[0]
+    try:
+        engine.set_option("split_rows", -1)
+        engine.set_matrix_csr(M, K, rp, ci, v)
+        rs = np.random.RandomState(3)
+        B = rs.uniform(-1, 1, (K, N)).astype(np.float32); C0 = rs.uniform(-1, 1, (M, N)).astype(np.float32)
+        want = _want(oracle, M, K, N, rp, ci, v, B, C0)
+        got = _run(engine, M, K, N, B, C0)
+        hub = engine.reassociated_rows()
+        assert len(hub) > 0 and "+long_rows" in engine.last_kernel()
+        keep = np.ones(M, bool); keep[hub] = False
+        assert np.array_equal(got[keep].view(np.uint32), want[keep].view(np.uint32))
+        A = np.zeros(M)
+        absB = np.abs(B).max()
+        for r in hub:
+            A[r] = np.abs(v[rp[r]:rp[r + 1]]).sum() * absB
+        assert np.all(np.abs(got[hub].astype(np.float64) - want[hub]) <= 1e-4 * (abs(ALPHA) * A[hub][:, None] + np.abs(BETA * C0[hub])) + 1e-30)
+    finally:
+        engine.set_option("split_rows", 0)
