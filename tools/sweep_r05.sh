@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/sweep_r05.sh -- the paper-style sweep (reference README.md:18,31: N up to 512 over many matrices) on one MI355X: every synthetic
 # class of round 4 + the HOLDOUT classes of round 5 (kron(T_850, nasa4704) in three numberings, rectangular, unsymmetric pattern) at
-# N in {8 ... 512}, column-major entry points; every class but the power-law one once more through the ROW-major entry point
+# N in {8 ... 512}, column-major entry points; every class once more through the ROW-major entry point
 # (records carry "layout": "rm").  One JSON record per (matrix, N); step time = layout passes + kernels.
 OUT=gpurun_out/r05_sweep.jsonl
 ERR=gpurun_out/r05_sweep.err
@@ -20,5 +20,6 @@ python -m sextans_amd.sweep --rp 20 --n $NS --opt row_cluster=0 synth:femperm:11
 python -m sextans_amd.sweep --rp 20 --n 64,128,256 --opt exact=0 synth:fem3d:110:110:110:3 2>>$ERR | grep '^{' | sed 's/"matrix": "synth:fem3d/"options": "exact=0 (FMA, opt-in)", "matrix": "synth:fem3d/' >> $OUT
 python -m sextans_amd.sweep --rp 20 --n $NS --opt split_rows=-1 synth:powerlaw:1000000:6:120:400000 2>>$ERR | grep '^{' | sed 's/"matrix": "synth:powerlaw/"options": "split_rows=-1", "matrix": "synth:powerlaw/' >> $OUT
 python -m sextans_amd.sweep --rp 20 --n $NS synth:powerlaw:1000000:6:120:400000 2>>$ERR | grep '^{' | sed 's/"matrix": "synth:powerlaw/"options": "default (strict order)", "matrix": "synth:powerlaw/' >> $OUT
+python -m sextans_amd.sweep --rp 20 --n $NS --rm synth:powerlaw:1000000:6:120:400000 2>>$ERR | grep '^{' | sed 's/"matrix": "synth:powerlaw/"options": "default (strict order)", "matrix": "synth:powerlaw/' >> $OUT
 python -m sextans_amd.sweep --rp 50 --n $NS --check matrices/nasa4704/nasa4704.mtx tests/golden/cases/*.mtx 2>>$ERR | grep '^{' >> $OUT
 wc -l $OUT
