@@ -292,6 +292,10 @@ int sextans_destroy(sextans_handle_t h);
  *   of the list (stats "index_stream_entries", "value_stream_entries"); the exported plan carries every row's own list.
  * "colwise_max_len" (default 6; "kernel" = 4 forces it): rows of at most this mean length in a numbering with locality (stat
  *   "row_coherence" >= 0.7) run on the lane-per-row kernel over the caller's column-major operands (no B repack; stat "colwise").
+ * "colwise_tiles_adjacent" (default 1; 0 = the tile as the slow grid axis, 2 = neighbours at every N): where the lane-per-row kernel puts
+ *   the 16-column tiles of a row at N >= 32.  Row-major operands: groups of T lanes per row take neighbouring tiles, so a wavefront's
+ *   loads cover whole 128-byte lines (0.25 -> 0.51 of the roofline at N = 32 .. 256); column-major: the two tiles of N = 32 are
+ *   neighbours in the launch order (the row block's CSR entries come from HBM once).  Bit-identical either way.
  * "cluster_group" (default 6), "cluster_shape" (0 = default bricks): layout tunables of form (1); measurement switches (below).
  * "small_v2" (default 1: small matrices staged from column-major B size the launch's dictionary capacity and register-resident
  * batches from the plan; 0 = the full-capacity form, for measurements),

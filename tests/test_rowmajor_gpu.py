@@ -89,13 +89,16 @@ def test_rowmajor_alpha_beta_special_values(engine, oracle):
 
 
 def test_rowmajor_lane_per_row_kernel(engine, oracle):
-    """Very short rows in a local numbering (5-point stencil): spmm_csr_colwise on the row-major operands -- 16-byte accesses."""
+    """Very short rows in a local numbering (5-point stencil): spmm_csr_colwise on the row-major operands -- 16-byte accesses; from
+    N = 32 on groups of T lanes per row take neighbouring 16-column tiles (T = 2 .. 8 incl. the odd group sizes 3, 5, 7: 85 / 51 / 36
+    rows per workgroup) so that a wavefront's loads cover whole lines; a tile count without a divisor up to 8 (11) and the 8-column
+    tail keep one lane per row and tile."""
     from sextans_amd import api
-    rp, ci, v = api.gen_stencil2d_host(90, 80, 5, 1, 3)
-    M = K = 7200
+    rp, ci, v = api.gen_stencil2d_host(90, 81, 5, 1, 3)
+    M = K = 7290
     engine.set_matrix_csr(M, K, rp, ci, v)
     rs = np.random.RandomState(12)
-    for N in (8, 16, 24, 64):
+    for N in (8, 16, 24, 32, 48, 64, 80, 96, 112, 128, 136, 176, 256):
         B = rs.uniform(-1, 1, (K, N)).astype(np.float32); C0 = rs.uniform(-1, 1, (M, N)).astype(np.float32)
         want = _want(oracle, M, K, N, rp, ci, v, B, C0)
         for kw in ({}, {"ldb": N + 4, "ldc_in": N + 8, "ldc": N + 4}, {"inplace": True}):
