@@ -66,6 +66,13 @@ def test_four_engines_four_threads_one_device(sx, oracle):
                         stream.synchronize()
                         got = out.cpu().numpy()
                         assert np.array_equal(got.view(np.uint32), wants[i].view(np.uint32)), (name, it, e.last_kernel())
+                    if it % 6 == 3:                       # the row-major entry point on the same engine (its first call builds what it needs:
+                        with torch.cuda.stream(stream):   # allocations and a host sync while other threads capture and launch)
+                            rB = tB.view(N, K).t().contiguous(); rC = tC.view(N, M).t().contiguous(); rO = torch.empty_like(rC)
+                        e.spmm_device_rm(N, float(ALPHA), rB.data_ptr(), N, float(BETA), rC.data_ptr(), N, rO.data_ptr(), N, stream.cuda_stream)
+                        stream.synchronize()
+                        got = rO.t().contiguous().cpu().numpy().reshape(-1)
+                        assert np.array_equal(got.view(np.uint32), wants[i].view(np.uint32)), (name, it, "row-major", e.last_kernel())
                 # a failing call in this thread: the error text is thread-local
                 with pytest.raises(api.SextansError):
                     e.set_option("no_such_option", 1)
