@@ -386,6 +386,9 @@ def secondaries(api, torch, dev, stream, args):
                         ("config5_blocked_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream)),
                         ("blockbanded_ell_bf16_N256", lambda: bell_secondary(api, torch, dev, stream, banded_half_width=127)),
                         ("powerlaw_1M_rows_N16", lambda: powerlaw_secondary(api, torch, dev, stream)),
+                        ("kkt_3M_rows_N16", lambda: kkt_secondary(api, torch, dev, stream, 16)),
+                        ("rowmajor_kkt_3M_rows_N16", lambda: kkt_secondary(api, torch, dev, stream, 16, layout="rm")),
+                        ("rowmajor_kkt_3M_rows_N128", lambda: kkt_secondary(api, torch, dev, stream, 128, layout="rm")),
                         ("config4_matrix_N32", lambda: uniform_secondary(api, torch, dev, stream, args, 32)),
                         ("rowmajor_config4_matrix_N16", lambda: uniform_secondary(api, torch, dev, stream, args, 16, layout="rm")),
                         ("rowmajor_config4_matrix_N32", lambda: uniform_secondary(api, torch, dev, stream, args, 32, layout="rm")))
@@ -615,6 +618,22 @@ def powerlaw_secondary(api, torch, dev, stream):
     u = _measure(api, torch, e, M, K, 16, nnz_u, dev, stream, 50)
     out["uniform_same_nnz_us_per_step"] = u["us_per_step"]
     out["ratio_to_uniform"] = round(out["us_per_step"] / u["us_per_step"], 3)
+    e.close()
+    for q in (p, i, v):
+        api.device_free(dev.index, q)
+    return out
+
+
+def kkt_secondary(api, torch, dev, stream, N, layout="cm"):
+    """KKT / arrow system (2M variables with a pentadiagonal Hessian, 1M constraints, 4 dense borders): short rows on the LDS-panel
+    kernel + border rows on the long-row paths (bucketed pieces, exact chains: strict order, bit-identical).  layout "rm": the same
+    through the row-major entry point, long-row kernels included (no copies)."""
+    M = K = api.kkt_rows(2_000_000, 4)
+    p, i, v, nnz = api.gen_kkt_device(dev.index, 2_000_000, 4, 3)
+    e = api.Engine(dev.index)
+    e.set_matrix_csr_device(M, K, nnz, p, i, v)
+    out = _measure(api, torch, e, M, K, N, nnz, dev, stream, 30, layout)
+    out.update(piece_path_rows=int(e.get_stat("piece_path_rows")), exact_chain_rows=int(e.get_stat("exact_chain_rows")))
     e.close()
     for q in (p, i, v):
         api.device_free(dev.index, q)
