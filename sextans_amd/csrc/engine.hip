@@ -62,19 +62,22 @@ template <int LPR>
 void launch_rowgroup(sextans_engine *h, const int *rp, const int *rend, const int *ci, const float *va, bool pieces,
                      const unsigned char *skip, const float *dBp,
                      const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc, int row_begin, int row_end, int ntiles,
-                     float alpha, float beta, hipStream_t s, int64_t rm_ldb = 0) {
+                     float alpha, float beta, hipStream_t s, int64_t rm_ldb = 0, bool round_robin = false, const int *groups = nullptr, int ngroups = 0) {
+    // groups: the launch covers only these groups of 128 rows (row_begin must be 0)
     // rm_ldb > 0: dBp / dCin / dCout are the caller's ROW-major operands at this segment's first column (sextans_spmm_device_rm)
+    // round_robin: workgroups to the XCDs in launch order (the split form of a mixed plan: most workgroups leave at once, and contiguous
+    // chunks per XCD would put all the working ones on one or two XCDs)
     constexpr int RB = sx::kBlock / LPR;
     constexpr int CH = 2048;
-    const int nrowblk = (row_end - row_begin + RB - 1) / RB;
+    const int nrowblk = groups ? ngroups * std::max(1, 128 / RB) : (row_end - row_begin + RB - 1) / RB;
     if (nrowblk <= 0) return;
     const unsigned nwg = (unsigned)nrowblk * (unsigned)ntiles;
     const int64_t pstride = rm_ldb > 0 ? rm_ldb : (int64_t)h->K * 4 * LPR;
-    const int xcd = (int)h->opt_xcd;
+    const int xcd = round_robin ? 0 : (int)h->opt_xcd;
 #define SX_LAUNCH(EX, ST, R)                                                                       \
     hipLaunchKernelGGL((sx::spmm_csr_rowgroup<LPR, CH, EX, ST, R>), dim3(nwg), dim3(sx::kBlock), 0, \
                        s, rp, rend, ci, va, dBp, pstride, dCin, ldc_in, dCout, ldc, row_begin,          \
-                       row_end, ntiles, nrowblk, alpha, beta, xcd, skip)
+                       row_end, ntiles, nrowblk, alpha, beta, xcd, skip, groups)
     // The LDS-staged A stream walks a block's non-zeros in order, which serialises row groups when rows
     // are long pieces of one hub row (split mode): there every row group streams its own piece directly.
     const bool stage = h->opt_stage && !pieces;
@@ -134,7 +137,8 @@ constexpr bool kReorderedContiguous = true;
 template <int H>
 int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int64_t ldc_in, float *dCout, int64_t ldc,
                       int nsuper, float alpha, float beta, hipStream_t s, int64_t bcol_ld, int blk_begin, int blk_end,
-                      int row_base, int mode = 0, int last_cols = 16, int64_t rm_ldb = 0) {
+                      int row_base, int mode = 0, int last_cols = 16, int64_t rm_ldb = 0, bool dict_blocks_only = false) {
+    // dict_blocks_only (mixed plan, split form): the launch walks P.d_dict_blocks instead of [blk_begin, blk_end)
     // rm_ldb > 0 (sextans_spmm_device_rm): dBp is the caller's ROW-major B with that leading dimension, dCin / dCout its row-major C
     // (ldc_in / ldc = row strides); mode 2 then reads B through the plan's dictionaries translated back to the caller's column
     // numbers (h->d_dict_nat) instead of permuted panels.
@@ -147,7 +151,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
     const int *slot_row = (mode == 1 || mode == 2) ? h->d_slot_row : nullptr;
     const unsigned char *skip = mode == 3 ? nullptr : (const unsigned char *)h->d_skip;   // rows on the piece path: never written by this kernel (mode 2: their staging rows keep C_in)
     const bool crow = mode == 2 || mode == 3;
-    const int nblk = blk_end - blk_begin;
+    const int nblk = dict_blocks_only ? P.n_dict_blocks : blk_end - blk_begin;
     if (nblk <= 0 || nsuper <= 0) return SEXTANS_OK;
     if (mode == 0)
         if (int rc = restore_plan_streams(h)) return rc;   // (released while a clustered plan served the whole-matrix calls)
@@ -197,7 +201,7 @@ int launch_panel_v2(sextans_engine *h, const float *dBp, const float *dCin, int6
         hipLaunchKernelGGL(kern, dim3((unsigned)nblk * (unsigned)ngrp), dim3(sx::kBlock), lds, s, (const int2 *)P.d_row_off,
                            P.d_lidx, P.d_pval, P.d_blk_row, P.d_dict_ptr, dict, P.plan_dict_stride,
                            dBp, pstride, dCin, ldc_in, dCout, ldc, nsuper, tpw, nblk, alpha, beta, xcd,
-                           P.plan_pad_row, blk_begin, row_base, skip, (long long *)h->d_dbg, slot_row, (const int2 *)P.d_ioff, last_cols);
+                           P.plan_pad_row, blk_begin, row_base, skip, (long long *)h->d_dbg, slot_row, (const int2 *)P.d_ioff, last_cols, dict_blocks_only ? (const int *)P.d_dict_blocks : (const int *)nullptr);
         return SEXTANS_OK;
     };
     if constexpr (H > 1) {
@@ -455,6 +459,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "refine_rows")) return &h->opt_refine_rows;
     if (!strcmp(key, "colwise_max_len")) return &h->opt_colwise_max_len;
     if (!strcmp(key, "colwise_tiles_adjacent")) return &h->opt_colwise_tiles_adjacent;
+    if (!strcmp(key, "split_mixed")) return &h->opt_split_mixed;
     if (!strcmp(key, "cluster_shape")) return &h->opt_cluster_shape;
     if (!strcmp(key, "cluster_group")) return &h->opt_cluster_group;
     if (!strcmp(key, "window_rows")) return &h->opt_win_rows;
@@ -525,7 +530,7 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
 int sextans_phase_timing_read(sextans_handle_t h, int64_t out[8]) {
     if (!h || !out || !h->d_dbg) return SEXTANS_ERR_STATE;
     SX_HIP(hipSetDevice(h->device));
-    SX_HIP(hipDeviceSynchronize());
+    SX_HIP((hipDeviceSynchronize)());   // (debug aid: the kernels that wrote d_dbg ran on the caller's streams)
     SX_HIP(hipMemcpy(out, h->d_dbg, 64, hipMemcpyDeviceToHost));
     return SEXTANS_OK;
 }
@@ -719,6 +724,7 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "col_range_hi")) *value = (double)h->col_hi;
     else if (!strcmp(key, "b_rows_repacked")) *value = h->d_touched ? (double)h->touched_segments * 64.0 : (double)(h->col_hi - h->col_lo);
     else if (!strcmp(key, "colwise")) *value = (double)h->colwise_state;
+    else if (!strcmp(key, "mixed_plan")) *value = h->ps.plan_built && h->ps.plan_mixed ? (h->ps.d_rg_skip && h->opt_split_mixed != 0 ? 2.0 : 1.0) : 0.0;   // 2: runs in its split form
     else if (!strcmp(key, "row_sets")) *value = (double)(h->cluster_state > 0 ? h->psc.plan_sets : h->ps.plan_sets);
     else if (!strcmp(key, "row_coherence")) *value = h->row_coherence;
     else if (!strcmp(key, "panel_blocks_clustered")) *value = (double)h->psc.plan_nblk;
@@ -1145,6 +1151,23 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             // (long rows + column-major staging: the 256-register instantiation, for launches that cannot fill the chip -- option
             // "panel_v2" = 1 asks for it, the automatic setting keeps spmm_csr_panel there: measured)
             const bool big_ok = fuse_b && !short_rows && h->opt_panel_v2 == 1 && (int64_t)(blk1 - blk0) * g.ntiles <= 8192;
+            // MIXED plans, split form (round 5): the blocks that have a dictionary run on the register-resident kernel (it leaves the others
+            // alone), the rows of the blocks without one -- no reuse between their rows -- on the gather kernel behind it (its skip table
+            // names the rows that are not its own).  One launch of spmm_csr_panel<MIXED> did both at the speed of neither: FEM rows + 10 / 30 /
+            // 60 % uniformly random rows, N = 16: 311 / 468 / 698 us per step -> 280 / 424 / 644; through the row-major entry point 406 / 581 / 832
+            // (column-major copies around the mixed kernel) -> 235 / 375 / 611 (tools/mixed_rm_probe.py).  Both launches walk compact lists
+            // (blocks with a dictionary; groups of 128 rows with a gather row): a launch over everything whose other workgroups leave at
+            // once hands the XCDs unequal shares -- measured 2 x slower.
+            const bool split_mixed = panel_here && g.width == 16 && h->ps.plan_mixed && h->ps.d_rg_skip && h->opt_split_mixed != 0 && h->opt_panel_v2 != 0 &&
+                                     !fuse_b && wide_ok && h->opt_kernel == 0 && whole;   // (whole-matrix calls: the launches walk lists made for the whole plan)
+            if (split_mixed) {
+                if (int rc = launch_panel_v2<1>(h, bsrc, cin, ldc_in, cout, ldc, g.ntiles, alpha, beta, s, 0, blk0, blk1, row_begin, 0, 16, 0, true)) return rc;
+                launch_rowgroup<4>(h, h->m_rp, h->m_rp + 1, h->m_ci, h->m_v, false, h->ps.d_rg_skip, bp, cin, ldc_in, cout, ldc, row_begin, row_end, g.ntiles, alpha, beta, s, 0, false,
+                                   h->ps.d_rg_groups, h->ps.rg_ngroups);
+                v2_used = true;
+                if (hubs) launch_hub_pieces<4>(h, pt, bp, g.ntiles, g.col0, v0, v1, s);
+                continue;
+            }
             if (panel_here && g.width == 16 && !h->ps.plan_mixed && h->opt_panel_v2 != 0 && (!fuse_b || short_rows || big_ok) && wide_ok) {
                 // whole-matrix calls on repacked panels: the plan over the rows in clustered (brick) order when the matrix has one
                 const bool clustered = whole && !fuse_b && h->cluster_state == 1;
@@ -1329,7 +1352,7 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
         h->dense_W == 0 && !(colwise && h->nhub == 0 && h->nchain == 0) && aligned && fits && h->m_nnz > 0) {
         if (h->cluster_state == 2) mode = 2;
         else if (h->cluster_state == 1) mode = 1;
-        else if (use_panel && !h->ps.plan_mixed && h->ps.plan_max_dict <= sx::kWideMaxDict) mode = 0;
+        else if (use_panel && (!h->ps.plan_mixed || (h->ps.d_rg_skip && h->opt_split_mixed != 0 && h->opt_kernel == 0)) && h->ps.plan_max_dict <= sx::kWideMaxDict) mode = 0;
     }
     if (mode == 2 && h->d_colpos && !h->d_dict_nat) {   // the plan's dictionaries hold relabelled columns: translate them back once
         const long long n = (long long)h->psc.plan_nblk * h->psc.plan_dict_stride;
@@ -1408,7 +1431,14 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
         const int ntiles = (N + 15) / 16, last_cols = N % 16 ? 8 : 16;
         const sextans_engine::PanelState &P = mode ? h->psc : h->ps;
         if (int rc = chains_fork()) return rc;
-        if (int rc = launch_panel_v2<1>(h, d_B, d_C_in, ldc_in, d_C_out, ldc, ntiles, alpha, beta, s, 0, 0, P.plan_nblk, 0, mode, last_cols, ldb)) return rc;
+        const bool split = mode == 0 && h->ps.plan_mixed;   // mixed plan: dictionary blocks here, the other blocks' rows on the gather kernel
+        if (int rc = launch_panel_v2<1>(h, d_B, d_C_in, ldc_in, d_C_out, ldc, ntiles, alpha, beta, s, 0, 0, P.plan_nblk, 0, mode, last_cols, ldb, split)) return rc;
+        if (split) {
+            int col = 0;
+            if (N / 32) { launch_rowgroup<8>(h, h->m_rp, h->m_rp + 1, h->m_ci, h->m_v, false, h->ps.d_rg_skip, d_B, d_C_in, ldc_in, d_C_out, ldc, 0, h->M, N / 32, alpha, beta, s, ldb, false, h->ps.d_rg_groups, h->ps.rg_ngroups); col = N / 32 * 32; }
+            if ((N - col) / 16) { launch_rowgroup<4>(h, h->m_rp, h->m_rp + 1, h->m_ci, h->m_v, false, h->ps.d_rg_skip, d_B + col, d_C_in + col, ldc_in, d_C_out + col, ldc, 0, h->M, 1, alpha, beta, s, ldb, false, h->ps.d_rg_groups, h->ps.rg_ngroups); col += 16; }
+            if (N - col) launch_rowgroup<2>(h, h->m_rp, h->m_rp + 1, h->m_ci, h->m_v, false, h->ps.d_rg_skip, d_B + col, d_C_in + col, ldc_in, d_C_out + col, ldc, 0, h->M, 1, alpha, beta, s, ldb, false, h->ps.d_rg_groups, h->ps.rg_ngroups);
+        }
         if (int rc = long_rows_join()) return rc;
         h->last_kernel = mode == 2 ? (hubs || chains ? "spmm_csr_panel_v2_rowmajor_clustered+long_rows" : "spmm_csr_panel_v2_rowmajor_clustered")
                                    : (hubs || chains ? "spmm_csr_panel_v2_rowmajor+long_rows" : "spmm_csr_panel_v2_rowmajor");

@@ -20,9 +20,30 @@ namespace sxe {
 
 static_assert(sx::kPlanPadRows == sx::kWidePadRows, "the plan builder and the kernels agree on the +1.0f rows of a panel");
 
+namespace {
+// mixed plans: flag the rows the gather kernel must NOT write -- rows of blocks that have a dictionary (spmm_csr_panel_v2 writes them)
+// and rows on the piece path
+__global__ __launch_bounds__(256) void mixed_row_flags(int nblk, const int *__restrict__ blk_row, const int *__restrict__ dict_cnt,
+                                                       const unsigned char *__restrict__ piece_rows, unsigned char *__restrict__ out) {
+    const int blk = blockIdx.x;
+    if (blk >= nblk) return;
+    const int r0 = blk_row[blk], r1 = blk_row[blk + 1];
+    const bool dict = dict_cnt[blk] > 0;
+    for (int r = r0 + (int)threadIdx.x; r < r1; r += 256) out[r] = dict || (piece_rows && piece_rows[r]) ? 1 : 0;
+}
+// groups of 128 rows with at least one row of the gather kernel's, appended in any order; list[ngroups_max] counts them
+__global__ __launch_bounds__(256) void mixed_group_list(int M, const unsigned char *__restrict__ flags, int *__restrict__ list, int *__restrict__ count) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if ((int64_t)g * 128 >= M) return;
+    bool any = false;
+    for (int r = g * 128; r < min(M, (g + 1) * 128) && !any; ++r) any = flags[r] == 0;
+    if (any) list[atomicAdd(count, 1)] = g;
+}
+}  // namespace
+
 void free_panel_state(sextans_engine::PanelState &p) {
     (void)hipFree(p.d_dict_ptr); (void)hipFree(p.d_dict); (void)hipFree(p.d_lidx); (void)hipFree(p.d_blk_row);
-    (void)hipFree(p.d_row_off); (void)hipFree(p.d_pcol32); (void)hipFree(p.d_pval); (void)hipFree(p.d_ioff);
+    (void)hipFree(p.d_row_off); (void)hipFree(p.d_pcol32); (void)hipFree(p.d_pval); (void)hipFree(p.d_ioff); (void)hipFree(p.d_rg_skip); (void)hipFree(p.d_rg_groups); (void)hipFree(p.d_dict_blocks);
     p = sextans_engine::PanelState();
 }
 
@@ -324,6 +345,40 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
     h->ps.plan_pad_row = cap;
     h->ps.plan_built = true;
     if (lpr == 4) h->plan_total_dict = dp.total_dict;
+    if (h->ps.plan_mixed && lpr == 4 && h->ps.plan_nblk > 0) {   // the split form of a mixed plan (engine.hip: split_mixed)
+        (void)hipFree(h->ps.d_rg_skip); h->ps.d_rg_skip = nullptr;
+        if (hipMalloc((void **)&h->ps.d_rg_skip, (size_t)std::max(h->M, 1)) == hipSuccess) {
+            hipLaunchKernelGGL(mixed_row_flags, dim3((unsigned)h->ps.plan_nblk), dim3(256), 0, nullptr, h->ps.plan_nblk, h->ps.d_blk_row, h->ps.d_dict_ptr,
+                               (const unsigned char *)h->d_skip, h->ps.d_rg_skip);
+            const int ng = (h->M + 127) / 128;
+            (void)hipFree(h->ps.d_rg_groups); h->ps.d_rg_groups = nullptr; h->ps.rg_ngroups = 0;
+            if (hipMalloc((void **)&h->ps.d_rg_groups, sizeof(int) * ((size_t)ng + 1)) == hipSuccess) {
+                SX_HIP(hipMemsetAsync(h->ps.d_rg_groups + ng, 0, sizeof(int), nullptr));
+                hipLaunchKernelGGL(mixed_group_list, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, nullptr, h->M, h->ps.d_rg_skip, h->ps.d_rg_groups, h->ps.d_rg_groups + ng);
+                SX_HIP(hipMemcpy(&h->ps.rg_ngroups, h->ps.d_rg_groups + ng, sizeof(int), hipMemcpyDeviceToHost));
+            } else {
+                (void)hipGetLastError();
+                (void)hipFree(h->ps.d_rg_skip); h->ps.d_rg_skip = nullptr;
+            }
+            SX_HIP(hipDeviceSynchronize());
+            // the blocks with a dictionary, in order (the register-resident kernel walks this list: every workgroup of its launch works,
+            // so the contiguous chunks of workgroups the XCDs get stay balanced)
+            std::vector<int> cnt((size_t)h->ps.plan_nblk), list;
+            SX_HIP(hipMemcpy(cnt.data(), h->ps.d_dict_ptr, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost));
+            for (int b = 0; b < h->ps.plan_nblk; ++b)
+                if (cnt[(size_t)b] > 0) list.push_back(b);
+            (void)hipFree(h->ps.d_dict_blocks); h->ps.d_dict_blocks = nullptr; h->ps.n_dict_blocks = 0;
+            if (h->ps.d_rg_skip && !list.empty() && hipMalloc((void **)&h->ps.d_dict_blocks, sizeof(int) * list.size()) == hipSuccess) {
+                SX_HIP(hipMemcpy(h->ps.d_dict_blocks, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice));
+                h->ps.n_dict_blocks = (int)list.size();
+            } else {
+                (void)hipGetLastError();
+                (void)hipFree(h->ps.d_rg_skip); h->ps.d_rg_skip = nullptr;   // (no split form)
+            }
+        } else {
+            (void)hipGetLastError();   // (without the table the mixed kernel runs)
+        }
+    }
     return SEXTANS_OK;
 }
 

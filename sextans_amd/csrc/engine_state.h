@@ -80,6 +80,11 @@ struct sextans_engine {
         int plan_nblk = 0;
         std::vector<int> h_blk_row;     // host copy of the plan's block boundaries (row-range calls, sextans_align_row)
         unsigned short *d_lidx = nullptr;
+        int *d_dict_blocks = nullptr;      // mixed plans, split form: the blocks that have a dictionary, ascending (n_dict_blocks of them)
+        int n_dict_blocks = 0;
+        int *d_rg_groups = nullptr;        // ... and the groups of 128 rows that hold a row of the gather kernel's (rg_ngroups of them)
+        int rg_ngroups = 0;
+        unsigned char *d_rg_skip = nullptr;   // mixed plans: 1 = the row is NOT the gather kernel's (it lies in a dictionary block, or on the piece path)
         int *d_ioff = nullptr;          // per (block, slot): start of the slot's index list in d_lidx when identical lists of consecutive rows are
                                         // stored once (plan_device.hip: share_index_lists); null = at the slot's first packed entry
         int64_t plan_idx_len = 0;       // entries of d_lidx (= plan_stream_len without sharing)
@@ -224,6 +229,7 @@ struct sextans_engine {
     int64_t opt_row_similarity = -1;    // graph clustering over the row-similarity graph: -1 when the matrix is rectangular or its pattern unsymmetric, 0 never, 1 always
     int64_t opt_relabel_columns = 1;    // graph clustering: B rows relabelled in first-touch order (permuted panels); 0 = natural panels
     int64_t opt_colwise_tiles_adjacent = 1;   // lane-per-row kernel, N >= 32: the tiles of a row block neighbours in the launch order (one XCD, same time)
+    int64_t opt_split_mixed = 1;         // mixed plans: dictionary blocks on spmm_csr_panel_v2, the rows of the other blocks on the gather kernel (0: spmm_csr_panel<MIXED>)
     int64_t opt_small_panel = 1;        // clustered plans of short-row matrices are packed for a 320-row panel when every dictionary fits (more workgroups per CU)
     int64_t opt_cluster_top = 1 << 30;  // graph clustering: the aggregation stops when clusters reach this many rows.  Default: never -- the whole
                                         // matrix becomes one merge tree, so that each XCD's contiguous chunk of row blocks is one region of the graph and

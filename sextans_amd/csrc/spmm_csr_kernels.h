@@ -88,7 +88,9 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
     const int *__restrict__ row_ptr, const int *__restrict__ row_end, const int *__restrict__ col_idx,
     const float *__restrict__ val, const float *__restrict__ Bp, int64_t panel_stride, const float *Cin,
     int64_t ldc_in, float *Cout, int64_t ldc, int row_begin, int M, int ntiles, int nrowblk, float alpha, float beta,
-    int use_xcd_remap, const unsigned char *__restrict__ skip) {
+    int use_xcd_remap, const unsigned char *__restrict__ skip, const int *__restrict__ groups) {
+    // groups (may be null; the split form of a mixed plan): the launch covers only the listed groups of 128 rows (those that hold a row
+    // of this kernel's) -- workgroup id / ntiles walks the list, 128 / RB workgroups per group.
     // skip (may be null): rows whose C is produced by the piece path (long rows taken out of the main matrix).
     // Row r holds entries [row_ptr[r], row_end[r]): row_end = row_ptr + 1 for a CSR matrix; the pieces of hub rows
     // (long-row splitting) come with their own end array and are not contiguous from one piece to the next.
@@ -103,8 +105,12 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
     const unsigned nwg = (unsigned)nrowblk * (unsigned)ntiles;
     unsigned wg = blockIdx.x;
     if (use_xcd_remap) wg = xcd_remap(wg, nwg);
-    const int rowblk = (int)(wg / (unsigned)ntiles);
+    int rowblk = (int)(wg / (unsigned)ntiles);
     const int tile = (int)(wg % (unsigned)ntiles);
+    if (groups) {
+        constexpr int PER = (128 / RB) > 0 ? 128 / RB : 1;
+        rowblk = groups[rowblk / PER] * PER + rowblk % PER;
+    }
 
     const int tid = threadIdx.x;
     const int slot = tid / LPR;
@@ -118,10 +124,15 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rowgroup(
         else return reinterpret_cast<const float4 *>(bq + (int64_t)c * NT);
     };
     int j = 0, jend = 0;
-    if (row < M) { j = row_ptr[row]; jend = row_end[row]; }
+    // rows named by `skip` are somebody else's: piece-path rows are empty in the main matrix anyway; in the split form of a MIXED plan
+    // they are the rows of the dictionary blocks, with all their entries -- not walked here, and a workgroup without a row of its own
+    // leaves before it stages anything
+    const bool mine = row < M && !(skip && skip[row]);
+    if (skip && __syncthreads_count(mine) == 0) return;
+    if (mine) { j = row_ptr[row]; jend = row_end[row]; }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 cin4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool cwrite = RM && row < M && !(skip && skip[row]);
+    const bool cwrite = RM && mine;
     if constexpr (RM)   // C_in early: in flight under the row loop
         if (cwrite) cin4 = *reinterpret_cast<const float4 *>(Cin + (int64_t)(row - row_begin) * ldc_in + tile * NT + 4 * q);
 

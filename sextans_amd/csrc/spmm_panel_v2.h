@@ -155,7 +155,10 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? (BCOL && DCAP == 9 ? SX_V
     const int *__restrict__ blk_row, const int *__restrict__ dict_cnt, const int *__restrict__ blk_dict, int dict_stride,
     const float *__restrict__ Bp, int64_t panel_stride, const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc,
     int nsuper, int tpw, int nblk, float alpha, float beta, int use_xcd_remap, int pad_row, int blk_begin, int row_base,
-    const unsigned char *__restrict__ skip, long long *dbg, const int *__restrict__ slot_row, const int2 *__restrict__ slot_ioff, int last_cols) {
+    const unsigned char *__restrict__ skip, long long *dbg, const int *__restrict__ slot_row, const int2 *__restrict__ slot_ioff, int last_cols,
+    const int *__restrict__ blk_list) {
+    // blk_list (mixed plans, split form; may be null): the launch walks the listed blocks only -- those that have a dictionary; the rows of
+    // the others belong to the gather kernel (nblk = length of the list, blk_begin unused)
     // last_cols (16-column tiles, column-major C): valid columns of the LAST super tile of the launch -- 8 when N = 16 t + 8 runs as
     // t + 1 tiles (its B panel is zero there): lanes whose 4 columns lie beyond neither load C_in nor store C for that tile
     // slot_ioff (may be null): {where a slot's 16-bit index list starts in p_idx16, shift in bytes to add to every offset of the list}
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? (BCOL && DCAP == 9 ? SX_V
     const unsigned nwg = (unsigned)nblk * (unsigned)ngrp;
     unsigned wg = blockIdx.x;
     if (use_xcd_remap) wg = xcd_remap(wg, nwg);
-    const int blk = blk_begin + (int)(wg / (unsigned)ngrp);
+    const int blk = blk_list ? blk_list[wg / (unsigned)ngrp] : blk_begin + (int)(wg / (unsigned)ngrp);
     const int grp = (int)(wg % (unsigned)ngrp);
     const int st_begin = grp * tpw, st_end = min(nsuper, st_begin + tpw);
 

@@ -1,4 +1,4 @@
-// thread_stream.h -- synchronous copies without the LEGACY default stream.
+// thread_stream.h -- synchronous copies and waits without the LEGACY default stream / the whole device.
 //
 // hipMemcpy / hipMemset wait on the process-wide legacy stream, and HIP fails them -- in EVERY host thread -- while ANY stream of the
 // device is being captured into a hipGraph ("operation would make the legacy stream depend on a capturing blocking stream"), and
@@ -29,3 +29,7 @@ inline hipError_t memset_on_thread_stream(void *dst, int value, size_t bytes) {
 #undef hipMemset
 #define hipMemcpy(dst, src, bytes, kind) sx::memcpy_on_thread_stream((dst), (src), (bytes), (kind))
 #define hipMemset(dst, value, bytes) sx::memset_on_thread_stream((dst), (value), (bytes))
+// hipDeviceSynchronize is refused likewise ("operation not permitted when stream is capturing") while another host thread captures.  What
+// the library's builders wait for is their OWN work -- kernels and copies on stream 0 = the calling thread's default stream -- so the
+// wait is for that stream.  (Write (hipDeviceSynchronize)() where the whole device is meant.)
+#define hipDeviceSynchronize() hipStreamSynchronize(hipStreamPerThread)
