@@ -1157,7 +1157,8 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             // 60 % uniformly random rows, N = 16: 311 / 468 / 698 us per step -> 280 / 424 / 644; through the row-major entry point 406 / 581 / 832
             // (column-major copies around the mixed kernel) -> 235 / 375 / 611 (tools/mixed_rm_probe.py).  Both launches walk compact lists
             // (blocks with a dictionary; groups of 128 rows with a gather row): a launch over everything whose other workgroups leave at
-            // once hands the XCDs unequal shares -- measured 2 x slower.
+            // once hands the XCDs unequal shares -- measured 2 x slower.  (The gather launch on a second stream beside the other one: built,
+            // measured equal -- the first launch fills every workgroup slot of the chip, the second queues behind it either way.)
             const bool split_mixed = panel_here && g.width == 16 && h->ps.plan_mixed && h->ps.d_rg_skip && h->opt_split_mixed != 0 && h->opt_panel_v2 != 0 &&
                                      !fuse_b && wide_ok && h->opt_kernel == 0 && whole;   // (whole-matrix calls: the launches walk lists made for the whole plan)
             if (split_mixed) {
