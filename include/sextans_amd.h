@@ -295,7 +295,9 @@ int sextans_destroy(sextans_handle_t h);
  * "split_mixed" (default 1; 0 = one launch of spmm_csr_panel<MIXED>): a MIXED plan -- some row blocks reuse B rows and have a dictionary,
  *   others (rows with uniformly random columns) do not -- runs in two launches: the blocks with a dictionary on spmm_csr_panel_v2, the
  *   rows of the others on the gather kernel; both walk compact lists.  Whole-matrix calls, column-major and row-major operands (the
- *   latter without copies).  Stat "mixed_plan": 0 no / 1 mixed, one launch / 2 mixed, split form.  Bit-identical either way.
+ *   latter without copies).  Whole-matrix calls take the split form from 15 % of the non-zeros in blocks with reuse on (the gather
+ *   kernel alone below that; every other use of the LDS-panel plan keeps its 50 % threshold).  Stat "mixed_plan": 0 no / 1 mixed, one
+ *   launch / 2 mixed, split form.  Bit-identical either way.
  * "colwise_tiles_adjacent" (default 1; 0 = the tile as the slow grid axis, 2 = neighbours at every N): where the lane-per-row kernel puts
  *   the 16-column tiles of a row at N >= 32.  Row-major operands: groups of T lanes per row take neighbouring tiles, so a wavefront's
  *   loads cover whole 128-byte lines (0.25 -> 0.51 of the roofline at N = 32 .. 256); column-major: the two tiles of N = 32 are

@@ -261,6 +261,9 @@ int sample_reuse(sextans_engine *h, int RB, int max_unique, double min_reuse, do
 // back from the device copy, so this works for host- and device-provided matrices alike; it runs once
 // per matrix ("upload once"), outside any timed region, like the reference's host-side scheduling
 // and packing (generate_edge_list_for_all_PEs + edge_list_64bit, sextans-host.cpp:114-148).
+// Share of the non-zeros in row blocks with reuse from which a whole-matrix call on a MIXED plan runs its split form (dictionary blocks
+// on spmm_csr_panel_v2 + the other rows on the gather kernel) instead of the gather kernel alone; everything else keeps 0.5.
+constexpr double kSplitMinFrac = 0.15;
 int ensure_plan(sextans_engine *h, int lpr, bool force) {
     if (h->ps.plan_lpr == lpr && h->ps.plan_min_reuse == plan_key(h) && (h->ps.plan_built || !force))
         return SEXTANS_OK;
@@ -295,7 +298,10 @@ int ensure_plan(sextans_engine *h, int lpr, bool force) {
     if (!force) {
         double frac = 0.0;
         if (int rc = sample_reuse(h, RB, kPanelFloats / (4 * lpr), min_reuse, narrow, &frac, &narrow_frac)) return rc;
-        if (frac < 0.5) {   // no reuse worth an LDS panel: remember the verdict, skip the build
+        // (the split form of a mixed plan pays from a much smaller share on: its blocks with reuse run at the panel kernel's speed, the
+        // rest at the gather kernel's, which they would run at anyway -- prepare(): kSplitMinFrac)
+        const double build_from = lpr == 4 && h->opt_split_mixed != 0 && h->opt_kernel == 0 ? kSplitMinFrac : 0.5;
+        if (frac < build_from) {   // no reuse worth an LDS panel: remember the verdict, skip the build
             h->ps.plan_lpr = lpr;
             h->ps.plan_min_reuse = plan_key(h);
             h->ps.plan_panel_frac = frac * 0.999;
@@ -1108,6 +1114,12 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
                 if (int rc = ensure(&h->d_Cs, &h->Cs_cap, (n16 / 16) * (size_t)h->M * 16)) return rc;
         }
         use_panel = h->ps.plan_built && ((h->opt_kernel == 2) || (h->ps.plan_panel_frac >= 0.5 && (N >= 32 || h->ps.plan_narrow_frac >= 0.5)));
+        // whole-matrix calls on a mixed plan that has its split form: from kSplitMinFrac on (FEM rows + 3 x / 6 x as many uniformly random
+        // rows, panel share 0.40 / 0.25: measured against the gather kernel alone, profiles/r05_mixed_plan_split.txt)
+        if (!use_panel && whole && lpr == 4 && h->opt_kernel == 0 && h->ps.plan_built && h->ps.plan_mixed && h->ps.d_rg_skip && h->opt_split_mixed != 0 &&
+            h->opt_panel_v2 != 0 && h->ps.plan_max_dict <= sx::kWideMaxDict && h->ps.plan_panel_frac >= kSplitMinFrac &&
+            (N >= 32 || h->ps.plan_narrow_frac >= kSplitMinFrac))
+            use_panel = true;
         // (a matrix that runs in the reordered form needs no natural-order plan for that: a randomly numbered mesh without any reuse between
         // consecutive rows has none -- its N = 8 calls fell to the gather kernel, 0.06 against 0.37 at N = 16 on the holdout class)
         const bool reorder8 = whole && h->cluster_state == 2 && h->cluster_cm_pays && h->opt_kernel != 1 && h->opt_kernel != 3;

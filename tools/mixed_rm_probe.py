@@ -9,7 +9,8 @@ import bench
 nx = 70
 frp, fci, fv = api.gen_fem3d_host(nx, nx, nx, 3, 5)
 Mf = nx * nx * nx * 3
-for frac in (0.1, 0.3, 0.6):
+import os
+for frac in tuple(float(x) for x in os.environ.get('MIXED_SHARES', '0.1,0.3,0.6').split(',')):
     Mu = int(Mf * frac)
     urp, uci, uv = api.gen_csr_host(Mu, Mf, 40.0, 4, 0, Mu)
     rp = np.concatenate([frp, frp[-1] + urp[1:]]).astype(np.int32); ci = np.concatenate([fci, uci]); v = np.concatenate([fv, uv])
