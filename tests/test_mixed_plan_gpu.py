@@ -83,3 +83,40 @@ def test_mixed_plan_split_form_is_bit_identical(engine, oracle, N):
             assert np.array_equal(slab.cpu().numpy().reshape(N, c1 - c0).view(np.uint32), want.reshape(N, M)[:, c0:c1].copy().view(np.uint32)), (N, split)
     finally:
         engine.set_option("split_mixed", 1)
+
+
+def test_split_form_from_a_small_share_of_blocks_with_reuse(engine, oracle, sx):
+    """Whole-matrix calls take the split form from 15 % of the non-zeros in blocks with reuse on (everything else keeps the 50 %
+    threshold of the LDS-panel plan): FEM rows holding ~30 % of the non-zeros of a matrix of uniformly random rows.  Same bits; with
+    "split_mixed" = 0 the gather kernel runs alone."""
+    import torch
+    from sextans_amd import api
+    frp, fci, fv = api.gen_fem3d_host(20, 19, 18, 3, 5)
+    Mf = 20 * 19 * 18 * 3
+    Mu = 110_000
+    urp, uci, uv = api.gen_csr_host(Mu, Mf, 36.0, 4, 0, Mu)
+    rp = np.concatenate([frp, frp[-1] + urp[1:]]).astype(np.int32); ci = np.concatenate([fci, uci]); v = np.concatenate([fv, uv])
+    M, K, N = Mf + Mu, Mf, 16
+    share = float(frp[-1]) / float(rp[-1])
+    assert 0.2 < share < 0.45
+    rs = np.random.RandomState(8)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32); C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    st = torch.cuda.current_stream().cuda_stream
+    Br = torch.from_numpy(np.ascontiguousarray(B.reshape(N, K).T)).cuda(); Cr = torch.from_numpy(np.ascontiguousarray(C0.reshape(N, M).T)).cuda()
+    try:
+        for split, cm_kernel, rm_kernel in ((1, "spmm_csr_panel_v2", "spmm_csr_panel_v2_rowmajor"), (0, "spmm_csr_rowgroup", "spmm_csr_rowgroup_rowmajor")):
+            engine.set_option("split_mixed", split)
+            engine.set_matrix_csr(M, K, rp, ci, v)
+            out = C0.copy()
+            engine.spmm(N, ALPHA, B, BETA, out)
+            assert engine.last_kernel() == cm_kernel, (split, engine.last_kernel(), engine.get_stat("panel_fraction"))
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), split
+            ro = torch.empty_like(Cr)
+            engine.spmm_device_rm(N, float(ALPHA), Br.data_ptr(), N, float(BETA), Cr.data_ptr(), N, ro.data_ptr(), N, st)
+            torch.cuda.synchronize()
+            assert engine.last_kernel() == rm_kernel, (split, engine.last_kernel())
+            assert np.array_equal(np.ascontiguousarray(ro.cpu().numpy().T).reshape(-1).view(np.uint32), want.view(np.uint32)), split
+    finally:
+        engine.set_option("split_mixed", 1)
