@@ -76,10 +76,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves -- the same command line under
+        # torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1); rank 0 of it prints the one JSON line.
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} needs {args.gpus} devices, found {have}", file=sys.stderr)
+            sys.exit(2)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` (it spawns its ranks) "
+                  f"or under torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
         sys.exit(2)
     api.lib()   # raises if the HIP library was not built: no fallback
     if not torch.cuda.is_available() or api.device_count() < 1:
@@ -117,10 +132,7 @@ def main():
         e0, e1 = ranges[rank]
         t_rp, t_ci, t_v, _ = api.gen_csr_device(local_rank, M, K, args.mean_nnz, 4, e0, e1)
         lens = torch.empty(e1 - e0 + 1, dtype=torch.int32, device=dev)
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
-        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-        assert hip.hipMemcpy(lens.data_ptr(), t_rp, 4 * (e1 - e0 + 1), 3) == 0
+        api.device_copy(local_rank, lens.data_ptr(), t_rp, 4 * (e1 - e0 + 1))   # (through the library's own HIP runtime)
         for q in (t_rp, t_ci, t_v):
             api.device_free(local_rank, q)
         ranges = sxd.balanced_ranges_from_even_slices(lens, M, rank)
@@ -215,9 +227,16 @@ def main():
             dt = float(t.item())
         return dt
 
+    if comm is not None:
+        # Collective preparation OUTSIDE the timed region (round 6): non-zero counts, "row_offset", this rank's plan build, cut lists,
+        # clustered-order flags and tables, workspaces -- and an error on every rank if any rank failed, instead of a hang.
+        eng.dist_prepare(comm, world, rank, ranges, N, nchunks=args.chunks, form=1 if args.rowmajor else 0, stream=stream)
+        setup_exchanges = eng.get_stat("dist_setup_exchanges")
     for _ in range(args.warmup):
         step()
     dt = timed(step, args.steps)
+    if comm is not None:   # nothing but data collectives inside the steps
+        assert eng.get_stat("dist_setup_exchanges") == setup_exchanges, "a timed step exchanged control data or synchronised with the host"
     dt_compute = timed(compute, args.steps) if multi else dt
 
     nnz_tot = nnz_loc
@@ -256,6 +275,10 @@ def main():
             traffic = tj.get("traffic_bytes_per_launch")
             traffic_source = ("stored, not measured in this run: profiles/" + os.path.basename(tpath) + " <- " +
                               str(tj.get("source")))
+        else:   # the dispatcher picked another kernel than the one the counters were collected on: say so, loudly
+            traffic_source = (f"NOT APPLICABLE: profiles/{os.path.basename(tpath)} was collected on kernel {tj.get('kernel')!r}, this run's dominant kernel is "
+                              f"{eng.last_kernel()!r} -- re-run tools/prof.sh")
+            print("bench.py: WARNING: " + traffic_source, file=sys.stderr)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": eng.last_kernel(), "kernel_us": round(k_ns / 1e3, 2),
@@ -316,8 +339,15 @@ def main():
                 also[key] = fn()
             except Exception as e:   # secondary measurements only
                 also[key] = {"error": str(e)}
+    # The secondary measurements travel on a line of their own IN FRONT of the headline (and into gpurun_out/bench_also.json when that
+    # directory exists): the LAST stdout line is the one JSON object of the contract, short enough for a log tail, with one number per
+    # secondary workload (fraction of the HBM roofline per step, algorithmic bytes) so that nothing is hidden by the split.
+    also_line = None
     if also:
-        out["also"] = also
+        also_line = json.dumps({"also": also})
+        out["also_step_frac"] = {k: (v.get("roofline_frac_step", v.get("roofline_frac_kernel")) if isinstance(v, dict) else v) for k, v in also.items()
+                                 if not isinstance(v, dict) or "roofline_frac_step" in v or "roofline_frac_kernel" in v or "error" in v}
+        out["also_line"] = "the line in front of this one: {\"also\": {...}} with every secondary record in full"
 
     if comm is not None:
         api.dist_comm_destroy(comm)
@@ -335,6 +365,14 @@ def main():
     if multi:
         dist.barrier()
     if rank == 0:
+        if also_line:
+            print(also_line, flush=True)
+            try:
+                if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+                    with open(os.path.join(ROOT, "gpurun_out", "bench_also.json"), "w") as f:
+                        f.write(also_line + "\n")
+            except OSError:
+                pass
         print(json.dumps(out), flush=True)
     if multi:
         dist.destroy_process_group()
@@ -694,11 +732,8 @@ def fem_secondary(api, torch, dev, stream, dims, N, iters, numbering="grid", opt
     if torch_op:     # the operator front end on the same matrix: wall time per call of torch_op.spmm on row-major tensors, in place
         from sextans_amd import torch_op as top
         rp_t = torch.empty(M + 1, dtype=torch.int32, device=dev); ci_t = torch.empty(nnz, dtype=torch.int32, device=dev); v_t = torch.empty(nnz, device=dev)
-        import ctypes as C
-        hip = C.CDLL("libamdhip64.so")
-        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         for dst, src, n in ((rp_t, p, M + 1), (ci_t, i, nnz), (v_t, v, nnz)):
-            assert hip.hipMemcpy(dst.data_ptr(), src, 4 * n, 3) == 0
+            api.device_copy(dev.index, dst.data_ptr(), src, 4 * n)
         A = torch.sparse_csr_tensor(rp_t, ci_t, v_t, size=(M, K))
         Bt = torch.empty((K, N), device=dev); Ct = torch.empty((M, N), device=dev); Ot = torch.empty((M, N), device=dev)
         api.gen_uniform_device(dev.index, Bt.data_ptr(), K * N, 41, stream); api.gen_uniform_device(dev.index, Ct.data_ptr(), M * N, 42, stream)

@@ -1,8 +1,11 @@
 // examples/dist_spmm.cpp -- multi-GPU SpMM through the C ABI alone (no Python, no torch): what a maintainer of the
 // reference host program would write to shard  C = alpha*A*B + beta*C  over the GPUs of one node.
 //
-//   dist_spmm <A.mtx> <N> [gpus] [rm]  one host thread per GPU; default gpus = all visible gfx950 devices;
-//                                      rm: row-major B and C through sextans_dist_spmm_rm as well (slabs in place, in-place all-gather)
+//   dist_spmm <A.mtx> <N> [gpus] [rm] [onedevice]
+//       one host thread per GPU; default gpus = all visible gfx950 devices;
+//       rm: row-major B and C through sextans_dist_spmm_rm as well (slabs in place, in-place all-gather);
+//       onedevice: `gpus` ranks as threads on device 0 -- with a collectives library that supports it (SEXTANS_RCCL_PATH = the
+//       loopback communicator of tests/fake_rccl.cpp): how the multi-rank code is exercised on a single-GPU box.
 //
 // Every rank loads the matrix (sextans_mtx_read), takes an nnz-balanced row range (sextans_partition_rows_by_nnz),
 // keeps its rows in its own engine, holds the full B and C_in, and calls sextans_dist_spmm; C_out is complete on
@@ -30,12 +33,13 @@
 #define HIP(call) do { if ((call) != hipSuccess) { fprintf(stderr, "%s failed\n", #call); exit(2); } } while (0)
 
 int main(int argc, char **argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s <A.mtx> <N> [gpus] [rm]\n", argv[0]); return 1; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <A.mtx> <N> [gpus] [rm] [onedevice]\n", argv[0]); return 1; }
     const bool rm = argc > 4 && !strcmp(argv[4], "rm");
+    const bool one_device = argc > 5 && !strcmp(argv[5], "onedevice");
     const int N = sextans_round_up_n(atoi(argv[2]));
     int world = 0;
     if (sextans_device_count(&world) != SEXTANS_OK || world < 1) { fprintf(stderr, "no gfx950 device\n"); return 2; }
-    if (argc > 3) world = std::min(world, std::max(1, atoi(argv[3])));
+    if (argc > 3) world = one_device ? std::max(1, atoi(argv[3])) : std::min(world, std::max(1, atoi(argv[3])));
     int M, K, nnz, *rp, *ci;
     float *va;
     CHECK(sextans_mtx_read(argv[1], SEXTANS_FMT_CSR, &M, &K, &nnz, &rp, &ci, &va));
@@ -57,11 +61,12 @@ int main(int argc, char **argv) {
     std::vector<std::thread> ranks;
     for (int g = 0; g < world; ++g)
         ranks.emplace_back([&, g]() {
-            HIP(hipSetDevice(g));
+            const int dev = one_device ? 0 : g;
+            HIP(hipSetDevice(dev));
             void *comm = nullptr;
-            CHECK(sextans_dist_comm_init(&comm, g, world, g, id));
+            CHECK(sextans_dist_comm_init(&comm, dev, world, g, id));
             sextans_handle_t h = nullptr;
-            CHECK(sextans_create(&h, g));
+            CHECK(sextans_create(&h, dev));
             const int r0 = ranges[2 * (size_t)g], r1 = ranges[2 * (size_t)g + 1];
             std::vector<int> lrp((size_t)(r1 - r0) + 1);
             for (int r = r0; r <= r1; ++r) lrp[(size_t)(r - r0)] = rp[r] - rp[r0];
@@ -73,6 +78,8 @@ int main(int argc, char **argv) {
             HIP(hipMemcpy(dCin, Cin.data(), Cin.size() * 4, hipMemcpyHostToDevice));
             hipStream_t st;
             HIP(hipStreamCreate(&st));
+            // everything collective or slow -- non-zero counts, plan build, cut lists -- outside the call a caller would time
+            CHECK(sextans_dist_prepare(h, comm, world, g, ranges.data(), N, 4, SEXTANS_DIST_CSR_COLMAJOR, (void *)st));
             CHECK(sextans_dist_spmm(h, comm, world, g, ranges.data(), N, alpha, dB, K, beta, dCin, M, dCout, M, 4, (void *)st));
             HIP(hipStreamSynchronize(st));
             result[(size_t)g].resize(Cin.size());
@@ -110,7 +117,7 @@ int main(int argc, char **argv) {
         printf("rank %d%s: not bit-identical; reference criterion: %d mismatches (%.4f %%)\n", g, form ? " (row-major)" : "", mism, pct);
         bad += mism;
     }
-    printf("dist_spmm: %d GPU(s), M=%d K=%d nnz=%d N=%d%s: %s\n", world, M, K, nnz, N, rm ? ", column-major and row-major forms" : "", bad ? "MISMATCH" : "all ranks match the single-GPU result");
+    printf("dist_spmm: %d rank(s), M=%d K=%d nnz=%d N=%d%s: %s\n", world, M, K, nnz, N, rm ? ", column-major and row-major forms" : "", bad ? "MISMATCH" : "all ranks match the single-GPU result");
     sextans_host_free(rp); sextans_host_free(ci); sextans_host_free(va);
     return bad ? 3 : 0;
 }

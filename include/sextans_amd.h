@@ -42,6 +42,7 @@ extern "C" {
 #define SEXTANS_ERR_NO_DEVICE 10   /* no HIP device / wrong architecture: NO CPU fallback */
 #define SEXTANS_ERR_HIP 11         /* a HIP runtime call failed; see sextans_last_error() */
 #define SEXTANS_ERR_STATE 12       /* e.g. spmm before set_matrix */
+#define SEXTANS_ERR_PEER 13        /* a collective preparation failed on ANOTHER rank (sextans_dist_prepare); this rank's own work was fine */
 
 #define SEXTANS_FMT_CSR 0          /* enum MATRIX_FORMAT {CSR, CSC}, sparse_helper.h:20 */
 #define SEXTANS_FMT_CSC 1
@@ -398,6 +399,14 @@ int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_
 int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb, float beta, const float *d_C_in,
                            int64_t ldc_in, float *d_C_out, int64_t ldc, void *stream);
 
+/* Everything the first SpMM call for (matrix, options, N, layout) would build inside itself -- packed row-bucketed plan, clustered row
+ * order, long-row tables, workspaces, side streams -- built NOW, outside any timed region or hipGraph capture (round 6).  The
+ * analogue of the reference preparing its streams before tapa::invoke (sextans-host.cpp:114-204).  Optional: the compute entry
+ * points prepare lazily.  `stream` is only used for the few device passes of the builders (it is synchronised). */
+#define SEXTANS_LAYOUT_COLMAJOR 0
+#define SEXTANS_LAYOUT_ROWMAJOR 1
+int sextans_prepare(sextans_handle_t h, int N, int layout, void *stream);
+
 /* Row-range form: computes rows [row_begin, row_end) only.  d_C_in / d_C_out address row_begin as
  * their row 0 (ldc_in, ldc_out >= row_end - row_begin).  Used to pipeline a rank's slab in chunks so the
  * all-gather of chunk i overlaps the SpMM of chunk i+1.  flags: SEXTANS_ROWS_REUSE_B_PANELS = the B
@@ -462,6 +471,29 @@ int sextans_invoke(sextans_handle_t h, const int32_t *edge_list_ptr, const uint6
 /* Contiguous row ranges with (nearly) equal non-zero counts for `world` ranks: ranges[2g], ranges[2g+1] = rows of rank g
  * (split points by binary search in row_ptr; host function, no device needed). */
 int sextans_partition_rows_by_nnz(int M, const int *row_ptr, int world, int *ranges);
+/* Which library the collectives come from (round 6).  By default the first of $SEXTANS_RCCL_PATH, librccl.so.1, /opt/rocm/lib/librccl.so.1,
+ * librccl.so that dlopen finds, bound at the first use.  sextans_dist_bind_library(path) binds `path` instead (NULL or "": back to the
+ * default search) -- a site's own RCCL build, or the loopback communicator of this repository's tests (tests/fake_rccl.cpp: ranks as
+ * threads of one process on one device, so that world > 1 runs on a single-GPU box).  The library must export ncclGetUniqueId,
+ * ncclCommInitRank, ncclCommDestroy, ncclAllGather (and ncclBroadcast, ncclGroupStart, ncclGroupEnd for row-major slabs of unequal
+ * length).  SEXTANS_ERR_STATE while communicators created through sextans_dist_comm_init are alive. */
+int sextans_dist_bind_library(const char *path);
+/* Everything a sextans_dist_spmm* call would otherwise do INSIDE ITS FIRST INVOCATION for a partition -- exchange of the ranks' non-zero
+ * counts (long-row thresholds follow the whole matrix), "row_offset", the plan build of this rank's slab (0.3-0.7 s for 3e8 non-zeros),
+ * the cut-list / clustered-order flag / position -> row table exchanges of the chunk pipeline, workspaces, streams and events -- as ONE
+ * collective call outside any timed region.  `form` selects the entry point it prepares for:
+ *   SEXTANS_DIST_CSR_COLMAJOR  sextans_dist_spmm      (nchunks as in that call)
+ *   SEXTANS_DIST_CSR_ROWMAJOR  sextans_dist_spmm_rm   (nchunks ignored; ldc of the later call assumed == N unless nchunks < 0: packed copy)
+ *   SEXTANS_DIST_BELL          sextans_dist_spmm_bell (nchunks ignored)
+ * Every rank of the communicator must call it (it is a collective).  It ends with an exchange of the ranks' status: it returns
+ * SEXTANS_OK on ALL ranks or an error on ALL ranks -- a rank whose own work failed gets its own code, the others SEXTANS_ERR_PEER --
+ * and no rank is left waiting in a collective for a rank that gave up.  After it, the dist call for the same (ranges, N, nchunks)
+ * performs no host synchronisation and no control collective (stat "dist_setup_exchanges" stays where it was).  Optional: the dist
+ * calls still prepare lazily when it was not called.  comm == NULL with world == 1: the local part alone. */
+#define SEXTANS_DIST_CSR_COLMAJOR 0
+#define SEXTANS_DIST_CSR_ROWMAJOR 1
+#define SEXTANS_DIST_BELL 2
+int sextans_dist_prepare(sextans_handle_t h, void *comm, int world, int rank, const int *row_ranges, int N, int nchunks, int form, void *stream);
 int sextans_dist_unique_id(char id[128]);
 int sextans_dist_comm_init(void **comm, int device, int world, int rank, const char id[128]);
 int sextans_dist_comm_destroy(void *comm);
@@ -597,6 +629,14 @@ int sextans_gen_uniform_bf16_device(int device, uint16_t *d_dst, int64_t n, uint
 int sextans_gen_uniform_host(float *dst, int64_t n, uint64_t seed);
 int sextans_gen_uniform_device(int device, float *d_dst, int64_t n, uint64_t seed, void *stream);
 int sextans_device_free(int device, void *d_ptr);
+/* Device memory helpers for callers of the device generators that have no HIP binding of their own (Python tools, the bench): they go
+ * through the ONE HIP runtime this library is linked against -- a second dlopen("libamdhip64.so") by another name can map a second
+ * runtime whose calls fail on this one's pointers.  Synchronous with respect to the host; kind = SEXTANS_COPY_*. */
+#define SEXTANS_COPY_HOST_TO_DEVICE 1
+#define SEXTANS_COPY_DEVICE_TO_HOST 2
+#define SEXTANS_COPY_DEVICE_TO_DEVICE 3
+int sextans_device_alloc(int device, size_t bytes, void **d_ptr);
+int sextans_device_copy(int device, void *dst, const void *src, size_t bytes, int kind);
 
 #ifdef __cplusplus
 }

@@ -61,9 +61,20 @@ class SextansError(RuntimeError):
         super().__init__(f"{where}: [{code}] {msg}" + (f" ({detail})" if detail else ""))
 
 
+# Entry points added after round 4: the only ones a comparison against an OLDER build (tools/nasa_ab.py loads the libraries of earlier
+# rounds for same-box A/Bs) may lack.  Any other missing name is a typo or a broken build and fails the load.
+_OPTIONAL_SYMBOLS = frozenset((
+    "sextans_spmm_device_rm", "sextans_dist_spmm_rm", "sextans_spmm_bell_device2", "sextans_dist_spmm_bell", "sextans_profile_read_post",
+    "sextans_gen_kron_host", "sextans_gen_kron_device", "sextans_csr_slice_rows_device", "sextans_csr_permute_symmetric_device",
+    "sextans_export_row_order", "sextans_mtx_read_cached", "sextans_matrix_save", "sextans_matrix_load",
+    "sextans_prepare", "sextans_dist_prepare", "sextans_dist_bind_library", "sextans_device_alloc", "sextans_device_copy",
+    "sextans_set_mode", "sextans_get_mode"))
+
+
 class _Optional:
-    """ctypes library proxy for lib(): declaring the prototype of an entry point that an OLDER build lacks (tools/nasa_ab.py loads
-    the libraries of earlier rounds for same-box comparisons) is skipped instead of failing the whole load."""
+    """ctypes library proxy for lib(): declaring the prototype of an entry point that an OLDER build lacks is skipped instead of
+    failing the whole load -- for the names in _OPTIONAL_SYMBOLS only; anything else raises AttributeError (a misspelled name would
+    otherwise lose its prototype silently and ctypes would truncate 64-bit arguments to int)."""
     class _Missing:
         argtypes = restype = None
     def __init__(self, L):
@@ -72,7 +83,9 @@ class _Optional:
         try:
             return getattr(self._L, name)
         except AttributeError:
-            return _Optional._Missing()
+            if name in _OPTIONAL_SYMBOLS:
+                return _Optional._Missing()
+            raise
 
 
 def lib():
@@ -133,7 +146,7 @@ def lib():
     L.sextans_dist_spmm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i32p, C.c_int, C.c_float, C.c_void_p,
                                     C.c_int64, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
                                     C.c_void_p]
-    if hasattr(L, "sextans_dist_spmm_rm"):
+    if hasattr(raw, "sextans_dist_spmm_rm"):
         L.sextans_dist_spmm_rm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i32p, C.c_int, C.c_float, C.c_void_p,
                                            C.c_int64, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     pp = C.POINTER(C.c_void_p)
@@ -171,7 +184,7 @@ def lib():
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.sextans_spmm_device2.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
-    if hasattr(L, "sextans_spmm_device_rm"):      # (absent from the older builds tools/nasa_ab.py compares against)
+    if hasattr(raw, "sextans_spmm_device_rm"):      # (absent from the older builds tools/nasa_ab.py compares against)
         L.sextans_spmm_device_rm.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
                                              C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     L.sextans_spmm_device_rows.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
@@ -216,7 +229,7 @@ def lib():
     L.sextans_set_matrix_bell_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.sextans_spmm_bell_device.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
                                            C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
-    if hasattr(L, "sextans_dist_spmm_bell"):
+    if hasattr(raw, "sextans_dist_spmm_bell"):
         L.sextans_spmm_bell_device2.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_float,
                                                 C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
         L.sextans_dist_spmm_bell.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i32p, C.c_int, C.c_float, C.c_void_p,
@@ -234,6 +247,11 @@ def lib():
     L.sextans_gen_uniform_device.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_uint64,
                                              C.c_void_p]
     L.sextans_device_free.argtypes = [C.c_int, C.c_void_p]
+    L.sextans_device_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.sextans_device_copy.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.sextans_prepare.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.sextans_dist_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _i32p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.sextans_dist_bind_library.argtypes = [C.c_char_p]
     _lib = raw
     return raw
 
@@ -533,6 +551,17 @@ class Engine:
         _check(lib().sextans_dist_spmm_rm(self._h, comm, world, rank, rr, N, alpha, d_B, ldb, beta, d_C_in, ldc_in, d_C_out, ldc, stream),
                "dist_spmm_rm")
 
+    def prepare(self, N, rowmajor=False, stream=None):
+        """Build everything the first SpMM call for N columns would build inside itself (sextans_prepare)."""
+        _check(lib().sextans_prepare(self._h, N, 1 if rowmajor else 0, C.c_void_p(stream or 0)), "sextans_prepare")
+
+    def dist_prepare(self, comm, world, rank, ranges, N, nchunks=4, form=0, stream=None):
+        """Collective: exchanges, plan build, tables and workspaces of the dist entry point `form` (0 sextans_dist_spmm, 1 _rm, 2 _bell)
+        outside the timed call; OK on all ranks or an error on all ranks (sextans_dist_prepare)."""
+        rr = np.ascontiguousarray(np.asarray(ranges, np.int32).reshape(-1))
+        _check(lib().sextans_dist_prepare(self._h, C.c_void_p(comm or 0), world, rank, rr, N, nchunks, form, C.c_void_p(stream or 0)),
+               "sextans_dist_prepare")
+
     def export_plan(self, lanes_per_row=4):
         """The packed row-bucketed form the engine built ON THE DEVICE for the current matrix, read back in the layout of
         pack_csr (the host builder of the same format): dict of numpy arrays + scalars."""
@@ -745,20 +774,32 @@ def gen_fem3d_host(nx, ny, nz, dof, seed, r0=0, r1=None):
     return out
 
 
+def device_alloc(device, nbytes):
+    """hipMalloc through the library's own HIP runtime (free with device_free)."""
+    ptr = C.c_void_p()
+    _check(lib().sextans_device_alloc(device, nbytes, C.byref(ptr)), "device_alloc")
+    return ptr.value
+
+
+COPY_H2D, COPY_D2H, COPY_D2D = 1, 2, 3
+
+
+def device_copy(device, dst, src, nbytes, kind=COPY_D2D):
+    """Synchronous copy through the library's own HIP runtime (never a second dlopen of libamdhip64 by another name: where torch
+    bundles its own copy that maps a second runtime, which fails on this one's pointers).  dst / src: integer addresses."""
+    _check(lib().sextans_device_copy(device, C.c_void_p(dst), C.c_void_p(src), nbytes, kind), "device_copy")
+
+
 def upload_csr(device, rp, ci, v):
     """Host CSR arrays -> device copies (torch allocations would be freed with their tensors; these are hipMalloc'ed through the
     library and freed with device_free).  Returns device pointers (rp, ci, v)."""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
     out = []
     for arr, dt in ((rp, np.int32), (ci, np.int32), (v, np.float32)):
         a = np.ascontiguousarray(arr, dt)
-        ptr = C.c_void_p()
-        if hip.hipSetDevice(device) != 0 or hip.hipMalloc(C.byref(ptr), C.c_size_t(max(a.nbytes, 4))) != 0:
-            raise SextansError("upload_csr: hipMalloc failed")
-        if a.nbytes and hip.hipMemcpy(ptr, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), 1) != 0:
-            raise SextansError("upload_csr: hipMemcpy failed")
-        out.append(ptr.value)
+        ptr = device_alloc(device, a.nbytes)
+        if a.nbytes:
+            device_copy(device, ptr, a.ctypes.data, a.nbytes, COPY_H2D)
+        out.append(ptr)
     return tuple(out)
 
 
@@ -953,6 +994,11 @@ def partition_rows_by_nnz(row_ptr, world):
     out = np.zeros(2 * world, np.int32)
     _check(lib().sextans_partition_rows_by_nnz(len(rp) - 1, rp, world, out), "partition_rows_by_nnz")
     return [(int(out[2 * g]), int(out[2 * g + 1])) for g in range(world)]
+
+
+def dist_bind_library(path=None):
+    """Which library the collectives come from (None: the default RCCL search); sextans_dist_bind_library."""
+    _check(lib().sextans_dist_bind_library(path.encode() if path else None), "sextans_dist_bind_library")
 
 
 def dist_unique_id():

@@ -470,6 +470,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "bell_generation")) return &h->opt_bell_gen;
     if (!strcmp(key, "bell_shared")) return &h->opt_bell_shared;
     if (!strcmp(key, "bell_debug")) return &h->opt_bell_debug;
+    if (!strcmp(key, "dist_broadcast_runs")) return &h->opt_dist_broadcast_runs;
     if (!strcmp(key, "mfma_dense_tiles")) return &h->opt_mfma_dense;
     if (!strcmp(key, "dense_tile_fill_x100")) return &h->opt_dense_fill_x100;
     return nullptr;
@@ -482,7 +483,8 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
     // Measurement switches -- ablation bits that corrupt C on purpose ("bell_debug"), brick shapes and groupings of the clustered
     // row order, per-phase cycle counters -- are not part of the drop-in surface: they exist only for processes started with
     // SEXTANS_DEBUG_OPTIONS=1 (tools/), and a value other than the default is refused otherwise.
-    if (slot == &h->opt_bell_debug || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_phase_timing || slot == &h->opt_reordered_xcd) {
+    if (slot == &h->opt_bell_debug || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_phase_timing || slot == &h->opt_reordered_xcd ||
+        slot == &h->opt_dist_broadcast_runs) {
         const char *dbg = getenv("SEXTANS_DEBUG_OPTIONS");
         if (!(dbg && dbg[0] == '1') && value != *slot) {
             g_last_error = std::string("option \"") + key + "\" is a measurement switch: set SEXTANS_DEBUG_OPTIONS=1 in the environment to use it";
@@ -513,7 +515,9 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
         h->cluster_rm_tried = false;
     }
     if (slot == &h->opt_colwise_max_len && *slot != value) h->colwise_state = 0;
-    if (slot == &h->opt_share_index && *slot != value) { (void)hipSetDevice(h->device); free_plan(h); }   // every packed form is rebuilt
+    // (every packed form is rebuilt; "split_mixed" moves the share of blocks with reuse from which a mixed plan is built at all, and a
+    // cached "not built" verdict or a plan built under the other threshold must not survive the toggle)
+    if ((slot == &h->opt_share_index || slot == &h->opt_split_mixed) && *slot != value) { (void)hipSetDevice(h->device); free_plan(h); }
     if (*slot != value) h->dist_cut_key.clear();   // chunk cuts are aligned to the packed forms the options select (all
                                                    // ranks of a partition must change options together: the cut
                                                    // exchange is a collective)
@@ -717,6 +721,7 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "cluster_shared_fraction")) *value = h->cluster_shared;
     else if (!strcmp(key, "cluster_decline")) *value = (double)h->cluster_decline;
     else if (!strcmp(key, "graph_fallbacks")) *value = (double)h->graph_fallbacks;   // rp_time loops launched one by one because their hipGraph capture was invalidated from outside
+    else if (!strcmp(key, "dist_setup_exchanges")) *value = (double)h->dist_exchanges;   // control collectives + host syncs of the dist entry points so far (0 new ones after sextans_dist_prepare)
     else if (!strcmp(key, "cluster_graph_kind")) *value = (double)h->cluster_graph_kind;
     else if (!strcmp(key, "cluster_runs")) *value = h->cluster_runs ? 1.0 : 0.0;
     else if (!strcmp(key, "pattern_symmetry")) *value = h->pattern_symmetry;
@@ -1315,16 +1320,13 @@ int sextans_export_row_order(sextans_handle_t h, int *order, int *clustered) {
 // Row-major operands.  The reference lays B and C out for its kernel on the host, OUTSIDE the timed call (sextans-host.cpp:150-195,
 // 264-270); a caller whose operands are row-major (torch tensors; the natural layout of a "K x N feature matrix") gets the same here:
 // no layout pass at all on the LDS-panel paths.
-int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb, float beta, const float *d_C_in,
-                           int64_t ldc_in, float *d_C_out, int64_t ldc, void *stream) {
-    if (!h || N <= 0 || (N % 8) != 0 || !d_B || !d_C_in || !d_C_out || ldb < N || ldc_in < N || ldc < N) return SEXTANS_ERR_INVALID;
-    if (!h->d_rp) return SEXTANS_ERR_STATE;
-    SX_HIP(hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)stream;
-    if (h->M == 0) return SEXTANS_OK;
-    std::vector<Seg> plan;
-    int W = 0;
-    bool use_panel = false, use_window = false;
+}  // extern "C"
+namespace sxe {
+// Planning half of sextans_spmm_device_rm: everything that allocates, builds or synchronises with the host -- the lean prepare(), the
+// reconsideration of a clustered plan declined for column-major calls only, and the clustered plan's dictionaries translated back to
+// the caller's column numbers.  Run by the first row-major call, or ahead of it by sextans_prepare / sextans_dist_prepare so that no
+// timed (or captured) call builds anything.
+int rm_plan(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_panel, bool &use_window, hipStream_t s) {
     // (N = 8 runs as one half-empty 16-column tile of the 16-column plan: without a repack to pay for there is no reason for a second
     // packed plan at 2 lanes per row)
     const int Nplan = N == 8 ? 16 : N;
@@ -1343,6 +1345,49 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
         h->cluster_for_rm = false;
         if (rc) return rc;
     }
+    if (W == 16 && h->cluster_state == 2 && h->d_colpos && !h->d_dict_nat) {   // the plan's dictionaries hold relabelled columns: translate them back once
+        const long long n = (long long)h->psc.plan_nblk * h->psc.plan_dict_stride;
+        int *colinv = nullptr;
+        if (hipMalloc((void **)&colinv, sizeof(int) * (size_t)std::max(h->K, 1)) != hipSuccess ||
+            hipMalloc((void **)&h->d_dict_nat, sizeof(int) * (size_t)std::max<long long>(n, 1)) != hipSuccess) {
+            (void)hipFree(colinv); (void)hipFree(h->d_dict_nat); h->d_dict_nat = nullptr; (void)hipGetLastError();
+            g_last_error = "row-major plan: out of device memory for the translated block dictionaries";
+            return SEXTANS_ERR_HIP;
+        }
+        hipLaunchKernelGGL(invert_positions, dim3((unsigned)((h->K + 255) / 256)), dim3(256), 0, s, h->K, h->d_colpos, colinv);
+        hipLaunchKernelGGL(translate_dict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, h->K, h->psc.d_dict, colinv, h->d_dict_nat);
+        const hipError_t se = hipStreamSynchronize(s);
+        (void)hipFree(colinv);
+        SX_HIP(se);
+    }
+    return SEXTANS_OK;
+}
+}  // namespace sxe
+extern "C" {
+
+int sextans_prepare(sextans_handle_t h, int N, int layout, void *stream) {
+    if (!h || N <= 0 || (N % 8) != 0 || (layout != SEXTANS_LAYOUT_COLMAJOR && layout != SEXTANS_LAYOUT_ROWMAJOR)) return SEXTANS_ERR_INVALID;
+    if (!h->d_rp) return SEXTANS_ERR_STATE;
+    SX_HIP(hipSetDevice(h->device));
+    if (h->M == 0) return SEXTANS_OK;
+    std::vector<Seg> plan;
+    int W = 0;
+    bool use_panel = false, use_window = false;
+    if (layout == SEXTANS_LAYOUT_ROWMAJOR) return rm_plan(h, N, plan, W, use_panel, use_window, (hipStream_t)stream);
+    return prepare(h, N, plan, W, use_panel, use_window, true);
+}
+
+int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *d_B, int64_t ldb, float beta, const float *d_C_in,
+                           int64_t ldc_in, float *d_C_out, int64_t ldc, void *stream) {
+    if (!h || N <= 0 || (N % 8) != 0 || !d_B || !d_C_in || !d_C_out || ldb < N || ldc_in < N || ldc < N) return SEXTANS_ERR_INVALID;
+    if (!h->d_rp) return SEXTANS_ERR_STATE;
+    SX_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (h->M == 0) return SEXTANS_OK;
+    std::vector<Seg> plan;
+    int W = 0;
+    bool use_panel = false, use_window = false;
+    if (int rc = rm_plan(h, N, plan, W, use_panel, use_window, s)) return rc;
     const bool colwise = h->opt_kernel == 4 || (h->opt_kernel == 0 && h->colwise_state == 1);
     const bool aligned = ((reinterpret_cast<uintptr_t>(d_B) | reinterpret_cast<uintptr_t>(d_C_in) | reinterpret_cast<uintptr_t>(d_C_out)) & 15) == 0 &&
                          ldb % 4 == 0 && ldc_in % 4 == 0 && ldc % 4 == 0;
@@ -1355,20 +1400,7 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
         else if (h->cluster_state == 1) mode = 1;
         else if (use_panel && (!h->ps.plan_mixed || (h->ps.d_rg_skip && h->opt_split_mixed != 0 && h->opt_kernel == 0)) && h->ps.plan_max_dict <= sx::kWideMaxDict) mode = 0;
     }
-    if (mode == 2 && h->d_colpos && !h->d_dict_nat) {   // the plan's dictionaries hold relabelled columns: translate them back once
-        const long long n = (long long)h->psc.plan_nblk * h->psc.plan_dict_stride;
-        int *colinv = nullptr;
-        if (hipMalloc((void **)&colinv, sizeof(int) * (size_t)std::max(h->K, 1)) != hipSuccess || hipMalloc((void **)&h->d_dict_nat, sizeof(int) * (size_t)std::max<long long>(n, 1)) != hipSuccess) {
-            (void)hipFree(colinv); (void)hipFree(h->d_dict_nat); h->d_dict_nat = nullptr; (void)hipGetLastError();
-            mode = -1;
-        } else {
-            hipLaunchKernelGGL(invert_positions, dim3((unsigned)((h->K + 255) / 256)), dim3(256), 0, s, h->K, h->d_colpos, colinv);
-            hipLaunchKernelGGL(translate_dict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, h->K, h->psc.d_dict, colinv, h->d_dict_nat);
-            const hipError_t se = hipStreamSynchronize(s);
-            (void)hipFree(colinv);
-            SX_HIP(se);
-        }
-    }
+    if (mode == 2 && h->d_colpos && !h->d_dict_nat) mode = -1;   // (cannot happen after rm_plan; kept as a guard)
     // Rows on the long-row paths (pieces, exact chains): from the caller's row-major B into its row-major C as well -- the piece kernel's
     // 16-byte gathers and the chain producers' LDS-DMA read B rows ldb floats apart instead of panel rows, the fold and the chain
     // consumer write C[r * ldc + n].  The main kernels skip those rows (d_skip), so the order between the launches does not matter;
@@ -1752,6 +1784,23 @@ const char *sextans_last_kernel(sextans_handle_t h) { return h ? h->last_kernel 
 int sextans_device_free(int device, void *d_ptr) {
     SX_HIP(hipSetDevice(device));
     SX_HIP(hipFree(d_ptr));
+    return SEXTANS_OK;
+}
+
+int sextans_device_alloc(int device, size_t bytes, void **d_ptr) {
+    if (!d_ptr) return SEXTANS_ERR_INVALID;
+    *d_ptr = nullptr;
+    SX_HIP(hipSetDevice(device));
+    SX_HIP(hipMalloc(d_ptr, std::max<size_t>(bytes, 4)));
+    return SEXTANS_OK;
+}
+
+int sextans_device_copy(int device, void *dst, const void *src, size_t bytes, int kind) {
+    if (kind < SEXTANS_COPY_HOST_TO_DEVICE || kind > SEXTANS_COPY_DEVICE_TO_DEVICE || (bytes && (!dst || !src))) return SEXTANS_ERR_INVALID;
+    if (!bytes) return SEXTANS_OK;
+    SX_HIP(hipSetDevice(device));
+    const hipMemcpyKind k = kind == SEXTANS_COPY_HOST_TO_DEVICE ? hipMemcpyHostToDevice : kind == SEXTANS_COPY_DEVICE_TO_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    SX_HIP(hipMemcpy(dst, src, bytes, k));   // (thread_stream.h: an asynchronous copy on the calling thread's stream + a wait -- never the legacy stream)
     return SEXTANS_OK;
 }
 

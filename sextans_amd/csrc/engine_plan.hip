@@ -1132,7 +1132,9 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
         }
     }
     // (the reordered form of a graph-clustered matrix runs 16-column tiles whether or not a natural-order plan exists)
-    const bool reorder = whole && h->cluster_state == 2 && h->cluster_cm_pays && h->opt_kernel != 1 && h->opt_kernel != 3 && lpr == 4;
+    // (a lean prepare -- on behalf of a row-major call -- also keeps 16-column tiles for a clustered plan that is kept for row-major calls
+    // only: sextans_spmm_device_rm needs W == 16 to use it, and at N >= 32 the switch to 8 lanes per row below took it to the gather kernel)
+    const bool reorder = whole && h->cluster_state == 2 && (h->cluster_cm_pays || h->lean_prepare) && h->opt_kernel != 1 && h->opt_kernel != 3 && lpr == 4;
     if (!h->opt_lpr && !use_panel && !reorder && N >= 32 && lpr != 8) { lpr = 8; tiles(); }
     // "kernel" 3 = K-windowed accumulator-resident kernel; auto picks it for matrices without B-row reuse
     // whose B does not fit the L2s when the traffic model says the sweep moves fewer bytes than the gather.

@@ -216,6 +216,7 @@ struct sextans_engine {
     int *d_dist_rows = nullptr;         //   ... and every rank's position -> global row table ([world][longest slab])
     size_t dist_rows_cap = 0;
     bool dist_cc = false;               //   ... in use for the partition of dist_cut_key (every rank agreed)
+    int64_t dist_exchanges = 0;         // control collectives + host synchronisations the dist entry points have performed (stat "dist_setup_exchanges")
     std::vector<int> dist_nnz_key;      // (ranges, rank) the whole matrix's non-zero count was exchanged for
     std::vector<int> dist_cut_key, dist_cuts;   // (ranges, N, nchunks, rank) the chunk cuts of all ranks were exchanged for
     std::vector<int> dist_meta;     // {first row, rows} per (chunk, rank) as last uploaded, and where
@@ -283,6 +284,7 @@ struct sextans_engine {
     int64_t opt_bell_shared = -1;       // N = 256: workgroups of 8 block rows share each B tile through an LDS ring
                                         // (spmm_bell_mfma_shared).  1 = always, 0 = never, -1 = when the 8 block rows of a
                                         // workgroup share block columns (blocks per distinct column >= 1.5)
+    int64_t opt_dist_broadcast_runs = 0;   // measurements / tests only: sextans_dist_spmm_rm exchanges ranges of EQUAL length by grouped broadcasts too
     int64_t opt_bell_debug = 0;         // measurements only (wrong results): ablation bits of spmm_bell_mfma_shared
     int64_t opt_bell_gen = 0;           // block rows per launch of the wide kernel (0 = all in one launch)
     int64_t opt_bell_wide = 1;          // 1 (default): N = 256 runs one wavefront per block row over all 8 column tiles
@@ -327,6 +329,7 @@ int launch_dense_tiles(sextans_engine *h, int N, float alpha, const float *d_B, 
                        int64_t ldc_in, float *d_C_out, int64_t ldc, hipStream_t s);
 
 // clustered-order chunks of sextans_dist_spmm (engine.hip)
+int rm_plan(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_panel, bool &use_window, hipStream_t s);   // planning half of sextans_spmm_device_rm
 int cc_prepare(sextans_engine *h, int N, bool *ok);
 void cc_table(sextans_engine *h, int row0, int *d_out, hipStream_t s);
 void cc_pre(sextans_engine *h, int N, const float *d_B, int64_t ldb, const float *d_C_in_slab, int64_t ldc_in, hipStream_t s);

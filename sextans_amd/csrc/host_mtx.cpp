@@ -707,6 +707,7 @@ const char *sextans_error_string(int code) {
         case SEXTANS_ERR_NO_DEVICE: return "no usable gfx950 HIP device (there is no CPU fallback)";
         case SEXTANS_ERR_HIP: return "HIP runtime error";
         case SEXTANS_ERR_STATE: return "engine state error (matrix not set?)";
+        case SEXTANS_ERR_PEER: return "a collective preparation failed on another rank";
         default: return "unknown error";
     }
 }

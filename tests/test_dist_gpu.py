@@ -140,8 +140,9 @@ def test_native_dist_spmm_rowmajor_single_rank(engine, oracle, sx, exchange, mon
     copy), natural / brick / gather-kernel matrices; C_in == C_out allowed."""
     import torch
     from sextans_amd import api
-    if exchange == "broadcast_runs":
-        monkeypatch.setenv("SEXTANS_DIST_BROADCAST_RUNS", "1")
+    if exchange == "broadcast_runs":   # (a measurement switch: the grouped-broadcast exchange on ranges of equal length too)
+        monkeypatch.setenv("SEXTANS_DEBUG_OPTIONS", "1")
+        engine.set_option("dist_broadcast_runs", 1)
     comm = api.dist_comm_init(0, 1, 0, api.dist_unique_id())
     try:
         st = torch.cuda.current_stream().cuda_stream
@@ -176,6 +177,8 @@ def test_native_dist_spmm_rowmajor_single_rank(engine, oracle, sx, exchange, mon
             engine.dist_spmm_rm(comm, 1, 0, [(0, M - 1)], N, ALPHA, dB.data_ptr(), N, BETA, cin.data_ptr(), ld, out.data_ptr(), ld, stream=st)
     finally:
         api.dist_comm_destroy(comm)
+        if exchange == "broadcast_runs":
+            engine.set_option("dist_broadcast_runs", 0)
 
 
 @pytest.mark.parametrize("with_comm", [True, False])
