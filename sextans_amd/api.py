@@ -553,13 +553,13 @@ class Engine:
 
     def prepare(self, N, rowmajor=False, stream=None):
         """Build everything the first SpMM call for N columns would build inside itself (sextans_prepare)."""
-        _check(lib().sextans_prepare(self._h, N, 1 if rowmajor else 0, C.c_void_p(stream or 0)), "sextans_prepare")
+        _check(lib().sextans_prepare(self._h, N, 1 if rowmajor else 0, stream), "sextans_prepare")
 
     def dist_prepare(self, comm, world, rank, ranges, N, nchunks=4, form=0, stream=None):
         """Collective: exchanges, plan build, tables and workspaces of the dist entry point `form` (0 sextans_dist_spmm, 1 _rm, 2 _bell)
         outside the timed call; OK on all ranks or an error on all ranks (sextans_dist_prepare)."""
         rr = np.ascontiguousarray(np.asarray(ranges, np.int32).reshape(-1))
-        _check(lib().sextans_dist_prepare(self._h, C.c_void_p(comm or 0), world, rank, rr, N, nchunks, form, C.c_void_p(stream or 0)),
+        _check(lib().sextans_dist_prepare(self._h, comm, world, rank, rr, N, nchunks, form, stream),
                "sextans_dist_prepare")
 
     def export_plan(self, lanes_per_row=4):
