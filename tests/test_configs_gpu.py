@@ -137,6 +137,19 @@ def test_config4_full_size(engine, oracle, kernel):
         oracle.spmm(len(rows), N, K, ALPHA, srp, sci, sv, Bh, BETA, c_s)
         got = o.view(N, M)[:, idx].cpu().numpy().reshape(-1)
         assert np.array_equal(got.view(np.uint32), c_s.view(np.uint32))
+        if kernel == 0:
+            # EVERY row of the full-size configuration against the oracle: the matrix comes back from HBM, the
+            # oracle's cpu_spmm_CSR loop nest runs row-parallel on the host cores (same arithmetic per row, rows are independent), and
+            # all 64 M outputs are compared bit for bit.
+            hrp = np.empty(M + 1, np.int32); hci = np.empty(nnz, np.int32); hv = np.empty(nnz, np.float32)
+            for dst, src in ((hrp, p), (hci, i), (hv, v)):
+                api.device_copy(0, dst.ctypes.data, src, dst.nbytes, api.COPY_D2H)
+            want = Cin.cpu().numpy().copy()
+            sec, threads = oracle.time_spmm_omp(M, N, K, ALPHA, hrp, hci, hv, Bh, BETA, want)
+            got_all = o.cpu().numpy()
+            assert np.array_equal(got_all.view(np.uint32), want.view(np.uint32)), "config 4 at full size differs from the oracle somewhere"
+            print(f"config 4 full size: all {M} rows x {N} columns bit-identical to the oracle ({sec:.1f} s on {threads} host threads)")
+            del hrp, hci, hv, want, got_all
     finally:
         engine.set_matrix_csr(1, 1, np.array([0, 0], np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
         _set(engine)

@@ -1,6 +1,6 @@
 """tools/ab_libs_opts.py <spec> <N> <iters> <opts k=v,..> lib1.so lib2.so ...: tools/ab_opts.py (kernel / pre / post / wall us) once per library build, each in its own process, 2 rounds."""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if sys.argv[1] == "--child":
     sys.path.insert(0, ROOT)
     import sextans_amd.api as api

@@ -1,6 +1,6 @@
 """Block-banded blocked-ELL, N = 256: shared-tile kernel vs per-wavefront kernel."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from sextans_amd import api

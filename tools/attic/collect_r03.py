@@ -2,7 +2,7 @@
 """tools/collect_r03.py -- turn what tools/prof_r03.sh left under gpurun_out/ into the tracked round-3 evidence files under profiles/
 (kernel stats of the bench, config-4 PMC + traffic JSON, FEM N=16 / N=128 PMC + power, block-banded MFMA counters + power)."""
 import glob, json, os, re, shutil, subprocess
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 G, P = os.path.join(ROOT, "gpurun_out") + "/", os.path.join(ROOT, "profiles") + "/"
 head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
 

@@ -2,7 +2,7 @@
 """tools/collect_r04.py -- turn what tools/evidence_r04.sh / tools/sweep_r04.sh / the experiment scripts left under gpurun_out/ into
 the tracked round-4 evidence files under profiles/."""
 import glob, json, os, re, shutil, subprocess
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 G, P = os.path.join(ROOT, "gpurun_out") + "/", os.path.join(ROOT, "profiles") + "/"
 head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
 

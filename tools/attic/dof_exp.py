@@ -1,6 +1,6 @@
 """FEM 27-point matrices with 1 .. 12 unknowns per node (rows of 27 .. 324 entries), N = 16 / 64: step time, fraction of 8 TB/s on algorithmic bytes, plan figures -- looking for cliffs between the classes the bench covers."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from sextans_amd import api

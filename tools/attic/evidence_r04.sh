@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/evidence_r04.sh -- the round-4 evidence run on one MI355X box: kernel-trace stats of the full bench at HEAD, config-4 PMC
 # passes (tools/prof.sh), PMC of the reordered form and of FEM N = 128, the per-rank slab times.  Summaries land in gpurun_out/.
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 REPO=$(pwd)
 export TMPDIR=/tmp
 mkdir -p gpurun_out

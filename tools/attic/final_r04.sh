@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/final_r04.sh -- the measurements of the final HEAD that are not in tools/evidence_r04.sh: bench line, sweep, renumbered classes, plan figures
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 python bench.py > gpurun_out/r04_bench_final.json 2> gpurun_out/r04_bench_final.err
 tail -c 600 gpurun_out/r04_bench_final.json
 bash tools/sweep_r04.sh

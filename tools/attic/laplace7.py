@@ -1,6 +1,6 @@
 """3-D 7-point Laplacian (the most common PDE matrix: 7 entries per row), 128^3 and 160^3, N = 16 / 64: automatic choice against the lane-per-row kernel (kernel = 4) and the panel kernel (kernel = 2)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, scipy.sparse as sp, torch
 from sextans_amd import api

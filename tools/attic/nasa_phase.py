@@ -1,7 +1,7 @@
 """Where a wavefront's life goes in the small-matrix case (VERDICT r02 task 5): nasa4704 N=16 and the config-3 stand-in, per kernel form.
 Engine option `phase_timing`: one workgroup in 16 (v2) / 128 (round-1 kernel) adds wavefront-0's cycle counts per phase."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from sextans_amd import api

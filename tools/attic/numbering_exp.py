@@ -1,6 +1,6 @@
 """The 3-dof FEM matrix under numberings real codes produce: node-major (generator), DOF-MAJOR (all x unknowns, then y, then z), z-fastest grid order, red-black (odd-even) node order; N = 16: what the automatic plan choice makes of each."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from sextans_amd import api

@@ -1,6 +1,6 @@
 """Sanity sweep over shapes the other tools do not generate: diagonal, tridiagonal, a 5-point stencil in random order, a FEM matrix with half of its rows emptied, block-diagonal dense blocks; N = 16: step time and fraction of 8 TB/s -- looking for anything an order of magnitude off."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, scipy.sparse as sp, torch
 from sextans_amd import api, meshgen

@@ -1,7 +1,7 @@
 """What would graph-compact row blocks buy?  The 4M-row FEM matrix with its ROWS permuted brick by brick (columns untouched: the
 result is the same C with permuted rows), against the natural order.  tools/perm_exp.py [bx by bz]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from sextans_amd import api

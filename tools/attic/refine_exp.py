@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/refine_exp.py <synth spec> <N> "k=v,k=v" ... -- plan figures + kernel time of the reordered form under option sets."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from sextans_amd import api, sweep

@@ -5,7 +5,7 @@ Cuthill-McKee (scipy on the 1-dof node graph), plus unstructured jittered meshes
 row_cluster = 0 (natural-order forms) against -1 (automatic), kernel / pre / post microseconds from HIP events, plan seconds, panel
 figures, and a bitwise comparison of the two results.  One JSON record per line."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

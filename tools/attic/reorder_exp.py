@@ -4,7 +4,7 @@
 Prints kernel / layout-pass / post-pass microseconds, plan seconds and the panel figures; every result is checked bitwise against the
 natural-order kernels (row_cluster = 0) of the same matrix."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

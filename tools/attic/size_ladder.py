@@ -1,6 +1,6 @@
 """3-dof FEM matrices from 50 K to 4 M rows at N = 16 / 64: where the dispatcher's policies switch (column-major staging while B fits the L2s, clustered plans from 4096 rows, ...) -- looking for cliffs."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from sextans_amd import api

@@ -1,6 +1,6 @@
 """Small canonical runs: nasa4704 N=16 (eager + rp_time loop) and the config-3 stand-in N=128, per option set."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from sextans_amd import api

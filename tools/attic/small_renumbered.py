@@ -1,6 +1,6 @@
 """Config-3-sized FEM matrices (13 965 rows) and a 100 K-row one in grid and random node order at N = 128 / 16: what small renumbered matrices cost and whether the graph plan would help below the 65 536-row limit of the automatic choice."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from sextans_amd import api, meshgen

@@ -2,7 +2,7 @@
 """tools/step_time.py <workload> [key=value ...] -- wall time per back-to-back spmm_device step (repack + kernel launches)."""
 import os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from sextans_amd import api  # noqa: E402
 from sweep import workload  # noqa: E402

@@ -1,6 +1,6 @@
 """FEM 4M N = 16 run back to back for ~8 s: step time per block of 500 steps (the power-capped kernel slows down as the package warms up; short A/B runs and the first `also` entries of bench.py see the fast end)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from sextans_amd import api

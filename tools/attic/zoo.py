@@ -1,6 +1,6 @@
 """A last zoo of classes at N = 16 (4M rows unless noted): narrow bands, very sparse random rows, 2-D multi-dof stencils -- sanity of the automatic choices."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from sextans_amd import api, sweep
