@@ -320,7 +320,33 @@ int sextans_destroy(sextans_handle_t h);
  * opts into bf16 for them: those tiles (values rounded to bf16) times bf16(B) run on v_mfma_f32_32x32x16_bf16 with
  * fp32 accumulation, the rest of A stays on the fp32 CSR kernels, whose epilogue adds the two parts; results then
  * meet the blocked-ELL tolerance (tests/test_dense_tiles_gpu.py), not bit identity.  Needs N % 32 == 0 and
- * whole-matrix calls.  Default 0: fp32 everywhere, bit-identical to cpu_spmm_CSR. */
+ * whole-matrix calls.  Default 0: fp32 everywhere, bit-identical to cpu_spmm_CSR.
+ * mfma_dense_tiles = 2 (round 6): NO precision trade -- dense blocks of 16 consecutive rows run on the FP32 matrix cores
+ * (v_mfma_f32_16x16x4_f32, csrc/rowblock_mfma_kernel.h; the reference's PEs multiply and accumulate in fp32 too, sextans.cpp:285-295,
+ * 425-446).  A block is routed when its rows are strictly ascending in their columns and its fill = entries / (64 x the groups of 4
+ * consecutive columns it touches) reaches dense_tile_fill_x100 %; routed rows are summed ONLY there, walked in ascending column order,
+ * and since the instruction is a k-ordered chain of fused multiply-adds the result is BIT-IDENTICAL to the "exact" = 0 kernels
+ * (acc = fmaf(a, b, acc), epilogue fmaf(alpha, acc, beta * c)) -- i.e. inside |d| <= 1e-4 * (|alpha| sum|a b| + |beta c|) of
+ * cpu_spmm_CSR -- for finite B (a padding zero times an infinite B entry would be NaN where the CSR kernels see no entry at all).  Any N
+ * (multiple of 8), whole-matrix and row-range calls, every rank of the multi-GPU forms; "dense_tiles" / "dense_tile_fraction" then
+ * count the routed blocks / the share of the non-zeros in them.  Pays at N >= 64, where the VALU kernels are issue-bound (the matrix
+ * cores run the same arithmetic at the vector peak); at N <= 32 it moves 4 / fill bytes per entry against 4.3 - 6 of the packed CSR
+ * forms.  Use it with "exact" = 0 (or SEXTANS_MODE_FAST) so that routed and unrouted rows follow one rounding rule. */
+/* ACCURACY MODES (round 6) -- one documented switch instead of three options:
+ *   sextans_set_option(h, "mode", SEXTANS_MODE_STRICT)  default.  "exact" = 1, "split_rows" = 0, "mfma_dense_tiles" = 0: every product
+ *       rounded, every row summed in CSR order: BIT-IDENTICAL to cpu_spmm_CSR (sparse_helper.h:262-290), stronger than the reference's
+ *       own pass criterion.
+ *   sextans_set_option(h, "mode", SEXTANS_MODE_FAST)    "exact" = 0 (fused multiply-adds), "split_rows" = -1 (hub rows above
+ *       max(1024, nnz / 16384) entries are cut into pieces summed in parallel and folded in order), "mfma_dense_tiles" = 2 (dense row
+ *       blocks on the fp32 matrix cores).  GUARANTEE, per output element:
+ *           |C_fast - C_ref| <= 1e-4 * (|alpha| * sum_j |a_ij * b_jn| + |beta * c_in|)
+ *       (the condition-aware form of north_star's "within 1e-4 relative error"; the reference's own check is a tolerance
+ *       too, sextans-host.cpp:272-282).  Measured distance is ~1e-7 of that scale: fp32 roundoff of a different, but still fp32,
+ *       summation.  Deterministic: the same call gives the same bits every time, on every rank count.
+ * sextans_get_option(h, "mode", &v): SEXTANS_MODE_STRICT / SEXTANS_MODE_FAST when the three options stand as that mode set them,
+ * -1 when they were set apart by hand. */
+#define SEXTANS_MODE_STRICT 0
+#define SEXTANS_MODE_FAST 1
 int sextans_set_option(sextans_handle_t h, const char *key, int64_t value);
 int sextans_get_option(sextans_handle_t h, const char *key, int64_t *value);
 /* Rows of the current matrix whose sums are re-associated under the current "split_rows" setting (ascending);

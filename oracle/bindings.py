@@ -55,6 +55,8 @@ class Oracle:
                                        _f32p, _f32p, C.c_float, _f32p]
         L.orc_cpu_spmm_csr_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                             _i32p, _i32p, _f32p, _f32p, C.c_float, _f32p]
+        L.orc_cpu_spmm_csr_fma.restype = None
+        L.orc_cpu_spmm_csr_fma.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, _i32p, _i32p, _f32p, _f32p, C.c_float, _f32p]
         L.orc_time_spmm_rows.restype = C.c_double
         L.orc_time_spmm_rows.argtypes = L.orc_cpu_spmm_csr_rows.argtypes
         L.orc_time_spmm_csr_omp.restype = C.c_double
@@ -120,6 +122,11 @@ class Oracle:
     def time_spmm_rows(self, r0, r1, M, N, K, alpha, row_ptr, col_idx, val, B, beta, C_inout):
         return self.lib.orc_time_spmm_rows(r0, r1, M, N, K, alpha, row_ptr, _pad(col_idx),
                                            _pad(val), B, beta, C_inout)
+
+    def spmm_fma(self, M, N, K, alpha, row_ptr, col_idx, val, B, beta, C_inout):
+        """cpu_spmm_CSR's loop nest with fused multiply-adds (psum = fmaf(a, b, psum), epilogue fmaf(alpha, psum, beta * c)): the CPU
+        statement of the engine's "exact" = 0 kernels and of its fp32 matrix-core path, which must agree with it bit for bit."""
+        self.lib.orc_cpu_spmm_csr_fma(M, N, K, alpha, row_ptr, _pad(col_idx), _pad(val), B, beta, C_inout)
 
     def time_spmm_omp(self, M, N, K, alpha, row_ptr, col_idx, val, B, beta, C_inout):
         """cpu_spmm_CSR's loop nest on all host cores (OpenMP); -> (seconds, threads used)."""

@@ -249,6 +249,37 @@ void orc_cpu_spmm_csr_rows(int r0, int r1, int M, int N, int K, float alpha, con
     free(psum);
 }
 
+/* The SAME loop nest with fused multiply-adds: what the engine's opt-in "exact" = 0 kernels and its fp32 matrix-core path
+ * ("mfma_dense_tiles" = 2, v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain, one rounding per step) compute -- psum = fmaf(a, b, psum)
+ * in CSR order, epilogue fmaf(alpha, psum, beta * c).  NOT the reference's arithmetic (cpu_spmm_CSR rounds every product,
+ * sparse_helper.h:283): this variant exists so that the tests can demand BIT EQUALITY between the engine's two in-tolerance paths and
+ * pin both to one CPU statement; the reference bound for them stays |d| <= 1e-4 * (|alpha| sum|a b| + |beta c|) against
+ * orc_cpu_spmm_csr.  fmaf() is correctly rounded by C99 whether or not the host has an FMA unit.  Row-parallel
+ * (rows are independent).  TEST INFRASTRUCTURE. */
+void orc_cpu_spmm_csr_fma(int M, int N, int K, float alpha, const int *row_ptr, const int *col_idx, const float *val, const float *B,
+                          float beta, float *C) {
+#pragma omp parallel
+    {
+        float psum[512];
+        float *ps = N <= 512 ? psum : (float *)malloc(sizeof(float) * (size_t)N);
+#pragma omp for schedule(dynamic, 256)
+        for (int i = 0; i < M; ++i) {
+            for (int nn = 0; nn < N; ++nn) ps[nn] = 0.0f;
+            for (int j = row_ptr[i]; j < row_ptr[i + 1]; ++j) {
+                const float a = val[j];
+                const float *bk = B + col_idx[j];
+                for (int nn = 0; nn < N; ++nn) ps[nn] = fmaf(a, bk[(size_t)K * nn], ps[nn]);
+            }
+            for (int nn = 0; nn < N; ++nn) {
+                size_t o = (size_t)i + (size_t)M * nn;
+                const float bc = beta * C[o];
+                C[o] = fmaf(alpha, ps[nn], bc);
+            }
+        }
+        if (ps != psum) free(ps);
+    }
+}
+
 /* Same loop nest, row-parallel on all host cores (SURVEY.md 8d baseline 2: "the same loop nest row-parallel with
  * OpenMP on all cores").  Rows are independent, every row is still summed sequentially in CSR order, so the
  * result is bit-identical to orc_cpu_spmm_csr.  Returns the wall seconds (steady clock) and writes the number

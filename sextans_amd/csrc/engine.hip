@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void position_rows(int nblk, int RB, const int
 
 bool cc_usable(sextans_engine *h, int N, int W, const std::vector<Seg> &plan) {
     return h->cluster_state == 2 && h->cluster_cm_pays && W == 16 && N % 16 == 0 && plan.size() == 1 && plan[0].width == 16 && h->nhub == 0 &&
-           h->nchain == 0 && h->dense_W == 0 && (h->opt_kernel == 0 || h->opt_kernel == 2) && h->opt_pipeline_tiles == 0 && h->d_Cs && h->d_slot_row &&
+           h->nchain == 0 && (h->dense_W == 0 && h->rb_n == 0) && (h->opt_kernel == 0 || h->opt_kernel == 2) && h->opt_pipeline_tiles == 0 && h->d_Cs && h->d_slot_row &&
            h->Cs_cap >= (size_t)(N / 16) * (size_t)h->M * 16 && h->Bp_cap >= (size_t)h->K * (size_t)N && h->psc.plan_sets == 1 &&
            (h->M >= 65536 || h->m_nnz * (int64_t)N >= ((int64_t)24 << 20)) && (int)h->psc.h_blk_row.size() == h->psc.plan_nblk + 1;
 }
@@ -478,6 +478,17 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
 
 int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
     if (!h || !key) return SEXTANS_ERR_INVALID;
+    if (!strcmp(key, "mode")) {   // the documented pair of accuracy modes (include/sextans_amd.h): one switch instead of three options nobody finds
+        if (value != SEXTANS_MODE_STRICT && value != SEXTANS_MODE_FAST) return SEXTANS_ERR_INVALID;
+        const bool fast = value == SEXTANS_MODE_FAST;
+        if (int rc = sextans_set_option(h, "exact", fast ? 0 : 1)) return rc;
+        if (int rc = sextans_set_option(h, "split_rows", fast ? -1 : 0)) return rc;
+        // (dense 32x32 tiles on the fp32 matrix cores: same products, same ascending-k order as the FMA chain of "exact" = 0 -- mode 2
+        // never changes a bit against it, so it belongs to the in-tolerance mode and costs strict mode nothing)
+        if (int rc = sextans_set_option(h, "mfma_dense_tiles", fast ? 2 : 0)) return rc;
+        h->opt_mode = value;
+        return SEXTANS_OK;
+    }
     int64_t *slot = option_slot(h, key);
     if (!slot) return SEXTANS_ERR_INVALID;
     // Measurement switches -- ablation bits that corrupt C on purpose ("bell_debug"), brick shapes and groupings of the clustered
@@ -541,6 +552,12 @@ int sextans_phase_timing_read(sextans_handle_t h, int64_t out[8]) {
 
 int sextans_get_option(sextans_handle_t h, const char *key, int64_t *value) {
     if (!h || !key || !value) return SEXTANS_ERR_INVALID;
+    if (!strcmp(key, "mode")) {   // what the three options it stands for say now (-1: set apart by hand)
+        const bool strict = h->opt_exact == 1 && h->opt_split_rows == 0 && h->opt_mfma_dense == 0;
+        const bool fast = h->opt_exact == 0 && h->opt_split_rows == -1 && h->opt_mfma_dense == 2;
+        *value = strict ? SEXTANS_MODE_STRICT : fast ? SEXTANS_MODE_FAST : -1;
+        return SEXTANS_OK;
+    }
     int64_t *slot = option_slot(h, key);
     if (!slot) return SEXTANS_ERR_INVALID;
     *value = *slot;
@@ -627,6 +644,10 @@ int sextans_spmm_device2(sextans_handle_t h, int N, float alpha, const float *d_
 namespace {
 // Hub rows inside [row_begin, row_end): pieces summed as virtual rows by the row-group kernel from B panels of width
 // 4 * LPR at dBp (ntiles panels), then folded in order into the C the main kernel has already written.
+const char *with_rowblocks(sextans_engine *h, const char *name) {   // (sextans_last_kernel: the launches of this call + the fp32 matrix-core one)
+    h->last_kernel_buf = std::string(name) + "+rowblock_mfma_f32";
+    return h->last_kernel_buf.c_str();
+}
 const char *kernel_name(int main, bool hubs, bool dense) {   // static strings for sextans_last_kernel
     static const char *names[4][2][2] = {
         {{"spmm_csr_rowgroup", "spmm_csr_rowgroup+dense_tiles_mfma"},
@@ -918,13 +939,18 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
                 launch_chains(h, p8, d_C_in, ldc_in, d_C_out, ldc, N, ch0, ch1, row_begin, alpha, beta, s);
             }
             h->last_kernel = kernel_name(2, hubs || chains, h->dense_W > 0);
+            if (h->rb_n > 0) {
+                const std::vector<Seg> p8{{8, 0, N / 8}};
+                if (int rc = launch_rowblocks(h, p8, d_C_in, ldc_in, d_C_out, ldc, N, row_begin, row_end, alpha, beta, s)) return rc;
+                h->last_kernel = with_rowblocks(h, h->last_kernel);
+            }
         }
         SX_HIP(hipGetLastError());
         return SEXTANS_OK;
     }
     // Short rows in a numbering with locality (or "kernel" = 4): one lane per row on the caller's column-major operands -- no B
     // repack, no LDS (spmm_colwise_kernel.h).  Rows on the long-row paths need the repacked panels: then the other kernels run.
-    if ((h->opt_kernel == 4 || (h->opt_kernel == 0 && h->colwise_state == 1)) && !hubs && !chains && h->dense_W == 0 && h->m_nnz > 0) {
+    if ((h->opt_kernel == 4 || (h->opt_kernel == 0 && h->colwise_state == 1)) && !hubs && !chains && (h->dense_W == 0 && h->rb_n == 0) && h->m_nnz > 0) {
         Prof p(h, &h->ev_kernel, s);
         const int nrowblk = (nrows + sx::kBlock - 1) / sx::kBlock;
         auto go = [&](auto kern, int col0, int ntiles) {
@@ -947,7 +973,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     }
     // Small B (fits the L2s), dictionary-only plan, one N segment: the panel kernel stages straight from the
     // caller's column-major B and the repack launch disappears.
-    const bool fuse_b = use_panel && !h->ps.plan_mixed && h->opt_fuse_b && !(flags & kRowsNoFuseB) && plan.size() == 1 &&
+    const bool fuse_b = use_panel && !h->ps.plan_mixed && h->opt_fuse_b && !(flags & kRowsNoFuseB) && plan.size() == 1 && h->rb_n == 0 &&   // (routed row blocks read the repacked panels)
                         plan[0].width == W && !hubs && !chains &&
                         (size_t)h->K * (size_t)N * sizeof(float) <= ((size_t)16 << 20) &&
                         // (a graph-clustered plan beats the natural-order blocks of a renumbered matrix also while B fits the L2s, once the
@@ -965,7 +991,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
     // rows of B in the plan's column order and C goes through the block-major staging buffer (reorder_kernels.h); an 8-column
     // remainder tile keeps the natural-order kernels and panels.  (Layout tag -W: such panels are never reused by a row-range call.)
     const bool reordered = whole && h->cluster_state == 2 && h->cluster_cm_pays && h->opt_kernel != 1 && h->opt_kernel != 3 && W == 16 && !fuse_b &&
-                           (!chains || h->d_chain_ci_perm) && h->dense_W == 0 && h->d_Cs &&
+                           (!chains || h->d_chain_ci_perm) && (h->dense_W == 0 && h->rb_n == 0) && h->d_Cs &&
                            // (the staging buffer is sized by prepare() for the N it saw: a plan that survived a set_option("kernel") and a
                            // larger N since then must not run past its end -- ADVICE r04)
                            h->Cs_cap >= (size_t)((N + 15) / 16) * (size_t)h->M * 16 && (N >= 16 || (N == 8 && !hubs && !chains));
@@ -984,13 +1010,13 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
             // (with rows on the piece / chain paths only where the main rows are long enough to matter: on the KKT class -- 6 entries per
             // row, arrow borders as chains -- the wider piece / chain work cost more than the gather tail: 1 510 -> 1 687 us at N = 24)
             ((h->nhub == 0 && h->nchain == 0) || (h->M > 0 && h->m_nnz / h->M >= 16)) &&
-            h->dense_W == 0 && h->opt_pipeline_tiles == 0 && h->Bp_cap >= (size_t)h->K * (size_t)(N + 8) &&
+            (h->dense_W == 0 && h->rb_n == 0) && h->opt_pipeline_tiles == 0 && h->Bp_cap >= (size_t)h->K * (size_t)(N + 8) &&
             (!reordered || h->Cs_cap >= (size_t)(N / 16 + 1) * (size_t)h->M * 16)) {
             plan[0].ntiles += 1;
             plan[0].last_cols = 8;
             plan.pop_back();
         } else if (v2_here && W == 16 && plan.size() == 1 && plan[0].width == 8 && plan[0].ntiles == 1 && h->nhub == 0 && h->nchain == 0 &&
-                   h->dense_W == 0 && h->Bp_cap >= (size_t)h->K * 16 && (!reordered || h->Cs_cap >= (size_t)h->M * 16)) {
+                   (h->dense_W == 0 && h->rb_n == 0) && h->Bp_cap >= (size_t)h->K * 16 && (!reordered || h->Cs_cap >= (size_t)h->M * 16)) {
             plan[0] = Seg{16, 0, 1, 8};   // N = 8 on the 16-column plan (engine_plan.hip: prepare, n8_wide)
         }
     }
@@ -1007,7 +1033,7 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
                           std::max(ldc, ldc_in) * 64 < ((int64_t)1 << 32);
     const bool v2_h1 = plan[0].width == 16 && W == 16 && (reordered || (use_panel && !h->ps.plan_mixed && h->opt_panel_v2 != 0 && !fuse_b &&
                                                                          wide_ok0 && h->opt_cols_per_lane != 8));
-    const bool pipelined = v2_h1 && plan[0].ntiles >= 2 && !skip_repack && !hubs && !chains && h->opt_pipeline_tiles != 0 && h->aux_stream &&
+    const bool pipelined = v2_h1 && plan[0].ntiles >= 2 && !skip_repack && !hubs && !chains && h->rb_n == 0 && h->opt_pipeline_tiles != 0 && h->aux_stream &&
                            h->ev_pipe[0];
     if (pipelined) {
         const Seg &g = plan[0];
@@ -1199,6 +1225,10 @@ int sextans_spmm_device_rows(sextans_handle_t h, int N, float alpha, const float
         if (hubs && !reordered) fold();
         if (chains && !reordered) SX_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
         h->last_kernel = reordered ? "spmm_csr_panel_v2_reordered" : kernel_name(v2_used ? 3 : use_panel ? 1 : 0, hubs || chains, h->dense_W > 0);
+        if (h->rb_n > 0) {   // dense blocks of 16 rows on the fp32 matrix cores, from the same panels (the kernels above skipped their rows)
+            if (int rc = launch_rowblocks(h, plan, d_C_in, ldc_in, d_C_out, ldc, N, row_begin, row_end, alpha, beta, s)) return rc;
+            h->last_kernel = with_rowblocks(h, h->last_kernel);
+        }
     }
     if (reordered) {
         Prof p(h, &h->ev_post, s);
@@ -1395,7 +1425,7 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
     const bool fits = (int64_t)h->K * ldb < ((int64_t)1 << 32);
     int mode = -1;
     if (W == 16 && (h->opt_kernel == 0 || h->opt_kernel == 2) && h->opt_panel_v2 != 0 && h->opt_cols_per_lane != 8 &&
-        h->dense_W == 0 && !(colwise && h->nhub == 0 && h->nchain == 0) && aligned && fits && h->m_nnz > 0) {
+        (h->dense_W == 0 && h->rb_n == 0) && !(colwise && h->nhub == 0 && h->nchain == 0) && aligned && fits && h->m_nnz > 0) {
         if (h->cluster_state == 2) mode = 2;
         else if (h->cluster_state == 1) mode = 1;
         else if (use_panel && (!h->ps.plan_mixed || (h->ps.d_rg_skip && h->opt_split_mixed != 0 && h->opt_kernel == 0)) && h->ps.plan_max_dict <= sx::kWideMaxDict) mode = 0;
@@ -1438,7 +1468,7 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
     };
     const bool long_ok = (!hubs && !chains) || (aligned && (!chains || (h->aux_stream && h->ev_fork && h->ev_join && ldb < ((int64_t)1 << 31))));
     if (!long_ok) mode = -1;
-    if (colwise && aligned && h->nhub == 0 && h->nchain == 0 && h->dense_W == 0 && h->m_nnz > 0) {   // short rows in a local numbering: lane per row, 16-byte accesses
+    if (colwise && aligned && h->nhub == 0 && h->nchain == 0 && (h->dense_W == 0 && h->rb_n == 0) && h->m_nnz > 0) {   // short rows in a local numbering: lane per row, 16-byte accesses
         Prof p(h, &h->ev_kernel, s);
         auto go = [&](auto kern, int col0, int ntiles) {
             // groups of T neighbouring lanes per row, one 16-column tile each (T = the largest divisor of the tile count up to 8): a
@@ -1480,7 +1510,7 @@ int sextans_spmm_device_rm(sextans_handle_t h, int N, float alpha, const float *
     }
     // The gather kernel on a matrix without rows on the piece / chain / dense-tile paths: a row of row-major B IS what its lanes fetch
     // per non-zero (the 4 * LPR floats of a panel row), and a lane's 4 accumulators are 16 bytes of its C row -- no repack, no passes.
-    if (!use_panel && !use_window && !(colwise && !hubs && !chains) && aligned && long_ok && (h->opt_kernel == 0 || h->opt_kernel == 1) && h->dense_W == 0 && h->m_nnz > 0) {
+    if (!use_panel && !use_window && !(colwise && !hubs && !chains) && aligned && long_ok && (h->opt_kernel == 0 || h->opt_kernel == 1) && (h->dense_W == 0 && h->rb_n == 0) && h->m_nnz > 0) {
         Prof p(h, &h->ev_kernel, s);
         std::vector<Seg> segs = plan;
         if (N == 8) segs.assign(1, Seg{8, 0, 1});   // (the plan above was made for 16 columns)

@@ -4,8 +4,11 @@
 #include <algorithm>
 #include <cstring>
 
+#include <thread>
+
 #include "bell_kernels.h"
 #include "engine_state.h"
+#include "rowblock_mfma_kernel.h"
 
 namespace sxe {
 
@@ -20,17 +23,162 @@ void free_bell(sextans_engine *h) {
 // when the caller has opted into bf16 for them ("mfma_dense_tiles" = 1), cuts them out of the main matrix into a
 // blocked-ELL bf16 side matrix for spmm_bell_mfma; the CSR kernels keep the remainder in fp32.  Only full 32-row
 // block rows are searched; at most 256 dense tiles per block row (the densest columns first come first served).
+// "mfma_dense_tiles" = 2 (round 6): dense ROW BLOCKS of 16 rows on the fp32 matrix cores (rowblock_mfma_kernel.h) -- bit-identical to the
+// "exact" = 0 kernels.  A block is routed when every row of it is strictly ascending in its columns (the chain order of a row IS its
+// CSR order; fragments hold one value per (row, column)) and its fill = entries / (64 x groups of 4 columns it touches) reaches the
+// threshold.  The routed rows are emptied in the source matrix (the CSR kernels skip them: ensure_split marks them), their groups and
+// fragments are stored in block order.  Host passes run on up to 32 threads; the fragments are filled on the device.
+int build_rowblocks(sextans_engine *h) {
+    const int nb = h->M / 16;
+    if (nb == 0 || h->nnz == 0) return SEXTANS_OK;
+    PlanTimer timer(h);
+    std::vector<int> rp, ci;
+    std::vector<float> va;
+    if (int rc = read_back_row_ptr(h, rp, 0)) return rc;
+    if (int rc = read_back_entries(h, ci, va, 0)) return rc;
+    const double thr = (double)h->opt_dense_fill_x100 / 100.0;
+    std::vector<int> ngroups((size_t)nb, 0);   // groups of a routed block, 0 = not routed
+    const unsigned nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    auto parallel_blocks = [&](auto fn) {
+        std::vector<std::thread> ts;
+        for (unsigned t = 0; t < nthreads; ++t)
+            ts.emplace_back([&, t]() {
+                const int b0 = (int)((int64_t)nb * t / nthreads), b1 = (int)((int64_t)nb * (t + 1) / nthreads);
+                fn(b0, b1);
+            });
+        for (auto &t : ts) t.join();
+    };
+    auto groups_of = [&](int b, std::vector<int> &g) -> bool {   // ascending distinct (column >> 2) of block b; false: a row is not strictly ascending
+        g.clear();
+        for (int r = 16 * b; r < 16 * b + 16; ++r)
+            for (int j = rp[(size_t)r]; j < rp[(size_t)r + 1]; ++j) {
+                if (j > rp[(size_t)r] && ci[(size_t)j] <= ci[(size_t)j - 1]) return false;
+                g.push_back(ci[(size_t)j] >> 2);
+            }
+        std::sort(g.begin(), g.end());
+        g.erase(std::unique(g.begin(), g.end()), g.end());
+        return true;
+    };
+    parallel_blocks([&](int b0, int b1) {
+        std::vector<int> g;
+        for (int b = b0; b < b1; ++b) {
+            const int64_t cnt = (int64_t)rp[(size_t)16 * b + 16] - rp[(size_t)16 * b];
+            if (cnt == 0 || (double)cnt < thr * 64.0) continue;             // (even a single group would be below the threshold)
+            if (!groups_of(b, g)) continue;
+            if ((double)cnt >= thr * 64.0 * (double)g.size()) ngroups[(size_t)b] = (int)g.size();
+        }
+    });
+    std::vector<int> row0, gptr(1, 0);
+    int64_t total = 0, routed_nnz = 0;
+    for (int b = 0; b < nb; ++b)
+        if (ngroups[(size_t)b] > 0) {
+            row0.push_back(16 * b);
+            total += ngroups[(size_t)b];
+            if (total > 0x7fffffff / 64) {   // 32-bit group indices / fragment offsets in ints on the host side
+                g_last_error = "mfma_dense_tiles = 2: more than 2^25 column groups; rows stay on the fp32 CSR kernels";
+                return SEXTANS_OK;
+            }
+            gptr.push_back((int)total);
+            routed_nnz += (int64_t)rp[(size_t)16 * b + 16] - rp[(size_t)16 * b];
+        }
+    h->dense_tiles = (int64_t)row0.size();
+    h->dense_nnz = routed_nnz;
+    if (row0.empty()) return SEXTANS_OK;
+    std::vector<int> gcol((size_t)total);
+    {
+        const int nrb = (int)row0.size();
+        std::vector<std::thread> ts;
+        for (unsigned t = 0; t < nthreads; ++t)
+            ts.emplace_back([&, t]() {
+                std::vector<int> g;
+                for (int i = (int)((int64_t)nrb * t / nthreads); i < (int)((int64_t)nrb * (t + 1) / nthreads); ++i) {
+                    groups_of(row0[(size_t)i] / 16, g);
+                    std::copy(g.begin(), g.end(), gcol.begin() + gptr[(size_t)i]);
+                }
+            });
+        for (auto &t : ts) t.join();
+    }
+    if (int rc = upload(&h->d_rb_row0, row0)) return rc;
+    if (int rc = upload(&h->d_rb_gptr, gptr)) return rc;
+    if (int rc = upload(&h->d_rb_gcol, gcol)) return rc;
+    SX_HIP(hipMalloc((void **)&h->d_rb_A, sizeof(float) * 64 * (size_t)total));
+    SX_HIP(hipMemsetAsync(h->d_rb_A, 0, sizeof(float) * 64 * (size_t)total, hipStreamPerThread));
+    hipLaunchKernelGGL(sx::rowblock_fill_fragments, dim3((unsigned)((row0.size() + 3) / 4)), dim3(256), 0, hipStreamPerThread, h->d_rp, h->d_ci, h->d_v, h->d_rb_row0,
+                       h->d_rb_gptr, h->d_rb_gcol, h->d_rb_A, (int)row0.size());
+    SX_HIP(hipStreamSynchronize(hipStreamPerThread));
+    // the remainder: routed rows emptied, as the source matrix of the long-row split
+    std::vector<int> mrp((size_t)h->M + 1, 0);
+    size_t w = 0;
+    for (int r = 0; r < h->M; ++r) {
+        const int b = r >> 4;
+        if (!(b < nb && ngroups[(size_t)b] > 0)) {
+            const int j0 = rp[(size_t)r], j1 = rp[(size_t)r + 1];
+            if (w != (size_t)j0) {
+                std::copy(ci.begin() + j0, ci.begin() + j1, ci.begin() + (ptrdiff_t)w);
+                std::copy(va.begin() + j0, va.begin() + j1, va.begin() + (ptrdiff_t)w);
+            }
+            w += (size_t)(j1 - j0);
+        }
+        mrp[(size_t)r + 1] = (int)w;
+    }
+    ci.resize(w ? w : 1); va.resize(w ? w : 1);
+    if (int rc = upload(&h->d_srp, mrp)) return rc;
+    if (int rc = upload(&h->d_sci, ci)) return rc;
+    if (int rc = upload(&h->d_sv, va)) return rc;
+    h->s_rp = h->d_srp; h->s_ci = h->d_sci; h->s_v = h->d_sv; h->s_nnz = (int64_t)w;
+    h->m_rp = h->s_rp; h->m_ci = h->s_ci; h->m_v = h->s_v; h->m_nnz = h->s_nnz;
+    h->rb_n = (int)row0.size();
+    h->rb_groups = total;
+    return SEXTANS_OK;
+}
+
+int mark_rowblock_skip(sextans_engine *h) {
+    if (!h->d_skip) {
+        SX_HIP(hipMalloc((void **)&h->d_skip, (size_t)std::max(h->M, 1)));
+        SX_HIP(hipMemsetAsync(h->d_skip, 0, (size_t)std::max(h->M, 1), hipStreamPerThread));
+    }
+    hipLaunchKernelGGL(sx::rowblock_mark_skip, dim3((unsigned)(((int64_t)h->rb_n * 16 + 255) / 256)), dim3(256), 0, hipStreamPerThread, h->d_rb_row0, h->rb_n, h->d_skip);
+    SX_HIP(hipStreamSynchronize(hipStreamPerThread));
+    return SEXTANS_OK;
+}
+
+// The routed blocks of [row_begin, row_end) over the B panels the main path has just laid out (`plan` = the segments of d_Bp).
+int launch_rowblocks(sextans_engine *h, const std::vector<Seg> &plan, const float *d_C_in, int64_t ldc_in, float *d_C_out, int64_t ldc, int N, int row_begin,
+                     int row_end, float alpha, float beta, hipStream_t s) {
+    for (const Seg &g : plan) {
+        const int ncols_panel = g.ntiles * g.width;
+        const int ncols = std::min(N - g.col0, g.last_cols ? (g.ntiles - 1) * g.width + g.last_cols : ncols_panel);
+        const int tiles16 = (ncols + 15) / 16;
+        if (tiles16 <= 0) continue;
+        const float *bp = h->d_Bp + (size_t)h->K * (size_t)g.col0;
+        const float *cin = d_C_in + (int64_t)g.col0 * ldc_in;
+        float *cout = d_C_out + (int64_t)g.col0 * ldc;
+        auto go = [&](auto kern, int NT) {
+            const int tgs = (tiles16 + NT - 1) / NT;
+            hipLaunchKernelGGL(kern, dim3((unsigned)((h->rb_n + 3) / 4) * (unsigned)tgs), dim3(256), 0, s, h->d_rb_row0, h->d_rb_gptr, h->d_rb_gcol, h->d_rb_A, bp,
+                               (int64_t)h->K * g.width, g.width, h->K, cin, ldc_in, cout, ldc, h->rb_n, tgs, ncols_panel, ncols, row_begin, row_end, alpha, beta);
+        };
+        if (tiles16 >= 8) go(sx::spmm_rowblock_mfma_f32<8>, 8);
+        else if (tiles16 >= 4) go(sx::spmm_rowblock_mfma_f32<4>, 4);
+        else if (tiles16 >= 2) go(sx::spmm_rowblock_mfma_f32<2>, 2);
+        else go(sx::spmm_rowblock_mfma_f32<1>, 1);
+    }
+    SX_HIP(hipGetLastError());
+    return SEXTANS_OK;
+}
+
 int ensure_dense(sextans_engine *h) {
     if (h->dense_built_mfma == h->opt_mfma_dense && h->dense_built_fill == h->opt_dense_fill_x100) return SEXTANS_OK;
-    if (h->dense_W > 0 || h->opt_mfma_dense) {   // the source matrix may change: everything downstream starts again
+    if (h->dense_W > 0 || h->rb_n > 0 || h->opt_mfma_dense) {   // the source matrix may change: everything downstream starts again
         free_plan(h);
         free_window(h);
     }
-    const bool had_tiles = h->dense_W > 0;
+    const bool had_tiles = h->dense_W > 0 || h->rb_n > 0;
     if (had_tiles || h->opt_mfma_dense) free_dense(h);
     else { h->dense_tiles = h->dense_nnz = 0; }
     h->dense_built_mfma = h->opt_mfma_dense;
     h->dense_built_fill = h->opt_dense_fill_x100;
+    if (h->opt_mfma_dense == 2) return build_rowblocks(h);
     const int mb = h->M / 32;
     if (mb == 0 || h->nnz == 0) return SEXTANS_OK;
     const int64_t thr = std::max<int64_t>(1, (h->opt_dense_fill_x100 * 1024 + 99) / 100);

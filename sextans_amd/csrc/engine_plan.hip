@@ -134,6 +134,9 @@ void free_dense(sextans_engine *h) {   // dense-tile state and everything downst
     h->d_dense_col = nullptr; h->d_dense_Af = nullptr;
     h->dense_mb = h->dense_W = 0;
     h->dense_tiles = h->dense_nnz = 0;
+    (void)hipFree(h->d_rb_row0); (void)hipFree(h->d_rb_gptr); (void)hipFree(h->d_rb_gcol); (void)hipFree(h->d_rb_A);
+    h->d_rb_row0 = h->d_rb_gptr = h->d_rb_gcol = nullptr; h->d_rb_A = nullptr;
+    h->rb_n = 0; h->rb_groups = 0;
     h->dense_built_mfma = h->dense_built_fill = -2;
     (void)hipFree(h->d_srp); (void)hipFree(h->d_sci); (void)hipFree(h->d_sv);
     h->d_srp = h->d_sci = nullptr;
@@ -883,7 +886,15 @@ int ensure_window(sextans_engine *h, bool force) {
 //     399 302): T = 512 / 1024 / 2021 -> 0.81 / 0.74 / 0.77 ms with 4964 / 2190 / 978 rows re-associated (uniform
 //     matrix of the same size: 0.64 ms), so the larger threshold costs nothing and touches fewer rows.
 
+static int ensure_split_rows(sextans_engine *h);
 int ensure_split(sextans_engine *h) {
+    const bool fresh = !(h->split_built_opt == h->opt_split_rows && h->bucket_built_opt == h->opt_bucket_rows &&
+                         h->split_built_gnnz == h->opt_global_nnz && h->chain_built_opt == h->opt_exact_chain);
+    if (int rc = ensure_split_rows(h)) return rc;
+    if (fresh && h->rb_n > 0) return mark_rowblock_skip(h);   // rows of blocks routed to the fp32 matrix cores: never written by the CSR kernels
+    return SEXTANS_OK;
+}
+static int ensure_split_rows(sextans_engine *h) {
     if (h->split_built_opt == h->opt_split_rows && h->bucket_built_opt == h->opt_bucket_rows &&
         h->split_built_gnnz == h->opt_global_nnz && h->chain_built_opt == h->opt_exact_chain)
         return SEXTANS_OK;

@@ -146,6 +146,11 @@ struct sextans_engine {
     void *d_dense_Af = nullptr;
     int64_t dense_tiles = 0, dense_nnz = 0;
     int64_t dense_built_mfma = -2, dense_built_fill = -2;
+    // "mfma_dense_tiles" = 2: dense blocks of 16 rows on the fp32 matrix cores (rowblock_mfma_kernel.h); dense_tiles / dense_nnz then count them
+    int rb_n = 0;                   // routed blocks
+    int64_t rb_groups = 0;          // their 16 x 4 fragments
+    int *d_rb_row0 = nullptr, *d_rb_gptr = nullptr, *d_rb_gcol = nullptr;   // first row, fragment range, column group per fragment
+    float *d_rb_A = nullptr;        // fragments in MFMA operand order (64 floats each)
     // blocked-ELL bf16 matrix (MFMA path)
     int bell_M = 0, bell_K = 0, bell_W = 0;
     int bell_max_union = 0;         // largest number of distinct block columns inside a group of 8 block rows
@@ -284,6 +289,7 @@ struct sextans_engine {
     int64_t opt_bell_shared = -1;       // N = 256: workgroups of 8 block rows share each B tile through an LDS ring
                                         // (spmm_bell_mfma_shared).  1 = always, 0 = never, -1 = when the 8 block rows of a
                                         // workgroup share block columns (blocks per distinct column >= 1.5)
+    int64_t opt_mode = 0;               // SEXTANS_MODE_* as last set through option "mode"
     int64_t opt_dist_broadcast_runs = 0;   // measurements / tests only: sextans_dist_spmm_rm exchanges ranges of EQUAL length by grouped broadcasts too
     int64_t opt_bell_debug = 0;         // measurements only (wrong results): ablation bits of spmm_bell_mfma_shared
     int64_t opt_bell_gen = 0;           // block rows per launch of the wide kernel (0 = all in one launch)
@@ -295,6 +301,7 @@ struct sextans_engine {
     // profiling
     std::vector<sxe::EventPair> ev_kernel, ev_repack, ev_post;   // ev_post: passes behind the kernel (C staging -> C)
     const char *last_kernel = "none";
+    std::string last_kernel_buf;        // storage for composed names
 };
 
 namespace sxe {
@@ -327,6 +334,10 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
 // dense 32x32 tiles on the matrix cores (engine_bell.hip): C_out = alpha * (A_dense * bf16(B)) + beta * C_in for the full block rows
 int launch_dense_tiles(sextans_engine *h, int N, float alpha, const float *d_B, int64_t ldb, float beta, const float *d_C_in,
                        int64_t ldc_in, float *d_C_out, int64_t ldc, hipStream_t s);
+// dense row blocks on the fp32 matrix cores (engine_bell.hip): the routed blocks of [row_begin, row_end) from the B panels in d_Bp
+int launch_rowblocks(sextans_engine *h, const std::vector<Seg> &plan, const float *d_C_in, int64_t ldc_in, float *d_C_out, int64_t ldc, int N, int row_begin,
+                     int row_end, float alpha, float beta, hipStream_t s);
+int mark_rowblock_skip(sextans_engine *h);   // after ensure_split: the routed rows join the rows the CSR kernels never write
 
 // clustered-order chunks of sextans_dist_spmm (engine.hip)
 int rm_plan(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_panel, bool &use_window, hipStream_t s);   // planning half of sextans_spmm_device_rm
