@@ -329,16 +329,19 @@ int sextans_destroy(sextans_handle_t h);
  * (acc = fmaf(a, b, acc), epilogue fmaf(alpha, acc, beta * c)) -- i.e. inside |d| <= 1e-4 * (|alpha| sum|a b| + |beta c|) of
  * cpu_spmm_CSR -- for finite B (a padding zero times an infinite B entry would be NaN where the CSR kernels see no entry at all).  Any N
  * (multiple of 8), whole-matrix and row-range calls, every rank of the multi-GPU forms; "dense_tiles" / "dense_tile_fraction" then
- * count the routed blocks / the share of the non-zeros in them.  Pays at N >= 64, where the VALU kernels are issue-bound (the matrix
- * cores run the same arithmetic at the vector peak); at N <= 32 it moves 4 / fill bytes per entry against 4.3 - 6 of the packed CSR
- * forms.  Use it with "exact" = 0 (or SEXTANS_MODE_FAST) so that routed and unrouted rows follow one rounding rule. */
+ * count the routed blocks / the share of the non-zeros in them.  MEASURED (round 6, profiles/r06_rowblock_mfma.jsonl): on a
+ * block-tridiagonal matrix of fully dense 32 x 32 blocks the path runs at 0.34 of the HBM roofline per step at N = 128 against 0.39 of
+ * the VALU kernels with "exact" = 0 (kernel 620 us against 567; the matrix cores are 38 - 45 % busy, the loop is bound by load latency
+ * and address arithmetic, not by the MFMA rate), and FEM matrices fill their fragments to 0.34 (3 dof) - 0.52 (6 dof) only, so two to
+ * three times as many multiply-adds are issued as the matrix holds: 2 x slower there.  An option for experiments, not a default.
+ * Use it with "exact" = 0 so that routed and unrouted rows follow one rounding rule. */
 /* ACCURACY MODES (round 6) -- one documented switch instead of three options:
  *   sextans_set_option(h, "mode", SEXTANS_MODE_STRICT)  default.  "exact" = 1, "split_rows" = 0, "mfma_dense_tiles" = 0: every product
  *       rounded, every row summed in CSR order: BIT-IDENTICAL to cpu_spmm_CSR (sparse_helper.h:262-290), stronger than the reference's
  *       own pass criterion.
  *   sextans_set_option(h, "mode", SEXTANS_MODE_FAST)    "exact" = 0 (fused multiply-adds), "split_rows" = -1 (hub rows above
- *       max(1024, nnz / 16384) entries are cut into pieces summed in parallel and folded in order), "mfma_dense_tiles" = 2 (dense row
- *       blocks on the fp32 matrix cores).  GUARANTEE, per output element:
+ *       max(1024, nnz / 16384) entries are cut into pieces summed in parallel and folded in order); "mfma_dense_tiles" stays 0 (its
+ *       fp32 form, 2, is bit-identical to this mode and may be added by hand; measured, it does not pay yet).  GUARANTEE, per output element:
  *           |C_fast - C_ref| <= 1e-4 * (|alpha| * sum_j |a_ij * b_jn| + |beta * c_in|)
  *       (the condition-aware form of north_star's "within 1e-4 relative error"; the reference's own check is a tolerance
  *       too, sextans-host.cpp:272-282).  Measured distance is ~1e-7 of that scale: fp32 roundoff of a different, but still fp32,

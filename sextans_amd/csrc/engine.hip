@@ -483,9 +483,9 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
         const bool fast = value == SEXTANS_MODE_FAST;
         if (int rc = sextans_set_option(h, "exact", fast ? 0 : 1)) return rc;
         if (int rc = sextans_set_option(h, "split_rows", fast ? -1 : 0)) return rc;
-        // (dense 32x32 tiles on the fp32 matrix cores: same products, same ascending-k order as the FMA chain of "exact" = 0 -- mode 2
-        // never changes a bit against it, so it belongs to the in-tolerance mode and costs strict mode nothing)
-        if (int rc = sextans_set_option(h, "mfma_dense_tiles", fast ? 2 : 0)) return rc;
+        // ("mfma_dense_tiles" = 2 -- dense row blocks on the fp32 matrix cores -- never changes a bit against "exact" = 0, but as measured in
+        // round 6 it does not beat the VALU kernels either (profiles/r06_rowblock_mfma.jsonl): it stays an option of its own, off in both modes)
+        if (int rc = sextans_set_option(h, "mfma_dense_tiles", 0)) return rc;
         h->opt_mode = value;
         return SEXTANS_OK;
     }
@@ -554,7 +554,7 @@ int sextans_get_option(sextans_handle_t h, const char *key, int64_t *value) {
     if (!h || !key || !value) return SEXTANS_ERR_INVALID;
     if (!strcmp(key, "mode")) {   // what the three options it stands for say now (-1: set apart by hand)
         const bool strict = h->opt_exact == 1 && h->opt_split_rows == 0 && h->opt_mfma_dense == 0;
-        const bool fast = h->opt_exact == 0 && h->opt_split_rows == -1 && h->opt_mfma_dense == 2;
+        const bool fast = h->opt_exact == 0 && h->opt_split_rows == -1 && h->opt_mfma_dense == 0;
         *value = strict ? SEXTANS_MODE_STRICT : fast ? SEXTANS_MODE_FAST : -1;
         return SEXTANS_OK;
     }

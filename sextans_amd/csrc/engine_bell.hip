@@ -101,8 +101,53 @@ int build_rowblocks(sextans_engine *h) {
     if (int rc = upload(&h->d_rb_row0, row0)) return rc;
     if (int rc = upload(&h->d_rb_gptr, gptr)) return rc;
     if (int rc = upload(&h->d_rb_gcol, gcol)) return rc;
-    SX_HIP(hipMalloc((void **)&h->d_rb_A, sizeof(float) * 64 * (size_t)total));
-    SX_HIP(hipMemsetAsync(h->d_rb_A, 0, sizeof(float) * 64 * (size_t)total, hipStreamPerThread));
+    {   // super blocks of 4 routed blocks: the ascending union of their groups + who owns each (the kernel loads a B fragment once per entry)
+        const int nrb = (int)row0.size(), nsb = (nrb + 3) / 4;
+        std::vector<int> ucount((size_t)nsb, 0);
+        auto merge4 = [&](int sb, int *ucol, unsigned char *umask) -> int {   // null outputs: count only
+            int pos[4], end[4], n = 0;
+            for (int q = 0; q < 4; ++q) {
+                const int rb = 4 * sb + q;
+                pos[q] = rb < nrb ? gptr[(size_t)rb] : 0;
+                end[q] = rb < nrb ? gptr[(size_t)rb + 1] : 0;
+            }
+            for (;;) {
+                int c = 0x7fffffff;
+                for (int q = 0; q < 4; ++q)
+                    if (pos[q] < end[q]) c = std::min(c, gcol[(size_t)pos[q]]);
+                if (c == 0x7fffffff) break;
+                unsigned m = 0;
+                for (int q = 0; q < 4; ++q)
+                    if (pos[q] < end[q] && gcol[(size_t)pos[q]] == c) { m |= 1u << q; ++pos[q]; }
+                if (ucol) { ucol[n] = c; umask[n] = (unsigned char)m; }
+                ++n;
+            }
+            return n;
+        };
+        auto parallel_sb = [&](auto fn) {
+            std::vector<std::thread> ts;
+            for (unsigned t = 0; t < nthreads; ++t)
+                ts.emplace_back([&, t]() {
+                    for (int sb = (int)((int64_t)nsb * t / nthreads); sb < (int)((int64_t)nsb * (t + 1) / nthreads); ++sb) fn(sb);
+                });
+            for (auto &t : ts) t.join();
+        };
+        parallel_sb([&](int sb) { ucount[(size_t)sb] = merge4(sb, nullptr, nullptr); });
+        std::vector<int> uptr((size_t)nsb + 1, 0);
+        for (int sb = 0; sb < nsb; ++sb) uptr[(size_t)sb + 1] = uptr[(size_t)sb] + ucount[(size_t)sb];
+        std::vector<int> ucol((size_t)uptr[(size_t)nsb]);
+        std::vector<unsigned char> umask((size_t)uptr[(size_t)nsb]);
+        parallel_sb([&](int sb) { merge4(sb, ucol.data() + uptr[(size_t)sb], umask.data() + uptr[(size_t)sb]); });
+        std::vector<int> uent(2 * ucol.size());   // {column group, owner mask} pairs: one 8-byte scalar load per entry
+        for (size_t k = 0; k < ucol.size(); ++k) { uent[2 * k] = ucol[k]; uent[2 * k + 1] = umask[k]; }
+        if (int rc = upload(&h->d_sb_uptr, uptr)) return rc;
+        if (int rc = upload(&h->d_sb_ucol, uent)) return rc;
+        h->sb_n = nsb;
+        h->sb_entries = uptr[(size_t)nsb];
+    }
+    // (+ 1: the all-zero fragment that blocks multiply for the groups they do not own)
+    SX_HIP(hipMalloc((void **)&h->d_rb_A, sizeof(float) * 64 * ((size_t)total + 1)));
+    SX_HIP(hipMemsetAsync(h->d_rb_A, 0, sizeof(float) * 64 * ((size_t)total + 1), hipStreamPerThread));
     hipLaunchKernelGGL(sx::rowblock_fill_fragments, dim3((unsigned)((row0.size() + 3) / 4)), dim3(256), 0, hipStreamPerThread, h->d_rp, h->d_ci, h->d_v, h->d_rb_row0,
                        h->d_rb_gptr, h->d_rb_gcol, h->d_rb_A, (int)row0.size());
     SX_HIP(hipStreamSynchronize(hipStreamPerThread));
@@ -155,11 +200,12 @@ int launch_rowblocks(sextans_engine *h, const std::vector<Seg> &plan, const floa
         float *cout = d_C_out + (int64_t)g.col0 * ldc;
         auto go = [&](auto kern, int NT) {
             const int tgs = (tiles16 + NT - 1) / NT;
-            hipLaunchKernelGGL(kern, dim3((unsigned)((h->rb_n + 3) / 4) * (unsigned)tgs), dim3(256), 0, s, h->d_rb_row0, h->d_rb_gptr, h->d_rb_gcol, h->d_rb_A, bp,
-                               (int64_t)h->K * g.width, g.width, h->K, cin, ldc_in, cout, ldc, h->rb_n, tgs, ncols_panel, ncols, row_begin, row_end, alpha, beta);
+            hipLaunchKernelGGL(kern, dim3((unsigned)((h->sb_n + 3) / 4) * (unsigned)tgs), dim3(256), 0, s, h->d_rb_row0, h->d_rb_gptr, h->d_sb_uptr,
+                               (const int2 *)h->d_sb_ucol, h->d_rb_A, h->rb_groups, bp, (int64_t)h->K * g.width, g.width, h->K, cin, ldc_in, cout, ldc, h->rb_n, h->sb_n,
+                               tgs, ncols_panel, ncols, row_begin, row_end, alpha, beta);
         };
-        if (tiles16 >= 8) go(sx::spmm_rowblock_mfma_f32<8>, 8);
-        else if (tiles16 >= 4) go(sx::spmm_rowblock_mfma_f32<4>, 4);
+        // (a wavefront owns 64 rows x 16 NT columns of C: 16 NT accumulator registers)
+        if (tiles16 >= 4) go(sx::spmm_rowblock_mfma_f32<4>, 4);
         else if (tiles16 >= 2) go(sx::spmm_rowblock_mfma_f32<2>, 2);
         else go(sx::spmm_rowblock_mfma_f32<1>, 1);
     }

@@ -137,6 +137,9 @@ void free_dense(sextans_engine *h) {   // dense-tile state and everything downst
     (void)hipFree(h->d_rb_row0); (void)hipFree(h->d_rb_gptr); (void)hipFree(h->d_rb_gcol); (void)hipFree(h->d_rb_A);
     h->d_rb_row0 = h->d_rb_gptr = h->d_rb_gcol = nullptr; h->d_rb_A = nullptr;
     h->rb_n = 0; h->rb_groups = 0;
+    (void)hipFree(h->d_sb_uptr); (void)hipFree(h->d_sb_ucol); (void)hipFree(h->d_sb_umask);
+    h->d_sb_uptr = h->d_sb_ucol = nullptr; h->d_sb_umask = nullptr;
+    h->sb_n = 0; h->sb_entries = 0;
     h->dense_built_mfma = h->dense_built_fill = -2;
     (void)hipFree(h->d_srp); (void)hipFree(h->d_sci); (void)hipFree(h->d_sv);
     h->d_srp = h->d_sci = nullptr;

@@ -151,6 +151,10 @@ struct sextans_engine {
     int64_t rb_groups = 0;          // their 16 x 4 fragments
     int *d_rb_row0 = nullptr, *d_rb_gptr = nullptr, *d_rb_gcol = nullptr;   // first row, fragment range, column group per fragment
     float *d_rb_A = nullptr;        // fragments in MFMA operand order (64 floats each)
+    int sb_n = 0;                   // super blocks of 4 routed blocks: ascending union of their column groups + 4-bit owner masks
+    int64_t sb_entries = 0;
+    int *d_sb_uptr = nullptr, *d_sb_ucol = nullptr;
+    unsigned char *d_sb_umask = nullptr;
     // blocked-ELL bf16 matrix (MFMA path)
     int bell_M = 0, bell_K = 0, bell_W = 0;
     int bell_max_union = 0;         // largest number of distinct block columns inside a group of 8 block rows

@@ -13,11 +13,11 @@
 // fill reaches "dense_tile_fill_x100" % are routed here, all other rows stay on the CSR kernels, which skip the routed rows.
 // A fully dense 32 x 32 tile is 2 blocks x 8 groups at fill 1; a 6-dof FEM row block reaches ~0.6, a 3-dof one ~0.35.
 //
-// One wavefront = one routed block x NT tiles of 16 columns of C.  Per group: ONE coalesced 256-byte load of the A fragment, and per
-// tile ONE coalesced load of the B fragment -- lane l reads B[4 c + (l >> 4)][n0 + (l & 15)] from the row-major B panels the engine
-// repacks anyway (panel row = PW floats: the four rows of a group are 4 x 64 consecutive bytes; PW = 16: one 256-byte run) -- and one
-// MFMA, D^T = B^T-fragment x A^T-fragment, so that a register of D holds 16 consecutive rows of one column of C (64-byte runs of
-// column-major C).  The next group's fragments are requested before the current group's MFMAs issue.
+// Per group and block: ONE coalesced 256-byte load of the A fragment; per group and tile ONE coalesced load of the B fragment -- lane l
+// reads B[4 c + (l >> 4)][n0 + (l & 15)] from the row-major B panels the engine repacks anyway (panel row = PW floats: the four rows of
+// a group are 4 x 64 consecutive bytes; PW = 16: one 256-byte run) -- and one MFMA, D^T = B^T-fragment x A^T-fragment, so that a
+// register of D holds 16 consecutive rows of one column of C (64-byte runs of column-major C).  The next entry's fragments are
+// requested before the current entry's MFMAs issue.
 // Rate: 2 * 16 * 16 * 4 flop per 32 cycles per SIMD = the fp32 vector peak; at N >= 64 the VALU kernels reach ~1/4 of it (two issue
 // slots per multiply-add pair plus the operand moves), which is where this path pays.  At N <= 32 it is bound by the A stream:
 // 256 bytes per group = 4 / fill bytes per entry against 4.3 - 6 of the packed CSR forms.
@@ -26,77 +26,143 @@
 
 #include <cstdint>
 
+#include "spmm_csr_kernels.h"   // xcd_remap
+
 namespace sx {
 
 typedef float rb_f32x4 __attribute__((ext_vector_type(4)));
 
+// One wavefront = one SUPER BLOCK (up to 4 routed blocks = 64 rows, consecutive in the routed order) x NT tiles of 16 columns.
+// The super block walks the UNION of its blocks' column groups, ascending: per union entry the B fragments are loaded ONCE (NT
+// coalesced loads) and every block that owns the group (4-bit mask) multiplies its own A fragment into its own accumulators.  A first
+// form with one block per wavefront loaded the B fragments once per MFMA and was bound by L2 -> L1 traffic at 24 TFLOP/s on fully
+// dense blocks (profiles/r06_rowblock_mfma_v1.jsonl); the VALU kernels reuse a B row across the 64 rows of a row block through LDS,
+// this form reuses it across the same 64 rows through registers.
+// The walk is BRANCH-FREE: a block that does not own a group multiplies the all-zero fragment (stored once, behind the last real one)
+// -- fmaf(0, b, acc) = acc -- instead of skipping the instruction.  The first form of this loop branched on the owner mask and the
+// compiler answered with 128 accumulator moves between register files and a full vmcnt(0) in front of every MFMA group per iteration
+// (5 x slower than the VALU kernels); straight-line code keeps the accumulators where the MFMAs want them and lets the wait-count pass
+// count the prefetches properly.  Loads are unconditional too (clamped addresses, results masked by a select).
 template <int NT>
-__global__ __launch_bounds__(256) void spmm_rowblock_mfma_f32(const int *__restrict__ rb_row0, const int *__restrict__ rb_gptr, const int *__restrict__ rb_gcol,
-                                                              const float *__restrict__ rb_A, const float *__restrict__ Bp, int64_t panel_stride, int PW, int K,
-                                                              const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc, int nrb, int ntile_groups, int ncols_panel,
-                                                              int ncols, int row_begin, int row_end, float alpha, float beta) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rbi = (int)(blockIdx.x / (unsigned)ntile_groups) * 4 + wave;
-    const int tg = (int)(blockIdx.x % (unsigned)ntile_groups);
-    if (rbi >= nrb) return;
-    const int row0 = rb_row0[rbi];
-    if (row0 + 16 <= row_begin || row0 >= row_end) return;   // (row-range calls: blocks outside the range)
-    const int g0 = rb_gptr[rbi], g1 = rb_gptr[rbi + 1];
+__global__ __launch_bounds__(256) void spmm_rowblock_mfma_f32(const int *__restrict__ rb_row0, const int *__restrict__ rb_gptr, const int *__restrict__ sb_uptr,
+                                                              const int2 *__restrict__ sb_u, const float *__restrict__ rb_A, int64_t zero_frag,
+                                                              const float *__restrict__ Bp, int64_t panel_stride, int PW, int K, const float *Cin, int64_t ldc_in,
+                                                              float *Cout, int64_t ldc, int nrb, int nsb, int ntile_groups, int ncols_panel, int ncols,
+                                                              int row_begin, int row_end, float alpha, float beta) {
+    const int lane = threadIdx.x & 63;
+    // (workgroup b runs on XCD b % 8: every XCD gets a contiguous run of super blocks, so that neighbours -- which share B rows, and
+    // the tile groups of one super block, which share its A fragments -- meet in ONE L2.  Without it 95 % of the L2 requests of a
+    // block-tridiagonal matrix missed: profiles/r06_rowblock_mfma_pmc.txt)
+    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int sbi = __builtin_amdgcn_readfirstlane((int)(wg / (unsigned)ntile_groups) * 4 + (int)(threadIdx.x >> 6));
+    const int tg = (int)(wg % (unsigned)ntile_groups);
+    if (sbi >= nsb) return;
+    const int nb_here = min(4, nrb - 4 * sbi);
+    int row0[4];
+    int64_t fi[4];   // next A fragment of every block (its fragments are stored in ascending group order)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rb = min(4 * sbi + q, nrb - 1);
+        row0[q] = q < nb_here ? __builtin_amdgcn_readfirstlane(rb_row0[rb]) : -1000;
+        fi[q] = (int64_t)__builtin_amdgcn_readfirstlane(rb_gptr[rb]);
+    }
+    if (row0[0] >= row_end || (row0[nb_here - 1] + 16 <= row_begin)) return;   // (row-range calls: super blocks outside the range; row0 ascends)
+    const int u0 = __builtin_amdgcn_readfirstlane(sb_uptr[sbi]), u1 = __builtin_amdgcn_readfirstlane(sb_uptr[sbi + 1]);
+    if (u0 >= u1) return;   // (cannot happen: a routed block has entries)
     const int kq = lane >> 4, li = lane & 15;
-    // per tile: where this lane's B element sits inside a panel row, and whether the column exists in the panels at all
     int64_t boff[NT];
     bool bok[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int c = (tg * NT + i) * 16 + li;
         bok[i] = c < ncols_panel;
-        const int p = c / PW, pc = c - p * PW;
+        const int cc = bok[i] ? c : 0;
+        const int p = cc / PW, pc = cc - p * PW;
         boff[i] = (int64_t)p * panel_stride + pc;
     }
-    rb_f32x4 acc[NT];
+    rb_f32x4 acc[4][NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) acc[i] = rb_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[q][i] = rb_f32x4{0.f, 0.f, 0.f, 0.f};
     auto load_b = [&](int c4, float (&b)[NT]) {
-        const int k = 4 * c4 + kq;
-        const bool kok = k < K;
-        const int64_t rowoff = (int64_t)k * PW;
+        // (addresses clamped into the panels, values NOT masked: a row k >= K of the last group meets zeros in every A fragment, a
+        // column beyond the panels is never stored -- any finite value there is harmless, and an unconditional load is one the
+        // compiler can keep in flight across the MFMAs)
+        const int64_t rowoff = (int64_t)min(4 * c4 + kq, K - 1) * PW;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) b[i] = (kok && bok[i]) ? Bp[boff[i] + rowoff] : 0.f;
+        for (int i = 0; i < NT; ++i) b[i] = Bp[boff[i] + rowoff];
     };
-    float a_cur = 0.f, b_cur[NT];
-    if (g0 < g1) {
-        a_cur = rb_A[(int64_t)g0 * 64 + lane];
-        load_b(rb_gcol[g0], b_cur);
-    }
-    for (int g = g0; g < g1; ++g) {
-        float a_nxt = 0.f, b_nxt[NT];
-        if (g + 1 < g1) {   // the next group's fragments are in flight while this group's MFMAs issue
-            a_nxt = rb_A[(int64_t)(g + 1) * 64 + lane];
-            load_b(rb_gcol[g + 1], b_nxt);
-        } else {
+    auto load_a = [&](unsigned m, float (&a)[4]) {
 #pragma unroll
-            for (int i = 0; i < NT; ++i) b_nxt[i] = 0.f;
+        for (int q = 0; q < 4; ++q) {
+            const unsigned bit = (m >> q) & 1u;
+            const int64_t f = bit ? fi[q] : zero_frag;
+            a[q] = rb_A[f * 64 + lane];
+            fi[q] += bit;
         }
+    };
+    // Two register sets, walked alternately, with scheduling barriers between the phases: the loads of entry u + 1 are ISSUED before the
+    // MFMAs of entry u and awaited only behind them.  (Left to itself the scheduler sinks the prefetch below the MFMAs to shorten live
+    // ranges and the loop becomes load -> wait -> 16 MFMAs, one memory latency per entry: measured 6 x the MFMA time.)
+    auto fetch = [&](int u, float (&a)[4], float (&b)[NT]) {   // entry u, or past the end: the last entry again with no owner
+        const int2 e = sb_u[min(u, u1 - 1)];
+        load_a(u < u1 ? (unsigned)e.y : 0u, a);
+        load_b(e.x, b);
+    };
+    auto multiply = [&](const float (&a)[4], const float (&b)[NT]) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_cur[i], a_cur, acc[i], 0, 0, 0);
-        a_cur = a_nxt;
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int i = 0; i < NT; ++i) b_cur[i] = b_nxt[i];
+            for (int i = 0; i < NT; ++i) acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i], a[q], acc[q][i], 0, 0, 0);
+    };
+    // (a ring of four sets, three entries ahead: 24 loads in flight per wavefront.  With one entry ahead the kernel sat at 38 % MFMA
+    // busy with near-compulsory HBM traffic -- latency-bound: 3 wavefronts per SIMD x 8 loads cover ~1 500 cycles of latency)
+    float a0[4], b0[NT], a1[4], b1[NT], a2[4], b2[NT], a3[4], b3[NT];
+    fetch(u0, a0, b0);
+    fetch(u0 + 1, a1, b1);
+    fetch(u0 + 2, a2, b2);
+    for (int u = u0; u < u1; u += 4) {   // (entries past the end multiply all-zero fragments: nothing changes)
+        fetch(u + 3, a3, b3);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(u + 4, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(u + 5, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(a2, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(u + 6, a2, b2);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(a3, b3);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // D[n_local = 4 * (lane >> 4) + r][row_local = lane & 15]: 16 consecutive rows of one column per register
-    const int row = row0 + li;
-    if (row < row_begin || row >= row_end) return;
-    const int64_t r_in = (int64_t)(row - row_begin);
+    // D[n_local = 4 * (lane >> 4) + r][row_local = lane & 15]: 16 consecutive rows of one column per register.  All C_in values of a
+    // block are requested at once from clamped addresses (16 NT / 4 loads in flight), then masked stores.
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
+    for (int q = 0; q < 4; ++q) {
+        if (q >= nb_here) break;
+        const int row = row0[q] + li;
+        const bool row_ok = row >= row_begin && row < row_end;
+        const int64_t r_in = (int64_t)(min(max(row, row_begin), row_end - 1) - row_begin);
+        float cin[NT][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = (tg * NT + i) * 16 + 4 * kq + r;
-            if (c < ncols) {
-                const float cin = Cin[r_in + (int64_t)c * ldc_in];
-                Cout[r_in + (int64_t)c * ldc] = __builtin_fmaf(alpha, acc[i][r], beta * cin);   // = epilogue<false> of the CSR kernels
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = min((tg * NT + i) * 16 + 4 * kq + r, ncols - 1);
+                cin[i][r] = Cin[r_in + (int64_t)c * ldc_in];
             }
-        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = (tg * NT + i) * 16 + 4 * kq + r;
+                if (row_ok && c < ncols) Cout[r_in + (int64_t)c * ldc] = __builtin_fmaf(alpha, acc[q][i][r], beta * cin[i][r]);   // = epilogue<false> of the CSR kernels
+            }
     }
 }
 
