@@ -620,6 +620,18 @@ def bell_secondary(api, torch, dev, stream, M=1_048_576, W=328, N=256, iters=5, 
     if banded_half_width is not None:
         out["matrix"] = f"block-banded, {W} consecutive block columns per block row"
         out["blocks_per_distinct_column_in_a_workgroup"] = round(e.get_stat("bell_share"), 2)
+    # rocprof MFMA utilisation (north_star): a counter figure of the same workload, stored with its provenance -- never measured in this run
+    try:
+        stored = json.load(open(os.path.join(ROOT, "profiles", "r06_mfma_busy.json")))
+        rec = stored.get("blockbanded_ell_bf16_N256" if banded_half_width is not None else "config5_blocked_ell_bf16_N256")
+        if rec and (M, W, N) in ((1_048_576, 328, 256), (1_048_576, 255, 256)):
+            if rec.get("kernel") == e.last_kernel():
+                out["mfma_busy_frac"] = rec["mfma_busy_frac"]
+                out["mfma_busy_frac_source"] = rec["source"]
+            else:
+                out["mfma_busy_frac_source"] = f"NOT APPLICABLE: stored counters are for kernel {rec.get('kernel')!r}, this run used {e.last_kernel()!r}"
+    except (OSError, ValueError):
+        pass
     e.close()
     api.device_free(dev.index, dc)
     return out
