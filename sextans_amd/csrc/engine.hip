@@ -718,6 +718,51 @@ void launch_hub_pieces(sextans_engine *h, const sextans_engine::PieceTable &t, c
 }  // namespace
 extern "C" {
 
+}  // extern "C"
+namespace {
+// Round 6 (VERDICT r05 task 2, "measure first"): how many of a block's dictionary rows does the PREVIOUS block of the walk hold too?
+// One workgroup of 64 lanes per block: the previous dictionary into an LDS hash set (1024 slots, linear probing), this one probed.
+// out[0] += entries of block b found in block b - 1, out[1] += entries of block b  (b >= 1).
+__global__ __launch_bounds__(64) void dict_overlap(const int *__restrict__ dict_cnt, const int *__restrict__ dict, int stride, int nblk, unsigned long long *out) {
+    __shared__ int tab[1024];
+    const int b = (int)blockIdx.x + 1;
+    if (b >= nblk) return;
+    for (int i = threadIdx.x; i < 1024; i += 64) tab[i] = -1;
+    __syncthreads();
+    const int np = dict_cnt[b - 1], nc = dict_cnt[b];
+    for (int i = threadIdx.x; i < np; i += 64) {
+        const int c = dict[(int64_t)(b - 1) * stride + i];
+        unsigned s = ((unsigned)c * 2654435761u) >> 22;
+        while (atomicCAS(&tab[s], -1, c) != -1 && tab[s] != c) s = (s + 1) & 1023u;
+    }
+    __syncthreads();
+    unsigned found = 0;
+    for (int i = threadIdx.x; i < nc; i += 64) {
+        const int c = dict[(int64_t)b * stride + i];
+        unsigned s = ((unsigned)c * 2654435761u) >> 22;
+        while (tab[s] != -1 && tab[s] != c) s = (s + 1) & 1023u;
+        found += tab[s] == c;
+    }
+    for (int o = 32; o > 0; o >>= 1) found += __shfl_down(found, o);
+    if (threadIdx.x == 0) { atomicAdd(&out[0], (unsigned long long)found); atomicAdd(&out[1], (unsigned long long)nc); }
+}
+int dict_overlap_stat(sextans_engine *h, double *value) {
+    const sextans_engine::PanelState &P = h->cluster_state > 0 ? h->psc : h->ps;
+    *value = 0.0;
+    if (!P.plan_built || P.plan_nblk < 2 || !P.d_dict || !P.d_dict_ptr) return SEXTANS_OK;
+    unsigned long long *d = nullptr, hv[2] = {0, 0};
+    SX_HIP(hipMalloc((void **)&d, sizeof hv));
+    SX_HIP(hipMemset(d, 0, sizeof hv));
+    hipLaunchKernelGGL(dict_overlap, dim3((unsigned)P.plan_nblk - 1), dim3(64), 0, hipStreamPerThread, P.d_dict_ptr, P.d_dict, P.plan_dict_stride, P.plan_nblk, d);
+    const hipError_t e = hipMemcpy(hv, d, sizeof hv, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    SX_HIP(e);
+    *value = hv[1] ? (double)hv[0] / (double)hv[1] : 0.0;
+    return SEXTANS_OK;
+}
+}  // namespace
+extern "C" {
+
 int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     if (!h || !key || !value) return SEXTANS_ERR_INVALID;
     if (h->d_rp) {   // figures about the packed forms refer to the current options: bring the cheap ones up to date
@@ -742,6 +787,7 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "cluster_shared_fraction")) *value = h->cluster_shared;
     else if (!strcmp(key, "cluster_decline")) *value = (double)h->cluster_decline;
     else if (!strcmp(key, "graph_fallbacks")) *value = (double)h->graph_fallbacks;   // rp_time loops launched one by one because their hipGraph capture was invalidated from outside
+    else if (!strcmp(key, "dict_overlap_consecutive")) return dict_overlap_stat(h, value);   // share of a block's dictionary rows the previous block of the walk holds too (the plan whole-matrix calls use)
     else if (!strcmp(key, "dist_setup_exchanges")) *value = (double)h->dist_exchanges;   // control collectives + host syncs of the dist entry points so far (0 new ones after sextans_dist_prepare)
     else if (!strcmp(key, "cluster_graph_kind")) *value = (double)h->cluster_graph_kind;
     else if (!strcmp(key, "cluster_runs")) *value = h->cluster_runs ? 1.0 : 0.0;
