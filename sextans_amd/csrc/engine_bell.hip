@@ -65,7 +65,7 @@ int build_rowblocks(sextans_engine *h) {
             const int64_t cnt = (int64_t)rp[(size_t)16 * b + 16] - rp[(size_t)16 * b];
             if (cnt == 0 || (double)cnt < thr * 64.0) continue;             // (even a single group would be below the threshold)
             if (!groups_of(b, g)) continue;
-            if ((double)cnt >= thr * 64.0 * (double)g.size()) ngroups[(size_t)b] = (int)g.size();
+            if ((double)cnt >= thr * 64.0 * (double)g.size() && g.size() <= ((size_t)1 << 20)) ngroups[(size_t)b] = (int)g.size();   // (32-bit byte offsets inside a super block's fragments)
         }
     });
     std::vector<int> row0, gptr(1, 0);
@@ -145,9 +145,8 @@ int build_rowblocks(sextans_engine *h) {
         h->sb_n = nsb;
         h->sb_entries = uptr[(size_t)nsb];
     }
-    // (+ 1: the all-zero fragment that blocks multiply for the groups they do not own)
-    SX_HIP(hipMalloc((void **)&h->d_rb_A, sizeof(float) * 64 * ((size_t)total + 1)));
-    SX_HIP(hipMemsetAsync(h->d_rb_A, 0, sizeof(float) * 64 * ((size_t)total + 1), hipStreamPerThread));
+    SX_HIP(hipMalloc((void **)&h->d_rb_A, sizeof(float) * 64 * (size_t)total));
+    SX_HIP(hipMemsetAsync(h->d_rb_A, 0, sizeof(float) * 64 * (size_t)total, hipStreamPerThread));
     hipLaunchKernelGGL(sx::rowblock_fill_fragments, dim3((unsigned)((row0.size() + 3) / 4)), dim3(256), 0, hipStreamPerThread, h->d_rp, h->d_ci, h->d_v, h->d_rb_row0,
                        h->d_rb_gptr, h->d_rb_gcol, h->d_rb_A, (int)row0.size());
     SX_HIP(hipStreamSynchronize(hipStreamPerThread));
@@ -190,6 +189,12 @@ int mark_rowblock_skip(sextans_engine *h) {
 // The routed blocks of [row_begin, row_end) over the B panels the main path has just laid out (`plan` = the segments of d_Bp).
 int launch_rowblocks(sextans_engine *h, const std::vector<Seg> &plan, const float *d_C_in, int64_t ldc_in, float *d_C_out, int64_t ldc, int N, int row_begin,
                      int row_end, float alpha, float beta, hipStream_t s) {
+    if (h->K % 4) {
+        // the last column group reads up to 3 panel rows past row K - 1: inside the workspace that is the next panel (finite values, met by
+        // zeros of A), behind the LAST panel it is the slack prepare() allocates for this -- zeroed here (uninitialised memory may hold NaNs)
+        const size_t n16 = (size_t)((N + 15) / 16) * 16;
+        if (h->Bp_cap >= (size_t)h->K * n16 + 128) SX_HIP(hipMemsetAsync(h->d_Bp + (size_t)h->K * n16, 0, 128 * sizeof(float), s));
+    }
     for (const Seg &g : plan) {
         const int ncols_panel = g.ntiles * g.width;
         const int ncols = std::min(N - g.col0, g.last_cols ? (g.ntiles - 1) * g.width + g.last_cols : ncols_panel);
@@ -201,7 +206,7 @@ int launch_rowblocks(sextans_engine *h, const std::vector<Seg> &plan, const floa
         auto go = [&](auto kern, int NT) {
             const int tgs = (tiles16 + NT - 1) / NT;
             hipLaunchKernelGGL(kern, dim3((unsigned)((h->sb_n + 3) / 4) * (unsigned)tgs), dim3(256), 0, s, h->d_rb_row0, h->d_rb_gptr, h->d_sb_uptr,
-                               (const int2 *)h->d_sb_ucol, h->d_rb_A, h->rb_groups, bp, (int64_t)h->K * g.width, g.width, h->K, cin, ldc_in, cout, ldc, h->rb_n, h->sb_n,
+                               (const int2 *)h->d_sb_ucol, h->d_rb_A, bp, (int64_t)h->K * g.width, g.width, h->K, cin, ldc_in, cout, ldc, h->rb_n, h->sb_n,
                                tgs, ncols_panel, ncols, row_begin, row_end, alpha, beta);
         };
         // (a wavefront owns 64 rows x 16 NT columns of C: 16 NT accumulator registers)

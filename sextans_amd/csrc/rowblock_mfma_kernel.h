@@ -38,17 +38,19 @@ typedef float rb_f32x4 __attribute__((ext_vector_type(4)));
 // form with one block per wavefront loaded the B fragments once per MFMA and was bound by L2 -> L1 traffic at 24 TFLOP/s on fully
 // dense blocks (profiles/r06_rowblock_mfma_v1.jsonl); the VALU kernels reuse a B row across the 64 rows of a row block through LDS,
 // this form reuses it across the same 64 rows through registers.
-// The walk is BRANCH-FREE: a block that does not own a group multiplies the all-zero fragment (stored once, behind the last real one)
-// -- fmaf(0, b, acc) = acc -- instead of skipping the instruction.  The first form of this loop branched on the owner mask and the
-// compiler answered with 128 accumulator moves between register files and a full vmcnt(0) in front of every MFMA group per iteration
-// (5 x slower than the VALU kernels); straight-line code keeps the accumulators where the MFMAs want them and lets the wait-count pass
-// count the prefetches properly.  Loads are unconditional too (clamped addresses, results masked by a select).
+// The walk is BRANCH-FREE: a block that does not own a group multiplies zeros (a buffer load whose offset lies outside its resource
+// returns 0) -- fmaf(0, b, acc) = acc -- instead of skipping the instruction.  The first form of this loop branched on the owner mask
+// and the compiler answered with 128 accumulator moves between register files and a full vmcnt(0) in front of every MFMA group per
+// iteration; straight-line code keeps the accumulators where the MFMAs want them and lets the wait-count pass count the prefetches.
+// Every fragment load is a BUFFER load -- resource + per-lane offset that never changes + a scalar offset per entry -- so that an entry
+// costs scalar arithmetic only: the flat-address form spent ~60 vector instructions per entry on 64-bit address arithmetic, which
+// share the issue port with the 16 MFMAs (matrix cores 38 - 45 % busy, profiles/r06_rowblock_mfma_pmc.txt).
 template <int NT>
 __global__ __launch_bounds__(256) void spmm_rowblock_mfma_f32(const int *__restrict__ rb_row0, const int *__restrict__ rb_gptr, const int *__restrict__ sb_uptr,
-                                                              const int2 *__restrict__ sb_u, const float *__restrict__ rb_A, int64_t zero_frag,
-                                                              const float *__restrict__ Bp, int64_t panel_stride, int PW, int K, const float *Cin, int64_t ldc_in,
-                                                              float *Cout, int64_t ldc, int nrb, int nsb, int ntile_groups, int ncols_panel, int ncols,
-                                                              int row_begin, int row_end, float alpha, float beta) {
+                                                              const int2 *__restrict__ sb_u, const float *__restrict__ rb_A, const float *__restrict__ Bp,
+                                                              int64_t panel_stride, int PW, int K, const float *Cin, int64_t ldc_in, float *Cout, int64_t ldc,
+                                                              int nrb, int nsb, int ntile_groups, int ncols_panel, int ncols, int row_begin, int row_end,
+                                                              float alpha, float beta) {
     const int lane = threadIdx.x & 63;
     // (workgroup b runs on XCD b % 8: every XCD gets a contiguous run of super blocks, so that neighbours -- which share B rows, and
     // the tile groups of one super block, which share its A fragments -- meet in ONE L2.  Without it 95 % of the L2 requests of a
@@ -59,56 +61,52 @@ __global__ __launch_bounds__(256) void spmm_rowblock_mfma_f32(const int *__restr
     if (sbi >= nsb) return;
     const int nb_here = min(4, nrb - 4 * sbi);
     int row0[4];
-    int64_t fi[4];   // next A fragment of every block (its fragments are stored in ascending group order)
+    const int gbase = __builtin_amdgcn_readfirstlane(rb_gptr[4 * sbi]);
+    const int gend = __builtin_amdgcn_readfirstlane(rb_gptr[4 * sbi + nb_here]);
+    int fo[4];   // byte offset of every block's next A fragment inside this super block's run of fragments (stored in ascending group order)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int rb = min(4 * sbi + q, nrb - 1);
         row0[q] = q < nb_here ? __builtin_amdgcn_readfirstlane(rb_row0[rb]) : -1000;
-        fi[q] = (int64_t)__builtin_amdgcn_readfirstlane(rb_gptr[rb]);
+        fo[q] = (__builtin_amdgcn_readfirstlane(rb_gptr[rb]) - gbase) * 256;
     }
     if (row0[0] >= row_end || (row0[nb_here - 1] + 16 <= row_begin)) return;   // (row-range calls: super blocks outside the range; row0 ascends)
     const int u0 = __builtin_amdgcn_readfirstlane(sb_uptr[sbi]), u1 = __builtin_amdgcn_readfirstlane(sb_uptr[sbi + 1]);
     if (u0 >= u1) return;   // (cannot happen: a routed block has entries)
     const int kq = lane >> 4, li = lane & 15;
-    int64_t boff[NT];
-    bool bok[NT];
+    // A: one resource over the super block's fragments; a lane's offset is 4 * lane, or far outside for a block that does not own the entry
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(rb_A + (int64_t)gbase * 64), 0, (gend - gbase) * 256, 0x00020000);
+    // B: one resource per tile = the panel that holds it; a lane's offset inside a group of 4 panel rows never changes
+    __amdgpu_buffer_rsrc_t rbp[NT];
+    int bvo[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        const int c = (tg * NT + i) * 16 + li;
-        bok[i] = c < ncols_panel;
-        const int cc = bok[i] ? c : 0;
-        const int p = cc / PW, pc = cc - p * PW;
-        boff[i] = (int64_t)p * panel_stride + pc;
+        const int c0 = (tg * NT + i) * 16;
+        const int c0c = c0 < ncols_panel ? c0 : 0;                 // (a tile beyond the panels reads tile 0's: never stored)
+        const int p = c0c / PW, pc = c0c - p * PW + li;
+        rbp[i] = __builtin_amdgcn_make_buffer_rsrc((void *)(Bp + (int64_t)p * panel_stride), 0, 0x7fffffff, 0x00020000);
+        bvo[i] = (kq * PW + (pc < PW ? pc : 0)) * 4;               // (8-column tail panel: the lanes of columns 8 .. 15 read column 0's, never stored)
     }
     rb_f32x4 acc[4][NT];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int i = 0; i < NT; ++i) acc[q][i] = rb_f32x4{0.f, 0.f, 0.f, 0.f};
-    auto load_b = [&](int c4, float (&b)[NT]) {
-        // (addresses clamped into the panels, values NOT masked: a row k >= K of the last group meets zeros in every A fragment, a
-        // column beyond the panels is never stored -- any finite value there is harmless, and an unconditional load is one the
-        // compiler can keep in flight across the MFMAs)
-        const int64_t rowoff = (int64_t)min(4 * c4 + kq, K - 1) * PW;
-#pragma unroll
-        for (int i = 0; i < NT; ++i) b[i] = Bp[boff[i] + rowoff];
-    };
-    auto load_a = [&](unsigned m, float (&a)[4]) {
+    const int lane4 = lane * 4;
+    // (rows 4 c + kq >= K of the LAST group: A holds zeros there; what is read lies inside the panel workspace -- the next panel, or the
+    // zeroed slack behind the last one, launch_rowblocks -- and is finite)
+    auto fetch = [&](int u, float (&a)[4], float (&b)[NT]) {   // entry u, or past the end: the last entry again with no owner
+        const int2 e = sb_u[min(u, u1 - 1)];
+        const unsigned m = u < u1 ? (unsigned)e.y : 0u;
+        const int bso = e.x * 16 * PW;                             // bytes from the panel's first row to row 4 c
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const unsigned bit = (m >> q) & 1u;
-            const int64_t f = bit ? fi[q] : zero_frag;
-            a[q] = rb_A[f * 64 + lane];
-            fi[q] += bit;
+            a[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, lane4 + (bit ? 0 : 0x40000000), fo[q], 0));
+            fo[q] += bit ? 256 : 0;
         }
-    };
-    // Two register sets, walked alternately, with scheduling barriers between the phases: the loads of entry u + 1 are ISSUED before the
-    // MFMAs of entry u and awaited only behind them.  (Left to itself the scheduler sinks the prefetch below the MFMAs to shorten live
-    // ranges and the loop becomes load -> wait -> 16 MFMAs, one memory latency per entry: measured 6 x the MFMA time.)
-    auto fetch = [&](int u, float (&a)[4], float (&b)[NT]) {   // entry u, or past the end: the last entry again with no owner
-        const int2 e = sb_u[min(u, u1 - 1)];
-        load_a(u < u1 ? (unsigned)e.y : 0u, a);
-        load_b(e.x, b);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) b[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbp[i], bvo[i], bso, 0));
     };
     auto multiply = [&](const float (&a)[4], const float (&b)[NT]) {
 #pragma unroll
@@ -116,13 +114,14 @@ __global__ __launch_bounds__(256) void spmm_rowblock_mfma_f32(const int *__restr
 #pragma unroll
             for (int i = 0; i < NT; ++i) acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i], a[q], acc[q][i], 0, 0, 0);
     };
-    // (a ring of four sets, three entries ahead: 24 loads in flight per wavefront.  With one entry ahead the kernel sat at 38 % MFMA
-    // busy with near-compulsory HBM traffic -- latency-bound: 3 wavefronts per SIMD x 8 loads cover ~1 500 cycles of latency)
+    // A ring of four register sets, three entries ahead (24 loads in flight per wavefront), with scheduling barriers between the phases:
+    // the loads of entry u + 3 are ISSUED before the MFMAs of entry u and awaited only three entries later.  (Left to itself the
+    // scheduler sinks a prefetch below the MFMAs to shorten live ranges and the loop becomes load -> wait -> 16 MFMAs.)
     float a0[4], b0[NT], a1[4], b1[NT], a2[4], b2[NT], a3[4], b3[NT];
     fetch(u0, a0, b0);
     fetch(u0 + 1, a1, b1);
     fetch(u0 + 2, a2, b2);
-    for (int u = u0; u < u1; u += 4) {   // (entries past the end multiply all-zero fragments: nothing changes)
+    for (int u = u0; u < u1; u += 4) {   // (entries past the end multiply zeros: nothing changes)
         fetch(u + 3, a3, b3);
         __builtin_amdgcn_sched_barrier(0);
         multiply(a0, b0);
