@@ -267,7 +267,7 @@ def main():
     # (tools/prof.sh -> profiles/*_traffic.json); only valid for the default single-GPU workload.
     # It is NOT measured in this run: the value and its provenance are reported side by side.
     traffic = traffic_source = None
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_config4_traffic.json") for r in (5, 4, 3)) if os.path.exists(q)), "")
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_config4_traffic.json") for r in (6, 5, 4, 3)) if os.path.exists(q)), "")
     if world == 1 and args.rows == 4_000_000 and args.mean_nnz == 40.0 and N == 16 and not args.opt \
             and os.path.exists(tpath):
         tj = json.load(open(tpath))
@@ -427,6 +427,10 @@ def secondaries(api, torch, dev, stream, args):
                         ("kkt_3M_rows_N16", lambda: kkt_secondary(api, torch, dev, stream, 16)),
                         ("rowmajor_kkt_3M_rows_N16", lambda: kkt_secondary(api, torch, dev, stream, 16, layout="rm")),
                         ("rowmajor_kkt_3M_rows_N128", lambda: kkt_secondary(api, torch, dev, stream, 128, layout="rm")),
+                        ("modes_strict_vs_fast_powerlaw_N16", lambda: modes_secondary(api, torch, dev, stream, "powerlaw", 16)),
+                        ("modes_strict_vs_fast_kkt_N16", lambda: modes_secondary(api, torch, dev, stream, "kkt", 16)),
+                        ("modes_strict_vs_fast_fem_4M_N128", lambda: modes_secondary(api, torch, dev, stream, "fem", 128)),
+                        ("dense_blocks_fp32_mfma_vs_valu_N128", lambda: dense_blocks_secondary(api, torch, dev, stream, 128)),
                         ("config4_matrix_N32", lambda: uniform_secondary(api, torch, dev, stream, args, 32)),
                         ("rowmajor_config4_matrix_N16", lambda: uniform_secondary(api, torch, dev, stream, args, 16, layout="rm")),
                         ("rowmajor_config4_matrix_N32", lambda: uniform_secondary(api, torch, dev, stream, args, 32, layout="rm")))
@@ -685,6 +689,66 @@ def kkt_secondary(api, torch, dev, stream, N, layout="cm"):
     out = _measure(api, torch, e, M, K, N, nnz, dev, stream, 30, layout)
     out.update(piece_path_rows=int(e.get_stat("piece_path_rows")), exact_chain_rows=int(e.get_stat("exact_chain_rows")))
     e.close()
+    for q in (p, i, v):
+        api.device_free(dev.index, q)
+    return out
+
+
+def modes_secondary(api, torch, dev, stream, which, N):
+    """SEXTANS_MODE_STRICT (default: bit-identical to cpu_spmm_CSR) and SEXTANS_MODE_FAST ("exact" 0 + "split_rows" -1: inside
+    1e-4 * (|alpha| sum|a b| + |beta c|), include/sextans_amd.h) side by side on one matrix, one engine per mode.
+    which: "powerlaw" | "kkt" | "fem"."""
+    if which == "powerlaw":
+        M = K = 1_000_000
+        p, i, v, nnz = api.gen_powerlaw_device(dev.index, M, K, 6, 120, 400_000, 7); name = "powerlaw xmin 6, tail 1.2, max 400000, seed 7"; iters = 30
+    elif which == "kkt":
+        M = K = api.kkt_rows(2_000_000, 4)
+        p, i, v, nnz = api.gen_kkt_device(dev.index, 2_000_000, 4, 3); name = "kkt 2M variables, 1M constraints, 4 borders"; iters = 30
+    else:
+        M = K = 110 ** 3 * 3
+        p, i, v, nnz = api.gen_fem3d_device(dev.index, 110, 110, 110, 3, 3); name = "fem3d 110x110x110, 3 dof/node"; iters = 10
+    out = {"matrix": name, "N": N}
+    for label, mode in (("strict", 0), ("fast", 1)):
+        e = api.Engine(dev.index)
+        e.set_option("mode", mode)
+        e.set_matrix_csr_device(M, K, nnz, p, i, v)
+        d = _measure(api, torch, e, M, K, N, nnz, dev, stream, iters)
+        out[label] = {k: d[k] for k in ("kernel", "us_per_step", "kernel_us", "gflops", "roofline_frac_kernel", "roofline_frac_step")}
+        out[label]["reassociated_rows"] = int(e.get_stat("reassociated_rows"))
+        e.close()
+    out["fast_over_strict"] = round(out["strict"]["us_per_step"] / out["fast"]["us_per_step"], 3)
+    out["roofline_frac_step"] = out["strict"]["roofline_frac_step"]          # (the headline figure of the entry is the default mode's)
+    out["roofline_frac_kernel"] = out["strict"]["roofline_frac_kernel"]
+    out["guarantee_fast"] = "|C_fast - C_ref| <= 1e-4 * (|alpha| sum|a b| + |beta c|) per element; tests/test_rowblock_mfma_gpu.py::test_mode_switch_and_its_guarantee"
+    for q in (p, i, v):
+        api.device_free(dev.index, q)
+    return out
+
+
+def dense_blocks_secondary(api, torch, dev, stream, N):
+    """"MFMA only where a tile is actually dense", fp32: kron(T_32768, dense 32 x 32) -- block tridiagonal, fully dense blocks, 1 M rows,
+    100.6 M non-zeros -- on the VALU kernels ("exact" = 0) and with its row blocks routed to v_mfma_f32_16x16x4_f32 ("mfma_dense_tiles" = 2):
+    the SAME bits (tests/test_rowblock_mfma_gpu.py), side by side."""
+    import numpy as np
+    bs = 32
+    prp = (np.arange(bs + 1) * bs).astype(np.int32); pci = np.tile(np.arange(bs, dtype=np.int32), bs)
+    n = 32768
+    p, i, v, nnz, K = api.gen_kron_device(dev.index, n, prp, pci, bs, 0, 7)
+    M = n * bs
+    out = {"matrix": "kron(T_32768, dense 32x32): block tridiagonal, fully dense fp32 blocks", "N": N}
+    for label, opts in (("valu_exact0", {"exact": 0}), ("mfma_f32_row_blocks", {"exact": 0, "mfma_dense_tiles": 2})):
+        e = api.Engine(dev.index)
+        for k, val in opts.items():
+            e.set_option(k, val)
+        e.set_matrix_csr_device(M, K, nnz, p, i, v)
+        d = _measure(api, torch, e, M, K, N, nnz, dev, stream, 20)
+        out[label] = {k: d[k] for k in ("kernel", "us_per_step", "kernel_us", "repack_us", "gflops", "roofline_frac_kernel", "roofline_frac_step", "plan_build_s")}
+        out[label]["tflops"] = round(2.0 * N * nnz / (d["us_per_step"] * 1e-6) / 1e12, 2)
+        if "mfma_dense_tiles" in opts:
+            out[label]["routed_fraction"] = round(e.get_stat("dense_tile_fraction"), 4)
+        e.close()
+    out["roofline_frac_step"] = out["valu_exact0"]["roofline_frac_step"]
+    out["roofline_frac_kernel"] = out["valu_exact0"]["roofline_frac_kernel"]
     for q in (p, i, v):
         api.device_free(dev.index, q)
     return out
