@@ -209,11 +209,9 @@ def test_device_permutation_tool_matches_the_host_one():
     import torch
     nnz = d[3]
 
-    hip = ctypes.CDLL("libamdhip64.so")
-
-    def fetch(ptr, n, dt):
+    def fetch(ptr, n, dt):   # (through the library's own HIP runtime: no second dlopen of libamdhip64 by another name)
         out = np.empty(n, np.int32 if dt == torch.int32 else np.float32)
-        assert hip.hipMemcpy(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(out.nbytes), 2) == 0   # device -> host
+        api.device_copy(0, out.ctypes.data, ptr, out.nbytes, api.COPY_D2H)
         return out
     got = (fetch(p[0], M + 1, torch.int32), fetch(p[1], nnz, torch.int32), fetch(p[2], nnz, torch.float32))
     for a, b in zip(got, want):

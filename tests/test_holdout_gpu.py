@@ -11,12 +11,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _pull(ptr, n, dt):
-    import ctypes as C
+    """Device array -> numpy, through the library's own HIP runtime (no second dlopen of libamdhip64 by another name)."""
+    import torch
+    from sextans_amd import api
     out = np.empty(n, dt)
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    assert hip.hipDeviceSynchronize() == 0
-    assert hip.hipMemcpy(out.ctypes.data, ptr, out.nbytes, 2) == 0
+    torch.cuda.synchronize()
+    api.device_copy(0, out.ctypes.data, ptr, out.nbytes, api.COPY_D2H)
     return out
 
 
