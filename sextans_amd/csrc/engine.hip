@@ -746,6 +746,31 @@ __global__ __launch_bounds__(64) void dict_overlap(const int *__restrict__ dict_
     for (int o = 32; o > 0; o >>= 1) found += __shfl_down(found, o);
     if (threadIdx.x == 0) { atomicAdd(&out[0], (unsigned long long)found); atomicAdd(&out[1], (unsigned long long)nc); }
 }
+// Share of the clustered plan's row slots that sit in runs of >= 16 consecutive rows inside their block (round 6, VERDICT r05 task 4): only
+// such runs could be written to column-major C as 64-byte pieces straight from the SpMM kernel instead of through the staging buffer.
+int run16_stat(sextans_engine *h, double *value) {
+    *value = 0.0;
+    if (h->cluster_state <= 0 || !h->d_slot_row || h->psc.plan_nblk <= 0) return SEXTANS_OK;
+    const int RB = sx::kBlock / 4 * std::max(1, h->psc.plan_sets);
+    std::vector<int> sr((size_t)h->psc.plan_nblk * RB);
+    SX_HIP(hipMemcpy(sr.data(), h->d_slot_row, sizeof(int) * sr.size(), hipMemcpyDeviceToHost));
+    const std::vector<int> &br = h->psc.h_blk_row;
+    if ((int)br.size() != h->psc.plan_nblk + 1) return SEXTANS_OK;
+    int64_t in_runs = 0, slots = 0;
+    for (int b = 0; b < h->psc.plan_nblk; ++b) {
+        const int n = br[(size_t)b + 1] - br[(size_t)b];
+        const int *r = sr.data() + (size_t)b * RB;
+        slots += n;
+        for (int i = 0; i < n;) {
+            int j = i + 1;
+            while (j < n && r[j] == r[j - 1] + 1) ++j;
+            if (j - i >= 16) in_runs += j - i;
+            i = j;
+        }
+    }
+    *value = slots ? (double)in_runs / (double)slots : 0.0;
+    return SEXTANS_OK;
+}
 int dict_overlap_stat(sextans_engine *h, double *value) {
     const sextans_engine::PanelState &P = h->cluster_state > 0 ? h->psc : h->ps;
     *value = 0.0;
@@ -787,6 +812,7 @@ int sextans_get_stat(sextans_handle_t h, const char *key, double *value) {
     else if (!strcmp(key, "cluster_shared_fraction")) *value = h->cluster_shared;
     else if (!strcmp(key, "cluster_decline")) *value = (double)h->cluster_decline;
     else if (!strcmp(key, "graph_fallbacks")) *value = (double)h->graph_fallbacks;   // rp_time loops launched one by one because their hipGraph capture was invalidated from outside
+    else if (!strcmp(key, "cluster_run16_fraction")) return run16_stat(h, value);   // share of the clustered plan's slots in runs of >= 16 consecutive rows of their block
     else if (!strcmp(key, "dict_overlap_consecutive")) return dict_overlap_stat(h, value);   // share of a block's dictionary rows the previous block of the walk holds too (the plan whole-matrix calls use)
     else if (!strcmp(key, "dist_setup_exchanges")) *value = (double)h->dist_exchanges;   // control collectives + host syncs of the dist entry points so far (0 new ones after sextans_dist_prepare)
     else if (!strcmp(key, "cluster_graph_kind")) *value = (double)h->cluster_graph_kind;

@@ -19,6 +19,7 @@ def cases():
     M, K, p, i, v, nnz = holdout.kron_device(0, 850, "", "random"); yield "holdout random numbering", M, K, p, i, v, nnz
     M = K = 110 ** 3 * 3; p, i, v, nnz = api.gen_fem3d_device(0, 110, 110, 110, 3, 3); yield "fem3d 110^3 x 3 natural", M, K, p, i, v, nnz
     q = api.permute_symmetric_device(0, M, nnz, p, i, v, meshgen.node_permutation(M // 3, 3, 1)); yield "fem3d 110^3 x 3 random node order", M, K, q[0], q[1], q[2], nnz
+    M, K, p, i, v, nnz = holdout.kron_device(0, 850, "", "rcm"); yield "holdout RCM numbering", M, K, p, i, v, nnz
 
 
 for name, M, K, p, i, v, nnz in cases():
@@ -28,6 +29,7 @@ for name, M, K, p, i, v, nnz in cases():
         e.prepare(16, rowmajor=rm)
         print(json.dumps({"matrix": name, "prepare": "row-major" if rm else "column-major", "row_cluster": int(e.get_stat("row_cluster")),
                           "dict_overlap_consecutive": round(e.get_stat("dict_overlap_consecutive"), 4),
+                          "cluster_run16_fraction": round(e.get_stat("cluster_run16_fraction"), 4),
                           "panel_rows_natural": int(e.get_stat("panel_rows_natural")), "panel_rows_clustered": int(e.get_stat("panel_rows_clustered")),
                           "blocks": int(e.get_stat("panel_blocks_clustered") if e.get_stat("row_cluster") > 0 else e.get_stat("panel_blocks"))}), flush=True)
         e.close()
