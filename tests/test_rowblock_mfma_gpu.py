@@ -178,6 +178,11 @@ def test_mode_switch_and_its_guarantee(sx, oracle):
     rp, ci, v = random_csr(rs, 3000, 2500, 11, long_rows=2); cases.append(("random", rp, ci, v, 3000, 2500))
     rp, ci, v = api.gen_powerlaw_host(40_000, 40_000, 4, 120, 30_000, 3); cases.append(("power law", rp, ci, v, 40_000, 40_000))
     rp, ci, v = api.gen_fem3d_host(12, 10, 8, 6, 2); M = K = 12 * 10 * 8 * 6; cases.append(("fem 6 dof", rp, ci, v, M, K))
+    rp, ci, v = api.gen_stencil2d_host(120, 110, 5, 1, 4); cases.append(("5-point stencil (lane-per-row kernel)", rp, ci, v, 120 * 110, 120 * 110))
+    frp, fci, fv = api.gen_fem3d_host(14, 12, 10, 3, 8); Mf = 14 * 12 * 10 * 3                      # mixed plan: mesh rows + rows without reuse
+    rrp, rci, rv = random_csr(rs, 2000, Mf, 30)
+    cases.append(("mixed plan", np.concatenate([frp, frp[-1] + rrp[1:]]).astype(np.int32), np.concatenate([fci, rci]).astype(np.int32),
+                  np.concatenate([fv, rv]).astype(np.float32), Mf + 2000, Mf))
     with sx.Engine(0) as e:
         assert e.get_option("mode") == 0
         e.set_option("mode", 1)
