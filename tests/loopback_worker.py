@@ -306,7 +306,62 @@ def scenario_errors(world):
     return f"all {world} ranks saw the failure of rank {bad_rank} ({res}) and recovered"
 
 
+def scenario_config4_full(world):
+    """BASELINE config 4 AS STATED -- synthetic 4M x 4M CSR, ~1.6e8 non-zeros, N = 16, A row-split over `world` ranks (nnz-balanced ranges), B
+    replicated, all-gather of C -- at FULL SIZE, the ranks as threads on one GPU: every rank's complete C (column-major entry, 4 chunks;
+    row-major entry, in place) bit-identical to the single-engine result of the same matrix, which tests/test_configs_gpu.py holds to the
+    oracle on every row."""
+    import torch
+    from sextans_amd import api, dist as sxd
+    M = K = 4_000_000
+    N = 16
+    torch.cuda.set_device(0)
+    st0 = torch.cuda.current_stream().cuda_stream
+    B = torch.empty(K * N, device="cuda"); Cin = torch.empty(M * N, device="cuda")
+    api.gen_uniform_device(0, B.data_ptr(), K * N, 41, st0); api.gen_uniform_device(0, Cin.data_ptr(), M * N, 42, st0)
+    p, i, v, nnz = api.gen_csr_device(0, M, K, 40.0, 4)
+    hrp = np.empty(M + 1, np.int32)
+    api.device_copy(0, hrp.ctypes.data, p, hrp.nbytes, api.COPY_D2H)
+    ranges = sxd.partition_rows_by_nnz(hrp, world)
+    whole = torch.empty(M * N, device="cuda"); whole_rm = torch.empty(M * N, device="cuda")
+    with api.Engine(0) as e:
+        e.set_matrix_csr_device(M, K, nnz, p, i, v)
+        e.spmm_device(N, ALPHA, B.data_ptr(), K, BETA, Cin.data_ptr(), whole.data_ptr(), M, st0)
+        e.spmm_device_rm(N, ALPHA, B.data_ptr(), N, BETA, Cin.data_ptr(), N, whole_rm.data_ptr(), N, st0)   # (the same buffers read as row-major operands)
+        torch.cuda.synchronize()
+    for q in (p, i, v):
+        api.device_free(0, q)
+
+    def rank_fn(rank, comm, st):
+        r0, r1 = ranges[rank]
+        lp, li, lv, lnnz = api.gen_csr_device(0, M, K, 40.0, 4, r0, r1)   # the counter-based generator yields any row range
+        ok = {}
+        try:
+            with api.Engine(0) as e:
+                e.set_matrix_csr_device(r1 - r0, K, lnnz, lp, li, lv)
+                out = torch.full((M * N,), float("nan"), device="cuda")
+                e.dist_prepare(comm, world, rank, ranges, N, nchunks=4, form=0, stream=st)
+                e.dist_spmm(comm, world, rank, ranges, N, ALPHA, B.data_ptr(), K, BETA, Cin.data_ptr(), M, out.data_ptr(), M, nchunks=4, stream=st)
+                torch.cuda.current_stream().synchronize()
+                ok["colmajor"] = bool(torch.equal(out, whole))
+                out.fill_(float("nan"))
+                e.dist_prepare(comm, world, rank, ranges, N, form=1, stream=st)
+                e.dist_spmm_rm(comm, world, rank, ranges, N, ALPHA, B.data_ptr(), N, BETA, Cin.data_ptr(), N, out.data_ptr(), N, stream=st)
+                torch.cuda.current_stream().synchronize()
+                ok["rowmajor"] = bool(torch.equal(out, whole_rm))
+                ok["kernel"] = e.last_kernel()
+        finally:
+            for q in (lp, li, lv):
+                api.device_free(0, q)
+        return ok
+
+    res = Ranks(world).run(rank_fn, timeout=1500)
+    assert all(r["colmajor"] and r["rowmajor"] for r in res), res
+    return f"config 4 at full size ({nnz} non-zeros) over {world} ranks, ranges {ranges[:2]} ...: every rank's C bit-identical to one engine holding every row ({res[0]['kernel']})"
+
+
 SCENARIOS = {
+    "config4_full": scenario_config4_full,
     "colmajor": scenario_colmajor,
     "colmajor_clustered": lambda w: scenario_colmajor(w, clustered=True),
     "rowmajor": scenario_rowmajor,
