@@ -360,7 +360,47 @@ def scenario_config4_full(world):
     return f"config 4 at full size ({nnz} non-zeros) over {world} ranks, ranges {ranges[:2]} ...: every rank's C bit-identical to one engine holding every row ({res[0]['kernel']})"
 
 
+def scenario_config5_full(world):
+    """BASELINE config 5 at full size (blocked-ELL 1M x 1M, 32x32 bf16 blocks, 1 % block fill, N = 256) over `world` block-row ranges:
+    sextans_dist_spmm_bell on every rank, complete C bit-identical to the single-engine call ("Config 5 likewise")."""
+    import torch
+    from sextans_amd import api
+    M = K = 1_048_576
+    W, N = 328, 256
+    torch.cuda.set_device(0)
+    st0 = torch.cuda.current_stream().cuda_stream
+    dc, dv = api.gen_bell_device(0, M, K, W, 5)
+    B = torch.empty(K * N, dtype=torch.int16, device="cuda"); Cin = torch.empty(M * N, device="cuda")
+    api.gen_uniform_bf16_device(0, B.data_ptr(), K * N, 51, st0); api.gen_uniform_device(0, Cin.data_ptr(), M * N, 52, st0)
+    whole = torch.empty(M * N, device="cuda")
+    with api.Engine(0) as e:
+        e.set_matrix_bell_device(M, K, W, dc, dv)
+        e.spmm_bell_device(N, ALPHA, B.data_ptr(), K, BETA, Cin.data_ptr(), whole.data_ptr(), M, st0)
+        torch.cuda.synchronize()
+    nbr = M // 32
+    cuts = [nbr * g // world for g in range(world)] + [nbr]
+    cuts[1] -= 3                                            # unequal ranges: slabs padded to the longest
+    rg = [(cuts[g] * 32, cuts[g + 1] * 32) for g in range(world)]
+
+    def rank_fn(rank, comm, st):
+        b0, b1 = rg[rank]
+        with api.Engine(0) as e:
+            e.set_matrix_bell_device(b1 - b0, K, W, dc + (b0 // 32) * W * 4, dv + (b0 // 32) * W * 2048)
+            out = torch.full((M * N,), float("nan"), device="cuda")
+            e.dist_prepare(comm, world, rank, rg, N, form=2, stream=st)
+            e.dist_spmm_bell(comm, world, rank, rg, N, ALPHA, B.data_ptr(), K, BETA, Cin.data_ptr(), M, out.data_ptr(), M, stream=st)
+            torch.cuda.current_stream().synchronize()
+            return bool(torch.equal(out, whole))
+
+    res = Ranks(world).run(rank_fn, timeout=1500)
+    for q in (dc, dv):
+        api.device_free(0, q)
+    assert all(res), res
+    return f"config 5 at full size over {world} block-row ranges: every rank's C bit-identical to the single-engine result"
+
+
 SCENARIOS = {
+    "config5_full": scenario_config5_full,
     "config4_full": scenario_config4_full,
     "colmajor": scenario_colmajor,
     "colmajor_clustered": lambda w: scenario_colmajor(w, clustered=True),

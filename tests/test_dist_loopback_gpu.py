@@ -71,6 +71,12 @@ def test_config4_as_stated_row_split_over_8_ranks_at_full_size(sx):
     _run("config4_full", 8, timeout=1800)
 
 
+def test_config5_block_row_ranges_over_8_ranks_at_full_size(sx):
+    """BASELINE config 5 (blocked-ELL 1M x 1M, 1 % block fill, N = 256, bf16 MFMA path) in 8 unequal block-row ranges: every
+    rank's complete fp32 C bit-identical to the single-engine call -- same wavefront code on the same operands."""
+    _run("config5_full", 8, timeout=1800)
+
+
 def test_cpp_example_with_ranks_on_one_device(sx):
     """examples/dist_spmm.cpp (no Python, no torch in the data path) with 3 and 8 ranks as threads on device 0 over the loopback
     communicator: column-major and row-major forms against the single-GPU result."""
