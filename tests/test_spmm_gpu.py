@@ -394,6 +394,10 @@ def test_cli_canonical_run(sx):
     r = subprocess.run([sx.api.CLI_PATH, NASA, "100", "5", "1.25", "0.5"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "N = 104" in r.stdout and "Success!" in r.stdout
     assert "num_mismatch = 0" in r.stdout
+    # SEXTANS_MODE=fast (round 6): the documented in-tolerance mode through the same program; the reference's own criterion still passes
+    r = subprocess.run([sx.api.CLI_PATH, os.path.join(CASES, "real_general.mtx"), "24", "3"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, SEXTANS_MODE="fast"))
+    assert r.returncode == 0 and "Success!" in r.stdout, r.stdout + r.stderr
 
 
 def test_invalid_csr_is_rejected_not_dereferenced(engine, sx):
