@@ -471,6 +471,7 @@ static int64_t *option_slot(sextans_handle_t h, const char *key) {
     if (!strcmp(key, "bell_shared")) return &h->opt_bell_shared;
     if (!strcmp(key, "bell_debug")) return &h->opt_bell_debug;
     if (!strcmp(key, "dist_broadcast_runs")) return &h->opt_dist_broadcast_runs;
+    if (!strcmp(key, "rowblock_tiles")) return &h->opt_rb_tiles;
     if (!strcmp(key, "mfma_dense_tiles")) return &h->opt_mfma_dense;
     if (!strcmp(key, "dense_tile_fill_x100")) return &h->opt_dense_fill_x100;
     return nullptr;
@@ -495,7 +496,7 @@ int sextans_set_option(sextans_handle_t h, const char *key, int64_t value) {
     // row order, per-phase cycle counters -- are not part of the drop-in surface: they exist only for processes started with
     // SEXTANS_DEBUG_OPTIONS=1 (tools/), and a value other than the default is refused otherwise.
     if (slot == &h->opt_bell_debug || slot == &h->opt_cluster_shape || slot == &h->opt_cluster_group || slot == &h->opt_phase_timing || slot == &h->opt_reordered_xcd ||
-        slot == &h->opt_dist_broadcast_runs) {
+        slot == &h->opt_dist_broadcast_runs || slot == &h->opt_rb_tiles) {
         const char *dbg = getenv("SEXTANS_DEBUG_OPTIONS");
         if (!(dbg && dbg[0] == '1') && value != *slot) {
             g_last_error = std::string("option \"") + key + "\" is a measurement switch: set SEXTANS_DEBUG_OPTIONS=1 in the environment to use it";

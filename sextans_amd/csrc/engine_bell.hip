@@ -209,8 +209,10 @@ int launch_rowblocks(sextans_engine *h, const std::vector<Seg> &plan, const floa
                                (const int2 *)h->d_sb_ucol, h->d_rb_A, bp, (int64_t)h->K * g.width, g.width, h->K, cin, ldc_in, cout, ldc, h->rb_n, h->sb_n,
                                tgs, ncols_panel, ncols, row_begin, row_end, alpha, beta);
         };
-        // (a wavefront owns 64 rows x 16 NT columns of C: 16 NT accumulator registers)
-        if (tiles16 >= 4) go(sx::spmm_rowblock_mfma_f32<4>, 4);
+        // (a wavefront owns 64 rows x 16 NT columns of C: 16 NT accumulator registers.  NT = 2 = 4 wavefronts per SIMD measured 2 - 4 % ahead of
+        // NT = 4 = 2 per SIMD on the dense-block matrix at N = 64 .. 256 -- occupancy over B-fragment reuse; "rowblock_tiles" forces 1 / 4)
+        if (tiles16 >= 4 && h->opt_rb_tiles == 4) go(sx::spmm_rowblock_mfma_f32<4>, 4);
+        else if (h->opt_rb_tiles == 1) go(sx::spmm_rowblock_mfma_f32<1>, 1);
         else if (tiles16 >= 2) go(sx::spmm_rowblock_mfma_f32<2>, 2);
         else go(sx::spmm_rowblock_mfma_f32<1>, 1);
     }

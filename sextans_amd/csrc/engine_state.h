@@ -293,6 +293,7 @@ struct sextans_engine {
     int64_t opt_bell_shared = -1;       // N = 256: workgroups of 8 block rows share each B tile through an LDS ring
                                         // (spmm_bell_mfma_shared).  1 = always, 0 = never, -1 = when the 8 block rows of a
                                         // workgroup share block columns (blocks per distinct column >= 1.5)
+    int64_t opt_rb_tiles = 0;           // measurements only: tiles of 16 columns per wavefront of the fp32 row-block MFMA kernel (0 = 4 where N allows)
     int64_t opt_mode = 0;               // SEXTANS_MODE_* as last set through option "mode"
     int64_t opt_dist_broadcast_runs = 0;   // measurements / tests only: sextans_dist_spmm_rm exchanges ranges of EQUAL length by grouped broadcasts too
     int64_t opt_bell_debug = 0;         // measurements only (wrong results): ablation bits of spmm_bell_mfma_shared

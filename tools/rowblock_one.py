@@ -27,10 +27,17 @@ else:
 e = api.Engine(0)
 for k, val in dict(exact=0, dense_tile_fill_x100=thr, mfma_dense_tiles=2).items():
     e.set_option(k, val)
+if len(sys.argv) > 4:   # measurement switch (SEXTANS_DEBUG_OPTIONS=1): tiles of 16 columns per wavefront
+    e.set_option("rowblock_tiles", int(sys.argv[4]))
 e.set_matrix_csr_device(M, K, nnz, p, i, v)
 B = torch.empty(K * N, device="cuda"); Cin = torch.empty(M * N, device="cuda"); Cout = torch.empty(M * N, device="cuda")
 api.gen_uniform_device(0, B.data_ptr(), K * N, 41, st); api.gen_uniform_device(0, Cin.data_ptr(), M * N, 42, st)
 for _ in range(6):
     e.spmm_device(N, 0.85, B.data_ptr(), K, -2.06, Cin.data_ptr(), Cout.data_ptr(), M, st)
 torch.cuda.synchronize()
-print(e.last_kernel(), e.get_stat("dense_tile_fraction"))
+import time
+t0 = time.perf_counter()
+for _ in range(20):
+    e.spmm_device(N, 0.85, B.data_ptr(), K, -2.06, Cin.data_ptr(), Cout.data_ptr(), M, st)
+torch.cuda.synchronize()
+print(e.last_kernel(), e.get_stat("dense_tile_fraction"), "us_per_step", round((time.perf_counter() - t0) / 20 * 1e6, 1))
