@@ -310,7 +310,7 @@ int sextans_destroy(sextans_handle_t h);
  * "bell_shared" (blocked-ELL, N = 256: -1 = use the union-walk kernel spmm_bell_mfma_shared when 8 consecutive block rows
  * share block columns, stat "bell_share" >= 1.5; 0 never; 1 whenever the unions fit), "bell_debug" (measurements only:
  * ablation bits of that kernel, results are wrong when non-zero).  Unknown keys -> SEXTANS_ERR_INVALID.
- * MEASUREMENT SWITCHES -- "bell_debug", "cluster_shape", "cluster_group", "phase_timing", "reordered_xcd" -- are not part of the drop-in surface:
+ * MEASUREMENT SWITCHES -- "bell_debug", "cluster_shape", "cluster_group", "phase_timing", "reordered_xcd", "dist_broadcast_runs", "rowblock_tiles" -- are not part of the drop-in surface:
  * setting one to anything but its default returns SEXTANS_ERR_INVALID unless the process runs with SEXTANS_DEBUG_OPTIONS=1 in
  * its environment (tools/ do; "bell_debug" corrupts C on purpose). */
 /* "mfma_dense_tiles" / "dense_tile_fill_x100": north_star's "MFMA only where a tile is actually dense".  The engine
