@@ -125,8 +125,26 @@ def test_random_plan_forms_are_bit_identical(engine, oracle, seed):
             if os.environ.get("SEXTANS_FUZZ_VERBOSE"):
                 print(f"[fuzz] {name} N={N} rc={opts['row_cluster']}: {engine.last_kernel()} state={int(engine.get_stat('row_cluster'))} "
                       f"sets={int(engine.get_stat('row_sets'))} idx/val={engine.get_stat('index_stream_entries') / max(engine.get_stat('value_stream_entries'), 1):.2f}")
+            if trial == 3:
+                # Round 6: the SAME plan form with fused multiply-adds ("exact" = 0, the arithmetic of SEXTANS_MODE_FAST; rows stay whole, so
+                # nothing is re-associated) -- bit-identical to the oracle's fmaf chain whatever kernel the options selected, with and without
+                # dense row blocks routed to the fp32 matrix cores, through both entry points.
+                want_fma = C0.copy()
+                oracle.spmm_fma(M, N, K, ALPHA, rp, ci, v, B, BETA, want_fma)
+                engine.set_option("exact", 0)
+                for tiles in (0, 2):
+                    engine.set_option("dense_tile_fill_x100", int(rs.choice([20, 35, 50])))
+                    engine.set_option("mfma_dense_tiles", tiles)
+                    out = C0.copy()
+                    engine.spmm(N, ALPHA, B, BETA, out)
+                    assert np.array_equal(out.view(np.uint32), want_fma.view(np.uint32)), (name, N, opts, "exact=0", tiles, engine.last_kernel())
+                    to.fill_(-3.0)
+                    engine.spmm_device_rm(N, float(ALPHA), tb.data_ptr(), ldb, float(BETA), ti.data_ptr(), ldi, to.data_ptr(), ldo, torch.cuda.current_stream().cuda_stream)
+                    torch.cuda.synchronize()
+                    got = np.ascontiguousarray(to[:, :N].cpu().numpy().T).reshape(-1)
+                    assert np.array_equal(got.view(np.uint32), want_fma.view(np.uint32)), (name, N, opts, "exact=0 row-major", tiles, engine.last_kernel())
     finally:
-        for k, val in DEFAULTS.items():
+        for k, val in dict(DEFAULTS, exact=1, mfma_dense_tiles=0, dense_tile_fill_x100=50).items():
             engine.set_option(k, val)
 
 
