@@ -278,10 +278,15 @@ def _rccl_worker(rank, world, port, q):
                 dist.broadcast_object_list(ids, src=0)
                 comm = api.dist_comm_init(rank, world, rank, ids[0])
                 out = torch.full((M * N,), float("nan"), device=dev)
+                if mode == "nnz":   # (round 6: the collective preparation over real RCCL; the even-rows leg keeps the lazy path)
+                    e.dist_prepare(comm, world, rank, ranges, N, nchunks=3, form=0, stream=st)
+                    x0 = e.get_stat("dist_setup_exchanges")
                 e.dist_spmm(comm, world, rank, ranges, N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr(), M, out.data_ptr(), M,
                             nchunks=3, stream=st)
                 torch.cuda.synchronize()
                 ok["native_" + mode] = bool(np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)))
+                if mode == "nnz":
+                    ok["prepared_call_exchanged_nothing"] = e.get_stat("dist_setup_exchanges") == x0
                 # row-major operands: slabs written in place, in-place all-gather (equal ranges) / grouped broadcasts (nnz-balanced)
                 want_rm = np.ascontiguousarray(want.reshape(N, M).T)
                 dBr = torch.from_numpy(np.ascontiguousarray(B.reshape(N, K).T)).to(dev)
