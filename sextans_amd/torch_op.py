@@ -33,7 +33,7 @@ def clear_cache():
         _evict(key)
 
 
-def _engine_for(A, dev):
+def _engine_for(A, dev, fast=False):
     """One engine per sparse matrix, at most _MAX_ENGINES of them (LRU: every entry pins an engine with its device
     workspaces).  The key holds the addresses AND the version counters of A's three tensors, so an in-place update
     of A gets a fresh engine (the packed forms snapshot the values); tensors without version counters (inference mode)
@@ -48,7 +48,7 @@ def _engine_for(A, dev):
         except RuntimeError:
             return None
     vers = (ver(crow), ver(col), ver(val))
-    key = (dev, crow.data_ptr(), col.data_ptr(), val.data_ptr(), vers, M, K, val.numel())
+    key = (dev, crow.data_ptr(), col.data_ptr(), val.data_ptr(), vers, M, K, val.numel(), bool(fast))
     # Without version counters an in-place update of A (same storage, same addresses) cannot be told from no update, and the
     # packed forms snapshot the values: such matrices are never served from the cache -- a stale entry under the same
     # addresses is dropped and the engine is rebuilt on every call.
@@ -62,6 +62,8 @@ def _engine_for(A, dev):
     crow32, col32 = crow.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
     val32 = val.to(torch.float32).contiguous()
     eng = api.Engine(dev)
+    if fast:   # SEXTANS_MODE_FAST: FMA + re-associated hub rows, |d| <= 1e-4 * (|alpha| sum|a b| + |beta c|); the default is bit identity with cpu_spmm_CSR
+        eng.set_option("mode", 1)
     eng.set_matrix_csr_device(M, K, val32.numel(), crow32.data_ptr(), col32.data_ptr(), val32.data_ptr())
     _cache[key] = (eng, (crow32, col32, val32), (crow, col, val))   # the engine does not copy: keep its arrays alive
     while len(_cache) > _MAX_ENGINES:
@@ -79,8 +81,10 @@ def _rowmajor(t, rows, cols, colsp):
     return out
 
 
-def spmm(A, B, alpha=1.0, beta=0.0, C=None, out=None):
-    """out (optional): an (M, N) fp32 row-major tensor that receives the result (N % 8 == 0); may be C itself (in place)."""
+def spmm(A, B, alpha=1.0, beta=0.0, C=None, out=None, fast=False):
+    """out (optional): an (M, N) fp32 row-major tensor that receives the result (N % 8 == 0); may be C itself (in place).
+    fast (round 6): the engine's documented in-tolerance mode (include/sextans_amd.h, SEXTANS_MODE_FAST) instead of bit identity with the
+    reference's cpu_spmm_CSR; a matrix used in both modes keeps one engine per mode."""
     if A.layout != torch.sparse_csr or not A.is_cuda or not B.is_cuda:
         raise TypeError("spmm expects a CUDA/HIP torch.sparse_csr matrix and a CUDA/HIP dense B")
     M, K = A.shape
@@ -89,7 +93,7 @@ def spmm(A, B, alpha=1.0, beta=0.0, C=None, out=None):
     N = B.shape[1]
     Np = api.round_up_n(N)
     dev = A.device.index or 0
-    eng = _engine_for(A, dev)
+    eng = _engine_for(A, dev, fast)
     Brm = _rowmajor(B, K, N, Np)
     if C is not None and beta != 0.0:
         if tuple(C.shape) != (M, N):

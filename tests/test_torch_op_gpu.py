@@ -104,3 +104,28 @@ def test_engine_cache_follows_the_matrix(sx, oracle):
     for a in keep:
         check(*a, B)
     assert len(torch_op._cache) <= torch_op._MAX_ENGINES
+
+
+def test_op_fast_mode_matches_the_fma_chain(sx, oracle):
+    """Round 6: spmm(..., fast=True) = SEXTANS_MODE_FAST.  On a matrix without hub rows nothing is re-associated, so the result is the
+    oracle's fmaf chain bit for bit; the strict engine of the same matrix stays cached beside it and stays bit-identical to cpu_spmm_CSR."""
+    import torch
+    from sextans_amd import api, torch_op
+    rp, ci, v = api.gen_fem3d_host(14, 13, 12, 3, 7)
+    M = K = 14 * 13 * 12 * 3
+    N = 32
+    A = torch.sparse_csr_tensor(torch.from_numpy(rp.astype(np.int64)), torch.from_numpy(ci.astype(np.int64)), torch.from_numpy(v), size=(M, K)).cuda()
+    rs = np.random.RandomState(2)
+    B = rs.uniform(-1, 1, (K, N)).astype(np.float32); C0 = rs.uniform(-1, 1, (M, N)).astype(np.float32)
+    alpha, beta = np.float32(0.85), np.float32(-2.06)
+    Bc, Cc = np.ascontiguousarray(B.T).reshape(-1), np.ascontiguousarray(C0.T).reshape(-1)
+    strict = Cc.copy(); oracle.spmm(M, N, K, alpha, rp, ci, v, Bc, beta, strict)
+    fma = Cc.copy(); oracle.spmm_fma(M, N, K, alpha, rp, ci, v, Bc, beta, fma)
+    torch_op.clear_cache()
+    tB, tC = torch.from_numpy(B).cuda(), torch.from_numpy(C0).cuda()
+    g_fast = torch_op.spmm(A, tB, float(alpha), float(beta), tC, fast=True).cpu().numpy()
+    g_strict = torch_op.spmm(A, tB, float(alpha), float(beta), tC).cpu().numpy()
+    assert len(torch_op._cache) == 2
+    assert np.array_equal(np.ascontiguousarray(g_fast.T).reshape(-1).view(np.uint32), fma.view(np.uint32))
+    assert np.array_equal(np.ascontiguousarray(g_strict.T).reshape(-1).view(np.uint32), strict.view(np.uint32))
+    torch_op.clear_cache()
