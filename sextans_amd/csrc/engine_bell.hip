@@ -31,6 +31,10 @@ void free_bell(sextans_engine *h) {
 int build_rowblocks(sextans_engine *h) {
     const int nb = h->M / 16;
     if (nb == 0 || h->nnz == 0) return SEXTANS_OK;
+    if (h->K > (1 << 24)) {   // (the kernel's buffer resources span one B panel: K x 32 floats must stay below 2^31 bytes)
+        g_last_error = "mfma_dense_tiles = 2: K > 2^24; rows stay on the fp32 CSR kernels";
+        return SEXTANS_OK;
+    }
     PlanTimer timer(h);
     std::vector<int> rp, ci;
     std::vector<float> va;
@@ -189,12 +193,6 @@ int mark_rowblock_skip(sextans_engine *h) {
 // The routed blocks of [row_begin, row_end) over the B panels the main path has just laid out (`plan` = the segments of d_Bp).
 int launch_rowblocks(sextans_engine *h, const std::vector<Seg> &plan, const float *d_C_in, int64_t ldc_in, float *d_C_out, int64_t ldc, int N, int row_begin,
                      int row_end, float alpha, float beta, hipStream_t s) {
-    if (h->K % 4) {
-        // the last column group reads up to 3 panel rows past row K - 1: inside the workspace that is the next panel (finite values, met by
-        // zeros of A), behind the LAST panel it is the slack prepare() allocates for this -- zeroed here (uninitialised memory may hold NaNs)
-        const size_t n16 = (size_t)((N + 15) / 16) * 16;
-        if (h->Bp_cap >= (size_t)h->K * n16 + 128) SX_HIP(hipMemsetAsync(h->d_Bp + (size_t)h->K * n16, 0, 128 * sizeof(float), s));
-    }
     for (const Seg &g : plan) {
         const int ncols_panel = g.ntiles * g.width;
         const int ncols = std::min(N - g.col0, g.last_cols ? (g.ntiles - 1) * g.width + g.last_cols : ncols_panel);

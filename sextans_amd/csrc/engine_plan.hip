@@ -1083,10 +1083,8 @@ int prepare(sextans_engine *h, int N, std::vector<Seg> &plan, int &W, bool &use_
     }
     const size_t n16 = (size_t)((N + 15) / 16) * 16;   // (N = 16 t + 8: room for the tail as a zero-padded 16-column tile)
     if (!h->lean_prepare && (h->Bp_cap < (size_t)h->K * n16 || !h->d_Bp)) h->bp_layout = 0;   // new workspace: nothing to reuse
-    // (+ 128 floats when blocks are routed to the fp32 matrix cores: the last column group of a K that is no multiple of 4 reads up to three
-    // 32-float panel rows past the last panel -- launch_rowblocks zeroes that slack)
     if (!h->lean_prepare)
-        if (int rc = ensure(&h->d_Bp, &h->Bp_cap, (size_t)h->K * n16 + (h->rb_n > 0 ? 128 : 0))) return rc;
+        if (int rc = ensure(&h->d_Bp, &h->Bp_cap, (size_t)h->K * n16)) return rc;
     // main tile width: 4*lanes_per_row, but never wider than N itself (N = 8 -> 2 lanes per row); then
     // 16- and 8-wide tiles for the remainder (N is a multiple of 8, the reference's N-tile
     // granularity: sextans.cpp:57-60).

@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void spmm_rowblock_mfma_f32(const int *__restr
         const int c0 = (tg * NT + i) * 16;
         const int c0c = c0 < ncols_panel ? c0 : 0;                 // (a tile beyond the panels reads tile 0's: never stored)
         const int p = c0c / PW, pc = c0c - p * PW + li;
-        rbp[i] = __builtin_amdgcn_make_buffer_rsrc((void *)(Bp + (int64_t)p * panel_stride), 0, 0x7fffffff, 0x00020000);
+        // (the resource ends with the panel: the rows 4 c + kq >= K of the LAST group of a K that is no multiple of 4 read as 0 -- behind row
+        // K - 1 lies the next panel, or memory no repack ever wrote, and 0 x NaN would not be 0)
+        rbp[i] = __builtin_amdgcn_make_buffer_rsrc((void *)(Bp + (int64_t)p * panel_stride), 0, K * PW * 4, 0x00020000);
         bvo[i] = (kq * PW + (pc < PW ? pc : 0)) * 4;               // (8-column tail panel: the lanes of columns 8 .. 15 read column 0's, never stored)
     }
     rb_f32x4 acc[4][NT];
@@ -93,12 +95,10 @@ __global__ __launch_bounds__(256) void spmm_rowblock_mfma_f32(const int *__restr
 #pragma unroll
         for (int i = 0; i < NT; ++i) acc[q][i] = rb_f32x4{0.f, 0.f, 0.f, 0.f};
     const int lane4 = lane * 4;
-    // (rows 4 c + kq >= K of the LAST group: A holds zeros there; what is read lies inside the panel workspace -- the next panel, or the
-    // zeroed slack behind the last one, launch_rowblocks -- and is finite)
     auto fetch = [&](int u, float (&a)[4], float (&b)[NT]) {   // entry u, or past the end: the last entry again with no owner
         const int2 e = sb_u[min(u, u1 - 1)];
         const unsigned m = u < u1 ? (unsigned)e.y : 0u;
-        const int bso = e.x * 16 * PW;                             // bytes from the panel's first row to row 4 c
+        const int bso = e.x * 16 * PW;                             // bytes from the panel's first row to row 4 c (added to the lane offset: the range check sees it)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const unsigned bit = (m >> q) & 1u;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void spmm_rowblock_mfma_f32(const int *__restr
             fo[q] += bit ? 256 : 0;
         }
 #pragma unroll
-        for (int i = 0; i < NT; ++i) b[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbp[i], bvo[i], bso, 0));
+        for (int i = 0; i < NT; ++i) b[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbp[i], bvo[i] + bso, 0, 0));
     };
     auto multiply = [&](const float (&a)[4], const float (&b)[NT]) {
 #pragma unroll

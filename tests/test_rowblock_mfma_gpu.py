@@ -224,3 +224,31 @@ def test_mode_switch_and_its_guarantee(sx, oracle):
                 assert float(np.max(np.abs(fr.astype(np.float64) - pinned) / bound)) <= 1.0, (name, N, e.last_kernel())
         print(f"SEXTANS_MODE_FAST: worst |fast - cpu_spmm_CSR| / (1e-4 * (|alpha| sum|a b| + |beta c|)) = {worst:.2e}")
         assert worst < 0.05      # fp32 roundoff of another fp32 summation: orders of magnitude inside the guarantee
+
+
+@pytest.mark.parametrize("K", [37, 38, 39, 64])
+def test_last_column_group_of_a_K_that_is_no_multiple_of_4(sx, oracle, K):
+    """A group covers 4 consecutive columns; the last group of K = 4 k + r reaches past row K - 1 of a B panel -- into the next panel or into
+    workspace memory no repack ever wrote.  The kernel's buffer resources end with the panel, so those rows read as 0 (0 x NaN would not be 0):
+    the workspace is first filled with NaNs by a wider call on a NaN B, then the real call must still give the fmaf chain bit for bit."""
+    rs = np.random.RandomState(K)
+    M = 80
+    dense = rs.rand(M, K) < 0.8
+    dense[:, K - 1] = True                                    # the last column is used by every row
+    rp = np.zeros(M + 1, np.int32); rp[1:] = np.cumsum(dense.sum(1))
+    ci = np.concatenate([np.nonzero(dense[r])[0] for r in range(M)]).astype(np.int32)
+    v = rs.uniform(-1, 1, len(ci)).astype(np.float32)
+    N = 24
+    B = rs.uniform(-1, 1, K * N).astype(np.float32); C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    want = C0.copy()
+    oracle.spmm_fma(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+    with sx.Engine(0) as e:
+        e.set_option("exact", 0)
+        e.set_option("mfma_dense_tiles", 2)
+        e.set_matrix_csr(M, K, rp, ci, v)
+        poison = np.full(K * 64, np.nan, np.float32)
+        e.spmm(64, ALPHA, poison, BETA, np.zeros(M * 64, np.float32))        # every panel of the workspace now holds NaNs
+        got = _run(e, M, N, K, B, C0)
+        assert "rowblock_mfma_f32" in e.last_kernel() and int(e.get_stat("dense_tiles")) == M // 16
+        assert not np.isnan(got).any()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), K
