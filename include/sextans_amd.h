@@ -330,9 +330,9 @@ int sextans_destroy(sextans_handle_t h);
  * cpu_spmm_CSR -- for finite B (a padding zero times an infinite B entry would be NaN where the CSR kernels see no entry at all).  Any N
  * (multiple of 8), whole-matrix and row-range calls, every rank of the multi-GPU forms; "dense_tiles" / "dense_tile_fraction" then
  * count the routed blocks / the share of the non-zeros in them.  MEASURED (round 6, profiles/r06_rowblock_mfma.jsonl): on a
- * block-tridiagonal matrix of fully dense 32 x 32 blocks the path runs the step at 0.71 / 0.44 / 0.35 / 0.31 of the HBM roofline at
- * N = 16 / 64 / 128 / 256 against 0.77 / 0.50 / 0.39 / 0.33 of the VALU kernels with "exact" = 0 (N = 128: kernels 594 us against 583 --
- * the matrix cores are 39 % busy, the loop waits for memory and for issue slots in equal parts at 2 wavefronts per SIMD), and FEM
+ * block-tridiagonal matrix of fully dense 32 x 32 blocks the path runs the step at 0.75 / 0.43 / 0.35 / 0.30 of the HBM roofline at
+ * N = 16 / 64 / 128 / 256 against 0.79 / 0.47 / 0.38 / 0.32 of the VALU kernels with "exact" = 0 (the matrix cores are ~40 % busy, the
+ * loop waits for memory and for issue slots in equal parts, and the matrix is within 1.4 x of its memory bound anyway), and FEM
  * matrices fill their fragments to 0.34 (3 dof) - 0.52 (6 dof) only, so two to three times as many multiply-adds are issued as the
  * matrix holds: 1.5 - 2.7 x slower there.  An option for experiments, not a default.
  * Use it with "exact" = 0 so that routed and unrouted rows follow one rounding rule. */
