@@ -67,8 +67,7 @@ _OPTIONAL_SYMBOLS = frozenset((
     "sextans_spmm_device_rm", "sextans_dist_spmm_rm", "sextans_spmm_bell_device2", "sextans_dist_spmm_bell", "sextans_profile_read_post",
     "sextans_gen_kron_host", "sextans_gen_kron_device", "sextans_csr_slice_rows_device", "sextans_csr_permute_symmetric_device",
     "sextans_export_row_order", "sextans_mtx_read_cached", "sextans_matrix_save", "sextans_matrix_load",
-    "sextans_prepare", "sextans_dist_prepare", "sextans_dist_bind_library", "sextans_device_alloc", "sextans_device_copy",
-    "sextans_set_mode", "sextans_get_mode"))
+    "sextans_prepare", "sextans_dist_prepare", "sextans_dist_bind_library", "sextans_device_alloc", "sextans_device_copy"))
 
 
 class _Optional:

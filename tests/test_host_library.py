@@ -176,3 +176,27 @@ def test_round5_entry_points_reject_bad_arguments(sx):
         api.gen_kron_host(3, prp, pci, 2, 0, 1)
     with pytest.raises(api.SextansError):
         api.gen_kron_host(3, prp, np.array([0, 1], np.int32), 2, 7, 1)                                      # unknown variant
+
+
+def test_collectives_library_binding_without_a_gpu(sx):
+    """sextans_dist_bind_library (round 6) needs no device: an unloadable path is SEXTANS_ERR_STATE (never a silent fallback to another
+    library), the loopback communicator of the multi-rank tests (tests/fake_rccl.cpp, cross-compiled here) exports RCCL's entry points and
+    hands out its own ids, and the default search can be restored."""
+    import ctypes as C
+    from loopback_worker import fake_rccl_path
+    api = sx.api
+    with pytest.raises(api.SextansError) as ei:
+        api.dist_bind_library("/nonexistent/librccl_of_nobody.so")
+    assert ei.value.code == 12
+    path = fake_rccl_path()
+    fake = C.CDLL(path)
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllGather", "ncclBroadcast", "ncclGroupStart", "ncclGroupEnd",
+                 "ncclGetErrorString"):
+        assert hasattr(fake, name), name
+    api.dist_bind_library(path)
+    uid = api.dist_unique_id()
+    assert bytes(uid)[:8] == b"loopback"
+    try:
+        api.dist_bind_library(None)          # back to the default search (RCCL is part of the image; a box without it reports ERR_STATE)
+    except api.SextansError as ex:
+        assert ex.code == 12
