@@ -34,8 +34,12 @@
 
 int main(int argc, char **argv) {
     if (argc < 3) { fprintf(stderr, "usage: %s <A.mtx> <N> [gpus] [rm] [onedevice]\n", argv[0]); return 1; }
-    const bool rm = argc > 4 && !strcmp(argv[4], "rm");
-    const bool one_device = argc > 5 && !strcmp(argv[5], "onedevice");
+    bool rm = false, one_device = false;   // (keywords in any order behind the rank count)
+    for (int a = 4; a < argc; ++a) {
+        if (!strcmp(argv[a], "rm")) rm = true;
+        else if (!strcmp(argv[a], "onedevice")) one_device = true;
+        else { fprintf(stderr, "unknown argument %s\n", argv[a]); return 1; }
+    }
     const int N = sextans_round_up_n(atoi(argv[2]));
     int world = 0;
     if (sextans_device_count(&world) != SEXTANS_OK || world < 1) { fprintf(stderr, "no gfx950 device\n"); return 2; }
