@@ -399,7 +399,59 @@ def scenario_config5_full(world):
     return f"config 5 at full size over {world} block-row ranges: every rank's C bit-identical to the single-engine result"
 
 
+def scenario_hub_rows(world):
+    """Hub rows across ranks: with "split_rows" = -1 (part of SEXTANS_MODE_FAST) the cut threshold T = max(1024, nnz / 16384) follows the non-zeros
+    of the WHOLE matrix, which only the exchange of the ranks' counts can know (sextans_dist_prepare / the first dist call): every rank
+    then cuts its hub rows exactly as one GPU holding all rows does, and the N-rank result equals the 1-GPU result bit for bit."""
+    import torch
+    from sextans_amd import api, dist as sxd
+    M = K = 600_000
+    N = 8
+    rp, ci, v = api.gen_powerlaw_host(M, K, 6, 120, 400_000, 7)
+    nnz = int(rp[-1])
+    assert nnz // 16384 > 1100                              # the global threshold lies above the floor a rank's own count would give
+    rs = np.random.RandomState(5)
+    B = rs.uniform(-1, 1, K * N).astype(np.float32); C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+    torch.cuda.set_device(0)
+    st0 = torch.cuda.current_stream().cuda_stream
+    dB = torch.from_numpy(B).cuda(); dCin = torch.from_numpy(C0).cuda()
+    whole = torch.empty(M * N, device="cuda")
+    with api.Engine(0) as e:
+        e.set_option("mode", 1)
+        e.set_matrix_csr(M, K, rp, ci, v)
+        e.spmm_device(N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr(), whole.data_ptr(), M, st0)
+        torch.cuda.synchronize()
+        hubs = e.reassociated_rows()
+    assert len(hubs) > 0
+    ranges = sxd.partition_rows_by_nnz(rp, world)
+
+    def rank_fn(rank, comm, st):
+        r0, r1 = ranges[rank]
+        lrp, lci, lv = sxd.slice_csr(rp, ci, v, r0, r1)
+        with api.Engine(0) as e:
+            e.set_option("mode", 1)
+            e.set_matrix_csr(r1 - r0, K, lrp, lci, lv)
+            res = {}
+            for form in ("lazy", "prepared"):
+                if form == "prepared":
+                    e.dist_prepare(comm, world, rank, ranges, N, nchunks=2, form=0, stream=st)
+                out = torch.full((M * N,), float("nan"), device="cuda")
+                e.dist_spmm(comm, world, rank, ranges, N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr(), M, out.data_ptr(), M, nchunks=2, stream=st)
+                torch.cuda.current_stream().synchronize()
+                res[form] = bool(torch.equal(out, whole))
+            res["threshold"] = int(e.get_stat("split_threshold"))
+            res["hubs"] = (e.reassociated_rows() + r0).tolist()
+        return res
+
+    res = Ranks(world).run(rank_fn)
+    assert all(r["lazy"] and r["prepared"] for r in res), res
+    assert all(r["threshold"] == nnz // 16384 for r in res), [r["threshold"] for r in res]
+    assert sorted(sum((r["hubs"] for r in res), [])) == list(hubs)
+    return f"{len(hubs)} hub rows cut at the global threshold {nnz // 16384} on every one of {world} ranks; all ranks bit-identical to one GPU"
+
+
 SCENARIOS = {
+    "hub_rows": scenario_hub_rows,
     "config5_full": scenario_config5_full,
     "config4_full": scenario_config4_full,
     "colmajor": scenario_colmajor,

@@ -63,6 +63,12 @@ def test_dist_prepare_fails_on_every_rank_or_on_none(sx, world):
     _run("errors", world)
 
 
+def test_hub_rows_are_cut_at_the_global_threshold_on_every_rank(sx):
+    """SEXTANS_MODE_FAST across ranks: the hub-split threshold follows the whole matrix's non-zero count, known only through the exchange
+    of the ranks' counts -- 3 ranks of a power-law matrix give the single-GPU fast-mode result bit for bit, lazily and prepared."""
+    _run("hub_rows", 3)
+
+
 def test_config4_as_stated_row_split_over_8_ranks_at_full_size(sx):
     """BASELINE.json config 4: "Synthetic 4Mx4M CSR, ~0.001% density, N=16, A row-split across 8xMI355X with RCCL all-gather(C)" -- the full-size
     matrix, 8 ranks with nnz-balanced ranges, sextans_dist_prepare + sextans_dist_spmm (4 chunks) and sextans_dist_spmm_rm: every rank ends
