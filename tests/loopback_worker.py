@@ -450,7 +450,55 @@ def scenario_hub_rows(world):
     return f"{len(hubs)} hub rows cut at the global threshold {nnz // 16384} on every one of {world} ranks; all ranks bit-identical to one GPU"
 
 
+def scenario_empty_ranges(world):
+    """More ranks than rows with non-zeros: nnz-balanced ranges leave some ranks with NO rows (and one rank's rows may all be empty).  Every
+    form must still complete on every rank with the whole C."""
+    import torch
+    from oracle.bindings import Oracle
+    from sextans_amd import api, dist as sxd
+    o = Oracle()
+    rs = np.random.RandomState(3)
+    M, K = (37 if world < 8 else 11), 50                    # (8 ranks over 11 mostly empty rows: nnz-balanced ranges with empty members)
+    rp, ci, v = random_csr(rs, M, K, 6, empty_frac=0.6)
+    out_all = {}
+    for N in (8, 16):
+        B = rs.uniform(-1, 1, K * N).astype(np.float32); C0 = rs.uniform(-1, 1, M * N).astype(np.float32)
+        want = C0.copy()
+        o.spmm(M, N, K, ALPHA, rp, ci, v, B, BETA, want)
+        want_rm = np.ascontiguousarray(want.reshape(N, M).T)
+        for mode in ("nnz", "front"):
+            ranges = sxd.partition_rows_by_nnz(rp, world) if mode == "nnz" else [(0, M)] + [(M, M)] * (world - 1)   # everything on rank 0
+            assert mode == "nnz" or any(a == b for a, b in ranges)
+
+            def rank_fn(rank, comm, st):
+                r0, r1 = ranges[rank]
+                lrp, lci, lv = sxd.slice_csr(rp, ci, v, r0, r1)
+                dB = torch.from_numpy(B).cuda(); dCin = torch.from_numpy(C0).cuda()
+                dBr = torch.from_numpy(np.ascontiguousarray(B.reshape(N, K).T)).cuda()
+                ok = []
+                with api.Engine(0) as e:
+                    e.set_matrix_csr(r1 - r0, K, lrp, lci, lv)
+                    for nchunks in (1, 3):
+                        e.dist_prepare(comm, world, rank, ranges, N, nchunks=nchunks, form=0, stream=st)
+                        out = torch.full((M * N,), float("nan"), device="cuda")
+                        e.dist_spmm(comm, world, rank, ranges, N, ALPHA, dB.data_ptr(), K, BETA, dCin.data_ptr(), M, out.data_ptr(), M, nchunks=nchunks, stream=st)
+                        torch.cuda.current_stream().synchronize()
+                        ok.append(bool(np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))))
+                    cin = torch.from_numpy(np.ascontiguousarray(C0.reshape(N, M).T)).cuda()
+                    outr = torch.full((M, N), float("nan"), device="cuda")
+                    e.dist_spmm_rm(comm, world, rank, ranges, N, ALPHA, dBr.data_ptr(), N, BETA, cin.data_ptr(), N, outr.data_ptr(), N, stream=st)
+                    torch.cuda.current_stream().synchronize()
+                    ok.append(bool(np.array_equal(outr.cpu().numpy().view(np.uint32), want_rm.view(np.uint32))))
+                return ok
+
+            res = Ranks(world).run(rank_fn)
+            assert all(all(r) for r in res), (N, mode, ranges, res)
+            out_all[(N, mode)] = ranges
+    return f"ranks without rows complete every form: {out_all[(16, 'nnz')]}"
+
+
 SCENARIOS = {
+    "empty_ranges": scenario_empty_ranges,
     "hub_rows": scenario_hub_rows,
     "config5_full": scenario_config5_full,
     "config4_full": scenario_config4_full,

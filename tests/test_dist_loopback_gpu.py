@@ -63,6 +63,14 @@ def test_dist_prepare_fails_on_every_rank_or_on_none(sx, world):
     _run("errors", world)
 
 
+@pytest.mark.parametrize("world", [3, 8])
+def test_ranks_without_rows(sx, world):
+    """Ragged partitions (the reference's tests hold empty and ragged inputs too): a 37-row matrix, mostly empty rows, over 3 and 8 ranks --
+    nnz-balanced ranges with empty members, and everything on rank 0 -- through sextans_dist_prepare, sextans_dist_spmm (1 / 3 chunks) and
+    sextans_dist_spmm_rm."""
+    _run("empty_ranges", world)
+
+
 def test_hub_rows_are_cut_at_the_global_threshold_on_every_rank(sx):
     """SEXTANS_MODE_FAST across ranks: the hub-split threshold follows the whole matrix's non-zero count, known only through the exchange
     of the ranks' counts -- 3 ranks of a power-law matrix give the single-GPU fast-mode result bit for bit, lazily and prepared."""
