@@ -39,7 +39,7 @@ def main():
             p, i, v, nnz = api.gen_fem3d_device(0, *dims, 3); name = "fem3d 110^3 x 3 dof"; Ns = (32, 64, 128, 256)
         elif w == "fem6":
             dims = (80, 80, 80, 6); M = K = 80 ** 3 * 6
-            p, i, v, nnz = api.gen_fem3d_device(0, *dims, 3); name = "fem3d 80^3 x 6 dof"; Ns = (16, 64, 128)
+            p, i, v, nnz = api.gen_fem3d_device(0, *dims, 3); name = "fem3d 80^3 x 6 dof"; Ns = (16, 64, 128, 256)
         else:
             prp, pci = dense_pattern(32)
             n = 32768
