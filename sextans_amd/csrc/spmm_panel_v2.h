@@ -275,12 +275,18 @@ __global__ __launch_bounds__(kBlock, (H == 1 && !BIG ? (BCOL && DCAP == 9 ? SX_V
     // unwritten and are never read).
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool cvalid = BCOL || H != 1 || 4 * q < last_cols;   // my 4 columns exist in the last tile too (column-major staging never merges a tail)
+    // (TIMING-ONLY builds, tools/build_variant.py -DSX_TIMING_DMA_PERCENT=p: only the first p % of a block's dictionary rows are copied --
+    // WRONG results -- to bound what a workgroup that kept rows of the previous block in LDS could save: profiles/r06_panel_copy_bound.txt)
+#ifndef SX_TIMING_DMA_PERCENT
+#define SX_TIMING_DMA_PERCENT 100
+#endif
+    const int nu_dma = SX_TIMING_DMA_PERCENT == 100 ? nu : nu * SX_TIMING_DMA_PERCENT / 100;
     auto dma_panel = [&](int st) {
 #pragma unroll
         for (int u = 0; u < MAXD; ++u)
 #pragma unroll
             for (int h = 0; h < H; ++h)
-                if (u * RB + slot < nu && (!RM || cvalid || st + 1 < nsuper))
+                if (u * RB + slot < nu_dma && (!RM || cvalid || st + 1 < nsuper))
                     glds16(Bp + (RM ? (int64_t)st * 16 : (int64_t)(st * H + h) * panel_stride) + boff[u], lds + h * kWideHalfBytes + (u * RB + wave * 16) * 64);
         // the +1.0f rows the padding entries (value -0.0f) address: kWidePadRows of them, a shifted shared list points further in
 #pragma unroll
